@@ -1,0 +1,713 @@
+/*
+ * oracle_path.c -- TEST INFRASTRUCTURE (see fastlio_oracle.h header).  PARITY UNPINNED.
+ *
+ * Plain-C restatement of
+ *   h_share_model                               src/laserMapping.cpp:638-754
+ *   esekf::update_iterated_dyn_share_modified   include/IKFoM_toolkit/esekfom/esekfom.hpp:1619-1931
+ *   map_incremental (add/skip decision only)    src/laserMapping.cpp:427-474
+ * and an exact 5-NN k-d tree standing in for ikd-Tree's Nearest_Search (source absent from the
+ * snapshot: include/ikd-Tree is an un-vendored submodule, .gitmodules:1-4).  Semantics kept:
+ * exact 5-NN, squared-L2 in fp32, ascending; ties broken by lower map index (our convention).
+ *
+ * The reference's static 100 000-point caps (laserMapping.cpp:76,94,112-114) are lifted: all per-
+ * point arrays are sized by N.
+ */
+#include "fastlio_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NDOF ORC_NDOF
+#define K ORC_K
+enum { X_POS = 0, X_ROT = 3, X_OFFR = 7, X_OFFT = 11, X_VEL = 14, X_BG = 17, X_BA = 20, X_GRAV = 23 };
+
+static double now_s(void) {
+#ifdef _OPENMP
+    return omp_get_wtime();
+#else
+    return 0.0;
+#endif
+}
+
+/* =================================================================== exact 5-NN k-d tree */
+#define LEAF 12
+typedef struct {
+    float split;
+    int32_t dim;   /* -1 = leaf */
+    int32_t left;  /* child index, or first point for leaves */
+    int32_t right; /* child index, or point count for leaves */
+} kd_node;
+struct orc_kdtree {
+    size_t M;
+    float* pts;     /* M x 3, tree order */
+    int32_t* index; /* original indices, tree order */
+    kd_node* nodes;
+    int32_t nnodes, cap;
+};
+
+static inline float dist2f(const float* a, const float* b) {
+    float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return (dx * dx + dy * dy) + dz * dz;
+}
+/* (d2, idx) lexicographic "a before b" */
+static inline int before(float d2a, int32_t ia, float d2b, int32_t ib) {
+    return d2a < d2b || (d2a == d2b && ia < ib);
+}
+typedef struct {
+    int n;
+    int32_t idx[K];
+    float d2[K];
+} top5;
+static inline void top5_insert(top5* t, float d2, int32_t idx) {
+    if (t->n == K && !before(d2, idx, t->d2[K - 1], t->idx[K - 1])) return;
+    int pos = t->n < K ? t->n : K - 1;
+    while (pos > 0 && before(d2, idx, t->d2[pos - 1], t->idx[pos - 1])) {
+        t->d2[pos] = t->d2[pos - 1];
+        t->idx[pos] = t->idx[pos - 1];
+        pos--;
+    }
+    t->d2[pos] = d2;
+    t->idx[pos] = idx;
+    if (t->n < K) t->n++;
+}
+
+static void swap_pt(orc_kdtree* t, size_t a, size_t b) {
+    if (a == b) return;
+    float tmp[3];
+    memcpy(tmp, t->pts + 3 * a, sizeof(tmp));
+    memcpy(t->pts + 3 * a, t->pts + 3 * b, sizeof(tmp));
+    memcpy(t->pts + 3 * b, tmp, sizeof(tmp));
+    int32_t ti = t->index[a];
+    t->index[a] = t->index[b];
+    t->index[b] = ti;
+}
+/* quickselect on dimension d so that element k is in sorted position within [lo,hi) */
+static void nth_element(orc_kdtree* t, size_t lo, size_t hi, size_t k, int d) {
+    while (hi - lo > 1) {
+        size_t mid = lo + (hi - lo) / 2;
+        /* median of three */
+        float a = t->pts[3 * lo + d], b = t->pts[3 * mid + d], c = t->pts[3 * (hi - 1) + d];
+        size_t pi = (a < b) ? ((b < c) ? mid : (a < c ? hi - 1 : lo)) : ((a < c) ? lo : (b < c ? hi - 1 : mid));
+        float pv = t->pts[3 * pi + d];
+        swap_pt(t, pi, hi - 1);
+        size_t st = lo;
+        for (size_t i = lo; i + 1 < hi; i++)
+            if (t->pts[3 * i + d] < pv) swap_pt(t, i, st++);
+        swap_pt(t, st, hi - 1);
+        /* handle runs of equal keys to avoid quadratic behaviour on lattices */
+        size_t eq = st + 1;
+        for (size_t i = st + 1; i < hi; i++)
+            if (t->pts[3 * i + d] == pv) swap_pt(t, i, eq++);
+        if (k < st) hi = st;
+        else if (k >= eq) lo = eq;
+        else return;
+    }
+}
+static int32_t new_node(orc_kdtree* t) {
+    if (t->nnodes == t->cap) {
+        t->cap = t->cap ? t->cap * 2 : 1024;
+        t->nodes = (kd_node*)realloc(t->nodes, sizeof(kd_node) * (size_t)t->cap);
+    }
+    return t->nnodes++;
+}
+static int32_t build_rec(orc_kdtree* t, size_t lo, size_t hi) {
+    int32_t id = new_node(t);
+    if (hi - lo <= LEAF) {
+        t->nodes[id].dim = -1;
+        t->nodes[id].left = (int32_t)lo;
+        t->nodes[id].right = (int32_t)(hi - lo);
+        t->nodes[id].split = 0;
+        return id;
+    }
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (size_t i = lo; i < hi; i++)
+        for (int d = 0; d < 3; d++) {
+            float v = t->pts[3 * i + d];
+            if (v < mn[d]) mn[d] = v;
+            if (v > mx[d]) mx[d] = v;
+        }
+    int d = 0;
+    if (mx[1] - mn[1] > mx[d] - mn[d]) d = 1;
+    if (mx[2] - mn[2] > mx[d] - mn[d]) d = 2;
+    if (mx[d] == mn[d]) { /* all points identical: oversized leaf */
+        t->nodes[id].dim = -1;
+        t->nodes[id].left = (int32_t)lo;
+        t->nodes[id].right = (int32_t)(hi - lo);
+        t->nodes[id].split = 0;
+        return id;
+    }
+    size_t mid = lo + (hi - lo) / 2;
+    nth_element(t, lo, hi, mid, d);
+    float split = t->pts[3 * mid + d];
+    /* left: [lo,mid) has values <= split; right: [mid,hi) has values >= split */
+    int32_t l = build_rec(t, lo, mid);
+    int32_t r = build_rec(t, mid, hi);
+    t->nodes[id].dim = d;
+    t->nodes[id].split = split;
+    t->nodes[id].left = l;
+    t->nodes[id].right = r;
+    return id;
+}
+orc_kdtree* orc_kdtree_build(const float* xyz, size_t stride, size_t M) {
+    orc_kdtree* t = (orc_kdtree*)calloc(1, sizeof(orc_kdtree));
+    t->M = M;
+    t->pts = (float*)malloc(sizeof(float) * 3 * (M ? M : 1));
+    t->index = (int32_t*)malloc(sizeof(int32_t) * (M ? M : 1));
+    for (size_t i = 0; i < M; i++) {
+        t->pts[3 * i + 0] = xyz[i * stride + 0];
+        t->pts[3 * i + 1] = xyz[i * stride + 1];
+        t->pts[3 * i + 2] = xyz[i * stride + 2];
+        t->index[i] = (int32_t)i;
+    }
+    if (M > 0) build_rec(t, 0, M);
+    return t;
+}
+void orc_kdtree_free(orc_kdtree* t) {
+    if (!t) return;
+    free(t->pts); free(t->index); free(t->nodes); free(t);
+}
+size_t orc_kdtree_size(const orc_kdtree* t) { return t->M; }
+
+static void search_rec(const orc_kdtree* t, int32_t id, const float* q, top5* best) {
+    const kd_node* n = &t->nodes[id];
+    if (n->dim < 0) {
+        const float* p = t->pts + 3 * (size_t)n->left;
+        for (int32_t i = 0; i < n->right; i++) top5_insert(best, dist2f(q, p + 3 * i), t->index[n->left + i]);
+        return;
+    }
+    float diff = q[n->dim] - n->split;
+    int32_t first = diff < 0 ? n->left : n->right;
+    int32_t second = diff < 0 ? n->right : n->left;
+    search_rec(t, first, q, best);
+    /* fl(diff*diff) is a valid lower bound of the fp32 d2 of anything on the far side (rounding is
+       monotone); do not prune on equality so equal-distance lower-index points are still found. */
+    float pd = diff * diff;
+    if (best->n < K || !(pd > best->d2[K - 1])) search_rec(t, second, q, best);
+}
+int orc_knn5(const orc_kdtree* t, const float q[3], int32_t idx[K], float d2[K]) {
+    top5 b;
+    b.n = 0;
+    if (t->M > 0) search_rec(t, 0, q, &b);
+    for (int i = 0; i < b.n; i++) { idx[i] = b.idx[i]; d2[i] = b.d2[i]; }
+    for (int i = b.n; i < K; i++) { idx[i] = -1; d2[i] = INFINITY; }
+    return b.n;
+}
+int orc_knn5_brute(const float* xyz, size_t stride, size_t M, const float q[3], int32_t idx[K], float d2[K]) {
+    top5 b;
+    b.n = 0;
+    for (size_t i = 0; i < M; i++) top5_insert(&b, dist2f(q, xyz + i * stride), (int32_t)i);
+    for (int i = 0; i < b.n; i++) { idx[i] = b.idx[i]; d2[i] = b.d2[i]; }
+    for (int i = b.n; i < K; i++) { idx[i] = -1; d2[i] = INFINITY; }
+    return b.n;
+}
+void orc_knn5_batch(const orc_kdtree* t, const float* q, size_t N, int32_t* idx, float* d2, uint8_t* cnt, int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 256)
+#endif
+    for (long i = 0; i < (long)N; i++) cnt[i] = (uint8_t)orc_knn5(t, q + 3 * i, idx + K * i, d2 + K * i);
+}
+
+/* =================================================================== scan context */
+orc_scan* orc_scan_create(const float* body, size_t stride, int N) {
+    orc_scan* s = (orc_scan*)calloc(1, sizeof(orc_scan));
+    size_t n = (size_t)(N > 0 ? N : 1);
+    s->N = N;
+    s->body = (float*)malloc(sizeof(float) * 3 * n);
+    s->world = (float*)calloc(3 * n, sizeof(float));
+    s->nn_idx = (int32_t*)malloc(sizeof(int32_t) * K * n);
+    s->nn_d2 = (float*)malloc(sizeof(float) * K * n);
+    s->nn_cnt = (uint8_t*)calloc(n, 1);
+    s->selected = (uint8_t*)malloc(n);
+    s->normvec = (float*)calloc(4 * n, sizeof(float));
+    s->res_last = (float*)calloc(n, sizeof(float));
+    for (int i = 0; i < N; i++) {
+        s->body[3 * i + 0] = body[(size_t)i * stride + 0];
+        s->body[3 * i + 1] = body[(size_t)i * stride + 1];
+        s->body[3 * i + 2] = body[(size_t)i * stride + 2];
+    }
+    for (size_t i = 0; i < K * n; i++) { s->nn_idx[i] = -1; s->nn_d2[i] = INFINITY; }
+    s->nthreads = 3; /* MP_PROC_NUM, CMakeLists.txt:21-24 */
+    s->search_radius2 = 0.0;
+    orc_scan_reset(s);
+    return s;
+}
+void orc_scan_reset(orc_scan* s) {
+    memset(s->selected, 1, (size_t)(s->N > 0 ? s->N : 1)); /* memset(point_selected_surf, true, ..), :812 */
+    s->match_time = s->solve_time = 0;
+    s->effct_feat_num = 0;
+    s->total_residual = 0;
+}
+void orc_scan_free(orc_scan* s) {
+    if (!s) return;
+    free(s->body); free(s->world); free(s->nn_idx); free(s->nn_d2); free(s->nn_cnt);
+    free(s->selected); free(s->normvec); free(s->res_last); free(s->h_x); free(s->h); free(s);
+}
+
+/* =================================================================== h_share_model */
+int orc_h_share_model(orc_scan* sc, const orc_kdtree* map, const float* map_xyz, size_t mstride,
+                      const double x[ORC_NSTATE], int converge, int extrinsic_est_en) {
+    double match_start = now_s();
+    const int N = sc->N;
+    sc->total_residual = 0.0; /* :643 */
+    const double* rot = x + X_ROT;
+    const double* offR = x + X_OFFR;
+    const double* offT = x + X_OFFT;
+    const double* pos = x + X_POS;
+#ifdef _OPENMP
+    if (sc->nthreads > 0) omp_set_num_threads(sc->nthreads);
+#pragma omp parallel for schedule(static)
+#endif
+    for (int i = 0; i < N; i++) { /* :650-693 */
+        const float* pb = sc->body + 3 * i;
+        float* pw = sc->world + 3 * i;
+        double p_body[3] = {pb[0], pb[1], pb[2]};
+        double t1[3], t2[3], p_global[3];
+        orc_quat_rot(offR, p_body, t1);
+        for (int d = 0; d < 3; d++) t1[d] = t1[d] + offT[d];
+        orc_quat_rot(rot, t1, t2);
+        for (int d = 0; d < 3; d++) p_global[d] = t2[d] + pos[d];
+        pw[0] = (float)p_global[0];
+        pw[1] = (float)p_global[1];
+        pw[2] = (float)p_global[2];
+
+        int32_t* nidx = sc->nn_idx + K * i;
+        float* nd2 = sc->nn_d2 + K * i;
+        if (converge) { /* :667-672 */
+            int cnt = orc_knn5(map, pw, nidx, nd2);
+            if (sc->search_radius2 > 0.0) { /* radius-bounded variant (validation of SURVEY 8a note) */
+                int c2 = 0;
+                for (int j = 0; j < cnt; j++)
+                    if (nd2[j] <= (float)sc->search_radius2) c2++;
+                for (int j = c2; j < K; j++) { nidx[j] = -1; nd2[j] = INFINITY; }
+                cnt = c2;
+            }
+            sc->nn_cnt[i] = (uint8_t)cnt;
+            sc->selected[i] = cnt < K ? 0 : (nd2[K - 1] > 5 ? 0 : 1);
+        }
+        if (!sc->selected[i]) continue; /* :674 */
+
+        float pts[15];
+        for (int j = 0; j < K; j++) {
+            const float* mp = map_xyz + (size_t)nidx[j] * mstride;
+            pts[3 * j + 0] = mp[0]; pts[3 * j + 1] = mp[1]; pts[3 * j + 2] = mp[2];
+        }
+        float pabcd[4];
+        sc->selected[i] = 0; /* :677 */
+        if (orc_esti_plane(pts, 0.1f, pabcd)) {
+            float pd2 = ((pabcd[0] * pw[0] + pabcd[1] * pw[1]) + pabcd[2] * pw[2]) + pabcd[3]; /* :680 */
+            double nb = sqrt((p_body[0] * p_body[0] + p_body[1] * p_body[1]) + p_body[2] * p_body[2]);
+            float s = (float)(1 - 0.9 * (double)fabsf(pd2) / sqrt(nb)); /* :681 */
+            if ((double)s > 0.9) { /* :683: float compared with the double literal */
+                sc->selected[i] = 1;
+                sc->normvec[4 * i + 0] = pabcd[0];
+                sc->normvec[4 * i + 1] = pabcd[1];
+                sc->normvec[4 * i + 2] = pabcd[2];
+                sc->normvec[4 * i + 3] = pd2;
+                sc->res_last[i] = fabsf(pd2);
+            }
+        }
+    }
+    /* serial compaction :695-706 */
+    int n_eff = 0;
+    for (int i = 0; i < N; i++)
+        if (sc->selected[i]) {
+            sc->total_residual += sc->res_last[i];
+            n_eff++;
+        }
+    sc->effct_feat_num = n_eff;
+    if (n_eff < 1) { /* :708-713 */
+        return 0;
+    }
+    sc->res_mean_last = sc->total_residual / n_eff; /* :715 */
+    sc->match_time += now_s() - match_start;
+    double solve_start = now_s();
+
+    if (n_eff > sc->cap_rows) {
+        free(sc->h_x); free(sc->h);
+        sc->cap_rows = n_eff;
+        sc->h_x = (double*)malloc(sizeof(double) * 12 * (size_t)n_eff);
+        sc->h = (double*)malloc(sizeof(double) * (size_t)n_eff);
+    }
+    double rotc[4] = {-rot[0], -rot[1], -rot[2], rot[3]};
+    double offRc[4] = {-offR[0], -offR[1], -offR[2], offR[3]};
+    int k = 0;
+    for (int i = 0; i < N; i++) { /* :723-752 (compaction fused: laserCloudOri[k] = body[i]) */
+        if (!sc->selected[i]) continue;
+        const float* pb = sc->body + 3 * i;
+        const float* nv = sc->normvec + 4 * i;
+        double pbe[3] = {pb[0], pb[1], pb[2]};
+        double pthis[3];
+        orc_quat_rot(offR, pbe, pthis);
+        for (int d = 0; d < 3; d++) pthis[d] = pthis[d] + offT[d];
+        double norm_vec[3] = {nv[0], nv[1], nv[2]};
+        double C[3], A[3];
+        orc_quat_rot(rotc, norm_vec, C);
+        /* A = hat(point_this) * C */
+        A[0] = (0.0 * C[0] + (-pthis[2]) * C[1]) + pthis[1] * C[2];
+        A[1] = (pthis[2] * C[0] + 0.0 * C[1]) + (-pthis[0]) * C[2];
+        A[2] = ((-pthis[1]) * C[0] + pthis[0] * C[1]) + 0.0 * C[2];
+        double row[12];
+        row[0] = nv[0]; row[1] = nv[1]; row[2] = nv[2];
+        row[3] = A[0]; row[4] = A[1]; row[5] = A[2];
+        if (extrinsic_est_en) {
+            /* B = hat(point_be) * offset_R_L_I.conjugate() * C :740 -- Eigen evaluates
+               (crossmat * R(q)) * C; restated as crossmat * (q^-1 rotates C) (rounding-level difference). */
+            double D[3], B[3];
+            orc_quat_rot(offRc, C, D);
+            B[0] = (0.0 * D[0] + (-pbe[2]) * D[1]) + pbe[1] * D[2];
+            B[1] = (pbe[2] * D[0] + 0.0 * D[1]) + (-pbe[0]) * D[2];
+            B[2] = ((-pbe[1]) * D[0] + pbe[0] * D[1]) + 0.0 * D[2];
+            row[6] = B[0]; row[7] = B[1]; row[8] = B[2];
+            row[9] = C[0]; row[10] = C[1]; row[11] = C[2];
+        } else {
+            for (int c = 6; c < 12; c++) row[c] = 0.0; /* :745: six literal zeros */
+        }
+        for (int c = 0; c < 12; c++) sc->h_x[(size_t)c * n_eff + k] = row[c];
+        sc->h[k] = -(double)nv[3]; /* :750 */
+        k++;
+    }
+    sc->solve_time += now_s() - solve_start;
+    return 1;
+}
+
+void orc_normal_equations(const orc_scan* sc, double HTH[144], double HTh[12]) {
+    int n = sc->effct_feat_num;
+    for (int a = 0; a < 12; a++) {
+        for (int b = 0; b < 12; b++) {
+            double s = 0;
+            for (int k = 0; k < n; k++) s += sc->h_x[(size_t)a * n + k] * sc->h_x[(size_t)b * n + k];
+            HTH[a * 12 + b] = s;
+        }
+        double s = 0;
+        for (int k = 0; k < n; k++) s += sc->h_x[(size_t)a * n + k] * sc->h[k];
+        HTh[a] = s;
+    }
+}
+
+/* =================================================================== IEKF host algebra */
+static void project_P(double* P, double* dx_new, const double x[ORC_NSTATE], const double x_prop[ORC_NSTATE],
+                      const double dx[NDOF]) {
+    /* esekfom.hpp:1659-1699: P <- J P J^T blockwise, dx_new <- J dx_new, J = A(dx_so3)^T / Nx*Mx */
+    static const int so3_idx[2] = {3, 6};
+    for (int s = 0; s < 2; s++) {
+        int idx = so3_idx[s];
+        double A[9], J[9];
+        orc_A_matrix(dx + idx, A);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) J[i * 3 + j] = A[j * 3 + i];
+        double t[3];
+        for (int r = 0; r < 3; r++) t[r] = J[r * 3] * dx_new[idx] + J[r * 3 + 1] * dx_new[idx + 1] + J[r * 3 + 2] * dx_new[idx + 2];
+        for (int r = 0; r < 3; r++) dx_new[idx + r] = t[r];
+        for (int i = 0; i < NDOF; i++) { /* rows */
+            double c0 = P[(idx)*NDOF + i], c1 = P[(idx + 1) * NDOF + i], c2 = P[(idx + 2) * NDOF + i];
+            for (int r = 0; r < 3; r++) P[(idx + r) * NDOF + i] = J[r * 3] * c0 + J[r * 3 + 1] * c1 + J[r * 3 + 2] * c2;
+        }
+        for (int i = 0; i < NDOF; i++) { /* cols: P(i, idx:idx+3) = P(i, idx:idx+3) * J^T */
+            double c0 = P[i * NDOF + idx], c1 = P[i * NDOF + idx + 1], c2 = P[i * NDOF + idx + 2];
+            for (int r = 0; r < 3; r++) P[i * NDOF + idx + r] = c0 * J[r * 3] + c1 * J[r * 3 + 1] + c2 * J[r * 3 + 2];
+        }
+    }
+    {
+        int idx = 21;
+        double Nx[6], Mx[6], J[4];
+        orc_S2_Nx_yy(x + X_GRAV, Nx);
+        orc_S2_Mx(x_prop + X_GRAV, dx + idx, Mx);
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++) J[i * 2 + j] = Nx[i * 3] * Mx[0 * 2 + j] + Nx[i * 3 + 1] * Mx[1 * 2 + j] + Nx[i * 3 + 2] * Mx[2 * 2 + j];
+        double t0 = J[0] * dx_new[idx] + J[1] * dx_new[idx + 1];
+        double t1 = J[2] * dx_new[idx] + J[3] * dx_new[idx + 1];
+        dx_new[idx] = t0; dx_new[idx + 1] = t1;
+        for (int i = 0; i < NDOF; i++) {
+            double c0 = P[idx * NDOF + i], c1 = P[(idx + 1) * NDOF + i];
+            P[idx * NDOF + i] = J[0] * c0 + J[1] * c1;
+            P[(idx + 1) * NDOF + i] = J[2] * c0 + J[3] * c1;
+        }
+        for (int i = 0; i < NDOF; i++) {
+            double c0 = P[i * NDOF + idx], c1 = P[i * NDOF + idx + 1];
+            P[i * NDOF + idx] = c0 * J[0] + c1 * J[1];
+            P[i * NDOF + idx + 1] = c0 * J[2] + c1 * J[3];
+        }
+    }
+}
+
+/* The tail of one pass: dx_ = K_h + (K_x - I) dx_new ; x boxplus dx_ (esekfom.hpp:1815-1817) */
+static void finish_pass(double x[ORC_NSTATE], const double K_h[NDOF], const double* K_x, const double dx_new[NDOF],
+                        double dx_out[NDOF]) {
+    for (int i = 0; i < NDOF; i++) {
+        double s = 0;
+        for (int j = 0; j < NDOF; j++) s += (K_x[i * NDOF + j] - (i == j ? 1.0 : 0.0)) * dx_new[j];
+        dx_out[i] = K_h[i] + s;
+    }
+    orc_state_boxplus(x, dx_out);
+}
+
+static void gain_info(const double* P, double R, const double HTH[144], const double* h_x_cm, const double* h, int n_eff,
+                      const double HTh_in[12], double K_h[NDOF], double* K_x) {
+    /* esekfom.hpp:1782-1809 */
+    double lPR[NDOF * NDOF], lPt[NDOF * NDOF], lPi[NDOF * NDOF];
+    for (int i = 0; i < NDOF * NDOF; i++) lPR[i] = P[i] / R;
+    orc_inverse(lPR, NDOF, lPt);
+    for (int a = 0; a < 12; a++)
+        for (int b = 0; b < 12; b++) lPt[a * NDOF + b] += HTH[a * 12 + b];
+    orc_inverse(lPt, NDOF, lPi);
+    if (h_x_cm) {
+        /* K_h = P_inv[:, :12] * h_x^T * h, evaluated left to right like Eigen (n x N_eff temp) */
+        double* T = (double*)malloc(sizeof(double) * (size_t)n_eff);
+        for (int i = 0; i < NDOF; i++) {
+            for (int k = 0; k < n_eff; k++) {
+                double s = 0;
+                for (int c = 0; c < 12; c++) s += lPi[i * NDOF + c] * h_x_cm[(size_t)c * n_eff + k];
+                T[k] = s;
+            }
+            double s = 0;
+            for (int k = 0; k < n_eff; k++) s += T[k] * h[k];
+            K_h[i] = s;
+        }
+        free(T);
+    } else {
+        for (int i = 0; i < NDOF; i++) {
+            double s = 0;
+            for (int c = 0; c < 12; c++) s += lPi[i * NDOF + c] * HTh_in[c];
+            K_h[i] = s;
+        }
+    }
+    memset(K_x, 0, sizeof(double) * NDOF * NDOF);
+    for (int i = 0; i < NDOF; i++)
+        for (int b = 0; b < 12; b++) {
+            double s = 0;
+            for (int c = 0; c < 12; c++) s += lPi[i * NDOF + c] * HTH[c * 12 + b];
+            K_x[i * NDOF + b] = s;
+        }
+}
+
+static void gain_small(const double* P, double R, const double* h_x_cm, const double* h, int m, double K_h[NDOF], double* K_x) {
+    /* esekfom.hpp:1715-1744: K = P H^T (H P H^T / R + I)^-1 / R, H zero-padded to m x 23 */
+    double* H = (double*)calloc((size_t)m * NDOF, sizeof(double));
+    for (int k = 0; k < m; k++)
+        for (int c = 0; c < 12; c++) H[k * NDOF + c] = h_x_cm[(size_t)c * m + k];
+    double* PHt = (double*)malloc(sizeof(double) * NDOF * (size_t)m);
+    for (int i = 0; i < NDOF; i++)
+        for (int k = 0; k < m; k++) {
+            double s = 0;
+            for (int j = 0; j < NDOF; j++) s += P[i * NDOF + j] * H[k * NDOF + j];
+            PHt[i * m + k] = s;
+        }
+    double* S = (double*)malloc(sizeof(double) * (size_t)m * m);
+    double* Si = (double*)malloc(sizeof(double) * (size_t)m * m);
+    for (int a = 0; a < m; a++)
+        for (int b = 0; b < m; b++) {
+            double s = 0;
+            for (int j = 0; j < NDOF; j++) s += H[a * NDOF + j] * PHt[j * m + b];
+            S[a * m + b] = s / R + (a == b ? 1.0 : 0.0);
+        }
+    orc_inverse(S, m, Si);
+    double* Kg = (double*)malloc(sizeof(double) * NDOF * (size_t)m);
+    for (int i = 0; i < NDOF; i++)
+        for (int k = 0; k < m; k++) {
+            double s = 0;
+            for (int j = 0; j < m; j++) s += PHt[i * m + j] * Si[j * m + k];
+            Kg[i * m + k] = s / R;
+        }
+    for (int i = 0; i < NDOF; i++) {
+        double s = 0;
+        for (int k = 0; k < m; k++) s += Kg[i * m + k] * h[k];
+        K_h[i] = s;
+        for (int j = 0; j < NDOF; j++) {
+            double w = 0;
+            for (int k = 0; k < m; k++) w += Kg[i * m + k] * H[k * NDOF + j];
+            K_x[i * NDOF + j] = w;
+        }
+    }
+    free(H); free(PHt); free(S); free(Si); free(Kg);
+}
+
+static void final_cov(double* P, double* K_x, const double x[ORC_NSTATE], const double x_prop[ORC_NSTATE], const double dx_[NDOF]) {
+    /* esekfom.hpp:1834-1924: L = P; project L, K_x, P by A(dx_)^T / Nx*Mx; P = L - K_x[:, :12] P[:12, :] */
+    double L[NDOF * NDOF];
+    memcpy(L, P, sizeof(L));
+    static const int so3_idx[2] = {3, 6};
+    for (int s = 0; s < 2; s++) {
+        int idx = so3_idx[s];
+        double A[9], J[9];
+        orc_A_matrix(dx_ + idx, A);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) J[i * 3 + j] = A[j * 3 + i];
+        for (int i = 0; i < NDOF; i++) { /* L rows from P rows */
+            double c0 = P[idx * NDOF + i], c1 = P[(idx + 1) * NDOF + i], c2 = P[(idx + 2) * NDOF + i];
+            for (int r = 0; r < 3; r++) L[(idx + r) * NDOF + i] = J[r * 3] * c0 + J[r * 3 + 1] * c1 + J[r * 3 + 2] * c2;
+        }
+        for (int i = 0; i < 12; i++) {
+            double c0 = K_x[idx * NDOF + i], c1 = K_x[(idx + 1) * NDOF + i], c2 = K_x[(idx + 2) * NDOF + i];
+            for (int r = 0; r < 3; r++) K_x[(idx + r) * NDOF + i] = J[r * 3] * c0 + J[r * 3 + 1] * c1 + J[r * 3 + 2] * c2;
+        }
+        for (int i = 0; i < NDOF; i++) {
+            double c0 = L[i * NDOF + idx], c1 = L[i * NDOF + idx + 1], c2 = L[i * NDOF + idx + 2];
+            for (int r = 0; r < 3; r++) L[i * NDOF + idx + r] = c0 * J[r * 3] + c1 * J[r * 3 + 1] + c2 * J[r * 3 + 2];
+            c0 = P[i * NDOF + idx]; c1 = P[i * NDOF + idx + 1]; c2 = P[i * NDOF + idx + 2];
+            for (int r = 0; r < 3; r++) P[i * NDOF + idx + r] = c0 * J[r * 3] + c1 * J[r * 3 + 1] + c2 * J[r * 3 + 2];
+        }
+    }
+    {
+        int idx = 21;
+        double Nx[6], Mx[6], J[4];
+        orc_S2_Nx_yy(x + X_GRAV, Nx);
+        orc_S2_Mx(x_prop + X_GRAV, dx_ + idx, Mx);
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++) J[i * 2 + j] = Nx[i * 3] * Mx[0 * 2 + j] + Nx[i * 3 + 1] * Mx[1 * 2 + j] + Nx[i * 3 + 2] * Mx[2 * 2 + j];
+        for (int i = 0; i < NDOF; i++) {
+            double c0 = P[idx * NDOF + i], c1 = P[(idx + 1) * NDOF + i];
+            L[idx * NDOF + i] = J[0] * c0 + J[1] * c1;
+            L[(idx + 1) * NDOF + i] = J[2] * c0 + J[3] * c1;
+        }
+        for (int i = 0; i < 12; i++) {
+            double c0 = K_x[idx * NDOF + i], c1 = K_x[(idx + 1) * NDOF + i];
+            K_x[idx * NDOF + i] = J[0] * c0 + J[1] * c1;
+            K_x[(idx + 1) * NDOF + i] = J[2] * c0 + J[3] * c1;
+        }
+        for (int i = 0; i < NDOF; i++) {
+            double c0 = L[i * NDOF + idx], c1 = L[i * NDOF + idx + 1];
+            L[i * NDOF + idx] = c0 * J[0] + c1 * J[1];
+            L[i * NDOF + idx + 1] = c0 * J[2] + c1 * J[3];
+            c0 = P[i * NDOF + idx]; c1 = P[i * NDOF + idx + 1];
+            P[i * NDOF + idx] = c0 * J[0] + c1 * J[1];
+            P[i * NDOF + idx + 1] = c0 * J[2] + c1 * J[3];
+        }
+    }
+    double Pn[NDOF * NDOF];
+    for (int i = 0; i < NDOF; i++)
+        for (int j = 0; j < NDOF; j++) {
+            double s = 0;
+            for (int c = 0; c < 12; c++) s += K_x[i * NDOF + c] * P[c * NDOF + j];
+            Pn[i * NDOF + j] = L[i * NDOF + j] - s;
+        }
+    memcpy(P, Pn, sizeof(Pn));
+}
+
+void orc_iekf_pass_info(double x[ORC_NSTATE], const double x_prop[ORC_NSTATE], const double P_prop[NDOF * NDOF], double R,
+                        const double HTH[144], const double HTh[12], double P_out[NDOF * NDOF], double K_x_out[NDOF * NDOF],
+                        double dx_out[NDOF]) {
+    double dx[NDOF], dx_new[NDOF], K_h[NDOF];
+    orc_state_boxminus(x, x_prop, dx);
+    memcpy(dx_new, dx, sizeof(dx));
+    memcpy(P_out, P_prop, sizeof(double) * NDOF * NDOF);
+    project_P(P_out, dx_new, x, x_prop, dx);
+    gain_info(P_out, R, HTH, NULL, NULL, 0, HTh, K_h, K_x_out);
+    finish_pass(x, K_h, K_x_out, dx_new, dx_out);
+}
+void orc_iekf_pass_gain(double x[ORC_NSTATE], const double x_prop[ORC_NSTATE], const double P_prop[NDOF * NDOF], double R,
+                        const double* h_x_cm, const double* h, int n_eff, double P_out[NDOF * NDOF], double K_x_out[NDOF * NDOF],
+                        double dx_out[NDOF]) {
+    double dx[NDOF], dx_new[NDOF], K_h[NDOF];
+    orc_state_boxminus(x, x_prop, dx);
+    memcpy(dx_new, dx, sizeof(dx));
+    memcpy(P_out, P_prop, sizeof(double) * NDOF * NDOF);
+    project_P(P_out, dx_new, x, x_prop, dx);
+    gain_small(P_out, R, h_x_cm, h, n_eff, K_h, K_x_out);
+    finish_pass(x, K_h, K_x_out, dx_new, dx_out);
+}
+
+void orc_update_iterated(orc_scan* sc, const orc_kdtree* map, const float* map_xyz, size_t mstride, double x[ORC_NSTATE],
+                         double P[NDOF * NDOF], double R, int maximum_iter, const double limit[NDOF], int extrinsic_est_en,
+                         orc_update_stats* st) {
+    /* esekfom.hpp:1619-1931 */
+    orc_update_stats lst;
+    if (!st) st = &lst;
+    memset(st, 0, sizeof(*st));
+    for (int i = 0; i < 8; i++) st->n_eff[i] = -1;
+    int converge = 1;
+    int t = 0;
+    double x_prop[ORC_NSTATE], P_prop[NDOF * NDOF];
+    memcpy(x_prop, x, sizeof(x_prop));
+    memcpy(P_prop, P, sizeof(P_prop));
+    double K_h[NDOF], K_x[NDOF * NDOF], dx_new[NDOF];
+    memset(dx_new, 0, sizeof(dx_new));
+    for (int i = -1; i < maximum_iter; i++) {
+        double t0 = now_s();
+        int valid = orc_h_share_model(sc, map, map_xyz, mstride, x, converge, extrinsic_est_en);
+        st->h_time += now_s() - t0;
+        if (st->passes < 8) {
+            st->pass_search[st->passes] = converge;
+            st->n_eff[st->passes] = sc->effct_feat_num;
+        }
+        st->passes++;
+        st->searches += converge ? 1 : 0;
+        if (!valid) continue; /* :1638-1641 */
+        double solve_start = now_s();
+        int dof_Measurement = sc->effct_feat_num;
+        double dx[NDOF];
+        orc_state_boxminus(x, x_prop, dx);
+        memcpy(dx_new, dx, sizeof(dx));
+        memcpy(P, P_prop, sizeof(P_prop));
+        project_P(P, dx_new, x, x_prop, dx);
+        if (NDOF > dof_Measurement) {
+            gain_small(P, R, sc->h_x, sc->h, dof_Measurement, K_h, K_x);
+        } else {
+            double HTH[144], HTh[12];
+            orc_normal_equations(sc, HTH, HTh);
+            gain_info(P, R, HTH, sc->h_x, sc->h, dof_Measurement, HTh, K_h, K_x);
+        }
+        double dx_[NDOF];
+        finish_pass(x, K_h, K_x, dx_new, dx_);
+        converge = 1;
+        for (int j = 0; j < NDOF; j++)
+            if (fabs(dx_[j]) > limit[j]) { converge = 0; break; }
+        if (converge) t++;
+        if (!t && i == maximum_iter - 2) converge = 1; /* :1829-1832 */
+        if (t > 1 || i == maximum_iter - 1) {          /* :1834 */
+            final_cov(P, K_x, x, x_prop, dx_);
+            st->returned_in_loop = 1;
+            st->solve_time += now_s() - solve_start;
+            return;
+        }
+        st->solve_time += now_s() - solve_start;
+    }
+}
+
+/* =================================================================== map_incremental decision */
+void orc_map_incremental_classify(const orc_scan* sc, const float* map_xyz, size_t mstride, const double x[ORC_NSTATE],
+                                  double fsm, int flg_EKF_inited, float* world_out, uint8_t* cls) {
+    /* src/laserMapping.cpp:427-474.  filter_size_map_min is a double global; mid_point members are
+       float (PointType), so each mid coordinate is a double expression narrowed to float. */
+    const int N = sc->N;
+    for (int i = 0; i < N; i++) {
+        const float* pb = sc->body + 3 * i;
+        double p_body[3] = {pb[0], pb[1], pb[2]}, t1[3], t2[3];
+        orc_quat_rot(x + X_OFFR, p_body, t1); /* pointBodyToWorld :166-176 */
+        for (int d = 0; d < 3; d++) t1[d] = t1[d] + x[X_OFFT + d];
+        orc_quat_rot(x + X_ROT, t1, t2);
+        float pw[3];
+        for (int d = 0; d < 3; d++) {
+            pw[d] = (float)(t2[d] + x[X_POS + d]);
+            world_out[3 * i + d] = pw[d];
+        }
+        int cnt = sc->nn_cnt[i];
+        if (cnt > 0 && flg_EKF_inited) {
+            float mid[3];
+            for (int d = 0; d < 3; d++) mid[d] = (float)(floor((double)pw[d] / fsm) * fsm + 0.5 * fsm);
+            float dist = ((pw[0] - mid[0]) * (pw[0] - mid[0]) + (pw[1] - mid[1]) * (pw[1] - mid[1])) + (pw[2] - mid[2]) * (pw[2] - mid[2]);
+            const float* n0 = map_xyz + (size_t)sc->nn_idx[K * i] * mstride;
+            if (fabs((double)(n0[0] - mid[0])) > 0.5 * fsm && fabs((double)(n0[1] - mid[1])) > 0.5 * fsm &&
+                fabs((double)(n0[2] - mid[2])) > 0.5 * fsm) {
+                cls[i] = 2;
+                continue;
+            }
+            int need_add = 1;
+            for (int r = 0; r < K; r++) {
+                if (cnt < K) break;
+                const float* pn = map_xyz + (size_t)sc->nn_idx[K * i + r] * mstride;
+                float dn = ((pn[0] - mid[0]) * (pn[0] - mid[0]) + (pn[1] - mid[1]) * (pn[1] - mid[1])) + (pn[2] - mid[2]) * (pn[2] - mid[2]);
+                if (dn < dist) { need_add = 0; break; }
+            }
+            cls[i] = need_add ? 1 : 0;
+        } else {
+            cls[i] = 1;
+        }
+    }
+}
