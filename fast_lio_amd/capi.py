@@ -1,0 +1,358 @@
+"""ctypes binding of libfastlio_hip.so (include/fastlio_hip.h).
+
+This is plumbing for tests and bench.py: every call goes straight through the C ABI a C++ node would
+use.  There is no Python/CPU fallback -- if the library or a HIP device is missing, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+NSTATE = 26
+NDOF = 23
+K = 5
+
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+class FlhConfig(C.Structure):
+    _fields_ = [
+        ("device", C.c_int),
+        ("cell_size", C.c_float),
+        ("plane_threshold", C.c_float),
+        ("max_sqdist", C.c_float),
+        ("stream", C.c_void_p),
+        ("lanes_per_query", C.c_int),
+        ("sort_queries", C.c_int),
+    ]
+
+
+class FlhTiming(C.Structure):
+    _fields_ = [("search_ms", C.c_float), ("fit_ms", C.c_float), ("total_ms", C.c_float), ("candidates", C.c_int64)]
+
+
+class FlhMeas(C.Structure):
+    _fields_ = [
+        ("valid", C.c_int),
+        ("n_eff", C.c_int64),
+        ("has_normal_eq", C.c_int),
+        ("HTH", C.c_double * 144),
+        ("HTh", C.c_double * 12),
+        ("h_x", C.POINTER(C.c_double)),
+        ("h", C.POINTER(C.c_double)),
+        ("total_residual", C.c_double),
+    ]
+
+
+class FlhUpdateStats(C.Structure):
+    _fields_ = [
+        ("passes", C.c_int),
+        ("searches", C.c_int),
+        ("returned_in_loop", C.c_int),
+        ("n_eff", C.c_int * 8),
+        ("pass_search", C.c_int * 8),
+        ("h_ms", C.c_double),
+        ("solve_ms", C.c_double),
+    ]
+
+
+MEAS_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(FlhMeas))
+
+# every symbol include/fastlio_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "flh_default_config", "flh_create", "flh_destroy", "flh_last_error", "flh_device_available", "flh_map_build",
+    "flh_map_size", "flh_scan_upload", "flh_scan_size", "flh_scan_stage", "flh_scan_activate", "flh_get_counters",
+    "flh_eval", "flh_eval_device", "flh_unpack_gram",
+    "flh_fetch_selected", "flh_fetch_neighbors", "flh_fetch_world", "flh_fetch_normvec", "flh_fetch_rows",
+    "flh_last_timing", "flh_enable_stats", "flh_time_kernel", "flh_esekf_create", "flh_esekf_destroy",
+    "flh_esekf_set_meas_model", "flh_esekf_change_x", "flh_esekf_change_P", "flh_esekf_get_x", "flh_esekf_get_P",
+    "flh_esekf_predict", "flh_esekf_update",
+]
+
+_lib = None
+
+
+class FlhError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (building if needed) the shared library.  Raises if it cannot be built/loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if _build.needs_build():
+        path = _build.build()
+    L = C.CDLL(path)
+    L.flh_last_error.restype = C.c_char_p
+    L.flh_device_available.restype = C.c_int
+    L.flh_default_config.argtypes = [C.POINTER(FlhConfig)]
+    L.flh_create.argtypes = [C.POINTER(FlhConfig), C.POINTER(C.c_void_p)]
+    L.flh_destroy.argtypes = [C.c_void_p]
+    L.flh_map_build.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+    L.flh_map_size.restype = C.c_size_t
+    L.flh_map_size.argtypes = [C.c_void_p]
+    L.flh_scan_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+    L.flh_scan_size.restype = C.c_size_t
+    L.flh_scan_size.argtypes = [C.c_void_p]
+    L.flh_scan_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t]
+    L.flh_scan_activate.argtypes = [C.c_void_p, C.c_int]
+    L.flh_get_counters.argtypes = [C.c_void_p, _f64p, C.c_int]
+    L.flh_eval.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, C.c_int, C.c_int, _f64p, _f64p,
+                           C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    L.flh_eval_device.argtypes = [C.c_void_p, _f64p, C.c_int, C.c_int, C.c_void_p]
+    L.flh_unpack_gram.argtypes = [_f64p, _f64p, _f64p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    L.flh_fetch_selected.argtypes = [C.c_void_p, C.c_void_p]
+    L.flh_fetch_neighbors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.flh_fetch_world.argtypes = [C.c_void_p, C.c_void_p]
+    L.flh_fetch_normvec.argtypes = [C.c_void_p, C.c_void_p]
+    L.flh_fetch_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.flh_last_timing.argtypes = [C.c_void_p, C.POINTER(FlhTiming)]
+    L.flh_enable_stats.argtypes = [C.c_void_p, C.c_int]
+    L.flh_time_kernel.argtypes = [C.c_void_p, C.c_int, _f64p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.flh_esekf_create.restype = C.c_void_p
+    L.flh_esekf_create.argtypes = [C.c_void_p, C.c_int, _f64p, C.c_int]
+    L.flh_esekf_destroy.argtypes = [C.c_void_p]
+    L.flh_esekf_set_meas_model.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.flh_esekf_change_x.argtypes = [C.c_void_p, _f64p]
+    L.flh_esekf_change_P.argtypes = [C.c_void_p, _f64p]
+    L.flh_esekf_get_x.argtypes = [C.c_void_p, _f64p]
+    L.flh_esekf_get_P.argtypes = [C.c_void_p, _f64p]
+    L.flh_esekf_predict.argtypes = [C.c_void_p, C.c_double, _f64p, _f64p, _f64p]
+    L.flh_esekf_update.argtypes = [C.c_void_p, C.c_double, C.POINTER(FlhUpdateStats)]
+    _lib = L
+    return L
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise FlhError(f"{what}: {lib().flh_last_error().decode()}")
+
+
+def device_available() -> bool:
+    return bool(lib().flh_device_available())
+
+
+class Handle:
+    """flh_handle: the device-resident map + current scan."""
+
+    def __init__(self, cell_size: float = 1.0, lanes_per_query: int = 32, device: int = -1, stream: int | None = None,
+                 plane_threshold: float = 0.1, max_sqdist: float = 5.0):
+        L = lib()
+        cfg = FlhConfig()
+        L.flh_default_config(C.byref(cfg))
+        cfg.device = device
+        cfg.cell_size = cell_size
+        cfg.lanes_per_query = lanes_per_query
+        cfg.plane_threshold = plane_threshold
+        cfg.max_sqdist = max_sqdist
+        cfg.stream = stream
+        self._h = C.c_void_p()
+        _chk(L.flh_create(C.byref(cfg), C.byref(self._h)), "flh_create")
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().flh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def map_build(self, xyz: np.ndarray):
+        a = np.ascontiguousarray(xyz, dtype=np.float32)
+        assert a.ndim == 2 and a.shape[1] in (3, 4, 12)
+        _chk(lib().flh_map_build(self._h, a.ctypes.data, a.strides[0], a.shape[0]), "flh_map_build")
+
+    def scan_upload(self, body: np.ndarray):
+        a = np.ascontiguousarray(body, dtype=np.float32)
+        assert a.ndim == 2 and a.shape[1] in (3, 4, 12)
+        _chk(lib().flh_scan_upload(self._h, a.ctypes.data, a.strides[0], a.shape[0]), "flh_scan_upload")
+
+    def scan_stage(self, slot: int, body: np.ndarray):
+        a = np.ascontiguousarray(body, dtype=np.float32)
+        _chk(lib().flh_scan_stage(self._h, slot, a.ctypes.data, a.strides[0], a.shape[0]), "flh_scan_stage")
+
+    def scan_activate(self, slot: int):
+        _chk(lib().flh_scan_activate(self._h, slot), "flh_scan_activate")
+
+    def counters(self, reset: bool = False):
+        out = np.zeros(6)
+        _chk(lib().flh_get_counters(self._h, out, int(reset)), "flh_get_counters")
+        return {"search_ms": out[0], "n_search": int(out[1]), "fit_ms": out[2], "n_fit": int(out[3]),
+                "eval_ms": out[4], "n_eval": int(out[5])}
+
+    @property
+    def N(self):
+        return int(lib().flh_scan_size(self._h))
+
+    @property
+    def M(self):
+        return int(lib().flh_map_size(self._h))
+
+    def eval(self, x: np.ndarray, do_search: bool, extrinsic_est_en: bool = False):
+        x = np.ascontiguousarray(x, np.float64)
+        HTH = np.zeros(144)
+        HTh = np.zeros(12)
+        n = C.c_int64()
+        tr = C.c_double()
+        _chk(lib().flh_eval(self._h, np.ascontiguousarray(x[3:7]), np.ascontiguousarray(x[0:3]),
+                            np.ascontiguousarray(x[7:11]), np.ascontiguousarray(x[11:14]), int(do_search),
+                            int(extrinsic_est_en), HTH, HTh, C.byref(n), C.byref(tr)), "flh_eval")
+        return HTH.reshape(12, 12), HTh, int(n.value), float(tr.value)
+
+    def eval_device(self, x: np.ndarray, do_search: bool, extrinsic_est_en: bool, d_gram_ptr: int):
+        _chk(lib().flh_eval_device(self._h, np.ascontiguousarray(x, np.float64), int(do_search), int(extrinsic_est_en),
+                                   C.c_void_p(d_gram_ptr)), "flh_eval_device")
+
+    def fetch_selected(self):
+        out = np.zeros(self.N, np.uint8)
+        _chk(lib().flh_fetch_selected(self._h, out.ctypes.data), "flh_fetch_selected")
+        return out
+
+    def fetch_neighbors(self):
+        n = self.N
+        idx = np.zeros((n, K), np.int32)
+        d2 = np.zeros((n, K), np.float32)
+        cnt = np.zeros(n, np.uint8)
+        _chk(lib().flh_fetch_neighbors(self._h, idx.ctypes.data, d2.ctypes.data, cnt.ctypes.data), "flh_fetch_neighbors")
+        return idx, d2, cnt
+
+    def fetch_world(self):
+        out = np.zeros((self.N, 3), np.float32)
+        _chk(lib().flh_fetch_world(self._h, out.ctypes.data), "flh_fetch_world")
+        return out
+
+    def fetch_normvec(self):
+        out = np.zeros((self.N, 4), np.float32)
+        _chk(lib().flh_fetch_normvec(self._h, out.ctypes.data), "flh_fetch_normvec")
+        return out
+
+    def fetch_rows(self):
+        n = C.c_int64()
+        _chk(lib().flh_fetch_rows(self._h, None, None, 0, C.byref(n)), "flh_fetch_rows")
+        rows = int(n.value)
+        hx = np.zeros((12, max(rows, 1)))
+        hv = np.zeros(max(rows, 1))
+        _chk(lib().flh_fetch_rows(self._h, hx.ctypes.data, hv.ctypes.data, rows, C.byref(n)), "flh_fetch_rows")
+        return np.ascontiguousarray(hx[:, :rows].T), hv[:rows]
+
+    def timing(self):
+        t = FlhTiming()
+        _chk(lib().flh_last_timing(self._h, C.byref(t)), "flh_last_timing")
+        return {"search_ms": t.search_ms, "fit_ms": t.fit_ms, "total_ms": t.total_ms, "candidates": int(t.candidates)}
+
+    def enable_stats(self, on=True):
+        _chk(lib().flh_enable_stats(self._h, int(on)), "flh_enable_stats")
+
+    def time_kernel(self, which: int, x: np.ndarray, extrinsic_est_en: bool = False, iters: int = 20) -> float:
+        ms = C.c_float()
+        _chk(lib().flh_time_kernel(self._h, which, np.ascontiguousarray(x, np.float64), int(extrinsic_est_en), iters,
+                                   C.byref(ms)), "flh_time_kernel")
+        return float(ms.value)
+
+
+class Esekf:
+    """flh_esekf: the host IEKF (C++ mirror of esekfom::esekf<state_ikfom,12,input_ikfom>)."""
+
+    def __init__(self, handle: Handle | None, max_iter: int = 3, limit=None, extrinsic_est_en: bool = False):
+        L = lib()
+        lim = np.ascontiguousarray(np.full(NDOF, 0.001) if limit is None else limit, np.float64)
+        self._handle = handle
+        self._e = C.c_void_p(L.flh_esekf_create(handle.ptr if handle is not None else None, max_iter, lim,
+                                                int(extrinsic_est_en)))
+        self._cb = None
+
+    def close(self):
+        if getattr(self, "_e", None) and self._e.value:
+            lib().flh_esekf_destroy(self._e)
+            self._e = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_meas_model(self, fn):
+        """fn(x: np.ndarray[26], converge: bool) -> dict(valid, n_eff, HTH(12x12)|None, HTh|None, h_x(n x12)|None, h|None)."""
+        if fn is None:
+            self._cb = None
+            lib().flh_esekf_set_meas_model(self._e, None, None)
+            return
+        keep = {}
+
+        def _tramp(ctx, xptr, converge, out):
+            x = np.ctypeslib.as_array(xptr, shape=(NSTATE,)).copy()
+            r = fn(x, bool(converge))
+            o = out.contents
+            o.valid = int(bool(r.get("valid", True)))
+            o.n_eff = int(r.get("n_eff", 0))
+            o.total_residual = float(r.get("total_residual", 0.0))
+            if r.get("HTH") is not None:
+                o.has_normal_eq = 1
+                C.memmove(o.HTH, np.ascontiguousarray(r["HTH"], np.float64).ctypes.data, 144 * 8)
+                C.memmove(o.HTh, np.ascontiguousarray(r["HTh"], np.float64).ctypes.data, 12 * 8)
+            else:
+                o.has_normal_eq = 0
+            if r.get("h_x") is not None and o.n_eff > 0:
+                keep["hx"] = np.ascontiguousarray(np.asarray(r["h_x"], np.float64).T)  # -> column-major n x 12
+                keep["h"] = np.ascontiguousarray(r["h"], np.float64)
+                o.h_x = keep["hx"].ctypes.data_as(C.POINTER(C.c_double))
+                o.h = keep["h"].ctypes.data_as(C.POINTER(C.c_double))
+            else:
+                o.h_x = None
+                o.h = None
+
+        self._cb = MEAS_FN(_tramp)
+        lib().flh_esekf_set_meas_model(self._e, C.cast(self._cb, C.c_void_p), None)
+
+    def change_x(self, x):
+        lib().flh_esekf_change_x(self._e, np.ascontiguousarray(x, np.float64))
+
+    def change_P(self, P):
+        lib().flh_esekf_change_P(self._e, np.ascontiguousarray(P, np.float64).reshape(-1))
+
+    def get_x(self):
+        x = np.zeros(NSTATE)
+        lib().flh_esekf_get_x(self._e, x)
+        return x
+
+    def get_P(self):
+        P = np.zeros(NDOF * NDOF)
+        lib().flh_esekf_get_P(self._e, P)
+        return P.reshape(NDOF, NDOF)
+
+    def predict(self, dt, Q, acc, gyro):
+        lib().flh_esekf_predict(self._e, float(dt), np.ascontiguousarray(Q, np.float64).reshape(-1),
+                                np.ascontiguousarray(acc, np.float64), np.ascontiguousarray(gyro, np.float64))
+
+    def update(self, R: float = 0.001):
+        st = FlhUpdateStats()
+        rc = lib().flh_esekf_update(self._e, float(R), C.byref(st))
+        if rc != 0:
+            raise FlhError("flh_esekf_update failed: " + lib().flh_last_error().decode())
+        return st
+
+
+def predict_fn(x, P, dt, Q, acc, gyro):
+    """esekf::predict through the product's host library (for synth.propagate_prior_cov)."""
+    kf = Esekf(None)
+    kf.change_x(x)
+    kf.change_P(P)
+    kf.predict(dt, Q, acc, gyro)
+    out = kf.get_x(), kf.get_P()
+    kf.close()
+    return out

@@ -1,0 +1,114 @@
+// flh_esekf.cpp -- layer 2 of the C ABI: a C binding of the C++ host filter in
+// include/fastlio_amd/esekfom.hpp (the mirror of esekfom::esekf<state_ikfom,12,input_ikfom>), so that
+// ctypes / C callers run exactly the code a C++ node would.
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "../../include/fastlio_amd/esekfom.hpp"
+#include "../../include/fastlio_amd/h_share_model.hpp"
+#include "../../include/fastlio_amd/use-ikfom.hpp"
+#include "../../include/fastlio_hip.h"
+
+typedef esekfom::esekf<state_ikfom, 12, input_ikfom> kf_t;
+
+struct flh_esekf {
+    kf_t kf;
+    fastlio_amd::HShareContext gpu_ctx;
+    flh_meas_fn user_h = nullptr;
+    void* user_ctx = nullptr;
+    std::string err;
+};
+
+// adapter: user-supplied C measurement model -> dyn_share_datastruct
+static void user_model_adapter(state_ikfom& s, esekfom::dyn_share_datastruct<double>& d, void* ctx) {
+    flh_esekf* e = static_cast<flh_esekf*>(ctx);
+    double x[FLH_NSTATE];
+    s.to_flat(x);
+    flh_meas m;
+    std::memset(&m, 0, sizeof(m));
+    m.valid = 1;
+    e->user_h(e->user_ctx, x, d.converge ? 1 : 0, &m);
+    d.valid = m.valid != 0;
+    d.n_eff = m.n_eff;
+    d.total_residual = m.total_residual;
+    d.has_normal_eq = m.has_normal_eq != 0;
+    if (m.has_normal_eq) {
+        std::memcpy(d.HTH, m.HTH, sizeof(m.HTH));
+        std::memcpy(d.HTh, m.HTh, sizeof(m.HTh));
+    }
+    if (m.h_x && m.h && m.n_eff > 0) {
+        d.h_x.assign(m.h_x, m.h_x + (size_t)m.n_eff * 12);
+        d.h.assign(m.h, m.h + (size_t)m.n_eff);
+        if (m.n_eff < state_ikfom::DOF) d.has_normal_eq = false;  // gain form works on rows
+    } else {
+        d.h_x.clear();
+        d.h.clear();
+        if (d.valid && m.n_eff < state_ikfom::DOF && m.n_eff > 0) d.valid = false;  // rows required but absent
+    }
+    if (m.n_eff < 1) d.valid = false;
+}
+static void gpu_model_adapter(state_ikfom& s, esekfom::dyn_share_datastruct<double>& d, void* ctx) {
+    flh_esekf* e = static_cast<flh_esekf*>(ctx);
+    fastlio_amd::h_share_model(s, d, &e->gpu_ctx);
+}
+
+extern "C" {
+
+flh_esekf* flh_esekf_create(flh_handle* handle, int maximum_iter, const double limit[FLH_NDOF], int extrinsic_est_en) {
+    flh_esekf* e = new flh_esekf();
+    e->gpu_ctx.handle = handle;
+    e->gpu_ctx.extrinsic_est_en = extrinsic_est_en != 0;
+    double lim[FLH_NDOF];
+    for (int i = 0; i < FLH_NDOF; ++i) lim[i] = limit ? limit[i] : 0.001;  // epsi, laserMapping.cpp:826-827
+    e->kf.init_dyn_share(get_f, df_dx, df_dw, gpu_model_adapter, maximum_iter, lim, e);
+    return e;
+}
+void flh_esekf_destroy(flh_esekf* e) { delete e; }
+void flh_esekf_set_meas_model(flh_esekf* e, flh_meas_fn h, void* ctx) {
+    if (!e) return;
+    e->user_h = h;
+    e->user_ctx = ctx;
+    e->kf.set_meas_model(h ? user_model_adapter : gpu_model_adapter, e);
+}
+void flh_esekf_change_x(flh_esekf* e, const double x[FLH_NSTATE]) {
+    state_ikfom s = e->kf.get_x();
+    s.from_flat(x);
+    e->kf.change_x(s);
+}
+void flh_esekf_change_P(flh_esekf* e, const double P[FLH_NDOF * FLH_NDOF]) {
+    kf_t::cov c;
+    std::memcpy(c.a, P, sizeof(c.a));
+    e->kf.change_P(c);
+}
+void flh_esekf_get_x(const flh_esekf* e, double x[FLH_NSTATE]) { e->kf.get_x().to_flat(x); }
+void flh_esekf_get_P(const flh_esekf* e, double P[FLH_NDOF * FLH_NDOF]) { std::memcpy(P, e->kf.get_P().a, sizeof(double) * FLH_NDOF * FLH_NDOF); }
+void flh_esekf_predict(flh_esekf* e, double dt, const double Q[144], const double acc[3], const double gyro[3]) {
+    kf_t::processnoisecovariance q;
+    std::memcpy(q.a, Q, sizeof(q.a));
+    input_ikfom in;
+    for (int i = 0; i < 3; ++i) { in.acc[i] = acc[i]; in.gyro[i] = gyro[i]; }
+    e->kf.predict(dt, q, in);
+}
+int flh_esekf_update(flh_esekf* e, double R, flh_update_stats* st) {
+    if (!e) return -1;
+    double solve_time = 0;
+    try {
+        e->kf.update_iterated_dyn_share_modified(R, solve_time);
+    } catch (const std::exception& ex) {
+        e->err = ex.what();
+        return -1;
+    }
+    if (st) {
+        const kf_t::update_stats& s = e->kf.last_stats();
+        st->passes = s.passes;
+        st->searches = s.searches;
+        st->returned_in_loop = s.returned_in_loop;
+        for (int i = 0; i < 8; ++i) { st->n_eff[i] = s.n_eff[i]; st->pass_search[i] = s.pass_search[i]; }
+        st->h_ms = s.h_ms;
+        st->solve_ms = s.solve_ms;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,30 @@
+// flh_kernels.hpp -- host-callable launch wrappers for the kernels in flh_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "flh_device.hpp"
+
+namespace flh {
+
+hipError_t launch_map_keys(const GridParams& g, const float4* pts, uint32_t M, unsigned long long* keys,
+                           uint32_t* vals, hipStream_t st);
+hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const unsigned long long* kin, unsigned long long* kout,
+                      const uint32_t* vin, uint32_t* vout, uint32_t M, hipStream_t st);
+hipError_t inclusive_sum(void* tmp, size_t& tmp_bytes, const uint32_t* in, uint32_t* out, uint32_t M, hipStream_t st);
+hipError_t launch_map_gather(const float4* pts, const unsigned long long* ks, const uint32_t* vs, uint32_t M,
+                             float4* out, uint32_t* brick_head, hipStream_t st);
+hipError_t launch_map_cells(const unsigned long long* ks, const uint32_t* rank_incl, uint32_t M, uint2* cells,
+                            uint2* hash, uint32_t hash_mask, int hash_shift, hipStream_t st);
+
+hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const float4* body, int N, float max_sqdist,
+                         int rmax, float4* world, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
+                         unsigned long long* cand_counter, hipStream_t st);
+
+int fit_blocks(int N);
+int reduce1_blocks(int nblk, int* per_out);
+hipError_t launch_fit(const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
+                      uint8_t* selected, float4* normvec, double* partials, double* part2, double* out256,
+                      hipStream_t st);
+
+}  // namespace flh

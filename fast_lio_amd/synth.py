@@ -37,7 +37,9 @@ class Sensor:
 
 SENSORS = {
     # config/avia.yaml:11,19-24 ; Avia FoV 70.4 x 77.2 deg
-    "avia": Sensor("avia", (-35.2, 35.2), (-38.6, 38.6), 4.0, 450.0, (0.04165, 0.02326, -0.0284), height=6.0),
+    # height 60 m: a UAV-borne Avia looking over the 20 m wall slabs -- a ground-level sensor in box-city
+    # sees < 45k distinct 0.5 m voxels, short of the 100k-point stress scan BASELINE.json asks for
+    "avia": Sensor("avia", (-35.2, 35.2), (-38.6, 38.6), 4.0, 450.0, (0.04165, 0.02326, -0.0284), height=60.0),
     # config/velodyne.yaml (extrinsic_T [0,0,0.28], det_range 100, blind 2), spinning 360 x +-15 deg
     "velodyne": Sensor("velodyne", (-180.0, 180.0), (-15.0, 15.0), 2.0, 100.0, (0.0, 0.0, 0.28), height=2.0),
     # config/ouster64.yaml (det_range 150, blind 4), 360 x +-22.5 deg
@@ -230,12 +232,15 @@ def make_scan(scene: Scene, sensor: Sensor, N: int, x_true: np.ndarray, seed: in
     batch = max(4 * N, 20000)
     for _ in range(64):
         az = np.deg2rad(rng.uniform(sensor.az_deg[0], sensor.az_deg[1], batch))
-        # half the rays uniform in elevation, half concentrated near the horizon so that far
-        # ground / walls receive enough rays to fill N distinct voxels
+        # 40 % of the rays uniform in elevation (walls, near field); 60 % aimed so that their ground
+        # footprint is uniform in AREA out to det_range -- otherwise the far field, where one 0.5 m voxel
+        # subtends ~0.01 deg of elevation, never fills up and N distinct voxels are unreachable
         u = rng.uniform(0, 1, batch)
         el_lo, el_hi = np.deg2rad(sensor.el_deg[0]), np.deg2rad(sensor.el_deg[1])
-        el = np.where(rng.uniform(0, 1, batch) < 0.5, el_lo + (el_hi - el_lo) * u,
-                      np.clip(rng.normal(0.0, np.deg2rad(3.0), batch), el_lo, el_hi))
+        h_eff = max(float(o[2]), 0.2)
+        rg = np.sqrt(rng.uniform(sensor.blind ** 2, min(sensor.det_range, 0.75 * scene.L) ** 2, batch))
+        el_ground = np.clip(-np.arctan2(h_eff, rg), el_lo, el_hi)
+        el = np.where(rng.uniform(0, 1, batch) < 0.4, el_lo + (el_hi - el_lo) * u, el_ground)
         dl = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], axis=1)
         dw = dl @ Rw.T
         r = _raycast(scene, o, dw, sensor.blind, sensor.det_range)
@@ -282,7 +287,10 @@ def true_state(sensor: Sensor, seed: int, scene: Scene | None = None) -> np.ndar
     rng = np.random.default_rng(seed ^ 0x5EED)
     yaw0 = rng.uniform(-np.pi, np.pi)
     rp = np.deg2rad(rng.uniform(-2.0, 2.0, 2))
-    pos = np.array([rng.uniform(-3, 3), rng.uniform(-3, 3), sensor.height])
+    # small test scenes cannot be seen from 60 m up (the nearest ground return would fall outside the
+    # square): scale the height with the scene, 0.08 * L capped by the sensor's nominal height
+    hgt = sensor.height if scene is None else max(2.0, min(sensor.height, 0.08 * scene.L))
+    pos = np.array([rng.uniform(-3, 3), rng.uniform(-3, 3), hgt])
     vel = rng.normal(0, 0.2, 3)
     bg = rng.normal(0, 1e-3, 3)
     ba = rng.normal(0, 1e-2, 3)

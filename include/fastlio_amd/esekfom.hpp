@@ -1,0 +1,369 @@
+// esekfom.hpp -- host-side iterated error-state Kalman filter with the call surface of the reference's
+// esekfom::esekf<state, process_noise_dof, input> (include/IKFoM_toolkit/esekfom/esekfom.hpp), restricted
+// to what FAST-LIO2's node uses: init_dyn_share, predict, update_iterated_dyn_share_modified, get_x/get_P,
+// change_x/change_P.  The other seven update_* variants and the USE_sparse paths are dead code for that
+// node and are not provided.
+//
+// One extension: dyn_share_datastruct carries the fused normal equations (HTH, HTh, n_eff) so that a
+// measurement model running on the GPU never has to materialise the N_eff x 12 Jacobian; h_x/h are
+// still honoured when a model fills them instead.
+#pragma once
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "mtk.hpp"
+#include "smallmat.hpp"
+
+namespace esekfom {
+using fastlio_amd::Mat;
+using fastlio_amd::Vec;
+
+// esekfom.hpp:79-89 (+ has_normal_eq/HTH/HTh/n_eff)
+template <typename T>
+struct dyn_share_datastruct {
+    bool valid = true;
+    bool converge = true;
+    std::vector<T> z;
+    std::vector<T> h;    // n_eff
+    std::vector<T> h_v;
+    std::vector<T> h_x;  // n_eff x 12, column-major (Eigen::MatrixXd layout)
+    std::vector<T> R;
+    // --- extension: fused normal equations
+    bool has_normal_eq = false;
+    int64_t n_eff = 0;
+    T HTH[144];  // row-major 12x12 = h_x^T h_x
+    T HTh[12];   // h_x^T h
+    T total_residual = 0;
+};
+
+template <typename state, int process_noise_dof, typename input = state>
+class esekf {
+   public:
+    enum { n = state::DOF, m = state::DIM };
+    typedef double scalar_type;
+    typedef Mat<n, n> cov;
+    typedef Vec<n> vectorized_state;
+    typedef Vec<m> flatted_state;
+    typedef flatted_state processModel(state&, const input&);
+    typedef Mat<m, n> processMatrix1(state&, const input&);
+    typedef Mat<m, process_noise_dof> processMatrix2(state&, const input&);
+    typedef Mat<process_noise_dof, process_noise_dof> processnoisecovariance;
+    // measurementModel_dyn_share (esekfom.hpp:129) with an opaque context pointer so that a C caller
+    // can bind one (the reference registers a plain function that reads globals).
+    typedef void measurementModel_dyn_share(state&, dyn_share_datastruct<scalar_type>&, void* ctx);
+
+    esekf(const state& x = state(), const cov& P = cov::Identity()) : x_(x), P_(P) {}
+
+    // esekfom.hpp:238-254
+    void init_dyn_share(processModel f_in, processMatrix1 f_x_in, processMatrix2 f_w_in,
+                        measurementModel_dyn_share h_dyn_share_in, int maximum_iteration, const scalar_type limit_vector[n],
+                        void* h_ctx = nullptr) {
+        f = f_in;
+        f_x = f_x_in;
+        f_w = f_w_in;
+        h_dyn_share = h_dyn_share_in;
+        h_ctx_ = h_ctx;
+        maximum_iter = maximum_iteration;
+        for (int i = 0; i < n; i++) limit[i] = limit_vector[i];
+        x_.build_S2_state();
+        x_.build_SO3_state();
+        x_.build_vect_state();
+    }
+    void set_meas_model(measurementModel_dyn_share h, void* ctx) { h_dyn_share = h; h_ctx_ = ctx; }
+
+    // esekfom.hpp:279-383 (dense path)
+    void predict(double& dt, processnoisecovariance& Q, const input& i_in) {
+        flatted_state f_ = f(x_, i_in);
+        Mat<m, n> f_x_ = f_x(x_, i_in);
+        cov f_x_final;
+        Mat<m, process_noise_dof> f_w_ = f_w(x_, i_in);
+        Mat<n, process_noise_dof> f_w_final;
+        state x_before = x_;
+        x_.oplus(f_, dt);
+        F_x1 = cov::Identity();
+        for (auto it = x_.vect_state.begin(); it != x_.vect_state.end(); it++) {
+            const int idx = it->first.first, dim = it->first.second, dof = it->second;
+            for (int i = 0; i < n; i++)
+                for (int j = 0; j < dof; j++) f_x_final(idx + j, i) = f_x_(dim + j, i);
+            for (int i = 0; i < process_noise_dof; i++)
+                for (int j = 0; j < dof; j++) f_w_final(idx + j, i) = f_w_(dim + j, i);
+        }
+        for (auto it = x_.SO3_state.begin(); it != x_.SO3_state.end(); it++) {
+            const int idx = it->first, dim = it->second;
+            fastlio_amd::V3 seg_SO3;
+            for (int i = 0; i < 3; i++) seg_SO3[i] = -1 * f_[dim + i] * dt;
+            // F_x1 block = exp(seg, scalar_type(1/2)).toRotationMatrix(): 1/2 is integer division -> the
+            // identity (esekfom.hpp:312); F_x1 already holds it.
+            const fastlio_amd::M3 res_temp_SO3 = MTK::A_matrix(seg_SO3);
+            for (int i = 0; i < n; i++) f_x_final.template set_block<3, 1>(idx, i, res_temp_SO3 * f_x_.template block<3, 1>(dim, i));
+            for (int i = 0; i < process_noise_dof; i++)
+                f_w_final.template set_block<3, 1>(idx, i, res_temp_SO3 * f_w_.template block<3, 1>(dim, i));
+        }
+        for (auto it = x_.S2_state.begin(); it != x_.S2_state.end(); it++) {
+            const int idx = it->first, dim = it->second;
+            fastlio_amd::V3 seg_S2;
+            for (int i = 0; i < 3; i++) seg_S2[i] = f_[dim + i] * dt;
+            Mat<2, 3> Nx;
+            Mat<3, 2> Mx;
+            x_.S2_Nx_yy(Nx, idx);
+            x_before.S2_Mx(Mx, Vec<2>::Zero(), idx);
+            // res = exp(seg_S2, scalar_type(1/2)) -> identity rotation (same quirk, :344)
+            F_x1.template set_block<2, 2>(idx, idx, Nx * Mx);
+            fastlio_amd::M3 x_before_hat;
+            x_before.S2_hat(x_before_hat, idx);
+            const Mat<2, 3> res_temp_S2 = ((-Nx) * x_before_hat) * MTK::A_matrix(seg_S2).transpose();
+            for (int i = 0; i < n; i++) f_x_final.template set_block<2, 1>(idx, i, res_temp_S2 * f_x_.template block<3, 1>(dim, i));
+            for (int i = 0; i < process_noise_dof; i++)
+                f_w_final.template set_block<2, 1>(idx, i, res_temp_S2 * f_w_.template block<3, 1>(dim, i));
+        }
+        F_x1 += f_x_final * dt;
+        const Mat<n, process_noise_dof> fw = f_w_final * dt;
+        P_ = (F_x1 * P_) * F_x1.transpose() + (fw * Q) * fw.transpose();
+    }
+
+    struct update_stats {
+        int passes = 0, searches = 0, returned_in_loop = 0;
+        int n_eff[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+        int pass_search[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double h_ms = 0, solve_ms = 0;
+    };
+    const update_stats& last_stats() const { return stats_; }
+
+    // esekfom.hpp:1619-1931
+    void update_iterated_dyn_share_modified(double R, double& solve_time) {
+        typedef std::chrono::steady_clock clk;
+        stats_ = update_stats();
+        dyn_share_datastruct<scalar_type>& dyn_share = dyn_share_;
+        dyn_share.valid = true;
+        dyn_share.converge = true;
+        int t = 0;
+        state x_propagated = x_;
+        cov P_propagated = P_;
+        int dof_Measurement;
+        Vec<n> K_h;
+        cov K_x;
+        vectorized_state dx_new = vectorized_state::Zero();
+        for (int i = -1; i < maximum_iter; i++) {
+            dyn_share.valid = true;
+            dyn_share.has_normal_eq = false;
+            const auto t_h0 = clk::now();
+            const bool searched = dyn_share.converge;
+            h_dyn_share(x_, dyn_share, h_ctx_);
+            stats_.h_ms += std::chrono::duration<double, std::milli>(clk::now() - t_h0).count();
+            if (stats_.passes < 8) {
+                stats_.pass_search[stats_.passes] = searched ? 1 : 0;
+                stats_.n_eff[stats_.passes] = dyn_share.valid ? (int)meas_rows(dyn_share) : 0;
+            }
+            stats_.passes++;
+            stats_.searches += searched ? 1 : 0;
+            if (!dyn_share.valid) continue;  // :1638-1641
+
+            const auto solve_start = clk::now();
+            dof_Measurement = (int)meas_rows(dyn_share);
+            vectorized_state dx;
+            x_.boxminus(dx, x_propagated);
+            dx_new = dx;
+            P_ = P_propagated;
+            project_cov(P_, dx_new, dx, x_, x_propagated);  // :1659-1699
+
+            if (n > dof_Measurement) {  // :1715-1744 gain form on explicit rows
+                gain_small(dyn_share, dof_Measurement, R, K_h, K_x);
+            } else {  // :1782-1809 information form
+                double HTH[144], HTh[12];
+                normal_equations(dyn_share, dof_Measurement, HTH, HTh);
+                cov P_temp = fastlio_amd::inverse(P_ / R);
+                for (int a = 0; a < 12; ++a)
+                    for (int b = 0; b < 12; ++b) P_temp(a, b) += HTH[a * 12 + b];
+                const cov P_inv = fastlio_amd::inverse(P_temp);
+                for (int r = 0; r < n; ++r) {
+                    double s = 0;
+                    for (int c = 0; c < 12; ++c) s += P_inv(r, c) * HTh[c];
+                    K_h[r] = s;
+                }
+                K_x = cov::Zero();
+                for (int r = 0; r < n; ++r)
+                    for (int b = 0; b < 12; ++b) {
+                        double s = 0;
+                        for (int c = 0; c < 12; ++c) s += P_inv(r, c) * HTH[c * 12 + b];
+                        K_x(r, b) = s;
+                    }
+            }
+            const Vec<n> dx_ = K_h + (K_x - cov::Identity()) * dx_new;  // :1815
+            x_.boxplus(dx_);
+            dyn_share.converge = true;
+            for (int j = 0; j < n; j++) {
+                if (std::fabs(dx_[j]) > limit[j]) {
+                    dyn_share.converge = false;
+                    break;
+                }
+            }
+            if (dyn_share.converge) t++;
+            if (!t && i == maximum_iter - 2) dyn_share.converge = true;  // :1829-1832
+
+            if (t > 1 || i == maximum_iter - 1) {  // :1834-1928
+                final_cov(P_, K_x, dx_, x_, x_propagated);
+                stats_.returned_in_loop = 1;
+                const double ms = std::chrono::duration<double, std::milli>(clk::now() - solve_start).count();
+                stats_.solve_ms += ms;
+                solve_time += ms * 1e-3;
+                return;
+            }
+            const double ms = std::chrono::duration<double, std::milli>(clk::now() - solve_start).count();
+            stats_.solve_ms += ms;
+            solve_time += ms * 1e-3;
+        }
+    }
+
+    void change_x(state& input_state) {  // :1933-1942
+        x_ = input_state;
+        if ((!x_.vect_state.size()) && (!x_.SO3_state.size()) && (!x_.S2_state.size())) {
+            x_.build_S2_state();
+            x_.build_SO3_state();
+            x_.build_vect_state();
+        }
+    }
+    void change_P(cov& input_cov) { P_ = input_cov; }
+    const state& get_x() const { return x_; }
+    const cov& get_P() const { return P_; }
+
+   private:
+    static int64_t meas_rows(const dyn_share_datastruct<scalar_type>& d) {
+        return d.has_normal_eq ? d.n_eff : (int64_t)d.h.size();
+    }
+    static void normal_equations(const dyn_share_datastruct<scalar_type>& d, int rows, double HTH[144], double HTh[12]) {
+        if (d.has_normal_eq) {
+            for (int i = 0; i < 144; ++i) HTH[i] = d.HTH[i];
+            for (int i = 0; i < 12; ++i) HTh[i] = d.HTh[i];
+            return;
+        }
+        for (int a = 0; a < 12; ++a) {
+            for (int b = 0; b < 12; ++b) {
+                double s = 0;
+                for (int k = 0; k < rows; ++k) s += d.h_x[(size_t)a * rows + k] * d.h_x[(size_t)b * rows + k];
+                HTH[a * 12 + b] = s;
+            }
+            double s = 0;
+            for (int k = 0; k < rows; ++k) s += d.h_x[(size_t)a * rows + k] * d.h[k];
+            HTh[a] = s;
+        }
+    }
+    // P <- J P J^T blockwise and dx_new <- J dx_new, J = A(dx_so3)^T (SO3) / Nx*Mx (S2): :1659-1699
+    static void project_cov(cov& P, vectorized_state& dx_new, const vectorized_state& dx, state& x, state& x_prop) {
+        for (auto it = x.SO3_state.begin(); it != x.SO3_state.end(); it++) {
+            const int idx = it->first;
+            fastlio_amd::V3 seg;
+            for (int i = 0; i < 3; i++) seg[i] = dx[idx + i];
+            const fastlio_amd::M3 J = MTK::A_matrix(seg).transpose();
+            dx_new.template set_block<3, 1>(idx, 0, J * dx_new.template block<3, 1>(idx, 0));
+            for (int i = 0; i < n; i++) P.template set_block<3, 1>(idx, i, J * P.template block<3, 1>(idx, i));
+            for (int i = 0; i < n; i++) P.template set_block<1, 3>(i, idx, P.template block<1, 3>(i, idx) * J.transpose());
+        }
+        for (auto it = x.S2_state.begin(); it != x.S2_state.end(); it++) {
+            const int idx = it->first;
+            Vec<2> seg;
+            for (int i = 0; i < 2; i++) seg[i] = dx[idx + i];
+            Mat<2, 3> Nx;
+            Mat<3, 2> Mx;
+            x.S2_Nx_yy(Nx, idx);
+            x_prop.S2_Mx(Mx, seg, idx);
+            const Mat<2, 2> J = Nx * Mx;
+            dx_new.template set_block<2, 1>(idx, 0, J * dx_new.template block<2, 1>(idx, 0));
+            for (int i = 0; i < n; i++) P.template set_block<2, 1>(idx, i, J * P.template block<2, 1>(idx, i));
+            for (int i = 0; i < n; i++) P.template set_block<1, 2>(i, idx, P.template block<1, 2>(i, idx) * J.transpose());
+        }
+    }
+    // :1836-1924
+    void final_cov(cov& P, cov& K_x, const Vec<n>& dx_, state& x, state& x_prop) {
+        L_ = P;
+        for (auto it = x.SO3_state.begin(); it != x.SO3_state.end(); it++) {
+            const int idx = it->first;
+            fastlio_amd::V3 seg;
+            for (int i = 0; i < 3; i++) seg[i] = dx_[i + idx];
+            const fastlio_amd::M3 J = MTK::A_matrix(seg).transpose();
+            for (int i = 0; i < n; i++) L_.template set_block<3, 1>(idx, i, J * P.template block<3, 1>(idx, i));
+            for (int i = 0; i < 12; i++) K_x.template set_block<3, 1>(idx, i, J * K_x.template block<3, 1>(idx, i));
+            for (int i = 0; i < n; i++) {
+                L_.template set_block<1, 3>(i, idx, L_.template block<1, 3>(i, idx) * J.transpose());
+                P.template set_block<1, 3>(i, idx, P.template block<1, 3>(i, idx) * J.transpose());
+            }
+        }
+        for (auto it = x.S2_state.begin(); it != x.S2_state.end(); it++) {
+            const int idx = it->first;
+            Vec<2> seg;
+            for (int i = 0; i < 2; i++) seg[i] = dx_[i + idx];
+            Mat<2, 3> Nx;
+            Mat<3, 2> Mx;
+            x.S2_Nx_yy(Nx, idx);
+            x_prop.S2_Mx(Mx, seg, idx);
+            const Mat<2, 2> J = Nx * Mx;
+            for (int i = 0; i < n; i++) L_.template set_block<2, 1>(idx, i, J * P.template block<2, 1>(idx, i));
+            for (int i = 0; i < 12; i++) K_x.template set_block<2, 1>(idx, i, J * K_x.template block<2, 1>(idx, i));
+            for (int i = 0; i < n; i++) {
+                L_.template set_block<1, 2>(i, idx, L_.template block<1, 2>(i, idx) * J.transpose());
+                P.template set_block<1, 2>(i, idx, P.template block<1, 2>(i, idx) * J.transpose());
+            }
+        }
+        cov Pn;
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < n; ++c) {
+                double s = 0;
+                for (int k = 0; k < 12; ++k) s += K_x(r, k) * P(k, c);
+                Pn(r, c) = L_(r, c) - s;
+            }
+        P = Pn;
+    }
+    // K = P H^T (H P H^T / R + I)^-1 / R with H zero-padded to rows x n (:1715-1744)
+    void gain_small(const dyn_share_datastruct<scalar_type>& d, int rows, double R, Vec<n>& K_h, cov& K_x) {
+        const int M = rows;
+        std::vector<double> H((size_t)M * n, 0.0), PHt((size_t)n * M), S((size_t)M * M), Si((size_t)M * M), Kg((size_t)n * M);
+        for (int k = 0; k < M; ++k)
+            for (int c = 0; c < 12; ++c) H[(size_t)k * n + c] = d.h_x[(size_t)c * M + k];
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < M; ++k) {
+                double s = 0;
+                for (int j = 0; j < n; ++j) s += P_(i, j) * H[(size_t)k * n + j];
+                PHt[(size_t)i * M + k] = s;
+            }
+        for (int a = 0; a < M; ++a)
+            for (int b = 0; b < M; ++b) {
+                double s = 0;
+                for (int j = 0; j < n; ++j) s += H[(size_t)a * n + j] * PHt[(size_t)j * M + b];
+                S[(size_t)a * M + b] = s / R + (a == b ? 1.0 : 0.0);
+            }
+        fastlio_amd::inverse_lu(S.data(), M, Si.data());
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < M; ++k) {
+                double s = 0;
+                for (int j = 0; j < M; ++j) s += PHt[(size_t)i * M + j] * Si[(size_t)j * M + k];
+                Kg[(size_t)i * M + k] = s / R;
+            }
+        for (int i = 0; i < n; ++i) {
+            double s = 0;
+            for (int k = 0; k < M; ++k) s += Kg[(size_t)i * M + k] * d.h[k];
+            K_h[i] = s;
+            for (int j = 0; j < n; ++j) {
+                double w = 0;
+                for (int k = 0; k < M; ++k) w += Kg[(size_t)i * M + k] * H[(size_t)k * n + j];
+                K_x(i, j) = w;
+            }
+        }
+    }
+
+    state x_;
+    cov P_;
+    cov F_x1 = cov::Identity();
+    cov L_ = cov::Identity();
+    processModel* f = nullptr;
+    processMatrix1* f_x = nullptr;
+    processMatrix2* f_w = nullptr;
+    measurementModel_dyn_share* h_dyn_share = nullptr;
+    void* h_ctx_ = nullptr;
+    int maximum_iter = 0;
+    scalar_type limit[n];
+    dyn_share_datastruct<scalar_type> dyn_share_;
+    update_stats stats_;
+};
+
+}  // namespace esekfom

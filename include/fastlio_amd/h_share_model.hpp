@@ -1,0 +1,59 @@
+// h_share_model.hpp -- the measurement model of FAST-LIO2 (src/laserMapping.cpp:638-754) as a thin host
+// wrapper over the HIP library: one flh_eval per call, normal equations straight into the extended
+// dyn_share_datastruct.  Registered with kf.init_dyn_share(get_f, df_dx, df_dw, fastlio_amd::h_share_model,
+// NUM_MAX_ITERATIONS, epsi, &ctx) exactly where the reference registers its own (laserMapping.cpp:828).
+#pragma once
+#include <stdexcept>
+#include <string>
+
+#include "../fastlio_hip.h"
+#include "esekfom.hpp"
+#include "use-ikfom.hpp"
+
+namespace fastlio_amd {
+
+// What the reference keeps in globals (laserMapping.cpp:69-114) and h_share_model needs.
+struct HShareContext {
+    flh_handle* handle = nullptr;
+    bool extrinsic_est_en = false;  // laserMapping.cpp:73
+    // outputs mirrored from the reference's globals
+    int effct_feat_num = 0;         // :93
+    double total_residual = 0.0;    // :86
+    double res_mean_last = 0.05;    // :86
+    double match_ms = 0.0;          // wall time inside flh_eval (match_time + solve_time buckets, :640,716-717,753)
+};
+
+inline void h_share_model(state_ikfom& s, esekfom::dyn_share_datastruct<double>& ekfom_data, void* ctx_) {
+    HShareContext* ctx = static_cast<HShareContext*>(ctx_);
+    if (!ctx || !ctx->handle) throw std::runtime_error("fastlio_amd::h_share_model: no flh_handle bound");
+    const double rot[4] = {s.rot.x, s.rot.y, s.rot.z, s.rot.w};
+    const double offR[4] = {s.offset_R_L_I.x, s.offset_R_L_I.y, s.offset_R_L_I.z, s.offset_R_L_I.w};
+    const double pos[3] = {s.pos[0], s.pos[1], s.pos[2]};
+    const double offT[3] = {s.offset_T_L_I[0], s.offset_T_L_I[1], s.offset_T_L_I[2]};
+    int64_t n_eff = 0;
+    double total_res = 0;
+    if (flh_eval(ctx->handle, rot, pos, offR, offT, ekfom_data.converge ? 1 : 0, ctx->extrinsic_est_en ? 1 : 0,
+                 ekfom_data.HTH, ekfom_data.HTh, &n_eff, &total_res) != 0)
+        throw std::runtime_error(std::string("flh_eval failed: ") + flh_last_error());
+    ctx->effct_feat_num = (int)n_eff;
+    ctx->total_residual = total_res;
+    ekfom_data.n_eff = n_eff;
+    ekfom_data.total_residual = total_res;
+    ekfom_data.has_normal_eq = true;
+    if (n_eff < 1) {  // laserMapping.cpp:708-713
+        ekfom_data.valid = false;
+        return;
+    }
+    ctx->res_mean_last = total_res / (double)n_eff;  // :715
+    if (n_eff < state_ikfom::DOF) {
+        // the gain-form branch (esekfom.hpp:1715-1744) needs explicit rows: fetch them (tiny)
+        ekfom_data.h_x.assign((size_t)n_eff * 12, 0.0);
+        ekfom_data.h.assign((size_t)n_eff, 0.0);
+        int64_t rows = 0;
+        if (flh_fetch_rows(ctx->handle, ekfom_data.h_x.data(), ekfom_data.h.data(), n_eff, &rows) != 0 || rows != n_eff)
+            throw std::runtime_error(std::string("flh_fetch_rows failed: ") + flh_last_error());
+        ekfom_data.has_normal_eq = false;
+    }
+}
+
+}  // namespace fastlio_amd

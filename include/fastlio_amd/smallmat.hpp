@@ -1,0 +1,159 @@
+// smallmat.hpp -- a minimal fixed-size dense matrix layer for the host side of the IEKF.
+// The reference uses Eigen (absent from this build environment); only what
+// esekf::update_iterated_dyn_share_modified / predict need is provided: fixed-size storage,
+// products, transposes, blocks and a partial-pivot LU inverse (Eigen's inverse() for n > 4).
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace fastlio_amd {
+
+template <int R, int C>
+struct Mat {
+    double a[R * C];
+    static constexpr int Rows = R, Cols = C;
+    Mat() { std::memset(a, 0, sizeof(a)); }
+    static Mat Zero() { return Mat(); }
+    static Mat Identity() {
+        Mat m;
+        for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = 1.0;
+        return m;
+    }
+    double& operator()(int i, int j) { return a[i * C + j]; }
+    const double& operator()(int i, int j) const { return a[i * C + j]; }
+    double& operator[](int i) { return a[i]; }  // vectors
+    const double& operator[](int i) const { return a[i]; }
+    Mat<C, R> transpose() const {
+        Mat<C, R> t;
+        for (int i = 0; i < R; ++i)
+            for (int j = 0; j < C; ++j) t(j, i) = (*this)(i, j);
+        return t;
+    }
+    Mat operator+(const Mat& o) const {
+        Mat r;
+        for (int i = 0; i < R * C; ++i) r.a[i] = a[i] + o.a[i];
+        return r;
+    }
+    Mat operator-(const Mat& o) const {
+        Mat r;
+        for (int i = 0; i < R * C; ++i) r.a[i] = a[i] - o.a[i];
+        return r;
+    }
+    Mat operator-() const {
+        Mat r;
+        for (int i = 0; i < R * C; ++i) r.a[i] = -a[i];
+        return r;
+    }
+    Mat operator*(double s) const {
+        Mat r;
+        for (int i = 0; i < R * C; ++i) r.a[i] = a[i] * s;
+        return r;
+    }
+    Mat operator/(double s) const {
+        Mat r;
+        for (int i = 0; i < R * C; ++i) r.a[i] = a[i] / s;
+        return r;
+    }
+    Mat& operator+=(const Mat& o) {
+        for (int i = 0; i < R * C; ++i) a[i] += o.a[i];
+        return *this;
+    }
+    template <int K>
+    Mat<R, K> operator*(const Mat<C, K>& o) const {
+        Mat<R, K> r;
+        for (int i = 0; i < R; ++i)
+            for (int j = 0; j < K; ++j) {
+                double s = 0;
+                for (int k = 0; k < C; ++k) s += (*this)(i, k) * o(k, j);
+                r(i, j) = s;
+            }
+        return r;
+    }
+    template <int BR, int BC>
+    Mat<BR, BC> block(int r0, int c0) const {
+        Mat<BR, BC> b;
+        for (int i = 0; i < BR; ++i)
+            for (int j = 0; j < BC; ++j) b(i, j) = (*this)(r0 + i, c0 + j);
+        return b;
+    }
+    template <int BR, int BC>
+    void set_block(int r0, int c0, const Mat<BR, BC>& b) {
+        for (int i = 0; i < BR; ++i)
+            for (int j = 0; j < BC; ++j) (*this)(r0 + i, c0 + j) = b(i, j);
+    }
+    double norm() const {
+        double s = 0;
+        for (int i = 0; i < R * C; ++i) s += a[i] * a[i];
+        return std::sqrt(s);
+    }
+    double squaredNorm() const {
+        double s = 0;
+        for (int i = 0; i < R * C; ++i) s += a[i] * a[i];
+        return s;
+    }
+};
+template <int N>
+using Vec = Mat<N, 1>;
+typedef Vec<3> V3;
+typedef Mat<3, 3> M3;
+
+inline M3 hat(const V3& v) {  // mtkmath.hpp:176-183
+    M3 r;
+    r(0, 1) = -v[2]; r(0, 2) = v[1];
+    r(1, 0) = v[2]; r(1, 2) = -v[0];
+    r(2, 0) = -v[1]; r(2, 1) = v[0];
+    return r;
+}
+
+// Dense n x n inverse, partial-pivot LU (row-major).  Stand-in for Eigen's inverse()
+// (esekfom.hpp:1738,1782,1802).  Returns false if a zero pivot was met.
+inline bool inverse_lu(const double* A, int n, double* Ainv) {
+    std::vector<double> LU(A, A + (size_t)n * n);
+    std::vector<int> perm(n);
+    std::vector<double> col(n);
+    for (int i = 0; i < n; ++i) perm[i] = i;
+    bool ok = true;
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        double best = std::fabs(LU[k * n + k]);
+        for (int i = k + 1; i < n; ++i) {
+            const double v = std::fabs(LU[i * n + k]);
+            if (v > best) { best = v; p = i; }
+        }
+        if (best == 0.0) ok = false;
+        if (p != k) {
+            for (int j = 0; j < n; ++j) std::swap(LU[k * n + j], LU[p * n + j]);
+            std::swap(perm[k], perm[p]);
+        }
+        const double piv = LU[k * n + k];
+        for (int i = k + 1; i < n; ++i) LU[i * n + k] /= piv;
+        for (int i = k + 1; i < n; ++i) {
+            const double l = LU[i * n + k];
+            for (int j = k + 1; j < n; ++j) LU[i * n + j] -= l * LU[k * n + j];
+        }
+    }
+    for (int c = 0; c < n; ++c) {
+        for (int i = 0; i < n; ++i) col[i] = (perm[i] == c) ? 1.0 : 0.0;
+        for (int i = 0; i < n; ++i) {
+            double s = col[i];
+            for (int j = 0; j < i; ++j) s -= LU[i * n + j] * col[j];
+            col[i] = s;
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            double s = col[i];
+            for (int j = i + 1; j < n; ++j) s -= LU[i * n + j] * col[j];
+            col[i] = s / LU[i * n + i];
+        }
+        for (int i = 0; i < n; ++i) Ainv[i * n + c] = col[i];
+    }
+    return ok;
+}
+template <int N>
+inline Mat<N, N> inverse(const Mat<N, N>& A) {
+    Mat<N, N> r;
+    inverse_lu(A.a, N, r.a);
+    return r;
+}
+
+}  // namespace fastlio_amd

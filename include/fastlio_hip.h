@@ -1,0 +1,181 @@
+/*
+ * fastlio_hip.h -- C ABI of libfastlio_hip.so: the MI355X (gfx950) implementation of FAST-LIO2's
+ * per-scan measurement-update hot path.
+ *
+ * This is the drop-in boundary.  Everything above it (the IEKF loop, the ROS node)
+ * stays host C++; everything below it is hand-written HIP.  Plain pointers and sizes only.
+ * All citations are file:line under the reference tree (hku-mars/FAST_LIO @ 2024-08-07).
+ *
+ * Layer 1 (flh_*)        replaces the body of h_share_model (src/laserMapping.cpp:638-754) and the
+ *                        ikd-Tree calls it makes (Build :919, Nearest_Search :670).
+ * Layer 2 (flh_esekf_*)  is the host-side iterated ESKF, a C binding of the C++ mirror in
+ *                        include/fastlio_amd/esekfom.hpp of
+ *                        esekfom::esekf<state_ikfom,12,input_ikfom> (esekfom.hpp:108-2005), so that
+ *                        non-C++ callers (the ctypes tests, bench.py) drive exactly the code the C++
+ *                        node would.
+ *
+ * Conventions
+ *   - state: 26 doubles  pos[3] rot_xyzw[4] offset_R_L_I_xyzw[4] offset_T_L_I[3] vel[3] bg[3] ba[3]
+ *     grav[3]   (member order of MTK_BUILD_MANIFOLD(state_ikfom,...), include/use-ikfom.hpp:12-21;
+ *     quaternions in Eigen coeffs() order x,y,z,w).
+ *   - covariances: 23x23 doubles, row-major, DOF order pos rot offR offT vel bg ba grav(2).
+ *   - points: fp32 xyz at a caller-given byte stride (16 for float4, 48 for pcl::PointXYZINormal,
+ *     12 for packed xyz); only the first three floats of each record are read.
+ *   - return value: 0 = ok, <0 = error (flh_last_error() gives the text).  "No effective points"
+ *     (src/laserMapping.cpp:708-713) is NOT an error: n_eff == 0 and the caller sets valid=false.
+ *   - one caller thread per handle; calls block until their result is on the host unless noted.
+ */
+#ifndef FASTLIO_HIP_H
+#define FASTLIO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLH_NSTATE 26
+#define FLH_NDOF 23
+#define FLH_K 5 /* NUM_MATCH_POINTS, include/common_lib.h:26 */
+
+typedef struct flh_handle flh_handle;
+
+typedef struct flh_config {
+    int device;             /* HIP device ordinal; -1 = current device */
+    float cell_size;        /* search-grid cell edge in metres; <=0 -> 1.0 (= 2 x filter_size_map 0.5) */
+    float plane_threshold;  /* esti_plane inlier threshold; <=0 -> 0.1f (src/laserMapping.cpp:678) */
+    float max_sqdist;       /* kNN gate on the 5th neighbour; <=0 -> 5.0f (src/laserMapping.cpp:671) */
+    void* stream;           /* hipStream_t to run on; NULL -> the handle creates its own */
+    int lanes_per_query;    /* search-kernel variant: 0 = default (32); 8/16/32/64 */
+    int sort_queries;       /* 1: Morton-sort scan points at upload for cache locality (default 1 if <0) */
+} flh_config;
+
+void flh_default_config(flh_config* cfg);
+int flh_create(const flh_config* cfg, flh_handle** out);
+void flh_destroy(flh_handle* h);
+const char* flh_last_error(void);
+/* 1 if a usable HIP device is visible to this process, else 0 (never throws, never aborts). */
+int flh_device_available(void);
+
+/* ikdtree.Build(feats_down_world->points) -- src/laserMapping.cpp:919.  Builds the device map and
+ * its spatial index (radix-sorted cell grid) from M world-frame points.  Map indices reported by
+ * flh_fetch_neighbors refer to positions in this array. */
+int flh_map_build(flh_handle* h, const void* xyz, size_t stride_bytes, size_t M);
+size_t flh_map_size(const flh_handle* h);
+
+/* feats_down_body for the coming update -- src/laserMapping.cpp:904-905,935-951.  Resets
+ * point_selected_surf to all-true (as memset at :812 leaves it for a fresh search) and clears the
+ * neighbour cache. */
+int flh_scan_upload(flh_handle* h, const void* pts, size_t stride_bytes, size_t N);
+size_t flh_scan_size(const flh_handle* h);
+
+/* Scan staging ring (double-buffering the H2D copy of scan k+1 behind the update of scan k).
+ * flh_scan_stage copies a scan into device slot `slot` (0..FLH_MAX_SLOTS-1) on a separate copy stream and
+ * returns once the host buffer may be reused; flh_scan_activate makes a staged scan the current one
+ * (waits for its copy, resets point_selected_surf / the neighbour cache) without touching PCIe. */
+#define FLH_MAX_SLOTS 64
+int flh_scan_stage(flh_handle* h, int slot, const void* pts, size_t stride_bytes, size_t N);
+int flh_scan_activate(flh_handle* h, int slot);
+
+/* One evaluation of h_share_model (src/laserMapping.cpp:638-754) at state s:
+ *   transform :652-661, 5-NN + gate :667-672 (only if do_search = ekfom_data.converge), plane fit
+ *   + residual gate :676-692, then -- instead of materialising h_x/h (:720-752) -- the normal
+ *   equations the IEKF needs (esekfom.hpp:1784,1804):
+ *     HTH[12*12] (row-major; symmetric) = h_x^T h_x,   HTh[12] = h_x^T h,
+ *     n_eff = effct_feat_num, total_residual (laserMapping.cpp:702).
+ * When extrinsic_est_en == 0 the last six columns are zero (laserMapping.cpp:745). */
+int flh_eval(flh_handle* h, const double rot_xyzw[4], const double pos[3], const double offR_xyzw[4],
+             const double offT[3], int do_search, int extrinsic_est_en, double HTH[144], double HTh[12],
+             int64_t* n_eff, double* total_residual);
+
+/* Same evaluation, but the reduced 16x16 Gram block is left in DEVICE memory at d_gram256 (256
+ * doubles, row-major G = sum_k v_k v_k^T with v = [row(12) | h | 1 | |pd2| | 0]) and the call
+ * returns after enqueueing on the handle's stream.  This is the hook for the multi-GPU path: the
+ * caller all-reduces d_gram256 across ranks (RCCL) and then unpacks it with flh_unpack_gram. */
+int flh_eval_device(flh_handle* h, const double state[FLH_NSTATE], int do_search, int extrinsic_est_en,
+                    double* d_gram256);
+void flh_unpack_gram(const double gram256[256], double HTH[144], double HTh[12], int64_t* n_eff,
+                     double* total_residual);
+
+/* Lazy D2H fetches of the globals later reference code reads (SURVEY.md 8b "Data passed implicitly"). */
+int flh_fetch_selected(flh_handle* h, uint8_t* flags /* N: point_selected_surf */);
+int flh_fetch_neighbors(flh_handle* h, int32_t* idx /* N x 5 map indices, -1 = none */,
+                        float* d2 /* N x 5, ascending */, uint8_t* cnt /* N, may be NULL */);
+int flh_fetch_world(flh_handle* h, float* xyz /* N x 3: feats_down_world */);
+int flh_fetch_normvec(flh_handle* h, float* abcd_pd2 /* N x 4: normvec (a,b,c, intensity=pd2) */);
+/* Materialise ekfom_data.h_x (n_eff x 12, column-major like Eigen::MatrixXd) and ekfom_data.h for
+ * the LAST evaluated state, in original scan order (src/laserMapping.cpp:720-752).  Needed by the
+ * n_eff < 23 gain-form branch (esekfom.hpp:1715-1744).  cap_rows = capacity of the caller buffers. */
+int flh_fetch_rows(flh_handle* h, double* h_x_colmajor, double* hvec, int64_t cap_rows, int64_t* n_rows);
+
+/* Per-call device timings of the last flh_eval, milliseconds (HIP events on the handle's stream). */
+typedef struct flh_timing {
+    float search_ms;  /* transform + 5-NN kernel (0 when do_search == 0) */
+    float fit_ms;     /* plane fit + residual + Jacobian + Gram kernels */
+    float total_ms;   /* first launch to result visible on the host */
+    int64_t candidates; /* map points examined by the last search (0 unless stats are enabled) */
+} flh_timing;
+int flh_last_timing(flh_handle* h, flh_timing* t);
+/* Accumulated device time (HIP events on the handle's stream) per kernel group since the last reset:
+ * out[0] = sum of search-kernel ms, out[1] = number of search launches, out[2] = sum of fit(+reduce) ms,
+ * out[3] = number of fit launches, out[4] = sum of first-launch-to-host-visible ms, out[5] = evaluations. */
+int flh_get_counters(flh_handle* h, double out[6], int reset);
+int flh_enable_stats(flh_handle* h, int on); /* count candidate points examined (slower) */
+/* Run one kernel of the hot path `iters` times back-to-back on the handle's stream and return the
+ * mean duration in ms, measured with HIP events on that stream (bench.py's roofline leg).
+ * which: 0 = search (transform + 5-NN), 1 = fit (plane fit + Jacobian + Gram + final reduce). */
+int flh_time_kernel(flh_handle* h, int which, const double state[FLH_NSTATE], int extrinsic_est_en,
+                    int iters, float* mean_ms);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layer 2: host-side iterated ESKF (C binding of include/fastlio_amd/esekfom.hpp).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct flh_esekf flh_esekf;
+
+/* What a measurement model hands back per evaluation: the extended dyn_share_datastruct
+ * (esekfom.hpp:79-89).  Either the fused normal equations (has_normal_eq) or explicit rows. */
+typedef struct flh_meas {
+    int valid;              /* ekfom_data.valid */
+    int64_t n_eff;          /* rows of h_x */
+    int has_normal_eq;      /* HTH/HTh filled */
+    double HTH[144];
+    double HTh[12];
+    const double* h_x;      /* optional: n_eff x 12 column-major; NULL if not materialised */
+    const double* h;        /* optional: n_eff */
+    double total_residual;
+} flh_meas;
+/* measurementModel_dyn_share (esekfom.hpp:129): h(state&, dyn_share&).  `converge` is the input
+ * flag ekfom_data.converge (re-run the kNN or reuse the cache). */
+typedef void (*flh_meas_fn)(void* ctx, const double state[FLH_NSTATE], int converge, flh_meas* out);
+
+typedef struct flh_update_stats {
+    int passes;            /* h evaluations */
+    int searches;          /* with converge == true */
+    int returned_in_loop;  /* final-covariance branch taken (esekfom.hpp:1834) */
+    int n_eff[8];
+    int pass_search[8];
+    double h_ms;           /* wall time inside the measurement model */
+    double solve_ms;       /* wall time of the host algebra (solve_H_time, esekfom.hpp:1649,1926) */
+} flh_update_stats;
+
+/* kf.init_dyn_share(get_f, df_dx, df_dw, h_share_model, NUM_MAX_ITERATIONS, epsi) -- laserMapping.cpp:828.
+ * The process model is fixed to the reference's get_f/df_dx/df_dw (use-ikfom.hpp:47-88).  With
+ * h == NULL the measurement model is the built-in GPU h_share_model bound to `handle`. */
+flh_esekf* flh_esekf_create(flh_handle* handle, int maximum_iter, const double limit[FLH_NDOF],
+                            int extrinsic_est_en);
+void flh_esekf_destroy(flh_esekf* kf);
+void flh_esekf_set_meas_model(flh_esekf* kf, flh_meas_fn h, void* ctx);
+void flh_esekf_change_x(flh_esekf* kf, const double x[FLH_NSTATE]);           /* esekfom.hpp:1933 */
+void flh_esekf_change_P(flh_esekf* kf, const double P[FLH_NDOF * FLH_NDOF]);  /* :1944 */
+void flh_esekf_get_x(const flh_esekf* kf, double x[FLH_NSTATE]);              /* :1949 */
+void flh_esekf_get_P(const flh_esekf* kf, double P[FLH_NDOF * FLH_NDOF]);     /* :1952 */
+/* kf.predict(dt, Q, in) -- esekfom.hpp:279-383; acc/gyro = input_ikfom. Q is 12x12 row-major. */
+void flh_esekf_predict(flh_esekf* kf, double dt, const double Q[144], const double acc[3], const double gyro[3]);
+/* kf.update_iterated_dyn_share_modified(R, solve_time) -- esekfom.hpp:1619-1931. */
+int flh_esekf_update(flh_esekf* kf, double R, flh_update_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTLIO_HIP_H */

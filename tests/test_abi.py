@@ -1,0 +1,42 @@
+"""The C-ABI library loads on a CPU-only box, exports every symbol include/fastlio_hip.h declares, and
+refuses to compute without a GPU (no silent CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from fast_lio_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    hdr = open(os.path.join(ROOT, "include", "fastlio_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(flh_[a-z_A-Z0-9]+)\s*\(", hdr)))
+    declared = [d for d in declared if d not in ("flh_meas_fn",)]
+    assert set(declared) == set(capi.EXPORTS), set(declared) ^ set(capi.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_unpack_gram_layout():
+    G = np.arange(256, dtype=np.float64)
+    HTH = np.zeros(144)
+    HTh = np.zeros(12)
+    n = C.c_int64()
+    tr = C.c_double()
+    capi.lib().flh_unpack_gram(G, HTH, HTh, C.byref(n), C.byref(tr))
+    Gm = G.reshape(16, 16)
+    np.testing.assert_array_equal(HTH.reshape(12, 12), Gm[:12, :12])
+    np.testing.assert_array_equal(HTh, Gm[:12, 12])
+    assert n.value == int(Gm[13, 13]) and tr.value == Gm[14, 13]
+
+
+def test_no_cpu_fallback_without_gpu():
+    if capi.device_available():
+        pytest.skip("a GPU is visible; the loud-failure path is for CPU-only boxes")
+    with pytest.raises(capi.FlhError, match="no HIP device"):
+        capi.Handle()

@@ -1,0 +1,308 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bars (BASELINE.json north_star): point_selected_surf bit-exact; neighbour indices bit-exact wherever
+they can influence the result (5th neighbour inside the d2 <= 5 gate); fp32 planes bit-exact; normal
+equations to 1e-10 relative (fp64 sums in a different order); posterior state within 1e-4 relative
+and pose within 1e-4 m; covariance within 1e-4 of max|P| (norm-wise: P = L - K_x P cancels, see
+tests/test_host_iekf.py).
+"""
+import numpy as np
+import pytest
+
+from fast_lio_amd import capi, synth
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+REL_NE = 1e-10   # normal equations, relative to max|entry|
+REL_X = 1e-4     # state, relative
+POSE_M = 1e-4    # pose, metres
+REL_P = 1e-4     # covariance, relative to max|P|
+
+
+@pytest.fixture(scope="module")
+def prob():
+    pr = synth.make_problem(200000, 20000, "avia", cfg=1)
+    m = po.Map(pr.map_xyz)
+    xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    return pr, m, xp, P, h
+
+
+def check_eval(h, sc, m, x, search, ext, tag=""):
+    HTH, HTh, n_eff, tres = h.eval(x, search, ext)
+    valid = sc.h_share_model(m, x, search, ext)
+    sel_g = h.fetch_selected()
+    np.testing.assert_array_equal(sel_g, sc.selected, err_msg=f"{tag}: point_selected_surf differs")
+    assert n_eff == sc.n_eff
+    if valid:
+        H0, h0 = sc.normal_equations()
+        sH = np.abs(H0).max()
+        np.testing.assert_allclose(HTH, H0, rtol=0, atol=REL_NE * sH, err_msg=tag)
+        np.testing.assert_allclose(HTh, h0, rtol=0, atol=REL_NE * max(np.abs(h0).max(), 1e-30) + 1e-12 * np.sqrt(sH), err_msg=tag)
+        assert abs(tres - sc.total_residual) <= 1e-9 * max(1.0, abs(sc.total_residual))
+        np.testing.assert_allclose(HTH, HTH.T, rtol=0, atol=1e-12 * sH)
+        if not ext:
+            assert np.all(HTH[6:, :] == 0) and np.all(HTH[:, 6:] == 0) and np.all(HTh[6:] == 0)
+    sel = sel_g.astype(bool)
+    # fp32 artefacts are bit-exact
+    np.testing.assert_array_equal(h.fetch_world().view(np.uint32), sc.world.view(np.uint32), err_msg=f"{tag}: world")
+    np.testing.assert_array_equal(h.fetch_normvec()[sel].view(np.uint32), sc.normvec[sel].view(np.uint32), err_msg=f"{tag}: normvec")
+    return n_eff
+
+
+def check_neighbors(h, sc):
+    idx, d2, cnt = h.fetch_neighbors()
+    o_idx, o_d2, o_cnt = sc.nn_idx, sc.nn_d2, sc.nn_cnt
+    gate = (o_cnt == 5) & (o_d2[:, 4] <= 5.0)  # every query whose result can matter downstream
+    np.testing.assert_array_equal(idx[gate], o_idx[gate])
+    np.testing.assert_array_equal(d2[gate].view(np.uint32), o_d2[gate].view(np.uint32))
+    np.testing.assert_array_equal(cnt[gate], 5)
+    # rejected queries: whatever the GPU kept must still be true neighbours in ascending order
+    rej = ~gate
+    assert np.all((cnt[rej] < 5) | (d2[rej][:, 4] > 5.0))
+    return int(gate.sum())
+
+
+@pytest.mark.parametrize("ext", [False, True])
+def test_eval_search_and_nosearch_passes(prob, ext):
+    pr, m, xp, P, h = prob
+    h.scan_upload(pr.body)
+    sc = po.Scan(pr.body, nthreads=8)
+    n1 = check_eval(h, sc, m, xp, True, ext, "search@prior")
+    assert n1 > 1000
+    assert check_neighbors(h, sc) > 1000
+    x2 = po.state_boxplus(xp, np.r_[0.02, -0.01, 0.015, 0.002, -0.001, 0.003, np.zeros(17)])
+    check_eval(h, sc, m, x2, False, ext, "no-search@x2")
+    check_eval(h, sc, m, pr.x_true, False, ext, "no-search@truth")
+    check_eval(h, sc, m, pr.x_true, True, ext, "search@truth")
+    check_neighbors(h, sc)
+
+
+@pytest.mark.parametrize("lpq", [8, 16, 32, 64])
+def test_search_kernel_variants(prob, lpq):
+    pr, m, xp, P, _ = prob
+    h = capi.Handle(lanes_per_query=lpq)
+    h.map_build(pr.map_xyz)
+    h.scan_upload(pr.body[:5000])
+    sc = po.Scan(pr.body[:5000], nthreads=8)
+    check_eval(h, sc, m, xp, True, False, f"lpq={lpq}")
+    check_neighbors(h, sc)
+    h.close()
+
+
+def test_fetch_rows_matches_oracle(prob):
+    pr, m, xp, P, h = prob
+    h.scan_upload(pr.body)
+    sc = po.Scan(pr.body, nthreads=8)
+    for ext in (False, True):
+        h.eval(xp, True, ext)
+        sc.h_share_model(m, xp, True, ext)
+        Hx, hv = h.fetch_rows()
+        assert Hx.shape == sc.h_x.shape
+        np.testing.assert_allclose(Hx, sc.h_x, rtol=1e-13, atol=1e-13)
+        np.testing.assert_array_equal(hv, sc.h)
+
+
+@pytest.mark.parametrize("ext", [False, True])
+def test_full_update_matches_oracle(prob, ext):
+    pr, m, xp, P, h = prob
+    h.scan_upload(pr.body)
+    kf = capi.Esekf(h, max_iter=3, extrinsic_est_en=ext)
+    kf.change_x(xp)
+    kf.change_P(P)
+    st = kf.update(0.001)
+    sc = po.Scan(pr.body, nthreads=8)
+    x_ref, P_ref, st_ref = sc.update_iterated(m, xp, P, extrinsic_est_en=ext)
+    assert st.passes == st_ref.passes and st.searches == st_ref.searches
+    assert list(st.pass_search)[: st.passes] == list(st_ref.pass_search)[: st.passes]
+    assert list(st.n_eff)[: st.passes] == list(st_ref.n_eff)[: st.passes]
+    x, Pn = kf.get_x(), kf.get_P()
+    assert np.linalg.norm(x[0:3] - x_ref[0:3]) <= POSE_M
+    np.testing.assert_allclose(x, x_ref, rtol=REL_X, atol=1e-7)
+    np.testing.assert_allclose(Pn, P_ref, rtol=0, atol=REL_P * np.abs(P_ref).max())
+    np.testing.assert_array_equal(h.fetch_selected(), sc.selected)
+    # run-to-run determinism of the GPU path (fixed reduction order)
+    h.scan_upload(pr.body)
+    kf.change_x(xp)
+    kf.change_P(P)
+    kf.update(0.001)
+    np.testing.assert_array_equal(kf.get_x(), x)
+    np.testing.assert_array_equal(kf.get_P(), Pn)
+
+
+def test_staged_scan_ring_equals_direct_upload(prob):
+    pr, m, xp, P, h = prob
+    h.scan_upload(pr.body)
+    a = h.eval(xp, True, False)
+    h.scan_stage(3, pr.body)
+    h.scan_stage(4, pr.body[:777])
+    h.scan_activate(4)
+    assert h.N == 777
+    h.eval(xp, True, False)
+    h.scan_activate(3)
+    b = h.eval(xp, True, False)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    assert a[2] == b[2]
+
+
+# ------------------------------------------------------------------ kNN on adversarial maps
+def test_knn_lattice_ties_and_duplicates():
+    rng = np.random.default_rng(7)
+    g = np.arange(-6, 7, dtype=np.float32) * 0.5
+    lat = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    lat = np.concatenate([lat, lat[:300]], axis=0)  # exact duplicates: ties resolved by lower map index
+    lat = lat[rng.permutation(len(lat))]
+    m = po.Map(lat)
+    h = capi.Handle()
+    h.map_build(lat)
+    q = (rng.integers(-6, 7, (3000, 3)) * 0.5 + rng.choice([0.0, 0.25], (3000, 3))).astype(np.float32)
+    h.scan_upload(q)
+    ident = synth.make_state()
+    h.eval(ident, True, False)
+    sc = po.Scan(q, nthreads=8)
+    sc.h_share_model(m, ident, True, False)
+    check_neighbors(h, sc)
+    np.testing.assert_array_equal(h.fetch_selected(), sc.selected)
+    h.close()
+
+
+def test_knn_sparse_map_needs_ring_expansion():
+    # spacing 1.3 m: the 5th neighbour is usually outside the 3x3x3 stencil's guaranteed radius
+    rng = np.random.default_rng(11)
+    pts = (rng.uniform(-40, 40, (12000, 3)) * np.array([1, 1, 0.05])).astype(np.float32)
+    m = po.Map(pts)
+    h = capi.Handle()
+    h.map_build(pts)
+    q = (rng.uniform(-45, 45, (8000, 3)) * np.array([1, 1, 0.08])).astype(np.float32)
+    h.scan_upload(q)
+    ident = synth.make_state()
+    h.eval(ident, True, False)
+    sc = po.Scan(q, nthreads=8)
+    sc.h_share_model(m, ident, True, False)
+    n = check_neighbors(h, sc)
+    assert n > 100
+    np.testing.assert_array_equal(h.fetch_selected(), sc.selected)
+    h.close()
+
+
+def test_knn_dense_cells_and_large_coordinates():
+    # 40 points per cell on average, coordinates near +-1900 m (fp32 ulp ~1e-4)
+    rng = np.random.default_rng(13)
+    pts = (rng.uniform(0, 12, (70000, 3)) + np.array([1900.0, -1900.0, 30.0])).astype(np.float32)
+    m = po.Map(pts)
+    h = capi.Handle()
+    h.map_build(pts)
+    q = (rng.uniform(-1, 13, (4000, 3)) + np.array([1900.0, -1900.0, 30.0])).astype(np.float32)
+    h.scan_upload(q)
+    ident = synth.make_state()
+    h.eval(ident, True, False)
+    sc = po.Scan(q, nthreads=8)
+    sc.h_share_model(m, ident, True, False)
+    check_neighbors(h, sc)
+    np.testing.assert_array_equal(h.fetch_selected(), sc.selected)
+    h.close()
+
+
+# ------------------------------------------------------------------ edge cases
+def test_edge_empty_scan_and_tiny_maps(prob):
+    pr, m, xp, P, _ = prob
+    h = capi.Handle()
+    h.map_build(pr.map_xyz[:3])          # fewer than 5 map points: nothing can be selected
+    h.scan_upload(pr.body[:100])
+    HTH, HTh, n_eff, tres = h.eval(xp, True, False)
+    assert n_eff == 0 and np.all(HTH == 0) and np.all(HTh == 0) and tres == 0
+    assert h.fetch_selected().sum() == 0
+    idx, d2, cnt = h.fetch_neighbors()
+    assert cnt.max() <= 3
+    h.map_build(np.zeros((0, 3), np.float32))  # empty map
+    h.scan_upload(pr.body[:100])
+    assert h.eval(xp, True, False)[2] == 0
+    h.map_build(pr.map_xyz)
+    h.scan_upload(np.zeros((0, 3), np.float32))  # empty scan
+    assert h.eval(xp, True, False)[2] == 0
+    for n in (1, 63, 64, 65, 257):         # ragged sizes around the wave / block width
+        h.scan_upload(pr.body[:n])
+        sc = po.Scan(pr.body[:n], nthreads=1)
+        check_eval(h, sc, m, xp, True, False, f"N={n}")
+    h.close()
+
+
+def test_edge_no_effective_points_and_gain_form(prob):
+    pr, m, xp, P, h = prob
+    far = xp.copy()
+    far[0:3] += 3000.0
+    h.scan_upload(pr.body)
+    kf = capi.Esekf(h, max_iter=3)
+    kf.change_x(far)
+    kf.change_P(P)
+    st = kf.update(0.001)
+    assert st.passes == 4 and st.returned_in_loop == 0 and list(st.n_eff)[:4] == [0, 0, 0, 0]
+    np.testing.assert_array_equal(kf.get_x(), far)     # every pass skipped (esekfom.hpp:1638-1641)
+    np.testing.assert_array_equal(kf.get_P(), P)
+    # fewer than 23 effective points -> gain-form branch through flh_fetch_rows
+    body = pr.body[:16]
+    h.scan_upload(body)
+    kf.change_x(xp)
+    kf.change_P(P)
+    st = kf.update(0.001)
+    sc = po.Scan(body, nthreads=1)
+    x_ref, P_ref, st_ref = sc.update_iterated(m, xp, P)
+    assert 0 < max(st_ref.n_eff) < 23
+    assert list(st.n_eff)[: st.passes] == list(st_ref.n_eff)[: st_ref.passes]
+    np.testing.assert_allclose(kf.get_x(), x_ref, rtol=REL_X, atol=1e-7)
+    np.testing.assert_allclose(kf.get_P(), P_ref, rtol=0, atol=REL_P * np.abs(P_ref).max())
+
+
+def test_nosearch_before_search_is_an_error(prob):
+    pr, m, xp, P, h = prob
+    h.scan_upload(pr.body[:100])
+    with pytest.raises(capi.FlhError, match="do_search == 0 before any search"):
+        h.eval(xp, False, False)
+
+
+def test_map_extent_limit_is_reported():
+    h = capi.Handle()
+    pts = np.array([[0, 0, 0], [5000, 0, 0], [1, 1, 1], [2, 2, 2], [3, 3, 3]], np.float32)
+    with pytest.raises(capi.FlhError, match="4096 cells"):
+        h.map_build(pts)
+    h2 = capi.Handle(cell_size=2.0)
+    h2.map_build(pts)
+    h.close()
+    h2.close()
+
+
+@pytest.mark.parametrize("sensor,M,N", [("velodyne", 150000, 12000), ("ouster64", 150000, 15000), ("mid360", 120000, 9000)])
+def test_other_sensors_full_update(sensor, M, N):
+    pr = synth.make_problem(M, N, sensor, cfg=3)
+    m = po.Map(pr.map_xyz)
+    xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    h.scan_upload(pr.body)
+    kf = capi.Esekf(h, max_iter=3)
+    kf.change_x(xp)
+    kf.change_P(P)
+    st = kf.update(0.001)
+    sc = po.Scan(pr.body, nthreads=8)
+    x_ref, P_ref, st_ref = sc.update_iterated(m, xp, P)
+    assert list(st.n_eff)[: st.passes] == list(st_ref.n_eff)[: st_ref.passes]
+    assert np.linalg.norm(kf.get_x()[0:3] - x_ref[0:3]) <= POSE_M
+    np.testing.assert_allclose(kf.get_x(), x_ref, rtol=REL_X, atol=1e-7)
+    np.testing.assert_allclose(kf.get_P(), P_ref, rtol=0, atol=REL_P * np.abs(P_ref).max())
+    np.testing.assert_array_equal(h.fetch_selected(), sc.selected)
+    h.close()
+
+
+def test_cell_size_variants(prob):
+    pr, m, xp, P, _ = prob
+    for c in (0.6, 1.5, 2.5):
+        h = capi.Handle(cell_size=c)
+        h.map_build(pr.map_xyz)
+        h.scan_upload(pr.body[:6000])
+        sc = po.Scan(pr.body[:6000], nthreads=8)
+        check_eval(h, sc, m, xp, True, False, f"cell={c}")
+        check_neighbors(h, sc)
+        h.close()
