@@ -65,7 +65,7 @@ MEAS_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTE
 # every symbol include/fastlio_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "flh_default_config", "flh_create", "flh_destroy", "flh_last_error", "flh_device_available", "flh_map_build",
-    "flh_map_size", "flh_scan_upload", "flh_scan_size", "flh_scan_stage", "flh_scan_activate", "flh_get_counters",
+    "flh_map_size", "flh_scan_upload", "flh_scan_size", "flh_scan_stage", "flh_scan_activate", "flh_get_counters", "flh_set_timing_stride",
     "flh_eval", "flh_eval_device", "flh_unpack_gram",
     "flh_fetch_selected", "flh_fetch_neighbors", "flh_fetch_world", "flh_fetch_normvec", "flh_fetch_rows",
     "flh_last_timing", "flh_enable_stats", "flh_time_kernel", "flh_esekf_create", "flh_esekf_destroy",
@@ -103,6 +103,7 @@ def lib():
     L.flh_scan_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t]
     L.flh_scan_activate.argtypes = [C.c_void_p, C.c_int]
     L.flh_get_counters.argtypes = [C.c_void_p, _f64p, C.c_int]
+    L.flh_set_timing_stride.argtypes = [C.c_void_p, C.c_int]
     L.flh_eval.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, C.c_int, C.c_int, _f64p, _f64p,
                            C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.flh_eval_device.argtypes = [C.c_void_p, _f64p, C.c_int, C.c_int, C.c_void_p]
@@ -141,8 +142,8 @@ def device_available() -> bool:
 class Handle:
     """flh_handle: the device-resident map + current scan."""
 
-    def __init__(self, cell_size: float = 1.0, lanes_per_query: int = 32, device: int = -1, stream: int | None = None,
-                 plane_threshold: float = 0.1, max_sqdist: float = 5.0):
+    def __init__(self, cell_size: float = 1.0, lanes_per_query: int = 4, device: int = -1, stream: int | None = None,
+                 plane_threshold: float = 0.1, max_sqdist: float = 5.0, sort_queries: int = -1):
         L = lib()
         cfg = FlhConfig()
         L.flh_default_config(C.byref(cfg))
@@ -152,6 +153,7 @@ class Handle:
         cfg.plane_threshold = plane_threshold
         cfg.max_sqdist = max_sqdist
         cfg.stream = stream
+        cfg.sort_queries = sort_queries
         self._h = C.c_void_p()
         _chk(L.flh_create(C.byref(cfg), C.byref(self._h)), "flh_create")
         self._keep = []
@@ -174,16 +176,16 @@ class Handle:
     def map_build(self, xyz: np.ndarray):
         a = np.ascontiguousarray(xyz, dtype=np.float32)
         assert a.ndim == 2 and a.shape[1] in (3, 4, 12)
-        _chk(lib().flh_map_build(self._h, a.ctypes.data, a.strides[0], a.shape[0]), "flh_map_build")
+        _chk(lib().flh_map_build(self._h, a.ctypes.data, a.shape[1] * 4, a.shape[0]), "flh_map_build")
 
     def scan_upload(self, body: np.ndarray):
         a = np.ascontiguousarray(body, dtype=np.float32)
         assert a.ndim == 2 and a.shape[1] in (3, 4, 12)
-        _chk(lib().flh_scan_upload(self._h, a.ctypes.data, a.strides[0], a.shape[0]), "flh_scan_upload")
+        _chk(lib().flh_scan_upload(self._h, a.ctypes.data, a.shape[1] * 4, a.shape[0]), "flh_scan_upload")
 
     def scan_stage(self, slot: int, body: np.ndarray):
         a = np.ascontiguousarray(body, dtype=np.float32)
-        _chk(lib().flh_scan_stage(self._h, slot, a.ctypes.data, a.strides[0], a.shape[0]), "flh_scan_stage")
+        _chk(lib().flh_scan_stage(self._h, slot, a.ctypes.data, a.shape[1] * 4, a.shape[0]), "flh_scan_stage")
 
     def scan_activate(self, slot: int):
         _chk(lib().flh_scan_activate(self._h, slot), "flh_scan_activate")
@@ -253,6 +255,9 @@ class Handle:
         t = FlhTiming()
         _chk(lib().flh_last_timing(self._h, C.byref(t)), "flh_last_timing")
         return {"search_ms": t.search_ms, "fit_ms": t.fit_ms, "total_ms": t.total_ms, "candidates": int(t.candidates)}
+
+    def set_timing_stride(self, every_n: int):
+        _chk(lib().flh_set_timing_stride(self._h, int(every_n)), "flh_set_timing_stride")
 
     def enable_stats(self, on=True):
         _chk(lib().flh_enable_stats(self._h, int(on)), "flh_enable_stats")

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -60,19 +61,22 @@ struct flh_handle {
     size_t M = 0;
     GridParams grid{};
     DevBuf<float4> map_sorted;
-    DevBuf<uint2> hash, cells;
+    DevBuf<uint2> hash;
+    DevBuf<uint32_t> starts;
     uint32_t nbricks = 0;
     int rmax = 3;
     // scan
     size_t N = 0;
-    DevBuf<float4> body, world, nn_pts, normvec;
+    DevBuf<float4> world, nn_pts, normvec;
     DevBuf<float> nn_d2;
     DevBuf<uint8_t> nn_cnt, selected;
     DevBuf<double> partials, part2, gram;
     DevBuf<u64> counter;
+    DevBuf<uint32_t> slow_list, slow_count;  // A1 -> A2 work list (striped) and its counters
+    DevBuf<float> slow_ub;
+    DevBuf<uint32_t> tickets;                // arrival tickets of the in-kernel reduction (self re-arming)                   // per-query search radius^2 handed from A1 to A2
     double* h_gram = nullptr;  // pinned 256 doubles
     u64* h_counter = nullptr;  // pinned
-    std::vector<float> h_body;  // host copy (original order) for flh_fetch_rows
     // last evaluation
     StateDev last_state{};
     int last_ext = 0;
@@ -80,18 +84,27 @@ struct flh_handle {
     bool stats = false;
     flh_timing timing{};
     bool searched_once = false;
+    int timing_stride = 1;   // record HIP events on every n-th evaluation (0 = never)
+    uint64_t eval_no = 0;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     // staging ring
     struct Slot {
-        DevBuf<float4> body;
-        std::vector<float> h_body;
+        DevBuf<float4> body;            // Morton-ordered (internal order); .w = original index
+        std::vector<float> h_body;      // host copy, original order (flh_fetch_rows)
+        std::vector<uint32_t> h_perm;   // internal index -> original index
         size_t N = 0;
         hipEvent_t ready = nullptr;
         bool used = false;
     };
-    Slot slots[FLH_MAX_SLOTS];
+    Slot slots[FLH_MAX_SLOTS + 1];      // [FLH_MAX_SLOTS] backs flh_scan_upload
     hipStream_t copy_stream = nullptr;
-    const float4* cur_body = nullptr;  // body.p or a slot's buffer
+    const float4* cur_body = nullptr;   // the active slot's buffer
+    const Slot* cur = nullptr;
+    // staging scratch (copy stream)
+    DevBuf<float4> st_raw;
+    DevBuf<u64> st_k0, st_k1;
+    DevBuf<uint32_t> st_v0, st_v1;
+    DevBuf<unsigned char> st_tmp;
 };
 
 extern "C" {
@@ -111,7 +124,7 @@ void flh_default_config(flh_config* c) {
     c->plane_threshold = 0.1f;
     c->max_sqdist = 5.0f;
     c->stream = nullptr;
-    c->lanes_per_query = 32;
+    c->lanes_per_query = 4;
     c->sort_queries = -1;
 }
 
@@ -126,7 +139,12 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.cell_size <= 0) cfg.cell_size = 1.0f;
     if (cfg.plane_threshold <= 0) cfg.plane_threshold = 0.1f;
     if (cfg.max_sqdist <= 0) cfg.max_sqdist = 5.0f;
-    if (cfg.lanes_per_query != 8 && cfg.lanes_per_query != 16 && cfg.lanes_per_query != 64) cfg.lanes_per_query = 32;
+    if (cfg.sort_queries < 0) cfg.sort_queries = 1;
+    {
+        const int l = cfg.lanes_per_query;  // 0 = exact kernel for every query
+        if (l != 0 && l != 2 && l != 8 && l != 16 && l != 204 && l != 208 && l != 216 && l != 1204 && l != 2204)
+            cfg.lanes_per_query = 4;
+    }
     flh_handle* h = new flh_handle();
     h->cfg = cfg;
     if (cfg.device >= 0) {
@@ -153,10 +171,12 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
         flh_destroy(h);
         return fail("hipHostMalloc failed");
     }
-    if (h->gram.reserve(256) != hipSuccess || h->counter.reserve(1) != hipSuccess) {
+    if (h->gram.reserve(256) != hipSuccess || h->counter.reserve(1) != hipSuccess || h->slow_count.reserve(flh::list_stripes()) != hipSuccess ||
+        hipMemset(h->slow_count.p, 0, flh::list_stripes() * sizeof(uint32_t)) != hipSuccess) {
         flh_destroy(h);
         return fail("hipMalloc failed");
     }
+    if (const char* e = std::getenv("FLH_TIMING_STRIDE")) h->timing_stride = std::max(0, std::atoi(e));
     h->rmax = (int)std::ceil((std::sqrt((double)cfg.max_sqdist) + 2e-3 * cfg.cell_size) / cfg.cell_size);
     if (h->rmax < 1) h->rmax = 1;
     *out = h;
@@ -167,14 +187,15 @@ void flh_destroy(flh_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->map_sorted.release(); h->hash.release(); h->cells.release();
-    h->body.release(); h->world.release(); h->nn_pts.release(); h->normvec.release();
+    h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
+    h->world.release(); h->nn_pts.release(); h->normvec.release();
     h->nn_d2.release(); h->nn_cnt.release(); h->selected.release();
     h->partials.release(); h->part2.release(); h->gram.release(); h->counter.release();
     for (auto& sl : h->slots) {
         sl.body.release();
         if (sl.ready) (void)hipEventDestroy(sl.ready);
     }
+    h->st_raw.release(); h->st_k0.release(); h->st_k1.release(); h->st_v0.release(); h->st_v1.release(); h->st_tmp.release();
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->h_gram) (void)hipHostFree(h->h_gram);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
@@ -266,23 +287,33 @@ int flh_map_build(flh_handle* h, const void* xyz, size_t stride_bytes, size_t M)
         HIPC_CL(hipMemcpyAsync(&nbricks, br.p + (M - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIPC_CL(hipStreamSynchronize(st));
     }
-    // directory + cell tables
+    // directory + per-brick prefix tables
     uint32_t hs = 1024;
     while (hs < 2 * (nbricks + 1)) hs <<= 1;
     int log2hs = 0;
     while ((1u << log2hs) < hs) ++log2hs;
+    DevBuf<uint32_t> bstart;
     HIPC_CL(h->hash.reserve(hs));
-    HIPC_CL(h->cells.reserve((size_t)(nbricks ? nbricks : 1) * 64));
+    HIPC_CL(h->starts.reserve((size_t)(nbricks ? nbricks : 1) * flh::kBrickStride));
     HIPC_CL(hipMemsetAsync(h->hash.p, 0xFF, (size_t)hs * sizeof(uint2), st));
-    HIPC_CL(hipMemsetAsync(h->cells.p, 0, (size_t)(nbricks ? nbricks : 1) * 64 * sizeof(uint2), st));
-    if (M > 0) HIPC_CL(flh::launch_map_cells(k1.p, br.p, Mu, h->cells.p, h->hash.p, hs - 1, 32 - log2hs, st));
+    if (M > 0) {
+        hipError_t e1 = bstart.reserve((size_t)nbricks + 1);
+        if (e1 != hipSuccess) { cleanup(); return fail(std::string("hipMalloc: ") + hipGetErrorString(e1)); }
+        hipError_t e2 = flh::launch_brick_starts(bh.p, br.p, Mu, bstart.p, st);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(bstart.p + nbricks, &Mu, sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        if (e2 == hipSuccess)
+            e2 = flh::launch_brick_tables(k1.p, bstart.p, nbricks, h->starts.p, h->hash.p, hs - 1, 32 - log2hs, st);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
+        bstart.release();
+        if (e2 != hipSuccess) { cleanup(); return fail(std::string("map tables: ") + hipGetErrorString(e2)); }
+    }
     HIPC_CL(hipStreamSynchronize(st));
     cleanup();
 #undef HIPC_CL
     g.hash_mask = hs - 1;
     g.hash_shift = 32 - log2hs;
     g.hash = h->hash.p;
-    g.cells = h->cells.p;
+    g.starts = h->starts.p;
     g.pts = h->map_sorted.p;
     h->grid = g;
     h->nbricks = nbricks;
@@ -297,9 +328,17 @@ static int prepare_scan_buffers(flh_handle* h, size_t N, bool full_clear) {
     const size_t n1 = N ? N : 1;
     HIPC(h->world.reserve(n1)); HIPC(h->nn_pts.reserve(5 * n1)); HIPC(h->normvec.reserve(n1));
     HIPC(h->nn_d2.reserve(5 * n1)); HIPC(h->nn_cnt.reserve(n1)); HIPC(h->selected.reserve(n1));
+    {
+        const size_t ln = (size_t)flh::list_stripes() * flh::list_stripe_cap((int)N);
+        HIPC(h->slow_list.reserve(ln)); HIPC(h->slow_ub.reserve(n1));
+    }
     const int nblk = flh::fit_blocks((int)N);
     HIPC(h->partials.reserve((size_t)nblk * 256));
-    HIPC(h->part2.reserve((size_t)flh::reduce1_blocks(nblk, nullptr) * 256));
+    const int ngroups = flh::reduce1_blocks(nblk, nullptr);
+    HIPC(h->part2.reserve((size_t)ngroups * 256));
+    HIPC(h->tickets.reserve((size_t)ngroups + 1));
+    HIPC(hipMemsetAsync(h->tickets.p, 0, ((size_t)ngroups + 1) * sizeof(uint32_t), st));
+    HIPC(hipMemsetAsync(h->slow_count.p, 0, flh::list_stripes() * sizeof(uint32_t), st));
     HIPC(hipMemsetAsync(h->selected.p, 1, n1, st));  // memset(point_selected_surf, true, ...) :812
     if (full_clear) {
         HIPC(hipMemsetAsync(h->nn_cnt.p, 0, n1, st));
@@ -314,44 +353,21 @@ static int prepare_scan_buffers(flh_handle* h, size_t N, bool full_clear) {
     return 0;
 }
 
-int flh_scan_upload(flh_handle* h, const void* pts, size_t stride_bytes, size_t N) {
-    if (!h) return fail("flh_scan_upload: null handle");
-    if (N > 0 && !pts) return fail("flh_scan_upload: null points");
-    if (stride_bytes < 12) return fail("flh_scan_upload: stride_bytes < 12");
-    if (N >= (1ull << 26)) return fail("flh_scan_upload: N too large");
-    HIPC(hipSetDevice(h->device));
-    hipStream_t st = h->stream;
-    const size_t n1 = N ? N : 1;
-    HIPC(h->body.reserve(n1));
-    h->h_body.resize(3 * n1);
-    std::vector<float4> hb(n1);
-    const unsigned char* src = (const unsigned char*)pts;
-    for (size_t i = 0; i < N; ++i) {
-        float p[3];
-        std::memcpy(p, src + i * stride_bytes, 12);
-        hb[i] = make_float4(p[0], p[1], p[2], 0.f);
-        h->h_body[3 * i] = p[0]; h->h_body[3 * i + 1] = p[1]; h->h_body[3 * i + 2] = p[2];
-    }
-    if (N > 0) HIPC(hipMemcpyAsync(h->body.p, hb.data(), N * sizeof(float4), hipMemcpyHostToDevice, st));
-    if (prepare_scan_buffers(h, N, true) != 0) return -1;
-    HIPC(hipStreamSynchronize(st));  // hb is a stack-owned staging buffer
-    h->cur_body = h->body.p;
-    return 0;
-}
-
-int flh_scan_stage(flh_handle* h, int slot, const void* pts, size_t stride_bytes, size_t N) {
-    if (!h) return fail("flh_scan_stage: null handle");
-    if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_stage: bad slot");
-    if (N > 0 && !pts) return fail("flh_scan_stage: null points");
-    if (stride_bytes < 12) return fail("flh_scan_stage: stride_bytes < 12");
-    if (N >= (1ull << 26)) return fail("flh_scan_stage: N too large");
+// Copies a scan to the device in Morton order of its body-frame coordinates (sort_queries != 0) on the
+// copy stream; returns when the host buffer may be reused.
+static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size_t stride_bytes, size_t N) {
+    if (N > 0 && !pts) return fail("scan staging: null points");
+    if (stride_bytes < 12 && N > 0) return fail("scan staging: stride_bytes < 12");
+    if (N >= (1ull << 26)) return fail("scan staging: N too large");
     HIPC(hipSetDevice(h->device));
     if (!h->copy_stream) HIPC(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-    flh_handle::Slot& sl = h->slots[slot];
+    hipStream_t cs = h->copy_stream;
     if (!sl.ready) HIPC(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
     const size_t n1 = N ? N : 1;
     HIPC(sl.body.reserve(n1));
+    HIPC(h->st_raw.reserve(n1));
     sl.h_body.resize(3 * n1);
+    sl.h_perm.resize(n1);
     std::vector<float4> hb(n1);
     const unsigned char* src = (const unsigned char*)pts;
     for (size_t i = 0; i < N; ++i) {
@@ -360,24 +376,58 @@ int flh_scan_stage(flh_handle* h, int slot, const void* pts, size_t stride_bytes
         hb[i] = make_float4(p[0], p[1], p[2], 0.f);
         sl.h_body[3 * i] = p[0]; sl.h_body[3 * i + 1] = p[1]; sl.h_body[3 * i + 2] = p[2];
     }
-    if (N > 0) HIPC(hipMemcpyAsync(sl.body.p, hb.data(), N * sizeof(float4), hipMemcpyHostToDevice, h->copy_stream));
-    HIPC(hipEventRecord(sl.ready, h->copy_stream));
-    HIPC(hipStreamSynchronize(h->copy_stream));  // hb is pageable and dies here
+    const bool do_sort = h->cfg.sort_queries != 0 && N > 1;
+    if (N > 0) HIPC(hipMemcpyAsync(h->st_raw.p, hb.data(), N * sizeof(float4), hipMemcpyHostToDevice, cs));
+    if (do_sort) {
+        const uint32_t Nu = (uint32_t)N;
+        HIPC(h->st_k0.reserve(N)); HIPC(h->st_k1.reserve(N)); HIPC(h->st_v0.reserve(N)); HIPC(h->st_v1.reserve(N));
+        HIPC(flh::launch_scan_keys(h->st_raw.p, Nu, 0.25f, h->st_k0.p, h->st_v0.p, cs));
+        size_t tb = 0;
+        HIPC(flh::sort_scan_pairs(nullptr, tb, h->st_k0.p, h->st_k1.p, h->st_v0.p, h->st_v1.p, Nu, cs));
+        HIPC(h->st_tmp.reserve(tb));
+        tb = h->st_tmp.cap;
+        HIPC(flh::sort_scan_pairs(h->st_tmp.p, tb, h->st_k0.p, h->st_k1.p, h->st_v0.p, h->st_v1.p, Nu, cs));
+        HIPC(flh::launch_scan_gather(h->st_raw.p, h->st_v1.p, Nu, sl.body.p, cs));
+        HIPC(hipMemcpyAsync(sl.h_perm.data(), h->st_v1.p, N * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+    } else {
+        HIPC(flh::launch_scan_gather(h->st_raw.p, nullptr, (uint32_t)N, sl.body.p, cs));
+        for (size_t i = 0; i < N; ++i) sl.h_perm[i] = (uint32_t)i;
+    }
+    HIPC(hipEventRecord(sl.ready, cs));
+    HIPC(hipStreamSynchronize(cs));  // hb is pageable and dies here; h_perm must be complete
     sl.N = N;
     sl.used = true;
     return 0;
 }
 
+static int activate(flh_handle* h, flh_handle::Slot& sl, bool full_clear) {
+    HIPC(hipSetDevice(h->device));
+    HIPC(hipStreamWaitEvent(h->stream, sl.ready, 0));
+    if (prepare_scan_buffers(h, sl.N, full_clear) != 0) return -1;
+    h->cur_body = sl.body.p;
+    h->cur = &sl;
+    return 0;
+}
+
+int flh_scan_upload(flh_handle* h, const void* pts, size_t stride_bytes, size_t N) {
+    if (!h) return fail("flh_scan_upload: null handle");
+    flh_handle::Slot& sl = h->slots[FLH_MAX_SLOTS];
+    if (stage_into(h, sl, pts, stride_bytes, N) != 0) return -1;
+    if (activate(h, sl, true) != 0) return -1;
+    HIPC(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int flh_scan_stage(flh_handle* h, int slot, const void* pts, size_t stride_bytes, size_t N) {
+    if (!h) return fail("flh_scan_stage: null handle");
+    if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_stage: bad slot");
+    return stage_into(h, h->slots[slot], pts, stride_bytes, N);
+}
+
 int flh_scan_activate(flh_handle* h, int slot) {
     if (!h) return fail("flh_scan_activate: null handle");
     if (slot < 0 || slot >= FLH_MAX_SLOTS || !h->slots[slot].used) return fail("flh_scan_activate: slot not staged");
-    HIPC(hipSetDevice(h->device));
-    flh_handle::Slot& sl = h->slots[slot];
-    HIPC(hipStreamWaitEvent(h->stream, sl.ready, 0));
-    if (prepare_scan_buffers(h, sl.N, false) != 0) return -1;
-    h->cur_body = sl.body.p;
-    h->h_body = sl.h_body;
-    return 0;
+    return activate(h, h->slots[slot], false);
 }
 
 static StateDev make_state(const double rot[4], const double pos[3], const double offR[4], const double offT[3]) {
@@ -394,14 +444,14 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
     if (timed) HIPC(hipEventRecord(h->ev[0], st));
     if (do_search) {
         if (h->stats) HIPC(hipMemsetAsync(h->counter.p, 0, sizeof(u64), st));
-        HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, h->cfg.max_sqdist, h->rmax,
-                                h->world.p, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
-                                h->stats ? h->counter.p : nullptr, st));
+        HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->M,
+                                h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
+                                h->slow_list.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr, st));
         h->searched_once = true;
     }
     if (timed) HIPC(hipEventRecord(h->ev[1], st));
     HIPC(flh::launch_fit(s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
-                         h->partials.p, h->part2.p, d_out, st));
+                         h->world.p, h->partials.p, h->part2.p, d_out, h->tickets.p, h->slow_count.p, st));
     if (timed) HIPC(hipEventRecord(h->ev[2], st));
     h->last_state = s;
     h->last_ext = ext;
@@ -424,24 +474,30 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     if (!rot || !pos || !offR || !offT || !HTH || !HTh) return fail("flh_eval: null argument");
     HIPC(hipSetDevice(h->device));
     const StateDev s = make_state(rot, pos, offR, offT);
-    if (enqueue_eval(h, s, do_search, ext, h->gram.p, true) != 0) return -1;
+    // the final reduce kernel writes the 16x16 block straight into pinned, device-mapped host memory:
+    // no copy kernel, no extra boundary -- the stream sync below is the only wait
+    const bool timed = h->timing_stride > 0 && (h->eval_no++ % (uint64_t)h->timing_stride) == 0;
+    if (enqueue_eval(h, s, do_search, ext, h->h_gram, timed) != 0) return -1;
     hipStream_t st = h->stream;
-    HIPC(hipMemcpyAsync(h->h_gram, h->gram.p, 256 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (h->stats && do_search) HIPC(hipMemcpyAsync(h->h_counter, h->counter.p, sizeof(u64), hipMemcpyDeviceToHost, st));
-    HIPC(hipEventRecord(h->ev[3], st));
+    if (timed) HIPC(hipEventRecord(h->ev[3], st));
     HIPC(hipStreamSynchronize(st));
     flh_unpack_gram(h->h_gram, HTH, HTh, n_eff, total_residual);
     float a = 0, b = 0, c = 0;
-    (void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
-    (void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
-    (void)hipEventElapsedTime(&c, h->ev[0], h->ev[3]);
+    if (timed) {
+        (void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
+        (void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
+        (void)hipEventElapsedTime(&c, h->ev[0], h->ev[3]);
+    }
     h->timing.search_ms = do_search ? a : 0.f;
     h->timing.fit_ms = b;
     h->timing.total_ms = c;
     h->timing.candidates = (h->stats && do_search) ? (int64_t)*h->h_counter : 0;
-    if (do_search) { h->acc[0] += a; h->acc[1] += 1; }
-    h->acc[2] += b; h->acc[3] += 1;
-    h->acc[4] += c; h->acc[5] += 1;
+    if (timed) {
+        if (do_search) { h->acc[0] += a; h->acc[1] += 1; }
+        h->acc[2] += b; h->acc[3] += 1;
+        h->acc[4] += c; h->acc[5] += 1;
+    }
     return 0;
 }
 
@@ -465,6 +521,12 @@ int flh_last_timing(flh_handle* h, flh_timing* t) {
     *t = h->timing;
     return 0;
 }
+int flh_set_timing_stride(flh_handle* h, int every_n) {
+    if (!h) return fail("flh_set_timing_stride: null handle");
+    h->timing_stride = every_n < 0 ? 0 : every_n;
+    h->eval_no = 0;
+    return 0;
+}
 int flh_enable_stats(flh_handle* h, int on) {
     if (!h) return fail("flh_enable_stats: null handle");
     h->stats = on != 0;
@@ -481,12 +543,14 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
     HIPC(hipEventRecord(h->ev[0], st));
     for (int it = 0; it < iters; ++it) {
         if (which == 0) {
-            HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, h->cfg.max_sqdist, h->rmax,
-                                    h->world.p, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p, nullptr, st));
+            HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->M,
+                                    h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
+                                    h->slow_list.p, h->slow_ub.p, h->slow_count.p, nullptr, st));
+            HIPC(hipMemsetAsync(h->slow_count.p, 0, flh::list_stripes() * sizeof(uint32_t), st));
             h->searched_once = true;
         } else {
             HIPC(flh::launch_fit(s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p,
-                                 h->normvec.p, h->partials.p, h->part2.p, h->gram.p, st));
+                                 h->normvec.p, h->world.p, h->partials.p, h->part2.p, h->gram.p, h->tickets.p, h->slow_count.p, st));
         }
     }
     HIPC(hipEventRecord(h->ev[3], st));
@@ -505,10 +569,14 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
 // ---------------------------------------------------------------------------------------------
 int flh_fetch_selected(flh_handle* h, uint8_t* flags) {
     if (!h || !flags) return fail("flh_fetch_selected: null argument");
-    if (h->N == 0) return 0;
+    const size_t N = h->N;
+    if (N == 0) return 0;
     HIPC(hipSetDevice(h->device));
-    HIPC(hipMemcpyAsync(flags, h->selected.p, h->N, hipMemcpyDeviceToHost, h->stream));
+    std::vector<uint8_t> tmp(N);
+    HIPC(hipMemcpyAsync(tmp.data(), h->selected.p, N, hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
+    const uint32_t* perm = h->cur->h_perm.data();
+    for (size_t i = 0; i < N; ++i) flags[perm[i]] = tmp[i];
     return 0;
 }
 
@@ -519,17 +587,22 @@ int flh_fetch_neighbors(flh_handle* h, int32_t* idx, float* d2, uint8_t* cnt) {
     HIPC(hipSetDevice(h->device));
     std::vector<float4> pts(5 * N);
     std::vector<float> dd(5 * N);
+    std::vector<uint8_t> cc(N);
     HIPC(hipMemcpyAsync(pts.data(), h->nn_pts.p, 5 * N * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipMemcpyAsync(dd.data(), h->nn_d2.p, 5 * N * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    if (cnt) HIPC(hipMemcpyAsync(cnt, h->nn_cnt.p, N, hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipMemcpyAsync(cc.data(), h->nn_cnt.p, N, hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
-    for (size_t i = 0; i < N; ++i)
+    const uint32_t* perm = h->cur->h_perm.data();
+    for (size_t i = 0; i < N; ++i) {
+        const size_t o = perm[i];
         for (int j = 0; j < 5; ++j) {
             int32_t id;
             std::memcpy(&id, &pts[(size_t)j * N + i].w, 4);
-            idx[i * 5 + j] = id;
-            d2[i * 5 + j] = id < 0 ? INFINITY : dd[(size_t)j * N + i];
+            idx[o * 5 + j] = id;
+            d2[o * 5 + j] = id < 0 ? INFINITY : dd[(size_t)j * N + i];
         }
+        if (cnt) cnt[o] = cc[i];
+    }
     return 0;
 }
 
@@ -541,16 +614,24 @@ int flh_fetch_world(flh_handle* h, float* xyz) {
     std::vector<float4> w(N);
     HIPC(hipMemcpyAsync(w.data(), h->world.p, N * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
-    for (size_t i = 0; i < N; ++i) { xyz[3 * i] = w[i].x; xyz[3 * i + 1] = w[i].y; xyz[3 * i + 2] = w[i].z; }
+    const uint32_t* perm = h->cur->h_perm.data();
+    for (size_t i = 0; i < N; ++i) {
+        const size_t o = perm[i];
+        xyz[3 * o] = w[i].x; xyz[3 * o + 1] = w[i].y; xyz[3 * o + 2] = w[i].z;
+    }
     return 0;
 }
 
 int flh_fetch_normvec(flh_handle* h, float* out) {
     if (!h || !out) return fail("flh_fetch_normvec: null argument");
-    if (h->N == 0) return 0;
+    const size_t N = h->N;
+    if (N == 0) return 0;
     HIPC(hipSetDevice(h->device));
-    HIPC(hipMemcpyAsync(out, h->normvec.p, h->N * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+    std::vector<float4> nv(N);
+    HIPC(hipMemcpyAsync(nv.data(), h->normvec.p, N * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
+    const uint32_t* perm = h->cur->h_perm.data();
+    for (size_t i = 0; i < N; ++i) std::memcpy(out + 4 * (size_t)perm[i], &nv[i], 16);
     return 0;
 }
 
@@ -583,13 +664,17 @@ int flh_fetch_rows(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* 
     *n_rows = n;
     if (!hx || !hv) return 0;
     if (cap < n) return fail("flh_fetch_rows: buffers too small");
+    std::vector<uint32_t> inv(N ? N : 1);
+    for (size_t i = 0; i < N; ++i) inv[h->cur->h_perm[i]] = (uint32_t)i;
+    const std::vector<float>& hbody = h->cur->h_body;
     const StateDev& s = h->last_state;
     const double rotc[4] = {-s.rot[0], -s.rot[1], -s.rot[2], s.rot[3]};
     const double offRc[4] = {-s.offR[0], -s.offR[1], -s.offR[2], s.offR[3]};
     int64_t k = 0;
-    for (size_t i = 0; i < N; ++i) {
+    for (size_t o = 0; o < N; ++o) {  // original scan order, like the compaction loop at :697-706
+        const size_t i = inv[o];
         if (!sel[i]) continue;
-        const double pb[3] = {h->h_body[3 * i], h->h_body[3 * i + 1], h->h_body[3 * i + 2]};
+        const double pb[3] = {hbody[3 * o], hbody[3 * o + 1], hbody[3 * o + 2]};
         double pt[3], C[3];
         host_quat_rot(s.offR, pb, pt);
         for (int d = 0; d < 3; ++d) pt[d] += s.offT[d];

@@ -25,7 +25,7 @@ struct GridParams {
     uint32_t hash_mask;
     int hash_shift;          // 32 - log2(hash size)
     const uint2* hash;       // (brick_key, brick_rank); empty = 0xFFFFFFFF
-    const uint2* cells;      // [nbricks * 64] (start, count) into pts
+    const uint32_t* starts;  // [nbricks * 65] prefix table: cell i of brick b holds pts[starts[b*65+i] .. starts[b*65+i+1])
     const float4* pts;       // map points sorted by (brick, cell); .w = original map index (bits)
 };
 
@@ -249,18 +249,29 @@ __device__ __forceinline__ void cell_of(const GridParams& g, float x, float y, f
     fx -= flx; fy -= fly; fz -= flz;
 }
 
+constexpr int kBrickStride = 65;  // 64 cells + end sentinel
+
+// rank of a brick in the sorted order, or 0xFFFFFFFF if the brick holds no points
+__device__ __forceinline__ uint32_t lookup_brick(const GridParams& g, uint32_t key) {
+    const unsigned long long* __restrict__ hash64 = reinterpret_cast<const unsigned long long*>(g.hash);
+    uint32_t slot = hash_slot(key, g.hash_shift);
+    for (;;) {
+        const unsigned long long e = hash64[slot];
+        if ((uint32_t)e == key) return (uint32_t)(e >> 32);
+        if ((uint32_t)e == kEmptyKey) return kEmptyKey;
+        slot = (slot + 1) & g.hash_mask;
+    }
+}
+
 // (start,count) of a cell, or count 0 when the cell / its brick is empty or out of range.
 __device__ __forceinline__ uint2 lookup_cell(const GridParams& g, int cx, int cy, int cz) {
     if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cy >= (unsigned)g.ny || (unsigned)cz >= (unsigned)g.nz)
         return make_uint2(0u, 0u);
-    const uint32_t key = brick_key(cx, cy, cz);
-    uint32_t slot = hash_slot(key, g.hash_shift);
-    for (;;) {
-        const uint2 e = g.hash[slot];
-        if (e.x == key) return g.cells[(size_t)e.y * 64 + cell_local(cx, cy, cz)];
-        if (e.x == kEmptyKey) return make_uint2(0u, 0u);
-        slot = (slot + 1) & g.hash_mask;
-    }
+    const uint32_t rank = lookup_brick(g, brick_key(cx, cy, cz));
+    if (rank == kEmptyKey) return make_uint2(0u, 0u);
+    const uint32_t* st = g.starts + (size_t)rank * kBrickStride + cell_local(cx, cy, cz);
+    const uint32_t a = st[0], b = st[1];
+    return make_uint2(a, b - a);
 }
 
 }  // namespace flh

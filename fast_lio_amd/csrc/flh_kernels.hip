@@ -13,12 +13,15 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+
 #include "flh_device.hpp"
 
 namespace flh {
 
 typedef unsigned long long u64;
 constexpr u64 kInfKey = ~0ull;
+constexpr int kStripes = 64;  // work-list stripes (one counter + one list segment each)
 
 // ------------------------------------------------------------------------------------------------
 // K0: map index
@@ -53,27 +56,39 @@ __global__ void __launch_bounds__(256) k_map_gather(const float4* __restrict__ p
     brick_head[i] = (i == 0 || (keys_sorted[i - 1] >> 6) != (k >> 6)) ? 1u : 0u;
 }
 
-// brick_rank_incl[i] = inclusive prefix sum of brick_head (rank+1).  Cell heads write (start,count);
-// brick heads insert (key -> rank) into the open-addressing directory.
-__global__ void __launch_bounds__(256) k_map_cells(const u64* __restrict__ keys_sorted,
-                                                   const uint32_t* __restrict__ brick_rank_incl, uint32_t M,
-                                                   uint2* __restrict__ cells, uint2* __restrict__ hash,
-                                                   uint32_t hash_mask, int hash_shift) {
+// brick_start[rank] = first sorted position of the brick (brick_start[nbricks] = M is written by the host)
+__global__ void __launch_bounds__(256) k_brick_starts(const uint32_t* __restrict__ brick_head,
+                                                      const uint32_t* __restrict__ brick_rank_incl, uint32_t M,
+                                                      uint32_t* __restrict__ brick_start) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
-    const u64 k = keys_sorted[i];
-    const bool cell_head = (i == 0) || keys_sorted[i - 1] != k;
-    if (!cell_head) return;
-    const uint32_t rank = brick_rank_incl[i] - 1;
-    uint32_t e = i + 1;
-    while (e < M && keys_sorted[e] == k) ++e;
-    cells[(size_t)rank * 64 + (uint32_t)(k & 63)] = make_uint2(i, e - i);
-    const bool bhead = (i == 0) || (keys_sorted[i - 1] >> 6) != (k >> 6);
-    if (bhead) {
-        const uint32_t bkey = (uint32_t)(k >> 6);
-        uint32_t slot = hash_slot(bkey, hash_shift);
+    if (brick_head[i]) brick_start[brick_rank_incl[i] - 1] = i;
+}
+
+// One thread per (brick, local cell 0..64): starts[b*65 + l] = lower_bound of key (bkey<<6 | l) inside the
+// brick's run of sorted keys, so that any run of consecutive local cells (an x-row segment) maps to ONE
+// contiguous point range.  Thread l == 0 also inserts (bkey -> rank) into the open-addressing directory.
+__global__ void __launch_bounds__(256) k_brick_tables(const u64* __restrict__ keys_sorted,
+                                                      const uint32_t* __restrict__ brick_start, uint32_t nbricks,
+                                                      uint32_t* __restrict__ starts, uint2* __restrict__ hash,
+                                                      uint32_t hash_mask, int hash_shift) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nbricks * (uint32_t)kBrickStride) return;
+    const uint32_t rank = t / kBrickStride, l = t - rank * kBrickStride;
+    const uint32_t b0 = brick_start[rank], b1 = brick_start[rank + 1];
+    const u64 bkey = keys_sorted[b0] >> 6;
+    const u64 target = (bkey << 6) + l;  // l == 64 -> first key of the next brick value
+    uint32_t lo = b0, hi = b1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (keys_sorted[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    starts[t] = lo;
+    if (l == 0) {
+        const uint32_t k32 = (uint32_t)bkey;
+        uint32_t slot = hash_slot(k32, hash_shift);
         for (;;) {
-            const uint32_t prev = atomicCAS(&hash[slot].x, kEmptyKey, bkey);
+            const uint32_t prev = atomicCAS(&hash[slot].x, kEmptyKey, k32);
             if (prev == kEmptyKey) {
                 hash[slot].y = rank;
                 break;
@@ -84,46 +99,358 @@ __global__ void __launch_bounds__(256) k_map_cells(const u64* __restrict__ keys_
 }
 
 // ------------------------------------------------------------------------------------------------
-// A: exact 5-NN.  LPQ lanes cooperate on one query: lane t owns the cells t, t+LPQ, ... of the
-// (2r+1)^3 cube around the query's cell, keeps a private sorted top-5 of what it sees, then the group
-// merges the private lists with 5 rounds of {64-bit min butterfly, ballot, pop}.  Keys are
-// (d2 bits << 32 | original map index): one unsigned compare orders by (d2, index), the tie-break the
-// oracle uses.  Ring r is exact once the 5th distance is within the cube's guaranteed radius
-// (r + distance to the nearest face of the centre cell) * c; otherwise the cube grows, up to the gate
-// radius sqrt(max_sqdist) beyond which a result can never be selected (src/laserMapping.cpp:671).
+// A: exact 5-NN, two kernels chained through a work list.
+//
+// A1 k_search_ring<4,1,..>  every query, the 3x3x3 cells around its cell (settles every query whose 5th
+//                           neighbour is provably inside that block and free of distance ties)
+// A2 k_search_exact         the rest, with the 5th distance A1 found as a search radius: one pass over the
+//                           cells intersecting that ball (never beyond the gate radius sqrt(max_sqdist) of
+//                           src/laserMapping.cpp:671), 64-bit (d2, map index) keys, 32 lanes per query.
+//
+// k_search_ring: LPQ lanes per query.  Each (y,z) row of the (2R+1)^3 block is an x-run of consecutive
+// local cells, i.e. ONE contiguous range of the cell-sorted map (two if the run crosses a brick boundary).
+// The 2(2R+1)^2 segment slots are resolved in parallel by the group's lanes (directory probe, then two
+// reads of the brick's prefix table), parked in LDS and prefix-summed, so that the group's T candidates
+// form one flat list dealt round-robin to its lanes, eight independent loads in flight per lane.
+//   pass A  d2 of every candidate (exact fp32 op order), cached in LDS, and the five smallest kept in
+//           registers with a payload-free insert: K0' = min(K0,t), Kj' = med3(K(j-1),Kj,t); lists merged
+//           over DPP with a bitonic network.
+//   pass B  walks the cached d2: the (five) candidates with d2 <= the 5th distance fetch their point and
+//           write themselves to the row of their rank (= number of kept distances below theirs).
+// A query is settled when its 5th distance lies within the block's guaranteed radius
+// (R + distance to the nearest face of the centre cell) * c and all distances involved are distinct
+// (equal distances need the oracle's (d2, map index) order); otherwise it goes to the next list.
 // ------------------------------------------------------------------------------------------------
-template <int LPQ>
-__global__ void __launch_bounds__(256)
-k_search(GridParams g, StateDev s, const float4* __restrict__ body, int N, float max_sqdist, int rmax,
-         float4* __restrict__ world, float4* __restrict__ nn_pts, float* __restrict__ nn_d2,
-         uint8_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected, u64* __restrict__ cand_counter) {
-    const int tid = blockIdx.x * 256 + threadIdx.x;
-    const int q = tid / LPQ;
-    const int lane = threadIdx.x & (LPQ - 1);
-    if (q >= N) return;  // group-uniform
-    const float4 b = body[q];
-    float qx, qy, qz;
-    body_to_world(s, b.x, b.y, b.z, qx, qy, qz);
-    int cx, cy, cz;
-    float fx, fy, fz;
-    cell_of(g, qx, qy, qz, cx, cy, cz, fx, fy, fz);
-    const float minfrac = fminf(fminf(fminf(fx, 1.f - fx), fminf(fy, 1.f - fy)), fminf(fz, 1.f - fz));
-
-    const int wl0 = (threadIdx.x & 63) & ~(LPQ - 1);  // first wave-lane of this group
-    const u64 gmask = (LPQ == 64) ? ~0ull : (((1ull << (LPQ & 63)) - 1ull) << wl0);
-
-    u64 rk[5];
-    uint32_t rp[5];
-    int cnt = 0;
-    float d5 = INFINITY;
-    float ub = max_sqdist;
-    uint32_t ncand = 0;
-
-    for (int r = 1; r <= rmax; ++r) {
-        u64 k[5];
-        uint32_t p[5];
+struct Top5 {
+    u64 k[5];
+    uint32_t p[5];
+    __device__ __forceinline__ void reset() {
 #pragma unroll
         for (int j = 0; j < 5; ++j) { k[j] = kInfKey; p[j] = 0; }
+    }
+    __device__ __forceinline__ void insert(u64 key, uint32_t pos) {
+        if (key < k[4]) {
+            k[4] = key;
+            p[4] = pos;
+#pragma unroll
+            for (int j = 4; j > 0; --j) {
+                if (k[j] < k[j - 1]) {
+                    const u64 tk = k[j]; k[j] = k[j - 1]; k[j - 1] = tk;
+                    const uint32_t tp = p[j]; p[j] = p[j - 1]; p[j - 1] = tp;
+                }
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ u64 make_key(float d, float w) {
+    return ((u64)__float_as_uint(d) << 32) | (u64)__float_as_uint(w);
+}
+
+// ---- sorted top-5 of fp32 distances with no payload: five independent VALU ops per insert
+__device__ __forceinline__ void ins5f(float (&K)[5], float t) {
+    const float n0 = fminf(K[0], t);
+    const float n1 = __builtin_amdgcn_fmed3f(K[0], K[1], t);
+    const float n2 = __builtin_amdgcn_fmed3f(K[1], K[2], t);
+    const float n3 = __builtin_amdgcn_fmed3f(K[2], K[3], t);
+    const float n4 = __builtin_amdgcn_fmed3f(K[3], K[4], t);
+    K[0] = n0; K[1] = n1; K[2] = n2; K[3] = n3; K[4] = n4;
+}
+__device__ __forceinline__ void cexf(float& a, float& b) {  // compare-exchange: a <= b afterwards
+    const float lo = fminf(a, b);
+    b = fmaxf(a, b);
+    a = lo;
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+// lowest five of (mine U partner's), sorted: bitonic half-cleaner, then a 9-comparator network for 5
+// (both verified exhaustively with the 0/1 principle)
+template <int CTRL>
+__device__ __forceinline__ void merge5f(float (&K)[5]) {
+    float B[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) B[j] = dpp_f32<CTRL>(K[j]);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) K[j] = fminf(K[j], B[4 - j]);
+    cexf(K[0], K[1]); cexf(K[3], K[4]); cexf(K[2], K[4]); cexf(K[2], K[3]); cexf(K[1], K[4]);
+    cexf(K[0], K[3]); cexf(K[0], K[2]); cexf(K[1], K[3]); cexf(K[1], K[2]);
+}
+template <int LPQ>
+__device__ __forceinline__ void merge_group5(float (&K)[5]) {
+    if (LPQ >= 2) merge5f<0xB1>(K);    // quad_perm [1,0,3,2]
+    if (LPQ >= 4) merge5f<0x4E>(K);    // quad_perm [2,3,0,1]
+    if (LPQ >= 8) merge5f<0x141>(K);   // row_half_mirror
+    if (LPQ >= 16) merge5f<0x140>(K);  // row_mirror
+}
+template <int LPQ>
+__device__ __forceinline__ int sum_group(int v) {
+    if (LPQ >= 2) v += dpp_i32<0xB1>(v);
+    if (LPQ >= 4) v += dpp_i32<0x4E>(v);
+    if (LPQ >= 8) v += dpp_i32<0x141>(v);
+    if (LPQ >= 16) v += dpp_i32<0x140>(v);
+    return v;
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_pt(__amdgpu_buffer_rsrc_t rsrc, uint32_t idx) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx << 4), 0, 0);  // out of range -> zeros
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+template <int LPQ, int RING, int CAP, int MODE, int ABL = 0>
+__global__ void __launch_bounds__(256)
+k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist,
+              float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
+              uint8_t* __restrict__ selected, const uint32_t* __restrict__ in_list, const uint32_t* __restrict__ in_count,
+              uint32_t* __restrict__ out_list, uint32_t* __restrict__ out_count, uint32_t stripe_cap,
+              float* __restrict__ ub_out, u64* __restrict__ cand_counter) {
+    // Work lists are striped kStripes ways (stripe = blockIdx & (kStripes-1)) and appended to with ONE global
+    // atomic per block: thousands of returning atomics on a single word serialise at ~11 ns each and were the
+    // whole runtime of an earlier version of this kernel.
+    constexpr int W = 2 * RING + 1;                // block edge in cells
+    constexpr int NR = W * W;                      // (y,z) rows: each an x-run of W consecutive cells
+    constexpr int NSEG = NR * 2;                   // a run crosses at most one brick boundary -> two segments
+    constexpr int SPL = (NSEG + LPQ - 1) / LPQ;    // segments resolved per lane
+    constexpr int GPB = 256 / LPQ;                 // query groups per block
+    constexpr int UNR = 8;                         // independent point loads in flight per lane
+    constexpr int CPL = CAP / LPQ;                 // cached distances per lane
+    // seg: (first point, length); after the prefix step: (first point - flat start, flat end), so that flat
+    // candidate t of the group lives at pts[seg.x + t] for t < seg.y
+    __shared__ uint2 seg[GPB][NSEG + 1];
+    // MODE 0: fp32 d2 cache for pass B; 2: no cache (pass B recomputes) -- the cache costs LDS, i.e. occupancy
+    __shared__ float dcache[MODE == 0 ? GPB : 1][MODE == 0 ? CAP : 1];
+    __shared__ uint32_t blk_n, blk_base;
+    const int grp = threadIdx.x / LPQ;
+    const int lane = threadIdx.x & (LPQ - 1);
+    const uint32_t stripe = blockIdx.x & (kStripes - 1);
+    const uint32_t sub = blockIdx.x / kStripes, nsub = gridDim.x / kStripes;  // position among the stripe's blocks
+    if (in_list) in_list += (size_t)stripe * stripe_cap;
+    out_list += (size_t)stripe * stripe_cap;
+    const uint32_t total = in_list ? in_count[stripe] : (uint32_t)N;
+    const uint32_t first_base = in_list ? sub * GPB : blockIdx.x * GPB;
+    const uint32_t step_base = in_list ? nsub * GPB : gridDim.x * GPB;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)g.pts, 0, (int)(map_points * 16u), 0x00020000);
+    const u64* __restrict__ hash64 = reinterpret_cast<const u64*>(g.hash);
+
+    for (uint32_t base = first_base; base < total; base += step_base) {  // block-uniform trip count
+        if (threadIdx.x == 0) blk_n = 0;
+        const uint32_t gi = base + grp;
+        const bool live = gi < total;
+        const int q = in_list ? (int)in_list[live ? gi : total - 1] : (int)(live ? gi : total - 1);
+        const float4 b = body[q];
+        float qx, qy, qz;
+        body_to_world(s, b.x, b.y, b.z, qx, qy, qz);
+        int cx, cy, cz;
+        float fx, fy, fz;
+        cell_of(g, qx, qy, qz, cx, cy, cz, fx, fy, fz);
+        const float minfrac = fminf(fminf(fminf(fx, 1.f - fx), fminf(fy, 1.f - fy)), fminf(fz, 1.f - fz));
+
+        // ---- phase 1: directory probes of this lane's segments
+        const int x0 = max(cx - RING, 0), x1 = min(cx + RING, g.nx - 1);
+        const bool xok = x0 <= x1;
+        const bool split = (x0 >> 2) != (x1 >> 2);
+        uint32_t key[SPL], slot[SPL], i0[SPL], i1[SPL];
+        u64 he[SPL];
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {
+            const int sl = lane + u * LPQ;
+            const int half = sl / NR, r = sl - half * NR;  // slots [0,NR): first segments, [NR,2NR): second (split rows)
+            const int rz = r / W, ry = r - rz * W;
+            const int y = cy + ry - RING, z = cz + rz - RING;
+            bool valid = (sl < NSEG) && xok && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
+            int xa, xb;
+            if (half == 0) { xa = x0; xb = split ? (x0 | 3) : x1; }
+            else { xa = x1 & ~3; xb = x1; valid = valid && split; }
+            key[u] = brick_key(xa, y, z);
+            i0[u] = cell_local(xa, y, z);
+            i1[u] = cell_local(xb, y, z) + 1;
+            slot[u] = hash_slot(key[u], g.hash_shift);
+            he[u] = valid ? hash64[slot[u]] : (u64)kEmptyKey;
+        }
+        // ---- phase 2: point ranges -> LDS
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {
+            const int sl = lane + u * LPQ;
+            u64 e = he[u];
+            while ((uint32_t)e != key[u] && (uint32_t)e != kEmptyKey) {  // collision: linear probing (rare)
+                slot[u] = (slot[u] + 1) & g.hash_mask;
+                e = hash64[slot[u]];
+            }
+            uint32_t a = 0, n = 0;
+            if ((uint32_t)e == key[u]) {
+                const uint32_t* st = g.starts + (size_t)(uint32_t)(e >> 32) * kBrickStride;
+                a = st[i0[u]];
+                n = st[i1[u]] - a;
+            }
+            if (sl < NSEG) seg[grp][sl] = make_uint2(a, n);
+        }
+        __syncthreads();
+        // ---- prefix over the group's segments (every lane runs the same sums; lane s % LPQ rewrites slot s)
+        uint32_t T = 0;
+        {
+            uint2 mine[SPL];
+#pragma unroll
+            for (int sidx = 0; sidx < NSEG; ++sidx) {
+                const uint2 an = seg[grp][sidx];
+                if ((sidx % LPQ) == lane) mine[sidx / LPQ] = make_uint2(an.x - T, T + an.y);
+                T += an.y;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < SPL; ++u)
+                if (lane + u * LPQ < NSEG) seg[grp][lane + u * LPQ] = mine[u];
+            if (lane == 0) seg[grp][NSEG] = make_uint2(0u, 0xFFFFFFFFu);  // sentinel: the walk never runs off the end
+        }
+        __syncthreads();
+        if (ABL == 1) {  // ablation: prologue only
+            if (live && lane == 0) nn_cnt[q] = (uint8_t)T;
+            __syncthreads();
+            continue;
+        }
+        // ---- pass A: d2 of every candidate; the group's T candidates are dealt round-robin to its lanes
+        float K[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) K[j] = INFINITY;
+        int cur = 0;
+        uint2 sg = seg[grp][0];
+        int k = 0;
+        for (uint32_t t0 = lane; t0 < T; t0 += LPQ * UNR) {
+            float4 v[UNR];
+#pragma unroll
+            for (int w = 0; w < UNR; ++w) {
+                const uint32_t t = t0 + (uint32_t)(w * LPQ);
+                while (t >= sg.y) sg = seg[grp][++cur];
+                v[w] = load_pt(rsrc, (t < T) ? sg.x + t : 0xFFFFFFFu);  // past the end: out-of-range -> zeros
+            }
+#pragma unroll
+            for (int w = 0; w < UNR; ++w) {
+                float d = dist2(qx, qy, qz, v[w].x, v[w].y, v[w].z);
+                d = (t0 + (uint32_t)(w * LPQ) < T) ? d : INFINITY;
+                if (MODE == 0) { if (k + w < CPL) dcache[grp][(k + w) * LPQ + lane] = d; }
+                ins5f(K, d);
+            }
+            k += UNR;
+        }
+        merge_group5<LPQ>(K);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) cnt += (K[j] < INFINITY) ? 1 : 0;
+        if (ABL == 2) {  // ablation: prologue + pass A
+            if (live && lane == 0) { nn_cnt[q] = (uint8_t)cnt; nn_d2[q] = K[4]; }
+            __syncthreads();
+            continue;
+        }
+        bool tie = false;  // equal distances inside the list: the (d2, map index) order needs the general path
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tie = tie || (K[j + 1] < INFINITY && K[j] == K[j + 1]);
+        const float d5 = (cnt == 5) ? K[4] : INFINITY;
+        const float gr = ((float)RING + minfrac) * g.c - 2e-3f * g.c;  // guaranteed-complete radius (fp margin)
+        const float gr2 = gr * gr;
+        const bool overflow = (MODE == 0) && (T > (uint32_t)CAP);
+        bool done = !tie && !overflow && ((cnt == 5 && d5 <= gr2) || gr2 >= max_sqdist);
+        if (cand_counter && live && lane == 0) atomicAdd(cand_counter, (u64)T);
+        // ---- pass B: every candidate whose distance made the list writes itself to its rank's row
+        int emitted = 0;
+        if (done && live) {
+            const float tau = d5;  // cnt < 5: INFINITY -> every real candidate qualifies
+            cur = 0;
+            sg = seg[grp][0];
+            k = 0;
+            for (uint32_t t0 = lane; t0 < T; t0 += LPQ * UNR) {
+                uint32_t idx[UNR];
+                float4 v[UNR];
+#pragma unroll
+                for (int w = 0; w < UNR; ++w) {
+                    const uint32_t t = t0 + (uint32_t)(w * LPQ);
+                    while (t >= sg.y) sg = seg[grp][++cur];
+                    idx[w] = (t < T) ? sg.x + t : 0xFFFFFFFu;
+                    if (MODE != 0) v[w] = load_pt(rsrc, idx[w]);
+                }
+#pragma unroll
+                for (int w = 0; w < UNR; ++w) {
+                    const bool in = t0 + (uint32_t)(w * LPQ) < T;
+                    float d;
+                    if (MODE == 0) d = dcache[grp][(k + w) * LPQ + lane];
+                    else d = dist2(qx, qy, qz, v[w].x, v[w].y, v[w].z);
+                    if (in && d <= tau) {
+                        if (MODE == 0) v[w] = load_pt(rsrc, idx[w]);
+                        const int rank = (d > K[0]) + (d > K[1]) + (d > K[2]) + (d > K[3]);
+                        nn_pts[(size_t)rank * N + q] = v[w];
+                        nn_d2[(size_t)rank * N + q] = d;
+                        ++emitted;
+                    }
+                }
+                k += UNR;
+            }
+        }
+        emitted = sum_group<LPQ>(emitted);
+        if (done && emitted != cnt) done = false;  // a 6th candidate ties with the 5th distance
+        uint32_t my_slot = 0;
+        const bool append = live && !done && lane == 0;
+        if (append) my_slot = atomicAdd(&blk_n, 1u);  // LDS atomic
+        if (live && done && lane == 0) {
+            for (int j = cnt; j < 5; ++j) {  // fewer than five points inside the gate radius: sentinel rows
+                nn_pts[(size_t)j * N + q] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+                nn_d2[(size_t)j * N + q] = INFINITY;
+            }
+            nn_cnt[q] = (uint8_t)cnt;
+            selected[q] = (cnt == 5 && !(d5 > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && blk_n) blk_base = atomicAdd(out_count + stripe, blk_n);
+        __syncthreads();
+        if (append) {
+            out_list[blk_base + my_slot] = (uint32_t)q;
+            ub_out[q] = d5;  // every point of the true answer has d2 <= the 5th distance found so far
+        }
+        __syncthreads();
+    }
+}
+
+// A2: general exact path over the queries A1 could not settle; 32 lanes per query, 8 queries per block.
+// One pass over the cells that intersect the ball of radius sqrt(ub) around the query, where ub is the 5th
+// distance A1 found (an upper bound of the true one) capped by the gate max_sqdist of
+// src/laserMapping.cpp:671 -- beyond the gate a result can never be selected.  64-bit keys
+// (d2 bits << 32 | original map index) give the oracle's (d2, index) order, ties included.
+__global__ void __launch_bounds__(256)
+k_search_exact(GridParams g, StateDev s, const float4* __restrict__ body, int N, float max_sqdist, int rmax,
+               float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
+               uint8_t* __restrict__ selected, const uint32_t* __restrict__ slow_list,
+               const uint32_t* __restrict__ slow_count, uint32_t stripe_cap, const float* __restrict__ ub_in,
+               int all_queries, u64* __restrict__ cand_counter) {
+    constexpr int LPQ = 32;
+    const int lane = threadIdx.x & (LPQ - 1);
+    const int grp = threadIdx.x / LPQ;
+    const uint32_t stripe = blockIdx.x & (kStripes - 1);
+    const uint32_t sub = blockIdx.x / kStripes, nsub = gridDim.x / kStripes;
+    if (!all_queries) slow_list += (size_t)stripe * stripe_cap;
+    const uint32_t total = all_queries ? (uint32_t)N : slow_count[stripe];
+    const uint32_t gi0 = all_queries ? blockIdx.x * 8 + grp : sub * 8 + grp;
+    const uint32_t gstep = all_queries ? gridDim.x * 8 : nsub * 8;
+    const int wl0 = (threadIdx.x & 63) & ~(LPQ - 1);
+    const u64 gmask = ((1ull << LPQ) - 1ull) << wl0;
+    for (uint32_t gi = gi0; gi < total; gi += gstep) {
+        const int q = all_queries ? (int)gi : (int)slow_list[gi];
+        const float4 b = body[q];
+        float qx, qy, qz;
+        body_to_world(s, b.x, b.y, b.z, qx, qy, qz);
+        int cx, cy, cz;
+        float fx, fy, fz;
+        cell_of(g, qx, qy, qz, cx, cy, cz, fx, fy, fz);
+        const float ub = all_queries ? max_sqdist : fminf(ub_in[q], max_sqdist);
+        // cells with |offset| <= R cover the ball; +1 absorbs the position inside the centre cell
+        const int r = min(rmax, (int)(sqrtf(ub) * g.inv_c) + 1);
+        const float ubp = ub * 1.0001f + 1e-6f;
+        Top5 L;
+        L.reset();
+        uint32_t ncand = 0;
         const int side = 2 * r + 1;
         const int side2 = side * side;
         const int ncell = side2 * side;
@@ -132,89 +459,63 @@ k_search(GridParams g, StateDev s, const float4* __restrict__ body, int N, float
             const int rem = t - iz * side2;
             const int iy = rem / side;
             const int dx = rem - iy * side - r, dy = iy - r, dz = iz - r;
-            if (r > 1) {
-                // lower bound of the distance from the query to this cell's box; skip if beyond the bound
-                const float gx = dx > 0 ? (float)dx - fx : (dx < 0 ? fx - (float)(dx + 1) : 0.f);
-                const float gy = dy > 0 ? (float)dy - fy : (dy < 0 ? fy - (float)(dy + 1) : 0.f);
-                const float gz = dz > 0 ? (float)dz - fz : (dz < 0 ? fz - (float)(dz + 1) : 0.f);
-                const float lb = ((gx * gx + gy * gy) + gz * gz) * (g.c * g.c) * 0.995f - 1e-5f;
-                if (lb > ub) continue;
-            }
+            // lower bound of the distance from the query to this cell's box; skip cells outside the ball
+            const float gx = dx > 0 ? (float)dx - fx : (dx < 0 ? fx - (float)(dx + 1) : 0.f);
+            const float gy = dy > 0 ? (float)dy - fy : (dy < 0 ? fy - (float)(dy + 1) : 0.f);
+            const float gz = dz > 0 ? (float)dz - fz : (dz < 0 ? fz - (float)(dz + 1) : 0.f);
+            const float lb = ((gx * gx + gy * gy) + gz * gz) * (g.c * g.c) * 0.995f - 1e-5f;
+            if (lb > ubp) continue;
             const uint2 e = lookup_cell(g, cx + dx, cy + dy, cz + dz);
-            const uint32_t end = e.x + e.y;
             ncand += e.y;
-            for (uint32_t i0 = e.x; i0 < end; i0 += 4) {
-                float4 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = g.pts[min(i0 + u, end - 1)];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (i0 + u < end) {
-                        const float d = dist2(qx, qy, qz, v[u].x, v[u].y, v[u].z);
-                        const u64 key = ((u64)__float_as_uint(d) << 32) | (u64)__float_as_uint(v[u].w);
-                        if (key < k[4]) {
-                            k[4] = key;
-                            p[4] = i0 + u;
-#pragma unroll
-                            for (int j = 4; j > 0; --j) {
-                                if (k[j] < k[j - 1]) {
-                                    const u64 tk = k[j]; k[j] = k[j - 1]; k[j - 1] = tk;
-                                    const uint32_t tp = p[j]; p[j] = p[j - 1]; p[j - 1] = tp;
-                                }
-                            }
-                        }
-                    }
-                }
+            for (uint32_t i = e.x; i < e.x + e.y; ++i) {
+                const float4 pv = g.pts[i];
+                L.insert(make_key(dist2(qx, qy, qz, pv.x, pv.y, pv.z), pv.w), i);
             }
         }
         // ---- group merge: 5 x (min butterfly, ballot, pop)
-        cnt = 0;
+        u64 rk[5];
+        uint32_t rp[5];
+        int cnt = 0;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            u64 m = k[0];
+            u64 m = L.k[0];
 #pragma unroll
             for (int off = LPQ / 2; off >= 1; off >>= 1) {
                 const u64 o = __shfl_xor(m, off, LPQ);
                 m = o < m ? o : m;
             }
-            const bool win = (k[0] == m) && (m != kInfKey);
+            const bool win = (L.k[0] == m) && (m != kInfKey);
             const u64 bal = __ballot(win) & gmask;
             const int wl = bal ? (__ffsll((long long)bal) - 1) : wl0;
-            const uint32_t wp = __shfl(p[0], wl, 64);
+            const uint32_t wp = __shfl(L.p[0], wl, 64);
             rk[j] = m;
             rp[j] = wp;
             if (m != kInfKey) ++cnt;
             if (win) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { k[t] = k[t + 1]; p[t] = p[t + 1]; }
-                k[4] = kInfKey;
+                for (int t = 0; t < 4; ++t) { L.k[t] = L.k[t + 1]; L.p[t] = L.p[t + 1]; }
+                L.k[4] = kInfKey;
             }
         }
-        d5 = (cnt == 5) ? __uint_as_float((uint32_t)(rk[4] >> 32)) : INFINITY;
-        const float gr = ((float)r + minfrac) * g.c - 2e-3f * g.c;  // guaranteed-complete radius (with fp margin)
-        const float gr2 = gr * gr;
-        if ((cnt == 5 && d5 <= gr2) || gr2 >= max_sqdist) break;
-        ub = fminf(d5, max_sqdist);
-    }
-
-    if (lane < 5) {
-        u64 kk = rk[0];
-        uint32_t pp = rp[0];
+        const float d5 = (cnt == 5) ? __uint_as_float((uint32_t)(rk[4] >> 32)) : INFINITY;
+        if (lane < 5) {
+            u64 kk = rk[0];
+            uint32_t pp = rp[0];
 #pragma unroll
-        for (int j = 1; j < 5; ++j)
-            if (lane == j) { kk = rk[j]; pp = rp[j]; }
-        const bool has = lane < cnt;
-        float4 v = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-        if (has) v = g.pts[pp];
-        nn_pts[(size_t)lane * N + q] = v;
-        nn_d2[(size_t)lane * N + q] = has ? __uint_as_float((uint32_t)(kk >> 32)) : INFINITY;
+            for (int j = 1; j < 5; ++j)
+                if (lane == j) { kk = rk[j]; pp = rp[j]; }
+            const bool has = lane < cnt;
+            float4 v = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            if (has) v = g.pts[pp];
+            nn_pts[(size_t)lane * N + q] = v;
+            nn_d2[(size_t)lane * N + q] = has ? __uint_as_float((uint32_t)(kk >> 32)) : INFINITY;
+        }
+        if (lane == 0) {
+            nn_cnt[q] = (uint8_t)cnt;
+            selected[q] = (cnt == 5 && !(d5 > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
+        }
+        if (cand_counter && ncand) atomicAdd(cand_counter, (u64)ncand);
     }
-    if (lane == 0) {
-        nn_cnt[q] = (uint8_t)cnt;
-        selected[q] = (cnt == 5 && !(d5 > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
-        world[q] = make_float4(qx, qy, qz, 0.f);
-    }
-    if (cand_counter) atomicAdd(cand_counter, (u64)ncand);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -225,12 +526,17 @@ k_search(GridParams g, StateDev s, const float4* __restrict__ body, int N, float
 // = the same register, one LDS transpose ([point][16] -> lane (col, point%4)) feeds both operands.
 // ------------------------------------------------------------------------------------------------
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int kRed1 = 16;   // blocks per first-level reduction group
+constexpr int kRed2 = 32;   // group sums added per unrolled batch at the top level
 constexpr int kTileStride = 17;  // doubles per row: 16 + 1 pad (conflict-free ds_write_b64 / ds_read_b64)
 
 __global__ void __launch_bounds__(256)
 k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn_pts, int N, int ext, float thr,
-      uint8_t* __restrict__ selected, float4* __restrict__ normvec, double* __restrict__ partials) {
+      uint8_t* __restrict__ selected, float4* __restrict__ normvec, float4* __restrict__ world,
+      double* __restrict__ partials, double* __restrict__ part2, double* __restrict__ out256,
+      uint32_t* __restrict__ tickets, uint32_t* __restrict__ slow_count) {
     __shared__ double lds[4 * 64 * kTileStride];
+    __shared__ uint32_t s_ticket;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -238,8 +544,14 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
 #pragma unroll
     for (int c = 0; c < 16; ++c) v[c] = 0.0;
 
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    float wx = 0.f, wy = 0.f, wz = 0.f;
+    if (i < N) {  // feats_down_world is rewritten for every point on every pass (laserMapping.cpp:656-661)
+        b = body[i];
+        body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
+        world[i] = make_float4(wx, wy, wz, 0.f);
+    }
     if (i < N && selected[i]) {  // laserMapping.cpp:674
-        const float4 b = body[i];
         float P[5][3];
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
@@ -251,8 +563,6 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
         bool sel = false;
         float pd2 = 0.f;
         if (ok) {
-            float wx, wy, wz;
-            body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
             pd2 = ((pabcd[0] * wx + pabcd[1] * wy) + pabcd[2] * wz) + pabcd[3];  // :680
             const double bx = (double)b.x, by = (double)b.y, bz = (double)b.z;
             const double nb = sqrt((bx * bx + by * by) + bz * bz);
@@ -308,30 +618,99 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
     __syncthreads();
     const int t = threadIdx.x;
     partials[(size_t)blockIdx.x * 256 + t] = (Rb[t] + Rb[256 + t]) + (Rb[512 + t] + Rb[768 + t]);
+
+    // ---- R: deterministic two-level cross-block sum inside this launch (no reduce kernels, no extra
+    // boundaries).  Blocks are grouped kRed1 at a time; the LAST block of a group to finish sums the group's
+    // partials in block order, the LAST group to finish sums the group sums in group order and writes the
+    // result (out256 is pinned host memory on the flh_eval path).  Fixed summation order -> run-to-run
+    // identical bits regardless of which block happens to arrive last.  Hand-off = the agent-scope
+    // release / ticket / acquire protocol (every storing wave drains, one lane releases, one lane acquires).
+    const int nblk = gridDim.x;
+    const int group = blockIdx.x / kRed1;
+    const int ngroups = (nblk + kRed1 - 1) / kRed1;
+    const int gsize = min(kRed1, nblk - group * kRed1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_ticket = __hip_atomic_fetch_add(&tickets[1 + group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_ticket != (uint32_t)(gsize - 1)) return;  // block-uniform
+    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    {
+        const int b0 = group * kRed1;
+        double v[kRed1];
+#pragma unroll
+        for (int j = 0; j < kRed1; ++j) v[j] = (j < gsize) ? partials[(size_t)(b0 + j) * 256 + t] : 0.0;
+        double s0 = 0.0;
+#pragma unroll
+        for (int j = 0; j < kRed1; ++j) s0 += v[j];
+        part2[(size_t)group * 256 + t] = s0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_ticket = __hip_atomic_fetch_add(&tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_ticket != (uint32_t)(ngroups - 1)) return;
+    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    {
+        double sum = 0.0;
+        for (int b0 = 0; b0 < ngroups; b0 += kRed2) {
+            double v[kRed2];
+#pragma unroll
+            for (int j = 0; j < kRed2; ++j) v[j] = (b0 + j < ngroups) ? part2[(size_t)(b0 + j) * 256 + t] : 0.0;
+#pragma unroll
+            for (int j = 0; j < kRed2; ++j) sum += v[j];
+        }
+        out256[t] = sum;
+    }
+    // re-arm: tickets for the next launch, and the A1 -> A2 work-list counters for the next search pass
+    for (int i = t; i < ngroups + 1; i += 256) tickets[i] = 0;
+    if (t < kStripes) slow_count[t] = 0;
 }
 
-// R: deterministic two-level sum of the per-block Gram partials (fixed order -> run-to-run identical)
-__global__ void __launch_bounds__(256)
-k_reduce1(const double* __restrict__ partials, int nblk, int per, double* __restrict__ part2) {
-    const int t = threadIdx.x;
-    const int b0 = blockIdx.x * per;
-    const int b1 = min(b0 + per, nblk);
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int b = b0;
-    for (; b + 4 <= b1; b += 4) {
-        s0 += partials[(size_t)(b + 0) * 256 + t];
-        s1 += partials[(size_t)(b + 1) * 256 + t];
-        s2 += partials[(size_t)(b + 2) * 256 + t];
-        s3 += partials[(size_t)(b + 3) * 256 + t];
-    }
-    for (; b < b1; ++b) s0 += partials[(size_t)b * 256 + t];
-    part2[(size_t)blockIdx.x * 256 + t] = (s0 + s1) + (s2 + s3);
+// ------------------------------------------------------------------------------------------------
+// Scan staging: Morton-order the scan in the BODY frame (a rigid transform keeps neighbours together,
+// so one sort per scan serves every IEKF pass).  Neighbouring lanes then walk the same bricks, cells
+// and map points, which is what turns the search from line-traffic-bound into cache-resident.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 spread3(uint32_t v) {  // 14 bits -> every third bit
+    u64 x = v & 0x3FFFu;
+    x = (x | (x << 16)) & 0x0000FF0000FFull;
+    x = (x | (x << 8)) & 0x00F00F00F00Full;
+    x = (x | (x << 4)) & 0x0C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x249249249249ull;
+    return x;
 }
-__global__ void __launch_bounds__(256) k_reduce2(const double* __restrict__ part2, int n2, double* __restrict__ out) {
-    const int t = threadIdx.x;
-    double s = 0.0;
-    for (int b = 0; b < n2; ++b) s += part2[(size_t)b * 256 + t];
-    out[t] = s;
+__global__ void __launch_bounds__(256) k_scan_keys(const float4* __restrict__ raw, uint32_t N, float inv_q,
+                                                   u64* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float4 p = raw[i];
+    const float lim = 16383.f;
+    const uint32_t x = (uint32_t)fminf(fmaxf(p.x * inv_q + 8192.f, 0.f), lim);
+    const uint32_t y = (uint32_t)fminf(fmaxf(p.y * inv_q + 8192.f, 0.f), lim);
+    const uint32_t z = (uint32_t)fminf(fmaxf(p.z * inv_q + 8192.f, 0.f), lim);
+    keys[i] = spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
+    vals[i] = i;
+}
+// body[i] = raw[perm[i]] with .w = original index; perm == nullptr -> identity
+__global__ void __launch_bounds__(256) k_scan_gather(const float4* __restrict__ raw, const uint32_t* __restrict__ perm,
+                                                     uint32_t N, float4* __restrict__ body) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t src = perm ? perm[i] : i;
+    float4 p = raw[src];
+    p.w = __uint_as_float(src);
+    body[i] = p;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -355,48 +734,82 @@ hipError_t launch_map_gather(const float4* pts, const u64* ks, const uint32_t* v
     hipLaunchKernelGGL(k_map_gather, dim3(cdiv(M, 256)), dim3(256), 0, st, pts, ks, vs, M, out, brick_head);
     return hipGetLastError();
 }
-hipError_t launch_map_cells(const u64* ks, const uint32_t* rank_incl, uint32_t M, uint2* cells, uint2* hash,
-                            uint32_t hash_mask, int hash_shift, hipStream_t st) {
-    hipLaunchKernelGGL(k_map_cells, dim3(cdiv(M, 256)), dim3(256), 0, st, ks, rank_incl, M, cells, hash, hash_mask,
-                       hash_shift);
+hipError_t launch_brick_starts(const uint32_t* brick_head, const uint32_t* rank_incl, uint32_t M, uint32_t* brick_start,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(k_brick_starts, dim3(cdiv(M, 256)), dim3(256), 0, st, brick_head, rank_incl, M, brick_start);
+    return hipGetLastError();
+}
+hipError_t launch_brick_tables(const u64* ks, const uint32_t* brick_start, uint32_t nbricks, uint32_t* starts, uint2* hash,
+                               uint32_t hash_mask, int hash_shift, hipStream_t st) {
+    if (nbricks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_brick_tables, dim3(cdiv((long long)nbricks * kBrickStride, 256)), dim3(256), 0, st, ks,
+                       brick_start, nbricks, starts, hash, hash_mask, hash_shift);
     return hipGetLastError();
 }
 
-hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const float4* body, int N, float max_sqdist,
-                         int rmax, float4* world, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
-                         u64* cand_counter, hipStream_t st) {
+hipError_t launch_scan_keys(const float4* raw, uint32_t N, float quantum, u64* keys, uint32_t* vals, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scan_keys, dim3(cdiv(N, 256)), dim3(256), 0, st, raw, N, 1.0f / quantum, keys, vals);
+    return hipGetLastError();
+}
+hipError_t sort_scan_pairs(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, const uint32_t* vin, uint32_t* vout,
+                           uint32_t N, hipStream_t st) {
+    return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kin, kout, vin, vout, (int)N, 0, 42, st);
+}
+hipError_t launch_scan_gather(const float4* raw, const uint32_t* perm, uint32_t N, float4* body, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scan_gather, dim3(cdiv(N, 256)), dim3(256), 0, st, raw, perm, N, body);
+    return hipGetLastError();
+}
+
+int list_stripes() { return kStripes; }
+uint32_t list_stripe_cap(int N) { return (uint32_t)(cdiv(cdiv(N > 0 ? N : 1, 16), kStripes) + 1) * 128u; }
+
+hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points,
+                         float max_sqdist, int rmax, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
+                         uint32_t* list1, float* ub, uint32_t* counts /* [kStripes] */, u64* cand_counter,
+                         hipStream_t st) {
     if (N <= 0) return hipSuccess;
     const dim3 blk(256);
-#define FLH_LAUNCH_SEARCH(L)                                                                                       \
-    hipLaunchKernelGGL((k_search<L>), dim3(cdiv((long long)N * L, 256)), blk, 0, st, g, s, body, N, max_sqdist, rmax, \
-                       world, nn_pts, nn_d2, nn_cnt, selected, cand_counter)
-    switch (lpq) {
-        case 8: FLH_LAUNCH_SEARCH(8); break;
-        case 16: FLH_LAUNCH_SEARCH(16); break;
-        case 64: FLH_LAUNCH_SEARCH(64); break;
-        default: FLH_LAUNCH_SEARCH(32); break;
+    const uint32_t cap = list_stripe_cap(N);
+    if (lpq == 0) {  // exact path for every query (validation / fallback)
+        hipLaunchKernelGGL(k_search_exact, dim3(std::min(cdiv(N, 8), 4096)), blk, 0, st, g, s, body, N, max_sqdist, rmax,
+                           nn_pts, nn_d2, nn_cnt, selected, list1, counts, cap, ub, 1, cand_counter);
+        return hipGetLastError();
     }
-#undef FLH_LAUNCH_SEARCH
+    // A1: ring 1, every query
+#define FLH_A1(L, C, MD)                                                                                              \
+    hipLaunchKernelGGL((k_search_ring<L, 1, C, MD>), dim3(std::min(cdiv(N, 256 / L), 8192)), blk, 0, st, g, s, body, N, \
+                       map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,             \
+                       (const uint32_t*)nullptr, list1, counts, cap, ub, cand_counter)
+    switch (lpq) {  // lanes per query + 100 * cache mode
+        case 2: FLH_A1(2, 128, 0); break;
+        case 8: FLH_A1(8, 256, 0); break;
+        case 16: FLH_A1(16, 512, 0); break;
+        case 204: FLH_A1(4, 128, 2); break;
+        case 208: FLH_A1(8, 256, 2); break;
+        case 216: FLH_A1(16, 512, 2); break;
+        default: FLH_A1(4, 128, 0); break;
+    }
+#undef FLH_A1
+    // A2 drains the list; a fixed grid that exits at once when the list is empty
+    hipLaunchKernelGGL(k_search_exact, dim3(kStripes * 16), blk, 0, st, g, s, body, N, max_sqdist, rmax, nn_pts, nn_d2,
+                       nn_cnt, selected, list1, counts, cap, ub, 0, cand_counter);
     return hipGetLastError();
 }
 
 int fit_blocks(int N) { return cdiv(N > 0 ? N : 1, 256); }
 int reduce1_blocks(int nblk, int* per_out) {
-    int per = 16;
-    int n2 = cdiv(nblk, per);
-    if (per_out) *per_out = per;
-    return n2;
+    if (per_out) *per_out = kRed1;
+    return cdiv(nblk, kRed1);
 }
 
 hipError_t launch_fit(const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
-                      uint8_t* selected, float4* normvec, double* partials, double* part2, double* out256,
-                      hipStream_t st) {
+                      uint8_t* selected, float4* normvec, float4* world, double* partials, double* part2,
+                      double* out256, uint32_t* tickets, uint32_t* slow_count, hipStream_t st) {
     const int nblk = fit_blocks(N);
-    hipLaunchKernelGGL(k_fit, dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, partials);
-    int per;
-    const int n2 = reduce1_blocks(nblk, &per);
-    hipLaunchKernelGGL(k_reduce1, dim3(n2), dim3(256), 0, st, partials, nblk, per, part2);
-    hipLaunchKernelGGL(k_reduce2, dim3(1), dim3(256), 0, st, part2, n2, out256);
+    hipLaunchKernelGGL(k_fit, dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world,
+                       partials, part2, out256, tickets, slow_count);
     return hipGetLastError();
 }
 

@@ -14,17 +14,27 @@ hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const unsigned long long* ki
 hipError_t inclusive_sum(void* tmp, size_t& tmp_bytes, const uint32_t* in, uint32_t* out, uint32_t M, hipStream_t st);
 hipError_t launch_map_gather(const float4* pts, const unsigned long long* ks, const uint32_t* vs, uint32_t M,
                              float4* out, uint32_t* brick_head, hipStream_t st);
-hipError_t launch_map_cells(const unsigned long long* ks, const uint32_t* rank_incl, uint32_t M, uint2* cells,
-                            uint2* hash, uint32_t hash_mask, int hash_shift, hipStream_t st);
+hipError_t launch_brick_starts(const uint32_t* brick_head, const uint32_t* rank_incl, uint32_t M, uint32_t* brick_start,
+                               hipStream_t st);
+hipError_t launch_brick_tables(const unsigned long long* ks, const uint32_t* brick_start, uint32_t nbricks,
+                               uint32_t* starts, uint2* hash, uint32_t hash_mask, int hash_shift, hipStream_t st);
 
-hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const float4* body, int N, float max_sqdist,
-                         int rmax, float4* world, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
-                         unsigned long long* cand_counter, hipStream_t st);
+hipError_t launch_scan_keys(const float4* raw, uint32_t N, float quantum, unsigned long long* keys, uint32_t* vals,
+                            hipStream_t st);
+hipError_t sort_scan_pairs(void* tmp, size_t& tmp_bytes, const unsigned long long* kin, unsigned long long* kout,
+                           const uint32_t* vin, uint32_t* vout, uint32_t N, hipStream_t st);
+hipError_t launch_scan_gather(const float4* raw, const uint32_t* perm, uint32_t N, float4* body, hipStream_t st);
+
+int list_stripes();
+uint32_t list_stripe_cap(int N);
+hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points,
+                         float max_sqdist, int rmax, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
+                         uint32_t* list1, float* ub, uint32_t* counts, unsigned long long* cand_counter, hipStream_t st);
 
 int fit_blocks(int N);
 int reduce1_blocks(int nblk, int* per_out);
 hipError_t launch_fit(const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
-                      uint8_t* selected, float4* normvec, double* partials, double* part2, double* out256,
-                      hipStream_t st);
+                      uint8_t* selected, float4* normvec, float4* world, double* partials, double* part2,
+                      double* out256, uint32_t* tickets, uint32_t* slow_count, hipStream_t st);
 
 }  // namespace flh

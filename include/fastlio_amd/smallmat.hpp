@@ -107,12 +107,24 @@ inline M3 hat(const V3& v) {  // mtkmath.hpp:176-183
 }
 
 // Dense n x n inverse, partial-pivot LU (row-major).  Stand-in for Eigen's inverse()
-// (esekfom.hpp:1738,1782,1802).  Returns false if a zero pivot was met.
+// (esekfom.hpp:1738,1782,1802).  The identity is carried through the elimination and the two triangular
+// solves row-wise, so every inner loop runs over contiguous memory (the 23x23 case is called twice per IEKF
+// pass and sits on the critical path between two GPU launches).  Returns false if a zero pivot was met.
 inline bool inverse_lu(const double* A, int n, double* Ainv) {
-    std::vector<double> LU(A, A + (size_t)n * n);
-    std::vector<int> perm(n);
-    std::vector<double> col(n);
-    for (int i = 0; i < n; ++i) perm[i] = i;
+    constexpr int kStack = 32;
+    double lu_s[kStack * kStack], x_s[kStack * kStack];
+    std::vector<double> lu_h, x_h;
+    double* LU = lu_s;
+    double* X = x_s;  // starts as the row-permuted identity, ends as the inverse
+    if (n > kStack) {
+        lu_h.resize((size_t)n * n);
+        x_h.resize((size_t)n * n);
+        LU = lu_h.data();
+        X = x_h.data();
+    }
+    std::memcpy(LU, A, sizeof(double) * (size_t)n * n);
+    std::memset(X, 0, sizeof(double) * (size_t)n * n);
+    for (int i = 0; i < n; ++i) X[i * n + i] = 1.0;
     bool ok = true;
     for (int k = 0; k < n; ++k) {
         int p = k;
@@ -124,29 +136,31 @@ inline bool inverse_lu(const double* A, int n, double* Ainv) {
         if (best == 0.0) ok = false;
         if (p != k) {
             for (int j = 0; j < n; ++j) std::swap(LU[k * n + j], LU[p * n + j]);
-            std::swap(perm[k], perm[p]);
+            for (int j = 0; j < n; ++j) std::swap(X[k * n + j], X[p * n + j]);
         }
         const double piv = LU[k * n + k];
-        for (int i = k + 1; i < n; ++i) LU[i * n + k] /= piv;
+        const double* rk = LU + k * n;
+        const double* xk = X + k * n;
         for (int i = k + 1; i < n; ++i) {
-            const double l = LU[i * n + k];
-            for (int j = k + 1; j < n; ++j) LU[i * n + j] -= l * LU[k * n + j];
+            const double l = LU[i * n + k] / piv;
+            LU[i * n + k] = l;
+            double* ri = LU + i * n;
+            for (int j = k + 1; j < n; ++j) ri[j] -= l * rk[j];
+            double* xi = X + i * n;  // forward substitution L y = P I, applied on the fly
+            for (int j = 0; j < n; ++j) xi[j] -= l * xk[j];
         }
     }
-    for (int c = 0; c < n; ++c) {
-        for (int i = 0; i < n; ++i) col[i] = (perm[i] == c) ? 1.0 : 0.0;
-        for (int i = 0; i < n; ++i) {
-            double s = col[i];
-            for (int j = 0; j < i; ++j) s -= LU[i * n + j] * col[j];
-            col[i] = s;
+    for (int i = n - 1; i >= 0; --i) {  // back substitution U x = y, all right-hand sides at once
+        double* xi = X + i * n;
+        for (int r = i + 1; r < n; ++r) {
+            const double u = LU[i * n + r];
+            const double* xr = X + r * n;
+            for (int j = 0; j < n; ++j) xi[j] -= u * xr[j];
         }
-        for (int i = n - 1; i >= 0; --i) {
-            double s = col[i];
-            for (int j = i + 1; j < n; ++j) s -= LU[i * n + j] * col[j];
-            col[i] = s / LU[i * n + i];
-        }
-        for (int i = 0; i < n; ++i) Ainv[i * n + c] = col[i];
+        const double inv = 1.0 / LU[i * n + i];
+        for (int j = 0; j < n; ++j) xi[j] *= inv;
     }
+    std::memcpy(Ainv, X, sizeof(double) * (size_t)n * n);
     return ok;
 }
 template <int N>

@@ -43,11 +43,14 @@ typedef struct flh_handle flh_handle;
 
 typedef struct flh_config {
     int device;             /* HIP device ordinal; -1 = current device */
-    float cell_size;        /* search-grid cell edge in metres; <=0 -> 1.0 (= 2 x filter_size_map 0.5) */
+    float cell_size;        /* search-grid cell edge in metres; <=0 -> 1.0 (= 2 x filter_size_map 0.5).  The fast
+                               kernel settles a query whose 5th neighbour is within ~cell_size; smaller cells
+                               mean fewer candidates but more queries on the slower ring-expansion path */
     float plane_threshold;  /* esti_plane inlier threshold; <=0 -> 0.1f (src/laserMapping.cpp:678) */
     float max_sqdist;       /* kNN gate on the 5th neighbour; <=0 -> 5.0f (src/laserMapping.cpp:671) */
     void* stream;           /* hipStream_t to run on; NULL -> the handle creates its own */
-    int lanes_per_query;    /* search-kernel variant: 0 = default (32); 8/16/32/64 */
+    int lanes_per_query;    /* fast search kernel: lanes cooperating on one query, 2/4/8/16 (default 4);
+                               0 = run the general exact kernel for every query */
     int sort_queries;       /* 1: Morton-sort scan points at upload for cache locality (default 1 if <0) */
 } flh_config;
 
@@ -121,6 +124,9 @@ int flh_last_timing(flh_handle* h, flh_timing* t);
  * out[0] = sum of search-kernel ms, out[1] = number of search launches, out[2] = sum of fit(+reduce) ms,
  * out[3] = number of fit launches, out[4] = sum of first-launch-to-host-visible ms, out[5] = evaluations. */
 int flh_get_counters(flh_handle* h, double out[6], int reset);
+/* The HIP events behind flh_last_timing / flh_get_counters cost ~15 us of host+queue time per evaluation:
+ * record them only on every n-th flh_eval (1 = always, the default; 0 = never). */
+int flh_set_timing_stride(flh_handle* h, int every_n);
 int flh_enable_stats(flh_handle* h, int on); /* count candidate points examined (slower) */
 /* Run one kernel of the hot path `iters` times back-to-back on the handle's stream and return the
  * mean duration in ms, measured with HIP events on that stream (bench.py's roofline leg).

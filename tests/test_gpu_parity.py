@@ -80,10 +80,10 @@ def test_eval_search_and_nosearch_passes(prob, ext):
     check_neighbors(h, sc)
 
 
-@pytest.mark.parametrize("lpq", [8, 16, 32, 64])
-def test_search_kernel_variants(prob, lpq):
+@pytest.mark.parametrize("lpq,sort", [(0, 1), (2, 1), (4, 0), (8, 1), (16, 0)])
+def test_search_kernel_variants(prob, lpq, sort):
     pr, m, xp, P, _ = prob
-    h = capi.Handle(lanes_per_query=lpq)
+    h = capi.Handle(lanes_per_query=lpq, sort_queries=sort)
     h.map_build(pr.map_xyz)
     h.scan_upload(pr.body[:5000])
     sc = po.Scan(pr.body[:5000], nthreads=8)
@@ -265,10 +265,10 @@ def test_nosearch_before_search_is_an_error(prob):
 
 def test_map_extent_limit_is_reported():
     h = capi.Handle()
-    pts = np.array([[0, 0, 0], [5000, 0, 0], [1, 1, 1], [2, 2, 2], [3, 3, 3]], np.float32)
+    pts = np.array([[0, 0, 0], [9000, 0, 0], [1, 1, 1], [2, 2, 2], [3, 3, 3]], np.float32)
     with pytest.raises(capi.FlhError, match="4096 cells"):
         h.map_build(pts)
-    h2 = capi.Handle(cell_size=2.0)
+    h2 = capi.Handle(cell_size=4.0)
     h2.map_build(pts)
     h.close()
     h2.close()
@@ -298,7 +298,7 @@ def test_other_sensors_full_update(sensor, M, N):
 
 def test_cell_size_variants(prob):
     pr, m, xp, P, _ = prob
-    for c in (0.6, 1.5, 2.5):
+    for c in (0.6, 1.0, 1.5, 3.0):
         h = capi.Handle(cell_size=c)
         h.map_build(pr.map_xyz)
         h.scan_upload(pr.body[:6000])
