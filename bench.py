@@ -46,32 +46,33 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--scans", type=int, default=8, help="distinct seeded scans cycled through")
-    ap.add_argument("--mode", default="auto", choices=["auto", "shard", "streams"],
-                    help="multi-GPU: shard = one scan's points split over ranks + RCCL all-reduce of the normal "
-                         "equations; streams = independent scan streams per rank (no collective)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "streams", "shard"],
+                    help="multi-GPU: streams = one independent scan stream per rank, replicated map, no collective "
+                         "(weak scaling; the headline value); shard = ONE scan's points split over the ranks + RCCL "
+                         "all-reduce of the 16x16 normal-equation block per pass (strong scaling).  auto = streams, "
+                         "plus a short shard-mode leg reported under \"shard_mode\"")
     ap.add_argument("--lpq", type=int, default=4)
-    ap.add_argument("--cell", type=float, default=1.0)
+    ap.add_argument("--cell", type=float, default=1.5)
     ap.add_argument("--sort", type=int, default=1, help="Morton-order the scan at staging (0 = keep input order)")
     ap.add_argument("--extrinsic-est", type=int, default=0)
     ap.add_argument("--timing-stride", type=int, default=8,
                     help="record the per-kernel HIP events on every n-th evaluation of the timed region")
     ap.add_argument("--cpu-scans", type=int, default=3, help="scans timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=3, help="OpenMP threads (reference MP_PROC_NUM = 3)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo for debugging")
+    ap.add_argument("--single-device", type=int, default=0, help="debug: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         log(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
     G = world
-    mode = args.mode
-    if mode == "auto":
-        mode = "shard" if G > 1 else "single"
 
     import torch
 
@@ -82,23 +83,36 @@ def main():
     if G > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
+    mode = args.mode
+    if mode == "auto":
+        mode = "streams"
+    run_shard_leg = G > 1 and args.mode in ("auto", "shard")
+
+    from fast_lio_amd import dist as fdist
 
     M, N, sensor = CONFIGS[args.config]
     ext = bool(args.extrinsic_est)
     t0 = time.time()
     scene = synth.make_scene(M, synth.CONFIG_SEED_BASE + args.config)
-    S = max(1, min(args.scans, 60))
-    probs = []
-    for s in range(S):
-        # streams mode: every rank follows its own scan stream; shard mode: all ranks see the same scans
-        seed_off = s + (1000 * rank if mode == "streams" else 0)
-        probs.append(synth.make_problem(M, N, sensor, cfg=args.config, scan_seed=seed_off, scene=scene))
-    priors = [synth.propagate_prior_cov(capi.predict_fn, p.x_prior) for p in probs]
-    if rank == 0:
-        log(f"[bench] config {args.config}: M={M} N={N} sensor={sensor} scans={S} mode={mode} gen {time.time() - t0:.1f}s")
+    S = max(1, min(args.scans, 28))
 
-    # the handle runs on torch's current stream so that torch.distributed (RCCL) orders after our kernels
+    def gen(seed_base):
+        pr = [synth.make_problem(M, N, sensor, cfg=args.config, scan_seed=seed_base + s, scene=scene) for s in range(S)]
+        return pr, [synth.propagate_prior_cov(capi.predict_fn, p.x_prior) for p in pr]
+
+    # streams: every rank follows its own scan stream; the shard leg uses scans common to all ranks
+    probs, priors = gen(1000 * rank if G > 1 else 0)
+    sh_probs, sh_priors = (gen(0) if run_shard_leg and rank != 0 else (probs, priors)) if run_shard_leg else (None, None)
+    if rank == 0:
+        log(f"[bench] config {args.config}: M={M} N={N} sensor={sensor} scans={S} ranks={G} mode={args.mode} "
+            f"gen {time.time() - t0:.1f}s")
+
+    # with more than one rank the handle runs on torch's current stream so torch.distributed (RCCL) orders
+    # after our kernels
     stream_ptr = None
     if G > 1:
         ts = torch.cuda.Stream()  # a non-default stream: its handle is a real hipStream_t (the default one is 0)
@@ -109,35 +123,14 @@ def main():
     t0 = time.time()
     h.map_build(scene.map_xyz)
     t_build = time.time() - t0
-    lo, hi = 0, N
-    if mode == "shard":
-        lo, hi = (rank * N) // G, ((rank + 1) * N) // G
     for s, p in enumerate(probs):
-        h.scan_stage(s, p.body[lo:hi])
+        h.scan_stage(s, p.body)
+    lo, hi = fdist.shard_bounds(N, rank, G)
+    if run_shard_leg:
+        for s, p in enumerate(sh_probs):
+            h.scan_stage(S + s, p.body[lo:hi])
     kf = capi.Esekf(h, max_iter=3, extrinsic_est_en=ext)
     h.set_timing_stride(args.timing_stride)
-
-    gram = None
-    if mode == "shard":
-        gram = torch.zeros(256, dtype=torch.float64, device="cuda")
-
-        def model(x, converge):
-            # h_share_model on this rank's shard, then the C1 exchange: RCCL all-reduce of the 16x16 Gram block
-            h.eval_device(x, converge, ext, gram.data_ptr())
-            dist.all_reduce(gram)
-            g = gram.cpu().numpy()
-            HTH = np.zeros(144)
-            HTh = np.zeros(12)
-            import ctypes as C
-
-            n = C.c_int64()
-            tr = C.c_double()
-            capi.lib().flh_unpack_gram(np.ascontiguousarray(g), HTH, HTh, C.byref(n), C.byref(tr))
-            if 0 < n.value < capi.NDOF:
-                raise RuntimeError("sharded path: fewer than 23 effective points (gain-form rows not gathered)")
-            return {"valid": n.value > 0, "n_eff": int(n.value), "HTH": HTH, "HTh": HTh, "total_residual": tr.value}
-
-        kf.set_meas_model(model)
 
     def sync():
         torch.cuda.synchronize()
@@ -145,70 +138,111 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    passes = searches = 0
+    def run(step_fn, n_warm, n_steps):
+        for i in range(n_warm):
+            step_fn(i)
+        sync()
+        h.counters(reset=True)
+        acc = [0, 0]
+        t1 = time.perf_counter()
+        for i in range(n_steps):
+            st = step_fn(i)
+            acc[0] += st.passes
+            acc[1] += st.searches
+        sync()
+        dt_ = time.perf_counter() - t1
+        if dist is not None:
+            tt = torch.tensor([dt_], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        return dt_, acc[0], acc[1], h.counters()
 
-    def step(i):
-        nonlocal passes, searches
+    def step_stream(i):
         s = i % S
         h.scan_activate(s)
         kf.change_x(priors[s][0])
         kf.change_P(priors[s][1])
-        st = kf.update(0.001)
-        passes += st.passes
-        searches += st.searches
-        return st
+        return kf.update(0.001)
 
-    for i in range(args.warmup):
-        step(i)
-    sync()
-    h.counters(reset=True)
-    passes = searches = 0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    sync()
-    dt = time.perf_counter() - t0
-    ctr = h.counters()
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    units = args.steps * (G if mode == "streams" else 1)
+    shard_out = None
+    if mode == "shard":
+        run_shard_leg = True
+    # ---------------- headline leg
+    if mode == "streams" or G == 1:
+        dt, passes, searches, ctr = run(step_stream, args.warmup, args.steps)
+        units = args.steps * G
+        n_pts = N
+    # ---------------- sharded leg: ONE scan's points over all ranks + all-reduce of the Gram block (C1)
+    if run_shard_leg:
+        gram = torch.zeros(256, dtype=torch.float64, device="cuda")
+
+        def eval_partial(x, converge):
+            h.eval_device(x, converge, ext, gram.data_ptr())
+            return gram
+
+        def gather_rows(x):
+            rows = [None] * G
+            hx, hv = h.fetch_rows()
+            dist.all_gather_object(rows, (hx, hv))
+            return np.concatenate([r[0] for r in rows], axis=0), np.concatenate([r[1] for r in rows])
+
+        kf.set_meas_model(fdist.make_sharded_model(eval_partial, lambda t: fdist.torch_allreduce(dist, t), gather_rows))
+
+        def step_shard(i):
+            s = i % S
+            h.scan_activate(S + s)
+            kf.change_x(sh_priors[s][0])
+            kf.change_P(sh_priors[s][1])
+            return kf.update(0.001)
+
+        k2 = args.steps if mode == "shard" else max(10, min(60, args.steps // 4))
+        dt2, p2, s2, _ = run(step_shard, max(3, args.warmup // 4), k2)
+        # every rank must have produced the same posterior
+        xs = [None] * G
+        dist.all_gather_object(xs, kf.get_x())
+        agree = float(max(np.abs(np.asarray(x_) - np.asarray(xs[0])).max() for x_ in xs))
+        shard_out = {"value": round(k2 / dt2, 3), "unit": "scans/s", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 4),
+                     "ms_per_iekf_pass": round(dt2 / max(p2, 1) * 1e3, 4), "points_per_rank": hi - lo,
+                     "collective": f"all_reduce(sum) of 256 f64 per pass over {args.backend}",
+                     "max_abs_state_disagreement_across_ranks": agree, "scaling": "strong"}
+        kf.set_meas_model(None)
+        if mode == "shard":
+            dt, passes, searches, ctr = dt2, p2, s2, h.counters()
+            units = args.steps
+            n_pts = hi - lo
     value = units / dt
     ms_per_step = dt / args.steps * 1e3
 
-    # ---- roofline of the dominant kernel (5-NN search), timed with HIP events inside the timed region
-    n_pts = hi - lo
+    # ---- roofline of the dominant kernels (the 5-NN search of one pass), HIP events inside the timed region
     roof = None
-    if mode in ("single", "streams") and ctr["n_search"] > 0:
+    if ctr["n_search"] > 0:
         dur_s = ctr["search_ms"] / ctr["n_search"] * 1e-3
         ach = ALG_BYTES_SEARCH * n_pts / dur_s / 1e9
-        roof = {"bound": "hbm", "kernel": f"k_search_ring<{args.lpq},1> (+ ring-2 / exact follow-ups)", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
-                "avg_kernel_us": round(dur_s * 1e6, 2), "alg_bytes_per_launch": ALG_BYTES_SEARCH * n_pts}
         fit_s = ctr["fit_ms"] / max(ctr["n_fit"], 1) * 1e-3
-        roof["fit_kernel_us"] = round(fit_s * 1e6, 2)
-        roof["fit_achieved_GBs"] = round(ALG_BYTES_NOSEARCH * n_pts / fit_s / 1e9, 2)
+        roof = {"bound": "hbm", "kernel": f"k_search_ring<{args.lpq},1> + k_search_exact (5-NN search of one pass)",
+                "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                "traffic": None, "avg_kernel_us": round(dur_s * 1e6, 2), "alg_bytes_per_launch": ALG_BYTES_SEARCH * n_pts,
+                "events_sampled": ctr["n_search"], "fit_kernel_us": round(fit_s * 1e6, 2),
+                "fit_achieved_GBs": round(ALG_BYTES_NOSEARCH * n_pts / fit_s / 1e9, 2),
+                "fit_frac": round(ALG_BYTES_NOSEARCH * n_pts / fit_s / 1e9 / HBM_PEAK_GBS, 5)}
     elif mode == "shard":
-        # eval_device path records no per-kernel events; time the kernels directly on this rank's shard
-        x0 = priors[0][0]
-        h.scan_activate(0)
+        x0 = sh_priors[0][0]
+        h.scan_activate(S)
         s_ms = h.time_kernel(0, x0, ext, 20)
         f_ms = h.time_kernel(1, x0, ext, 20)
         ach = ALG_BYTES_SEARCH * n_pts / (s_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": f"k_search_ring<{args.lpq},1> (+ ring-2 / exact follow-ups)", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+        roof = {"bound": "hbm", "kernel": f"k_search_ring<{args.lpq},1> + k_search_exact", "achieved": round(ach, 2),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                 "avg_kernel_us": round(s_ms * 1e3, 2), "alg_bytes_per_launch": ALG_BYTES_SEARCH * n_pts,
                 "fit_kernel_us": round(f_ms * 1e3, 2), "note": "per-rank shard, back-to-back launches"}
 
     # companion figure: mean map points examined per query by one search pass
-    cand_per_query = None
-    if mode in ("single", "streams"):
-        h.enable_stats(True)
-        h.scan_activate(0)
-        h.eval(priors[0][0], True, ext)
-        cand_per_query = h.timing()["candidates"] / max(n_pts, 1)
-        h.enable_stats(False)
+    h.enable_stats(True)
+    h.set_timing_stride(1)
+    h.scan_activate(0)
+    h.eval(priors[0][0], True, ext)
+    cand_per_query = h.timing()["candidates"] / max(N, 1)
+    h.enable_stats(False)
 
     out = {
         "metric": "scans/sec + ms/IEKF-iter, 100k-pt scan vs 5M-pt map, 1/2/4/8 MI355X",
@@ -219,31 +253,32 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak" if mode == "streams" else "strong",
+        "scaling": "strong" if mode == "shard" else "weak",
         "vs_baseline": None,
         "dtype": "f32 (kNN, plane fit) + f64 (transform, Jacobian, normal equations)",
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {sensor} {N}-pt scan vs {M}-pt box-city map, "
                                f"max_iteration=3, R=0.001, extrinsic_est_en={int(ext)}",
-                   "parallelism": {"single": "1 GPU", "shard": f"scan points sharded over {G} ranks + RCCL all-reduce of "
-                                   "the 16x16 normal-equation block per pass", "streams": f"{G} independent scan streams, "
-                                   "replicated map, no collective"}[mode],
+                   "parallelism": ("1 GPU" if G == 1 else
+                                   (f"scan points sharded over {G} ranks + all-reduce of the 16x16 normal-equation block "
+                                    f"per pass" if mode == "shard" else
+                                    f"{G} independent scan streams (one per rank), replicated map, no collective in the data path")),
                    "distinct_scans": S, "cell_size_m": args.cell, "lanes_per_query": args.lpq},
         "ms_per_iekf_pass": round(dt / max(passes, 1) * 1e3, 4),
         "passes_per_scan": round(passes / args.steps, 3),
         "searches_per_scan": round(searches / args.steps, 3),
         "map_build_s": round(t_build, 3),
     }
-    if ctr["n_eval"] > 0:
-        out["device_ms_per_pass"] = round(ctr["eval_ms"] / ctr["n_eval"], 4)
     if roof is not None:
-        if cand_per_query is not None:
-            roof["candidates_per_query"] = round(cand_per_query, 2)
-            roof["candidate_traffic_GBs"] = round(cand_per_query * 16 * n_pts / (roof["avg_kernel_us"] * 1e-6) / 1e9, 2)
+        roof["candidates_per_query"] = round(cand_per_query, 2)
+        roof["candidate_traffic_GBs"] = round(cand_per_query * 16 * n_pts / (roof["avg_kernel_us"] * 1e-6) / 1e9, 2)
         out["roofline"] = roof
+    if shard_out is not None and mode != "shard":
+        out["shard_mode"] = shard_out
 
-    # ---- PCIe-inclusive rate (scan handed over as a host buffer every step): stderr only
-    if rank == 0 and mode == "single":
+    # ---- PCIe-inclusive rate (scan handed over as a host buffer every step): never `value`
+    if rank == 0 and G == 1:
+        h.set_timing_stride(0)
         t1 = time.perf_counter()
         reps = max(5, min(50, args.steps // 4))
         for i in range(reps):
@@ -253,8 +288,7 @@ def main():
             kf.change_P(priors[s][1])
             kf.update(0.001)
         torch.cuda.synchronize()
-        pcie = reps / (time.perf_counter() - t1)
-        out["pcie_inclusive_scans_per_s"] = round(pcie, 3)
+        out["pcie_inclusive_scans_per_s"] = round(reps / (time.perf_counter() - t1), 3)
 
     # ---- CPU baseline: the oracle's restated reference path on this box's host cores (rank 0, N=1 only)
     if rank == 0 and G == 1 and args.cpu_scans > 0:
@@ -280,6 +314,7 @@ def main():
     kf.close()
     h.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

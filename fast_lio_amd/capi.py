@@ -142,7 +142,7 @@ def device_available() -> bool:
 class Handle:
     """flh_handle: the device-resident map + current scan."""
 
-    def __init__(self, cell_size: float = 1.0, lanes_per_query: int = 4, device: int = -1, stream: int | None = None,
+    def __init__(self, cell_size: float = 1.5, lanes_per_query: int = 4, device: int = -1, stream: int | None = None,
                  plane_threshold: float = 0.1, max_sqdist: float = 5.0, sort_queries: int = -1):
         L = lib()
         cfg = FlhConfig()

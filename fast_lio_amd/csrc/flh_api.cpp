@@ -120,7 +120,7 @@ int flh_device_available(void) {
 void flh_default_config(flh_config* c) {
     if (!c) return;
     c->device = -1;
-    c->cell_size = 1.0f;
+    c->cell_size = 1.5f;
     c->plane_threshold = 0.1f;
     c->max_sqdist = 5.0f;
     c->stream = nullptr;
@@ -136,14 +136,13 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     flh_config cfg;
     flh_default_config(&cfg);
     if (cfg_in) cfg = *cfg_in;
-    if (cfg.cell_size <= 0) cfg.cell_size = 1.0f;
+    if (cfg.cell_size <= 0) cfg.cell_size = 1.5f;
     if (cfg.plane_threshold <= 0) cfg.plane_threshold = 0.1f;
     if (cfg.max_sqdist <= 0) cfg.max_sqdist = 5.0f;
     if (cfg.sort_queries < 0) cfg.sort_queries = 1;
     {
         const int l = cfg.lanes_per_query;  // 0 = exact kernel for every query
-        if (l != 0 && l != 2 && l != 8 && l != 16 && l != 204 && l != 208 && l != 216 && l != 1204 && l != 2204)
-            cfg.lanes_per_query = 4;
+        if (l != 0 && l != 2 && l != 8 && l != 16) cfg.lanes_per_query = 4;
     }
     flh_handle* h = new flh_handle();
     h->cfg = cfg;

@@ -112,11 +112,12 @@ __global__ void __launch_bounds__(256) k_brick_tables(const u64* __restrict__ ke
 // The 2(2R+1)^2 segment slots are resolved in parallel by the group's lanes (directory probe, then two
 // reads of the brick's prefix table), parked in LDS and prefix-summed, so that the group's T candidates
 // form one flat list dealt round-robin to its lanes, eight independent loads in flight per lane.
-//   pass A  d2 of every candidate (exact fp32 op order), cached in LDS, and the five smallest kept in
-//           registers with a payload-free insert: K0' = min(K0,t), Kj' = med3(K(j-1),Kj,t); lists merged
-//           over DPP with a bitonic network.
-//   pass B  walks the cached d2: the (five) candidates with d2 <= the 5th distance fetch their point and
-//           write themselves to the row of their rank (= number of kept distances below theirs).
+//   pass A  d2 of every candidate (exact fp32 op order); the five smallest kept in registers with a
+//           payload-free insert: K0' = min(K0,t), Kj' = med3(K(j-1),Kj,t); lists merged over DPP with a
+//           bitonic network.
+//   pass B  re-walks the (cache-hot) candidates: the five with d2 <= the 5th distance write themselves to
+//           the row of their rank (= number of kept distances below theirs).  Recomputing d2 is cheaper
+//           than caching it: an LDS cache halves the occupancy, and the kernel is latency-bound.
 // A query is settled when its 5th distance lies within the block's guaranteed radius
 // (R + distance to the nearest face of the centre cell) * c and all distances involved are distinct
 // (equal distances need the oracle's (d2, map index) order); otherwise it goes to the next list.
@@ -203,7 +204,7 @@ __device__ __forceinline__ float4 load_pt(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int LPQ, int RING, int CAP, int MODE, int ABL = 0>
+template <int LPQ, int RING>
 __global__ void __launch_bounds__(256)
 k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist,
               float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
@@ -219,12 +220,9 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
     constexpr int SPL = (NSEG + LPQ - 1) / LPQ;    // segments resolved per lane
     constexpr int GPB = 256 / LPQ;                 // query groups per block
     constexpr int UNR = 8;                         // independent point loads in flight per lane
-    constexpr int CPL = CAP / LPQ;                 // cached distances per lane
     // seg: (first point, length); after the prefix step: (first point - flat start, flat end), so that flat
     // candidate t of the group lives at pts[seg.x + t] for t < seg.y
     __shared__ uint2 seg[GPB][NSEG + 1];
-    // MODE 0: fp32 d2 cache for pass B; 2: no cache (pass B recomputes) -- the cache costs LDS, i.e. occupancy
-    __shared__ float dcache[MODE == 0 ? GPB : 1][MODE == 0 ? CAP : 1];
     __shared__ uint32_t blk_n, blk_base;
     const int grp = threadIdx.x / LPQ;
     const int lane = threadIdx.x & (LPQ - 1);
@@ -309,18 +307,12 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             if (lane == 0) seg[grp][NSEG] = make_uint2(0u, 0xFFFFFFFFu);  // sentinel: the walk never runs off the end
         }
         __syncthreads();
-        if (ABL == 1) {  // ablation: prologue only
-            if (live && lane == 0) nn_cnt[q] = (uint8_t)T;
-            __syncthreads();
-            continue;
-        }
         // ---- pass A: d2 of every candidate; the group's T candidates are dealt round-robin to its lanes
         float K[5];
 #pragma unroll
         for (int j = 0; j < 5; ++j) K[j] = INFINITY;
         int cur = 0;
         uint2 sg = seg[grp][0];
-        int k = 0;
         for (uint32_t t0 = lane; t0 < T; t0 += LPQ * UNR) {
             float4 v[UNR];
 #pragma unroll
@@ -333,28 +325,20 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             for (int w = 0; w < UNR; ++w) {
                 float d = dist2(qx, qy, qz, v[w].x, v[w].y, v[w].z);
                 d = (t0 + (uint32_t)(w * LPQ) < T) ? d : INFINITY;
-                if (MODE == 0) { if (k + w < CPL) dcache[grp][(k + w) * LPQ + lane] = d; }
                 ins5f(K, d);
             }
-            k += UNR;
         }
         merge_group5<LPQ>(K);
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < 5; ++j) cnt += (K[j] < INFINITY) ? 1 : 0;
-        if (ABL == 2) {  // ablation: prologue + pass A
-            if (live && lane == 0) { nn_cnt[q] = (uint8_t)cnt; nn_d2[q] = K[4]; }
-            __syncthreads();
-            continue;
-        }
         bool tie = false;  // equal distances inside the list: the (d2, map index) order needs the general path
 #pragma unroll
         for (int j = 0; j < 4; ++j) tie = tie || (K[j + 1] < INFINITY && K[j] == K[j + 1]);
         const float d5 = (cnt == 5) ? K[4] : INFINITY;
         const float gr = ((float)RING + minfrac) * g.c - 2e-3f * g.c;  // guaranteed-complete radius (fp margin)
         const float gr2 = gr * gr;
-        const bool overflow = (MODE == 0) && (T > (uint32_t)CAP);
-        bool done = !tie && !overflow && ((cnt == 5 && d5 <= gr2) || gr2 >= max_sqdist);
+        bool done = !tie && ((cnt == 5 && d5 <= gr2) || gr2 >= max_sqdist);
         if (cand_counter && live && lane == 0) atomicAdd(cand_counter, (u64)T);
         // ---- pass B: every candidate whose distance made the list writes itself to its rank's row
         int emitted = 0;
@@ -362,32 +346,25 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             const float tau = d5;  // cnt < 5: INFINITY -> every real candidate qualifies
             cur = 0;
             sg = seg[grp][0];
-            k = 0;
             for (uint32_t t0 = lane; t0 < T; t0 += LPQ * UNR) {
-                uint32_t idx[UNR];
                 float4 v[UNR];
 #pragma unroll
                 for (int w = 0; w < UNR; ++w) {
                     const uint32_t t = t0 + (uint32_t)(w * LPQ);
                     while (t >= sg.y) sg = seg[grp][++cur];
-                    idx[w] = (t < T) ? sg.x + t : 0xFFFFFFFu;
-                    if (MODE != 0) v[w] = load_pt(rsrc, idx[w]);
+                    v[w] = load_pt(rsrc, (t < T) ? sg.x + t : 0xFFFFFFFu);
                 }
 #pragma unroll
                 for (int w = 0; w < UNR; ++w) {
                     const bool in = t0 + (uint32_t)(w * LPQ) < T;
-                    float d;
-                    if (MODE == 0) d = dcache[grp][(k + w) * LPQ + lane];
-                    else d = dist2(qx, qy, qz, v[w].x, v[w].y, v[w].z);
+                    const float d = dist2(qx, qy, qz, v[w].x, v[w].y, v[w].z);
                     if (in && d <= tau) {
-                        if (MODE == 0) v[w] = load_pt(rsrc, idx[w]);
                         const int rank = (d > K[0]) + (d > K[1]) + (d > K[2]) + (d > K[3]);
                         nn_pts[(size_t)rank * N + q] = v[w];
                         nn_d2[(size_t)rank * N + q] = d;
                         ++emitted;
                     }
                 }
-                k += UNR;
             }
         }
         emitted = sum_group<LPQ>(emitted);
@@ -617,56 +594,54 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
     for (int r = 0; r < 4; ++r) Rb[wave * 256 + (kq + 4 * r) * 16 + col] = acc[r];
     __syncthreads();
     const int t = threadIdx.x;
-    partials[(size_t)blockIdx.x * 256 + t] = (Rb[t] + Rb[256 + t]) + (Rb[512 + t] + Rb[768 + t]);
-
     // ---- R: deterministic two-level cross-block sum inside this launch (no reduce kernels, no extra
     // boundaries).  Blocks are grouped kRed1 at a time; the LAST block of a group to finish sums the group's
     // partials in block order, the LAST group to finish sums the group sums in group order and writes the
     // result (out256 is pinned host memory on the flh_eval path).  Fixed summation order -> run-to-run
-    // identical bits regardless of which block happens to arrive last.  Hand-off = the agent-scope
-    // release / ticket / acquire protocol (every storing wave drains, one lane releases, one lane acquires).
+    // identical bits regardless of which block happens to arrive last.
+    // Hand-off: partials are stored write-through (8-byte agent-scope stores = sc1), every storing wave
+    // drains, one lane takes a relaxed agent-scope ticket; the reducer reads them back with agent-scope
+    // (L1-bypassing) loads.  No release/acquire fence, hence no L2 write-back sweep per block.
+    typedef __attribute__((address_space(1))) double gdouble;
+    gdouble* gpart = (gdouble*)partials;
+    gdouble* gpart2 = (gdouble*)part2;
+    __hip_atomic_store(gpart + (size_t)blockIdx.x * 256 + t, (Rb[t] + Rb[256 + t]) + (Rb[512 + t] + Rb[768 + t]),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int nblk = gridDim.x;
     const int group = blockIdx.x / kRed1;
     const int ngroups = (nblk + kRed1 - 1) / kRed1;
     const int gsize = min(kRed1, nblk - group * kRed1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_ticket = __hip_atomic_fetch_add(&tickets[1 + group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (t == 0) s_ticket = __hip_atomic_fetch_add(&tickets[1 + group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_ticket != (uint32_t)(gsize - 1)) return;  // block-uniform
-    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
     {
         const int b0 = group * kRed1;
         double v[kRed1];
 #pragma unroll
-        for (int j = 0; j < kRed1; ++j) v[j] = (j < gsize) ? partials[(size_t)(b0 + j) * 256 + t] : 0.0;
+        for (int j = 0; j < kRed1; ++j)
+            v[j] = (j < gsize) ? __hip_atomic_load(gpart + (size_t)(b0 + j) * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : 0.0;
         double s0 = 0.0;
 #pragma unroll
         for (int j = 0; j < kRed1; ++j) s0 += v[j];
-        part2[(size_t)group * 256 + t] = s0;
+        __hip_atomic_store(gpart2 + (size_t)group * 256 + t, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_ticket = __hip_atomic_fetch_add(&tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (t == 0) s_ticket = __hip_atomic_fetch_add(&tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_ticket != (uint32_t)(ngroups - 1)) return;
-    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
     {
         double sum = 0.0;
         for (int b0 = 0; b0 < ngroups; b0 += kRed2) {
             double v[kRed2];
 #pragma unroll
-            for (int j = 0; j < kRed2; ++j) v[j] = (b0 + j < ngroups) ? part2[(size_t)(b0 + j) * 256 + t] : 0.0;
+            for (int j = 0; j < kRed2; ++j)
+                v[j] = (b0 + j < ngroups)
+                           ? __hip_atomic_load(gpart2 + (size_t)(b0 + j) * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                           : 0.0;
 #pragma unroll
             for (int j = 0; j < kRed2; ++j) sum += v[j];
         }
@@ -778,18 +753,15 @@ hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const 
         return hipGetLastError();
     }
     // A1: ring 1, every query
-#define FLH_A1(L, C, MD)                                                                                              \
-    hipLaunchKernelGGL((k_search_ring<L, 1, C, MD>), dim3(std::min(cdiv(N, 256 / L), 8192)), blk, 0, st, g, s, body, N, \
-                       map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,             \
+#define FLH_A1(L)                                                                                                 \
+    hipLaunchKernelGGL((k_search_ring<L, 1>), dim3(std::min(cdiv(N, 256 / L), 8192)), blk, 0, st, g, s, body, N, \
+                       map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,         \
                        (const uint32_t*)nullptr, list1, counts, cap, ub, cand_counter)
-    switch (lpq) {  // lanes per query + 100 * cache mode
-        case 2: FLH_A1(2, 128, 0); break;
-        case 8: FLH_A1(8, 256, 0); break;
-        case 16: FLH_A1(16, 512, 0); break;
-        case 204: FLH_A1(4, 128, 2); break;
-        case 208: FLH_A1(8, 256, 2); break;
-        case 216: FLH_A1(16, 512, 2); break;
-        default: FLH_A1(4, 128, 0); break;
+    switch (lpq) {
+        case 2: FLH_A1(2); break;
+        case 8: FLH_A1(8); break;
+        case 16: FLH_A1(16); break;
+        default: FLH_A1(4); break;
     }
 #undef FLH_A1
     // A2 drains the list; a fixed grid that exits at once when the list is empty

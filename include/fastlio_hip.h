@@ -43,7 +43,7 @@ typedef struct flh_handle flh_handle;
 
 typedef struct flh_config {
     int device;             /* HIP device ordinal; -1 = current device */
-    float cell_size;        /* search-grid cell edge in metres; <=0 -> 1.0 (= 2 x filter_size_map 0.5).  The fast
+    float cell_size;        /* search-grid cell edge in metres; <=0 -> 1.5 (= 3 x filter_size_map 0.5).  The fast
                                kernel settles a query whose 5th neighbour is within ~cell_size; smaller cells
                                mean fewer candidates but more queries on the slower ring-expansion path */
     float plane_threshold;  /* esti_plane inlier threshold; <=0 -> 0.1f (src/laserMapping.cpp:678) */

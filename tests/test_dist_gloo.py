@@ -1,0 +1,108 @@
+"""world_size-2 gloo test of the sharded update (the N>1 path of bench.py) on CPU.
+
+Each rank evaluates h_share_model on ITS shard of the scan (here with the oracle, since there is no GPU),
+packs the partial normal equations into the 16x16 Gram block, all-reduces it over gloo and feeds the
+product's host IEKF; the result must equal the single-process oracle update of the whole scan."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fast_lio_amd import capi, synth
+from fast_lio_amd import dist as fdist
+from oracle import pyoracle as po
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_scan, ext, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pr = synth.make_problem(60000, n_scan, "avia", cfg=103)
+        m = po.Map(pr.map_xyz)
+        xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
+        lo, hi = fdist.shard_bounds(n_scan, rank, world)
+        sc = po.Scan(pr.body[lo:hi], nthreads=1)
+        buf = torch.zeros(256, dtype=torch.float64)
+
+        def eval_partial(x, converge):
+            valid = sc.h_share_model(m, x, converge, ext)
+            if valid:
+                HTH, HTh = sc.normal_equations()
+                g = fdist.pack_gram(HTH, HTh, sc.n_eff, sc.total_residual)
+            else:
+                g = np.zeros(256)
+            buf.copy_(torch.from_numpy(g))
+            return buf
+
+        def gather_rows(x):
+            rows = [None] * world
+            n = sc.n_eff
+            dist.all_gather_object(rows, (sc.h_x if n else np.zeros((0, 12)), sc.h if n else np.zeros(0)))
+            return np.concatenate([r[0] for r in rows], axis=0), np.concatenate([r[1] for r in rows])
+
+        kf = capi.Esekf(None, max_iter=3, extrinsic_est_en=ext)
+        kf.set_meas_model(fdist.make_sharded_model(eval_partial, lambda t: fdist.torch_allreduce(dist, t), gather_rows))
+        kf.change_x(xp)
+        kf.change_P(P)
+        st = kf.update(0.001)
+        x, Pn = kf.get_x(), kf.get_P()
+        # every rank must hold the same posterior
+        xs = [None] * world
+        dist.all_gather_object(xs, (x, Pn))
+        for xo, Po in xs:
+            assert np.array_equal(xo, x) and np.array_equal(Po, Pn)
+        if rank == 0:
+            np.savez(out_path, x=x, P=Pn, passes=st.passes, searches=st.searches, n_eff=np.array(list(st.n_eff)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_scan,ext", [(3000, False), (3000, True), (14, False)])
+def test_sharded_update_matches_single_process(tmp_path, n_scan, ext):
+    world = 2
+    out = str(tmp_path / "r0.npz")
+    mp.spawn(_worker, args=(world, _free_port(), n_scan, ext, out), nprocs=world, join=True)
+    got = np.load(out)
+    pr = synth.make_problem(60000, n_scan, "avia", cfg=103)
+    m = po.Map(pr.map_xyz)
+    xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
+    sc = po.Scan(pr.body, nthreads=2)
+    x_ref, P_ref, st_ref = sc.update_iterated(m, xp, P, extrinsic_est_en=ext)
+    assert int(got["passes"]) == st_ref.passes and int(got["searches"]) == st_ref.searches
+    assert list(got["n_eff"])[: st_ref.passes] == list(st_ref.n_eff)[: st_ref.passes]
+    np.testing.assert_allclose(got["x"], x_ref, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(got["P"], P_ref, rtol=0, atol=1e-6 * np.abs(P_ref).max())
+
+
+def test_shard_bounds_cover_exactly():
+    for n in (0, 1, 7, 100000, 130001):
+        for w in (1, 2, 3, 8):
+            b = [fdist.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_unpack_gram_roundtrip():
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(30, 12))
+    h = rng.normal(size=30)
+    G = fdist.pack_gram(A.T @ A, A.T @ h, 30, 1.25)
+    HTH, HTh, n, tr = fdist.unpack_gram(G)
+    np.testing.assert_array_equal(HTH, A.T @ A)
+    np.testing.assert_array_equal(HTh, A.T @ h)
+    assert n == 30 and tr == 1.25

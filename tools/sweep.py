@@ -13,7 +13,7 @@ from fast_lio_amd import capi, synth  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=2)
-ap.add_argument("--variants", default="4:2.0:1,4:1.5:1,4:1.0:1,8:2.0:1,2:2.0:1,16:2.0:1,0:2.0:1")
+ap.add_argument("--variants", default="4:1.5:1,8:1.5:1,4:1.0:1,0:1.5:1")
 ap.add_argument("--steps", type=int, default=60)
 ap.add_argument("--scans", type=int, default=4)
 args = ap.parse_args()
