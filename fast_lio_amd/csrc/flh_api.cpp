@@ -72,7 +72,7 @@ struct flh_handle {
     DevBuf<uint8_t> nn_cnt, selected;
     DevBuf<double> partials, part2, gram;
     DevBuf<u64> counter;
-    DevBuf<uint32_t> slow_list, slow_count;  // A1 -> A2 work list (striped) and its counters
+    DevBuf<uint32_t> slow_list, slow_list2, slow_count;  // A1 -> A2 -> A3 work lists (striped) and their counters
     DevBuf<float> slow_ub;
     DevBuf<uint32_t> tickets;                // arrival tickets of the in-kernel reduction (self re-arming)                   // per-query search radius^2 handed from A1 to A2
     double* h_gram = nullptr;  // pinned 256 doubles
@@ -170,8 +170,8 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
         flh_destroy(h);
         return fail("hipHostMalloc failed");
     }
-    if (h->gram.reserve(256) != hipSuccess || h->counter.reserve(1) != hipSuccess || h->slow_count.reserve(flh::list_stripes()) != hipSuccess ||
-        hipMemset(h->slow_count.p, 0, flh::list_stripes() * sizeof(uint32_t)) != hipSuccess) {
+    if (h->gram.reserve(256) != hipSuccess || h->counter.reserve(1) != hipSuccess || h->slow_count.reserve(2 * flh::list_stripes()) != hipSuccess ||
+        hipMemset(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t)) != hipSuccess) {
         flh_destroy(h);
         return fail("hipMalloc failed");
     }
@@ -186,7 +186,7 @@ void flh_destroy(flh_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
+    h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_list2.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
     h->world.release(); h->nn_pts.release(); h->normvec.release();
     h->nn_d2.release(); h->nn_cnt.release(); h->selected.release();
     h->partials.release(); h->part2.release(); h->gram.release(); h->counter.release();
@@ -329,17 +329,25 @@ static int prepare_scan_buffers(flh_handle* h, size_t N, bool full_clear) {
     HIPC(h->nn_d2.reserve(5 * n1)); HIPC(h->nn_cnt.reserve(n1)); HIPC(h->selected.reserve(n1));
     {
         const size_t ln = (size_t)flh::list_stripes() * flh::list_stripe_cap((int)N);
-        HIPC(h->slow_list.reserve(ln)); HIPC(h->slow_ub.reserve(n1));
+        HIPC(h->slow_list.reserve(ln)); HIPC(h->slow_list2.reserve(ln)); HIPC(h->slow_ub.reserve(n1));
     }
     const int nblk = flh::fit_blocks((int)N);
     HIPC(h->partials.reserve((size_t)nblk * 256));
     const int ngroups = flh::reduce1_blocks(nblk, nullptr);
     HIPC(h->part2.reserve((size_t)ngroups * 256));
-    HIPC(h->tickets.reserve((size_t)ngroups + 1));
-    HIPC(hipMemsetAsync(h->tickets.p, 0, ((size_t)ngroups + 1) * sizeof(uint32_t), st));
-    HIPC(hipMemsetAsync(h->slow_count.p, 0, flh::list_stripes() * sizeof(uint32_t), st));
-    HIPC(hipMemsetAsync(h->selected.p, 1, n1, st));  // memset(point_selected_surf, true, ...) :812
+    {
+        const uint32_t* before = h->tickets.p;
+        HIPC(h->tickets.reserve((size_t)ngroups + 1));
+        if (h->tickets.p != before)  // fresh allocation: tickets must start at zero
+            HIPC(hipMemsetAsync(h->tickets.p, 0, h->tickets.cap * sizeof(uint32_t), st));
+    }
+    // Fast path (flh_scan_activate): no memsets at all.  point_selected_surf needs no reset because the first
+    // evaluation of a scan always searches (enforced in enqueue_eval) and the search rewrites every flag; the
+    // reduction tickets and work-list counters are re-armed by k_fit at the end of every evaluation.
     if (full_clear) {
+        HIPC(hipMemsetAsync(h->tickets.p, 0, ((size_t)ngroups + 1) * sizeof(uint32_t), st));
+        HIPC(hipMemsetAsync(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t), st));
+        HIPC(hipMemsetAsync(h->selected.p, 1, n1, st));  // memset(point_selected_surf, true, ...) :812
         HIPC(hipMemsetAsync(h->nn_cnt.p, 0, n1, st));
         HIPC(hipMemsetAsync(h->nn_pts.p, 0xFF, 5 * n1 * sizeof(float4), st));  // idx = -1
         HIPC(hipMemsetAsync(h->nn_d2.p, 0x7F, 5 * n1 * sizeof(float), st));    // large finite; rewritten by search
@@ -445,7 +453,7 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
         if (h->stats) HIPC(hipMemsetAsync(h->counter.p, 0, sizeof(u64), st));
         HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->M,
                                 h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
-                                h->slow_list.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr, st));
+                                h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr, st));
         h->searched_once = true;
     }
     if (timed) HIPC(hipEventRecord(h->ev[1], st));
@@ -544,8 +552,8 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
         if (which == 0) {
             HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->M,
                                     h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
-                                    h->slow_list.p, h->slow_ub.p, h->slow_count.p, nullptr, st));
-            HIPC(hipMemsetAsync(h->slow_count.p, 0, flh::list_stripes() * sizeof(uint32_t), st));
+                                    h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, nullptr, st));
+            HIPC(hipMemsetAsync(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t), st));
             h->searched_once = true;
         } else {
             HIPC(flh::launch_fit(s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p,

@@ -99,25 +99,25 @@ __global__ void __launch_bounds__(256) k_brick_tables(const u64* __restrict__ ke
 }
 
 // ------------------------------------------------------------------------------------------------
-// A: exact 5-NN, two kernels chained through a work list.
+// A: exact 5-NN, three kernels chained through two work lists.
 //
-// A1 k_search_ring<4,1,..>  every query, the 3x3x3 cells around its cell (settles every query whose 5th
-//                           neighbour is provably inside that block and free of distance ties)
-// A2 k_search_exact         the rest, with the 5th distance A1 found as a search radius: one pass over the
-//                           cells intersecting that ball (never beyond the gate radius sqrt(max_sqdist) of
-//                           src/laserMapping.cpp:671), 64-bit (d2, map index) keys, 32 lanes per query.
+// A1 k_search_ring<4,1>     every query, the 3x3x3 cells around its cell: settles every query whose 5th
+//                           neighbour is provably inside that block and free of distance ties
+// A2 k_search_ring<16,2>    the queries A1 listed, 5x5x5 cells clipped to the ball of A1's 5th distance
+// A3 k_search_exact         whatever is left (distance ties, 5th neighbour beyond the 5x5x5 block): one pass over
+//                           the cells intersecting the ball of the best bound so far -- never beyond the gate
+//                           radius sqrt(max_sqdist) of src/laserMapping.cpp:671 -- with 64-bit (d2, map index)
+//                           keys, 32 lanes per query.
 //
 // k_search_ring: LPQ lanes per query.  Each (y,z) row of the (2R+1)^3 block is an x-run of consecutive
 // local cells, i.e. ONE contiguous range of the cell-sorted map (two if the run crosses a brick boundary).
 // The 2(2R+1)^2 segment slots are resolved in parallel by the group's lanes (directory probe, then two
 // reads of the brick's prefix table), parked in LDS and prefix-summed, so that the group's T candidates
 // form one flat list dealt round-robin to its lanes, eight independent loads in flight per lane.
-//   pass A  d2 of every candidate (exact fp32 op order); the five smallest kept in registers with a
-//           payload-free insert: K0' = min(K0,t), Kj' = med3(K(j-1),Kj,t); lists merged over DPP with a
-//           bitonic network.
-//   pass B  re-walks the (cache-hot) candidates: the five with d2 <= the 5th distance write themselves to
-//           the row of their rank (= number of kept distances below theirs).  Recomputing d2 is cheaper
-//           than caching it: an LDS cache halves the occupancy, and the kernel is latency-bound.
+// One pass over the candidates: exact fp32 d2 (the oracle's op order) and a sorted top-6 in registers -- the
+// distances by K0' = min(K0,t), Kj' = med3(K(j-1),Kj,t), the positions riding on the six compares t < Kj;
+// the lanes' lists are merged over DPP with a bitonic half-cleaner + 12-comparator network.  The sixth
+// entry exists only to see a tie at the boundary.  Five point loads per query then write the result rows.
 // A query is settled when its 5th distance lies within the block's guaranteed radius
 // (R + distance to the nearest face of the centre cell) * c and all distances involved are distinct
 // (equal distances need the oracle's (d2, map index) order); otherwise it goes to the next list.
@@ -148,19 +148,31 @@ __device__ __forceinline__ u64 make_key(float d, float w) {
     return ((u64)__float_as_uint(d) << 32) | (u64)__float_as_uint(w);
 }
 
-// ---- sorted top-5 of fp32 distances with no payload: five independent VALU ops per insert
-__device__ __forceinline__ void ins5f(float (&K)[5], float t) {
+// ---- sorted top-6 of fp32 squared distances carrying the candidate's position in map_sorted.
+// Distances: K0' = min(K0,t), Kj' = med3(K(j-1),Kj,t) (six independent VALU ops); positions follow with the
+// six compares t < Kj.  Strict <: a candidate equal to a kept distance queues behind it, and equal
+// distances are later routed to the general path, so the visiting order never decides a result.
+__device__ __forceinline__ void ins6(float (&K)[6], uint32_t (&I)[6], float t, uint32_t idx) {
+    const bool c0 = t < K[0], c1 = t < K[1], c2 = t < K[2], c3 = t < K[3], c4 = t < K[4], c5 = t < K[5];
+    I[5] = c4 ? I[4] : (c5 ? idx : I[5]);
+    I[4] = c3 ? I[3] : (c4 ? idx : I[4]);
+    I[3] = c2 ? I[2] : (c3 ? idx : I[3]);
+    I[2] = c1 ? I[1] : (c2 ? idx : I[2]);
+    I[1] = c0 ? I[0] : (c1 ? idx : I[1]);
+    I[0] = c0 ? idx : I[0];
     const float n0 = fminf(K[0], t);
     const float n1 = __builtin_amdgcn_fmed3f(K[0], K[1], t);
     const float n2 = __builtin_amdgcn_fmed3f(K[1], K[2], t);
     const float n3 = __builtin_amdgcn_fmed3f(K[2], K[3], t);
     const float n4 = __builtin_amdgcn_fmed3f(K[3], K[4], t);
-    K[0] = n0; K[1] = n1; K[2] = n2; K[3] = n3; K[4] = n4;
+    const float n5 = __builtin_amdgcn_fmed3f(K[4], K[5], t);
+    K[0] = n0; K[1] = n1; K[2] = n2; K[3] = n3; K[4] = n4; K[5] = n5;
 }
-__device__ __forceinline__ void cexf(float& a, float& b) {  // compare-exchange: a <= b afterwards
-    const float lo = fminf(a, b);
-    b = fmaxf(a, b);
-    a = lo;
+__device__ __forceinline__ void cex2(float& ka, uint32_t& ia, float& kb, uint32_t& ib) {  // (ka,ia) <= (kb,ib) after
+    const bool sw = kb < ka;
+    const float lo = sw ? kb : ka, hi = sw ? ka : kb;
+    const uint32_t li = sw ? ib : ia, hi_i = sw ? ia : ib;
+    ka = lo; kb = hi; ia = li; ib = hi_i;
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
@@ -170,32 +182,30 @@ template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
 }
-// lowest five of (mine U partner's), sorted: bitonic half-cleaner, then a 9-comparator network for 5
+// lowest six of (mine U partner's), sorted: bitonic half-cleaner, then a 12-comparator network for 6
 // (both verified exhaustively with the 0/1 principle)
 template <int CTRL>
-__device__ __forceinline__ void merge5f(float (&K)[5]) {
-    float B[5];
+__device__ __forceinline__ void merge6(float (&K)[6], uint32_t (&I)[6]) {
+    float BK[6];
+    uint32_t BI[6];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) B[j] = dpp_f32<CTRL>(K[j]);
+    for (int j = 0; j < 6; ++j) { BK[j] = dpp_f32<CTRL>(K[j]); BI[j] = (uint32_t)dpp_i32<CTRL>((int)I[j]); }
 #pragma unroll
-    for (int j = 0; j < 5; ++j) K[j] = fminf(K[j], B[4 - j]);
-    cexf(K[0], K[1]); cexf(K[3], K[4]); cexf(K[2], K[4]); cexf(K[2], K[3]); cexf(K[1], K[4]);
-    cexf(K[0], K[3]); cexf(K[0], K[2]); cexf(K[1], K[3]); cexf(K[1], K[2]);
+    for (int j = 0; j < 6; ++j) {
+        const bool tk = BK[5 - j] < K[j];
+        K[j] = tk ? BK[5 - j] : K[j];
+        I[j] = tk ? BI[5 - j] : I[j];
+    }
+    cex2(K[1], I[1], K[2], I[2]); cex2(K[4], I[4], K[5], I[5]); cex2(K[0], I[0], K[2], I[2]); cex2(K[3], I[3], K[5], I[5]);
+    cex2(K[0], I[0], K[1], I[1]); cex2(K[3], I[3], K[4], I[4]); cex2(K[2], I[2], K[5], I[5]); cex2(K[0], I[0], K[3], I[3]);
+    cex2(K[1], I[1], K[4], I[4]); cex2(K[2], I[2], K[4], I[4]); cex2(K[1], I[1], K[3], I[3]); cex2(K[2], I[2], K[3], I[3]);
 }
 template <int LPQ>
-__device__ __forceinline__ void merge_group5(float (&K)[5]) {
-    if (LPQ >= 2) merge5f<0xB1>(K);    // quad_perm [1,0,3,2]
-    if (LPQ >= 4) merge5f<0x4E>(K);    // quad_perm [2,3,0,1]
-    if (LPQ >= 8) merge5f<0x141>(K);   // row_half_mirror
-    if (LPQ >= 16) merge5f<0x140>(K);  // row_mirror
-}
-template <int LPQ>
-__device__ __forceinline__ int sum_group(int v) {
-    if (LPQ >= 2) v += dpp_i32<0xB1>(v);
-    if (LPQ >= 4) v += dpp_i32<0x4E>(v);
-    if (LPQ >= 8) v += dpp_i32<0x141>(v);
-    if (LPQ >= 16) v += dpp_i32<0x140>(v);
-    return v;
+__device__ __forceinline__ void merge_group6(float (&K)[6], uint32_t (&I)[6]) {
+    if (LPQ >= 2) merge6<0xB1>(K, I);    // quad_perm [1,0,3,2]
+    if (LPQ >= 4) merge6<0x4E>(K, I);    // quad_perm [2,3,0,1]
+    if (LPQ >= 8) merge6<0x141>(K, I);   // row_half_mirror
+    if (LPQ >= 16) merge6<0x140>(K, I);  // row_mirror
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -204,16 +214,25 @@ __device__ __forceinline__ float4 load_pt(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int LPQ, int RING>
+// A query group never spans a wave, so the LDS hand-offs inside k_search_ring only need wave-level ordering:
+// LDS operations of one wave complete in order; this keeps the compiler from moving accesses across the point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int LPQ, int RING, bool BOUNDED>
 __global__ void __launch_bounds__(256)
 k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist,
               float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
               uint8_t* __restrict__ selected, const uint32_t* __restrict__ in_list, const uint32_t* __restrict__ in_count,
               uint32_t* __restrict__ out_list, uint32_t* __restrict__ out_count, uint32_t stripe_cap,
-              float* __restrict__ ub_out, u64* __restrict__ cand_counter) {
-    // Work lists are striped kStripes ways (stripe = blockIdx & (kStripes-1)) and appended to with ONE global
-    // atomic per block: thousands of returning atomics on a single word serialise at ~11 ns each and were the
-    // whole runtime of an earlier version of this kernel.
+              const float* ub_in, float* ub_out /* may alias ub_in */, u64* __restrict__ cand_counter) {
+    // BOUNDED: the query comes with an upper bound ub of its true 5th squared distance (found by a smaller
+    // ring); rows and row ends that lie entirely outside that ball are not visited.
+    // Work lists are striped kStripes ways (stripe = blockIdx & (kStripes-1)) and appended to with one global
+    // atomic per WAVE: thousands of returning atomics on a single word serialise at ~11 ns each and were the
+    // whole runtime of an earlier version of this kernel.  No block-level barrier anywhere: waves run free.
     constexpr int W = 2 * RING + 1;                // block edge in cells
     constexpr int NR = W * W;                      // (y,z) rows: each an x-run of W consecutive cells
     constexpr int NSEG = NR * 2;                   // a run crosses at most one brick boundary -> two segments
@@ -223,7 +242,6 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
     // seg: (first point, length); after the prefix step: (first point - flat start, flat end), so that flat
     // candidate t of the group lives at pts[seg.x + t] for t < seg.y
     __shared__ uint2 seg[GPB][NSEG + 1];
-    __shared__ uint32_t blk_n, blk_base;
     const int grp = threadIdx.x / LPQ;
     const int lane = threadIdx.x & (LPQ - 1);
     const uint32_t stripe = blockIdx.x & (kStripes - 1);
@@ -237,8 +255,7 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
         __builtin_amdgcn_make_buffer_rsrc((void*)g.pts, 0, (int)(map_points * 16u), 0x00020000);
     const u64* __restrict__ hash64 = reinterpret_cast<const u64*>(g.hash);
 
-    for (uint32_t base = first_base; base < total; base += step_base) {  // block-uniform trip count
-        if (threadIdx.x == 0) blk_n = 0;
+    for (uint32_t base = first_base; base < total; base += step_base) {
         const uint32_t gi = base + grp;
         const bool live = gi < total;
         const int q = in_list ? (int)in_list[live ? gi : total - 1] : (int)(live ? gi : total - 1);
@@ -251,9 +268,9 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
         const float minfrac = fminf(fminf(fminf(fx, 1.f - fx), fminf(fy, 1.f - fy)), fminf(fz, 1.f - fz));
 
         // ---- phase 1: directory probes of this lane's segments
-        const int x0 = max(cx - RING, 0), x1 = min(cx + RING, g.nx - 1);
-        const bool xok = x0 <= x1;
-        const bool split = (x0 >> 2) != (x1 >> 2);
+        float ubq = INFINITY;
+        if (BOUNDED) ubq = fminf(ub_in[q], max_sqdist) * 1.0001f + 1e-6f;
+        const float inv_c2 = g.inv_c * g.inv_c;
         uint32_t key[SPL], slot[SPL], i0[SPL], i1[SPL];
         u64 he[SPL];
 #pragma unroll
@@ -261,8 +278,23 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             const int sl = lane + u * LPQ;
             const int half = sl / NR, r = sl - half * NR;  // slots [0,NR): first segments, [NR,2NR): second (split rows)
             const int rz = r / W, ry = r - rz * W;
-            const int y = cy + ry - RING, z = cz + rz - RING;
-            bool valid = (sl < NSEG) && xok && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
+            const int dy = ry - RING, dz = rz - RING;
+            const int y = cy + dy, z = cz + dz;
+            int xlo = cx - RING, xhi = cx + RING;
+            bool inball = true;
+            if (BOUNDED) {
+                // distance (in cells) from the query to the row's (y,z) slab; what is left of the ball bounds x
+                const float gy = dy > 0 ? (float)dy - fy : (dy < 0 ? fy - (float)(dy + 1) : 0.f);
+                const float gz = dz > 0 ? (float)dz - fz : (dz < 0 ? fz - (float)(dz + 1) : 0.f);
+                const float rem = ubq * inv_c2 * 1.01f + 1e-4f - (gy * gy + gz * gz);
+                inball = rem >= 0.f;
+                const float gmax = sqrtf(fmaxf(rem, 0.f));
+                xlo = max(xlo, cx - (int)(gmax - fx + 1.f));  // dx < 0: gap = fx - (dx + 1) <= gmax
+                xhi = min(xhi, cx + (int)(gmax + fx));        // dx > 0: gap = dx - fx       <= gmax
+            }
+            const int x0 = max(xlo, 0), x1 = min(xhi, g.nx - 1);
+            const bool split = (x0 >> 2) != (x1 >> 2);
+            bool valid = (sl < NSEG) && inball && x0 <= x1 && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
             int xa, xb;
             if (half == 0) { xa = x0; xb = split ? (x0 | 3) : x1; }
             else { xa = x1 & ~3; xb = x1; valid = valid && split; }
@@ -289,7 +321,7 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             }
             if (sl < NSEG) seg[grp][sl] = make_uint2(a, n);
         }
-        __syncthreads();
+        wave_sync();
         // ---- prefix over the group's segments (every lane runs the same sums; lane s % LPQ rewrites slot s)
         uint32_t T = 0;
         {
@@ -300,100 +332,87 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
                 if ((sidx % LPQ) == lane) mine[sidx / LPQ] = make_uint2(an.x - T, T + an.y);
                 T += an.y;
             }
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (int u = 0; u < SPL; ++u)
                 if (lane + u * LPQ < NSEG) seg[grp][lane + u * LPQ] = mine[u];
             if (lane == 0) seg[grp][NSEG] = make_uint2(0u, 0xFFFFFFFFu);  // sentinel: the walk never runs off the end
         }
-        __syncthreads();
-        // ---- pass A: d2 of every candidate; the group's T candidates are dealt round-robin to its lanes
-        float K[5];
+        wave_sync();
+        // ---- one pass over the candidates: the group's T candidates are dealt round-robin to its lanes
+        float K[6];
+        uint32_t I[6];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) K[j] = INFINITY;
+        for (int j = 0; j < 6; ++j) { K[j] = INFINITY; I[j] = 0xFFFFFFFu; }
         int cur = 0;
         uint2 sg = seg[grp][0];
         for (uint32_t t0 = lane; t0 < T; t0 += LPQ * UNR) {
             float4 v[UNR];
+            uint32_t idx[UNR];
 #pragma unroll
             for (int w = 0; w < UNR; ++w) {
                 const uint32_t t = t0 + (uint32_t)(w * LPQ);
                 while (t >= sg.y) sg = seg[grp][++cur];
-                v[w] = load_pt(rsrc, (t < T) ? sg.x + t : 0xFFFFFFFu);  // past the end: out-of-range -> zeros
+                idx[w] = (t < T) ? sg.x + t : 0xFFFFFFFu;  // past the end: out-of-range -> zeros, masked below
+                v[w] = load_pt(rsrc, idx[w]);
             }
 #pragma unroll
             for (int w = 0; w < UNR; ++w) {
                 float d = dist2(qx, qy, qz, v[w].x, v[w].y, v[w].z);
                 d = (t0 + (uint32_t)(w * LPQ) < T) ? d : INFINITY;
-                ins5f(K, d);
+                ins6(K, I, d, idx[w]);
             }
         }
-        merge_group5<LPQ>(K);
+        merge_group6<LPQ>(K, I);
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < 5; ++j) cnt += (K[j] < INFINITY) ? 1 : 0;
-        bool tie = false;  // equal distances inside the list: the (d2, map index) order needs the general path
+        bool tie = false;  // equal distances among the best six: the (d2, map index) order needs the general path
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tie = tie || (K[j + 1] < INFINITY && K[j] == K[j + 1]);
+        for (int j = 0; j < 5; ++j) tie = tie || (K[j + 1] < INFINITY && K[j] == K[j + 1]);
         const float d5 = (cnt == 5) ? K[4] : INFINITY;
         const float gr = ((float)RING + minfrac) * g.c - 2e-3f * g.c;  // guaranteed-complete radius (fp margin)
         const float gr2 = gr * gr;
-        bool done = !tie && ((cnt == 5 && d5 <= gr2) || gr2 >= max_sqdist);
+        const bool done = !tie && ((cnt == 5 && d5 <= gr2) || gr2 >= max_sqdist);
         if (cand_counter && live && lane == 0) atomicAdd(cand_counter, (u64)T);
-        // ---- pass B: every candidate whose distance made the list writes itself to its rank's row
-        int emitted = 0;
+        // ---- results: rank j is written by lane j % LPQ (five point loads per query)
         if (done && live) {
-            const float tau = d5;  // cnt < 5: INFINITY -> every real candidate qualifies
-            cur = 0;
-            sg = seg[grp][0];
-            for (uint32_t t0 = lane; t0 < T; t0 += LPQ * UNR) {
-                float4 v[UNR];
 #pragma unroll
-                for (int w = 0; w < UNR; ++w) {
-                    const uint32_t t = t0 + (uint32_t)(w * LPQ);
-                    while (t >= sg.y) sg = seg[grp][++cur];
-                    v[w] = load_pt(rsrc, (t < T) ? sg.x + t : 0xFFFFFFFu);
-                }
-#pragma unroll
-                for (int w = 0; w < UNR; ++w) {
-                    const bool in = t0 + (uint32_t)(w * LPQ) < T;
-                    const float d = dist2(qx, qy, qz, v[w].x, v[w].y, v[w].z);
-                    if (in && d <= tau) {
-                        const int rank = (d > K[0]) + (d > K[1]) + (d > K[2]) + (d > K[3]);
-                        nn_pts[(size_t)rank * N + q] = v[w];
-                        nn_d2[(size_t)rank * N + q] = d;
-                        ++emitted;
-                    }
+            for (int j = 0; j < 5; ++j) {
+                if ((j % LPQ) == lane) {
+                    const bool has = j < cnt;
+                    float4 pv = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+                    if (has) pv = load_pt(rsrc, I[j]);
+                    nn_pts[(size_t)j * N + q] = pv;
+                    nn_d2[(size_t)j * N + q] = has ? K[j] : INFINITY;
                 }
             }
+            if (lane == 0) {
+                nn_cnt[q] = (uint8_t)cnt;
+                selected[q] = (cnt == 5 && !(d5 > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
+            }
         }
-        emitted = sum_group<LPQ>(emitted);
-        if (done && emitted != cnt) done = false;  // a 6th candidate ties with the 5th distance
-        uint32_t my_slot = 0;
+        // ---- unsettled queries go to the next stage's list: one global atomic per wave, 64 striped counters
         const bool append = live && !done && lane == 0;
-        if (append) my_slot = atomicAdd(&blk_n, 1u);  // LDS atomic
-        if (live && done && lane == 0) {
-            for (int j = cnt; j < 5; ++j) {  // fewer than five points inside the gate radius: sentinel rows
-                nn_pts[(size_t)j * N + q] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-                nn_d2[(size_t)j * N + q] = INFINITY;
+        const u64 bal = __ballot(append);
+        if (bal) {
+            const int wlane = threadIdx.x & 63;
+            const int leader = __ffsll((long long)bal) - 1;
+            uint32_t wbase = 0;
+            if (wlane == leader) wbase = atomicAdd(out_count + stripe, (uint32_t)__popcll(bal));
+            wbase = __shfl(wbase, leader, 64);
+            if (append) {
+                out_list[wbase + (uint32_t)__popcll(bal & ((1ull << wlane) - 1ull))] = (uint32_t)q;
+                ub_out[q] = BOUNDED ? fminf(d5, ub_in[q]) : d5;  // the true 5th distance is <= the one found so far
             }
-            nn_cnt[q] = (uint8_t)cnt;
-            selected[q] = (cnt == 5 && !(d5 > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
         }
-        __syncthreads();
-        if (threadIdx.x == 0 && blk_n) blk_base = atomicAdd(out_count + stripe, blk_n);
-        __syncthreads();
-        if (append) {
-            out_list[blk_base + my_slot] = (uint32_t)q;
-            ub_out[q] = d5;  // every point of the true answer has d2 <= the 5th distance found so far
-        }
-        __syncthreads();
+        wave_sync();  // seg[] is rewritten by the next trip
     }
 }
 
-// A2: general exact path over the queries A1 could not settle; 32 lanes per query, 8 queries per block.
+// A3: general exact path over the queries A1/A2 could not settle; 32 lanes per query, 8 queries per block.
 // One pass over the cells that intersect the ball of radius sqrt(ub) around the query, where ub is the 5th
-// distance A1 found (an upper bound of the true one) capped by the gate max_sqdist of
+// distance A1/A2 found (an upper bound of the true one) capped by the gate max_sqdist of
 // src/laserMapping.cpp:671 -- beyond the gate a result can never be selected.  64-bit keys
 // (d2 bits << 32 | original map index) give the oracle's (d2, index) order, ties included.
 __global__ void __launch_bounds__(256)
@@ -649,7 +668,7 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
     }
     // re-arm: tickets for the next launch, and the A1 -> A2 work-list counters for the next search pass
     for (int i = t; i < ngroups + 1; i += 256) tickets[i] = 0;
-    if (t < kStripes) slow_count[t] = 0;
+    if (t < 2 * kStripes) slow_count[t] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -742,8 +761,8 @@ uint32_t list_stripe_cap(int N) { return (uint32_t)(cdiv(cdiv(N > 0 ? N : 1, 16)
 
 hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points,
                          float max_sqdist, int rmax, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
-                         uint32_t* list1, float* ub, uint32_t* counts /* [kStripes] */, u64* cand_counter,
-                         hipStream_t st) {
+                         uint32_t* list1, uint32_t* list2, float* ub, uint32_t* counts /* [2 * kStripes] */,
+                         u64* cand_counter, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     const dim3 blk(256);
     const uint32_t cap = list_stripe_cap(N);
@@ -753,10 +772,10 @@ hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const 
         return hipGetLastError();
     }
     // A1: ring 1, every query
-#define FLH_A1(L)                                                                                                 \
-    hipLaunchKernelGGL((k_search_ring<L, 1>), dim3(std::min(cdiv(N, 256 / L), 8192)), blk, 0, st, g, s, body, N, \
-                       map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,         \
-                       (const uint32_t*)nullptr, list1, counts, cap, ub, cand_counter)
+#define FLH_A1(L)                                                                                                        \
+    hipLaunchKernelGGL((k_search_ring<L, 1, false>), dim3(std::min(cdiv(N, 256 / L), 8192)), blk, 0, st, g, s, body, N, \
+                       map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,                \
+                       (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, cand_counter)
     switch (lpq) {
         case 2: FLH_A1(2); break;
         case 8: FLH_A1(8); break;
@@ -764,9 +783,19 @@ hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const 
         default: FLH_A1(4); break;
     }
 #undef FLH_A1
-    // A2 drains the list; a fixed grid that exits at once when the list is empty
-    hipLaunchKernelGGL(k_search_exact, dim3(kStripes * 16), blk, 0, st, g, s, body, N, max_sqdist, rmax, nn_pts, nn_d2,
-                       nn_cnt, selected, list1, counts, cap, ub, 0, cand_counter);
+    const uint32_t* last_list = list1;
+    const uint32_t* last_counts = counts;
+    if (rmax >= 2) {
+        // A2: ring 2 over list 1, inside the ball A1's 5th distance defines
+        hipLaunchKernelGGL((k_search_ring<16, 2, true>), dim3(kStripes * 8), blk, 0, st, g, s, body, N, map_points, max_sqdist,
+                           nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)list1, (const uint32_t*)counts, list2,
+                           counts + kStripes, cap, (const float*)ub, ub, cand_counter);
+        last_list = list2;
+        last_counts = counts + kStripes;
+    }
+    // A3 drains what is left (ties, > 5x5x5); a fixed grid that exits at once when its list is empty
+    hipLaunchKernelGGL(k_search_exact, dim3(kStripes * 8), blk, 0, st, g, s, body, N, max_sqdist, rmax, nn_pts, nn_d2,
+                       nn_cnt, selected, last_list, last_counts, cap, ub, 0, cand_counter);
     return hipGetLastError();
 }
 

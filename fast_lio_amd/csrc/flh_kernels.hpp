@@ -29,7 +29,8 @@ int list_stripes();
 uint32_t list_stripe_cap(int N);
 hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points,
                          float max_sqdist, int rmax, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
-                         uint32_t* list1, float* ub, uint32_t* counts, unsigned long long* cand_counter, hipStream_t st);
+                         uint32_t* list1, uint32_t* list2, float* ub, uint32_t* counts, unsigned long long* cand_counter,
+                         hipStream_t st);
 
 int fit_blocks(int N);
 int reduce1_blocks(int nblk, int* per_out);
