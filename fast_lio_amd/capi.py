@@ -71,6 +71,7 @@ EXPORTS = [
     "flh_last_timing", "flh_enable_stats", "flh_time_kernel", "flh_esekf_create", "flh_esekf_destroy",
     "flh_esekf_set_meas_model", "flh_esekf_change_x", "flh_esekf_change_P", "flh_esekf_get_x", "flh_esekf_get_P",
     "flh_esekf_predict", "flh_esekf_update",
+    "flh_map_add", "flh_map_delete_boxes", "flh_map_download", "flh_map_incremental", "flh_fetch_map_incremental",
 ]
 
 _lib = None
@@ -98,6 +99,12 @@ def lib():
     L.flh_map_size.restype = C.c_size_t
     L.flh_map_size.argtypes = [C.c_void_p]
     L.flh_scan_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+    L.flh_map_add.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_double]
+    L.flh_map_delete_boxes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.flh_map_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.flh_map_incremental.argtypes = [C.c_void_p, _f64p, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_uint32)]
+    L.flh_fetch_map_incremental.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.flh_scan_size.restype = C.c_size_t
     L.flh_scan_size.argtypes = [C.c_void_p]
     L.flh_scan_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t]
@@ -177,6 +184,36 @@ class Handle:
         a = np.ascontiguousarray(xyz, dtype=np.float32)
         assert a.ndim == 2 and a.shape[1] in (3, 4, 12)
         _chk(lib().flh_map_build(self._h, a.ctypes.data, a.shape[1] * 4, a.shape[0]), "flh_map_build")
+
+    # ---- incremental map ----
+    def map_add(self, xyz: np.ndarray, downsample: bool = True, downsample_size: float = 0.5):
+        """ikdtree.Add_Points(points, downsample_on) -- src/laserMapping.cpp:470-471."""
+        a = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        _chk(lib().flh_map_add(self._h, a.ctypes.data, 12, a.shape[0], int(downsample), float(downsample_size)),
+             "flh_map_add")
+
+    def map_delete_boxes(self, boxes: np.ndarray):
+        """ikdtree.Delete_Point_Boxes -- src/laserMapping.cpp:275.  boxes: nb x (min xyz, max xyz)."""
+        b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
+        _chk(lib().flh_map_delete_boxes(self._h, b.ctypes.data, b.shape[0]), "flh_map_delete_boxes")
+
+    def map_download(self) -> np.ndarray:
+        out = np.zeros((self.M, 3), np.float32)
+        _chk(lib().flh_map_download(self._h, out.ctypes.data, out.shape[0]), "flh_map_download")
+        return out
+
+    def map_incremental(self, x, filter_size_map: float = 0.5, flg_EKF_inited: bool = True, apply: bool = True):
+        """map_incremental() -- src/laserMapping.cpp:427-474.  Returns (n_add, n_no_downsample)."""
+        n1, n2 = C.c_uint32(0), C.c_uint32(0)
+        _chk(lib().flh_map_incremental(self._h, np.ascontiguousarray(x, dtype=np.float64), float(filter_size_map),
+                                       int(flg_EKF_inited), int(apply), C.byref(n1), C.byref(n2)), "flh_map_incremental")
+        return int(n1.value), int(n2.value)
+
+    def fetch_map_incremental(self):
+        cls = np.zeros(self.N, np.uint8)
+        world = np.zeros((self.N, 3), np.float32)
+        _chk(lib().flh_fetch_map_incremental(self._h, cls.ctypes.data, world.ctypes.data), "flh_fetch_map_incremental")
+        return world, cls
 
     def scan_upload(self, body: np.ndarray):
         a = np.ascontiguousarray(body, dtype=np.float32)

@@ -60,7 +60,17 @@ struct flh_handle {
     // map
     size_t M = 0;
     GridParams grid{};
-    DevBuf<float4> map_sorted;
+    DevBuf<float4> map_sorted;             // cell-sorted copy the search reads (.w = index)
+    DevBuf<float4> map_orig, map_next;     // the map in index order, and the buffer the next version is built in
+    DevBuf<u64> mb_k0, mb_k1;              // index-build scratch (kept: the map is rebuilt after every change)
+    DevBuf<uint32_t> mb_v0, mb_v1, mb_bh, mb_br, mb_bstart, mb_aabb;
+    DevBuf<unsigned char> mb_tmp;
+    DevBuf<float4> mu_add, mi_world;       // incremental update: points to insert; map_incremental's world points
+    DevBuf<uint8_t> mu_dead, mu_alive, mi_cls;
+    DevBuf<uint32_t> mu_flags, mu_incl;
+    DevBuf<float> mu_boxes;
+    size_t mi_valid_N = (size_t)-1;        // N of the scan the last classification belongs to
+    StateDev search_state{};               // state of the last do_search evaluation (Nearest_Points refer to it)
     DevBuf<uint2> hash;
     DevBuf<uint32_t> starts;
     uint32_t nbricks = 0;
@@ -108,6 +118,8 @@ struct flh_handle {
 };
 
 extern "C" {
+
+static void release_build_scratch(flh_handle* h);
 
 const char* flh_last_error(void) { return g_err.c_str(); }
 
@@ -186,6 +198,9 @@ void flh_destroy(flh_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    release_build_scratch(h);
+    h->map_orig.release(); h->map_next.release(); h->mb_aabb.release(); h->mu_add.release(); h->mi_world.release();
+    h->mu_dead.release(); h->mu_alive.release(); h->mi_cls.release(); h->mu_flags.release(); h->mu_incl.release(); h->mu_boxes.release();
     h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_list2.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
     h->world.release(); h->nn_pts.release(); h->normvec.release();
     h->nn_d2.release(); h->nn_cnt.release(); h->selected.release();
@@ -208,34 +223,29 @@ size_t flh_map_size(const flh_handle* h) { return h ? h->M : 0; }
 size_t flh_scan_size(const flh_handle* h) { return h ? h->N : 0; }
 
 // ---------------------------------------------------------------------------------------------
-// ikdtree.Build -- src/laserMapping.cpp:919
-// ---------------------------------------------------------------------------------------------
-int flh_map_build(flh_handle* h, const void* xyz, size_t stride_bytes, size_t M) {
-    if (!h) return fail("flh_map_build: null handle");
-    if (M > 0 && !xyz) return fail("flh_map_build: null points");
-    if (stride_bytes < 12) return fail("flh_map_build: stride_bytes < 12");
-    if (M >= (1ull << 31)) return fail("flh_map_build: M too large");
-    HIPC(hipSetDevice(h->device));
+// Map index (re)build from a device array of points in INDEX order.  `pts` is h->map_orig or h->map_next; on
+// success it becomes h->map_orig.  On failure the previous map stays in place.
+static int rebuild_index(flh_handle* h, DevBuf<float4>& pts, size_t M) {
     hipStream_t st = h->stream;
-    h->M = 0;
-    h->searched_once = false;
     const float c = h->cfg.cell_size;
-    // host pass: re-stride to float4 and take the exact AABB
-    std::vector<float4> hp(M ? M : 1);
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    const unsigned char* src = (const unsigned char*)xyz;
-    for (size_t i = 0; i < M; ++i) {
-        float p[3];
-        std::memcpy(p, src + i * stride_bytes, 12);
-        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2]))
-            return fail("flh_map_build: non-finite map point at index " + std::to_string(i));
-        hp[i] = make_float4(p[0], p[1], p[2], 0.f);
-        for (int d = 0; d < 3; ++d) {
-            mn[d] = std::min(mn[d], p[d]);
-            mx[d] = std::max(mx[d], p[d]);
+    const uint32_t Mu = (uint32_t)M;
+    float mn[3] = {0.f, 0.f, 0.f}, mx[3] = {0.f, 0.f, 0.f};
+    if (M > 0) {  // exact AABB on the device
+        HIPC(h->mb_aabb.reserve(6));
+        const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+        uint32_t got[6];
+        HIPC(hipMemcpyAsync(h->mb_aabb.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+        HIPC(flh::launch_aabb(pts.p, Mu, h->mb_aabb.p, st));
+        HIPC(hipMemcpyAsync(got, h->mb_aabb.p, sizeof(got), hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+        for (int d = 0; d < 6; ++d) {
+            const uint32_t u = got[d];
+            const uint32_t bits = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+            float f;
+            std::memcpy(&f, &bits, 4);
+            (d < 3 ? mn[d] : mx[d - 3]) = f;
         }
     }
-    if (M == 0) mn[0] = mn[1] = mn[2] = mx[0] = mx[1] = mx[2] = 0.f;
     GridParams g{};
     g.c = c;
     g.inv_c = 1.0f / c;
@@ -246,69 +256,44 @@ int flh_map_build(flh_handle* h, const void* xyz, size_t stride_bytes, size_t M)
         o[d] = (std::floor(mn[d] / c) - PAD) * c;
         dims[d] = (int)std::floor((mx[d] - o[d]) / c) + 1 + PAD;
         if (dims[d] > 4096)
-            return fail("flh_map_build: map extent exceeds 4096 cells along an axis; raise flh_config.cell_size");
+            return fail("map index: map extent exceeds 4096 cells along an axis; raise flh_config.cell_size");
     }
     g.ox = o[0]; g.oy = o[1]; g.oz = o[2];
     g.nx = dims[0]; g.ny = dims[1]; g.nz = dims[2];
 
-    // device scratch
-    DevBuf<float4> d_in;
-    DevBuf<u64> k0, k1;
-    DevBuf<uint32_t> v0, v1, bh, br;
-    DevBuf<unsigned char> tmp;
-    const uint32_t Mu = (uint32_t)M;
-    auto cleanup = [&]() { d_in.release(); k0.release(); k1.release(); v0.release(); v1.release(); bh.release(); br.release(); tmp.release(); };
-#define HIPC_CL(expr)                                                                        \
-    do {                                                                                     \
-        hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess) {                                                              \
-            cleanup();                                                                       \
-            return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                  \
-        }                                                                                    \
-    } while (0)
-    HIPC_CL(h->map_sorted.reserve(M ? M : 1));
+    HIPC(h->map_sorted.reserve(M ? M : 1));
     uint32_t nbricks = 0;
     if (M > 0) {
-        HIPC_CL(d_in.reserve(M)); HIPC_CL(k0.reserve(M)); HIPC_CL(k1.reserve(M));
-        HIPC_CL(v0.reserve(M)); HIPC_CL(v1.reserve(M)); HIPC_CL(bh.reserve(M)); HIPC_CL(br.reserve(M));
-        HIPC_CL(hipMemcpyAsync(d_in.p, hp.data(), M * sizeof(float4), hipMemcpyHostToDevice, st));
-        GridParams gk = g;  // keys only need origin/extent
-        HIPC_CL(flh::launch_map_keys(gk, d_in.p, Mu, k0.p, v0.p, st));
+        HIPC(h->mb_k0.reserve(M)); HIPC(h->mb_k1.reserve(M));
+        HIPC(h->mb_v0.reserve(M)); HIPC(h->mb_v1.reserve(M)); HIPC(h->mb_bh.reserve(M)); HIPC(h->mb_br.reserve(M));
+        HIPC(flh::launch_map_keys(g, pts.p, Mu, h->mb_k0.p, h->mb_v0.p, st));  // keys only need origin/extent
         size_t tb1 = 0, tb2 = 0;
-        HIPC_CL(flh::sort_pairs(nullptr, tb1, k0.p, k1.p, v0.p, v1.p, Mu, st));
-        HIPC_CL(flh::inclusive_sum(nullptr, tb2, bh.p, br.p, Mu, st));
-        HIPC_CL(tmp.reserve(std::max(tb1, tb2)));
-        size_t tb = tmp.cap;
-        HIPC_CL(flh::sort_pairs(tmp.p, tb, k0.p, k1.p, v0.p, v1.p, Mu, st));
-        HIPC_CL(flh::launch_map_gather(d_in.p, k1.p, v1.p, Mu, h->map_sorted.p, bh.p, st));
-        tb = tmp.cap;
-        HIPC_CL(flh::inclusive_sum(tmp.p, tb, bh.p, br.p, Mu, st));
-        HIPC_CL(hipMemcpyAsync(&nbricks, br.p + (M - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIPC_CL(hipStreamSynchronize(st));
+        HIPC(flh::sort_pairs(nullptr, tb1, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, Mu, st));
+        HIPC(flh::inclusive_sum(nullptr, tb2, h->mb_bh.p, h->mb_br.p, Mu, st));
+        HIPC(h->mb_tmp.reserve(std::max(tb1, tb2)));
+        size_t tb = h->mb_tmp.cap;
+        HIPC(flh::sort_pairs(h->mb_tmp.p, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, Mu, st));
+        HIPC(flh::launch_map_gather(pts.p, h->mb_k1.p, h->mb_v1.p, Mu, h->map_sorted.p, h->mb_bh.p, st));
+        tb = h->mb_tmp.cap;
+        HIPC(flh::inclusive_sum(h->mb_tmp.p, tb, h->mb_bh.p, h->mb_br.p, Mu, st));
+        HIPC(hipMemcpyAsync(&nbricks, h->mb_br.p + (M - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
     }
     // directory + per-brick prefix tables
     uint32_t hs = 1024;
     while (hs < 2 * (nbricks + 1)) hs <<= 1;
     int log2hs = 0;
     while ((1u << log2hs) < hs) ++log2hs;
-    DevBuf<uint32_t> bstart;
-    HIPC_CL(h->hash.reserve(hs));
-    HIPC_CL(h->starts.reserve((size_t)(nbricks ? nbricks : 1) * flh::kBrickStride));
-    HIPC_CL(hipMemsetAsync(h->hash.p, 0xFF, (size_t)hs * sizeof(uint2), st));
+    HIPC(h->hash.reserve(hs));
+    HIPC(h->starts.reserve((size_t)(nbricks ? nbricks : 1) * flh::kBrickStride));
+    HIPC(hipMemsetAsync(h->hash.p, 0xFF, (size_t)hs * sizeof(uint2), st));
     if (M > 0) {
-        hipError_t e1 = bstart.reserve((size_t)nbricks + 1);
-        if (e1 != hipSuccess) { cleanup(); return fail(std::string("hipMalloc: ") + hipGetErrorString(e1)); }
-        hipError_t e2 = flh::launch_brick_starts(bh.p, br.p, Mu, bstart.p, st);
-        if (e2 == hipSuccess) e2 = hipMemcpyAsync(bstart.p + nbricks, &Mu, sizeof(uint32_t), hipMemcpyHostToDevice, st);
-        if (e2 == hipSuccess)
-            e2 = flh::launch_brick_tables(k1.p, bstart.p, nbricks, h->starts.p, h->hash.p, hs - 1, 32 - log2hs, st);
-        if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
-        bstart.release();
-        if (e2 != hipSuccess) { cleanup(); return fail(std::string("map tables: ") + hipGetErrorString(e2)); }
+        HIPC(h->mb_bstart.reserve((size_t)nbricks + 1));
+        HIPC(flh::launch_brick_starts(h->mb_bh.p, h->mb_br.p, Mu, h->mb_bstart.p, st));
+        HIPC(hipMemcpyAsync(h->mb_bstart.p + nbricks, &Mu, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIPC(flh::launch_brick_tables(h->mb_k1.p, h->mb_bstart.p, nbricks, h->starts.p, h->hash.p, hs - 1, 32 - log2hs, st));
     }
-    HIPC_CL(hipStreamSynchronize(st));
-    cleanup();
-#undef HIPC_CL
+    HIPC(hipStreamSynchronize(st));
     g.hash_mask = hs - 1;
     g.hash_shift = 32 - log2hs;
     g.hash = h->hash.p;
@@ -317,6 +302,138 @@ int flh_map_build(flh_handle* h, const void* xyz, size_t stride_bytes, size_t M)
     h->grid = g;
     h->nbricks = nbricks;
     h->M = M;
+    if (&pts != &h->map_orig) std::swap(h->map_orig, pts);
+    h->searched_once = false;  // cached neighbours refer to the previous map
+    return 0;
+}
+
+static void release_build_scratch(flh_handle* h) {
+    h->mb_k0.release(); h->mb_k1.release(); h->mb_v0.release(); h->mb_v1.release(); h->mb_bh.release(); h->mb_br.release();
+    h->mb_bstart.release(); h->mb_tmp.release();
+}
+
+// ---------------------------------------------------------------------------------------------
+// ikdtree.Build -- src/laserMapping.cpp:919
+// ---------------------------------------------------------------------------------------------
+static int upload_points(flh_handle* h, const char* who, const void* xyz, size_t stride_bytes, size_t n, DevBuf<float4>& dst) {
+    if (n > 0 && !xyz) return fail(std::string(who) + ": null points");
+    if (stride_bytes < 12) return fail(std::string(who) + ": stride_bytes < 12");
+    std::vector<float4> hp(n ? n : 1);
+    const unsigned char* src = (const unsigned char*)xyz;
+    for (size_t i = 0; i < n; ++i) {
+        float p[3];
+        std::memcpy(p, src + i * stride_bytes, 12);
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2]))
+            return fail(std::string(who) + ": non-finite point at index " + std::to_string(i));
+        hp[i] = make_float4(p[0], p[1], p[2], 0.f);
+    }
+    HIPC(dst.reserve(n ? n : 1));
+    if (n > 0) {
+        HIPC(hipMemcpyAsync(dst.p, hp.data(), n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+        HIPC(hipStreamSynchronize(h->stream));  // hp is pageable and dies here
+    }
+    return 0;
+}
+
+int flh_map_build(flh_handle* h, const void* xyz, size_t stride_bytes, size_t M) {
+    if (!h) return fail("flh_map_build: null handle");
+    if (M >= (1ull << 31)) return fail("flh_map_build: M too large");
+    HIPC(hipSetDevice(h->device));
+    if (upload_points(h, "flh_map_build", xyz, stride_bytes, M, h->map_next) != 0) return -1;
+    const int rc = rebuild_index(h, h->map_next, M);
+    if (rc != 0) {  // Build replaces the map: a failed build leaves none
+        h->M = 0;
+        h->searched_once = false;
+    }
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Incremental map -- SURVEY.md 8(f) row 1.  d_add holds n1 points to insert WITH down-sampling followed by n2
+// points to append; dead_old (M bytes) may already carry deletions.  Survivors keep their order (old, then new),
+// which is the index order the search's tie-break refers to.
+static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size_t n2, double ds, bool dead_prepared) {
+    hipStream_t st = h->stream;
+    const size_t M = h->M, n = n1 + n2, tot = M + n;
+    if (tot >= (1ull << 31)) return fail("map update: too many points");
+    if (!h->grid.hash) {  // no map yet: index an empty one so the voxel lookups have tables to probe
+        if (rebuild_index(h, h->map_orig, 0) != 0) return -1;
+    }
+    HIPC(h->mu_dead.reserve(M ? M : 1));
+    HIPC(h->mu_alive.reserve(n ? n : 1));
+    if (!dead_prepared && M > 0) HIPC(hipMemsetAsync(h->mu_dead.p, 0, M, st));
+    if (n1 > 0) HIPC(hipMemsetAsync(h->mu_alive.p, 0, n1, st));
+    if (n2 > 0) HIPC(hipMemsetAsync(h->mu_alive.p + n1, 1, n2, st));
+    if (n1 > 0) {
+        const uint32_t nu = (uint32_t)n1;
+        HIPC(h->mb_k0.reserve(n1)); HIPC(h->mb_k1.reserve(n1)); HIPC(h->mb_v0.reserve(n1)); HIPC(h->mb_v1.reserve(n1));
+        HIPC(flh::launch_add_keys(d_add, nu, ds, h->mb_k0.p, h->mb_v0.p, st));
+        size_t tb = 0;
+        HIPC(flh::sort_vox_pairs(nullptr, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, nu, st));
+        HIPC(h->mb_tmp.reserve(tb));
+        tb = h->mb_tmp.cap;
+        HIPC(flh::sort_vox_pairs(h->mb_tmp.p, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, nu, st));
+        HIPC(flh::launch_add_resolve(h->grid, d_add, h->mb_k1.p, h->mb_v1.p, nu, ds, h->mu_dead.p, h->mu_alive.p, st));
+    }
+    size_t total = 0;
+    if (tot > 0) {
+        HIPC(h->mu_flags.reserve(tot)); HIPC(h->mu_incl.reserve(tot));
+        HIPC(flh::launch_alive_flags(h->mu_dead.p, (uint32_t)M, h->mu_alive.p, (uint32_t)n, h->mu_flags.p, st));
+        size_t tb = 0;
+        HIPC(flh::inclusive_sum(nullptr, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)tot, st));
+        HIPC(h->mb_tmp.reserve(tb));
+        tb = h->mb_tmp.cap;
+        HIPC(flh::inclusive_sum(h->mb_tmp.p, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)tot, st));
+        uint32_t t32 = 0;
+        HIPC(hipMemcpyAsync(&t32, h->mu_incl.p + (tot - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+        total = t32;
+        HIPC(h->map_next.reserve(total ? total : 1));
+        HIPC(flh::launch_compact(h->map_orig.p, (uint32_t)M, d_add, (uint32_t)n, h->mu_flags.p, h->mu_incl.p, h->map_next.p, st));
+    } else {
+        HIPC(h->map_next.reserve(1));
+    }
+    return rebuild_index(h, h->map_next, total);
+}
+
+// ikdtree.Add_Points(points, downsample_on) -- src/laserMapping.cpp:470-471 (down-sampling length = the
+// filter_size_map_min handed to ikdtree.set_downsample_param, :868)
+int flh_map_add(flh_handle* h, const void* xyz, size_t stride_bytes, size_t n, int downsample, double downsample_size) {
+    if (!h) return fail("flh_map_add: null handle");
+    if (downsample && !(downsample_size > 0)) return fail("flh_map_add: downsample_size must be > 0");
+    HIPC(hipSetDevice(h->device));
+    if (upload_points(h, "flh_map_add", xyz, stride_bytes, n, h->mu_add) != 0) return -1;
+    return apply_map_changes(h, h->mu_add.p, downsample ? n : 0, downsample ? 0 : n, downsample_size, false);
+}
+
+// ikdtree.Delete_Point_Boxes(cub_needrm) -- src/laserMapping.cpp:275.  boxes: nb x {min xyz, max xyz}, a point is
+// removed when min <= p < max on every axis.
+int flh_map_delete_boxes(flh_handle* h, const float* boxes, size_t nb) {
+    if (!h) return fail("flh_map_delete_boxes: null handle");
+    if (nb > 0 && !boxes) return fail("flh_map_delete_boxes: null boxes");
+    if (nb == 0 || h->M == 0) return 0;
+    HIPC(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    HIPC(h->mu_boxes.reserve(6 * nb));
+    HIPC(h->mu_dead.reserve(h->M));
+    HIPC(hipMemcpyAsync(h->mu_boxes.p, boxes, 6 * nb * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPC(hipMemsetAsync(h->mu_dead.p, 0, h->M, st));
+    HIPC(flh::launch_delete_boxes(h->map_orig.p, (uint32_t)h->M, h->mu_boxes.p, (int)nb, h->mu_dead.p, st));
+    HIPC(hipStreamSynchronize(st));  // boxes is the caller's
+    return apply_map_changes(h, nullptr, 0, 0, 1.0, true);
+}
+
+// The map in index order (what PCL_Storage / flatten would hand back, src/laserMapping.cpp:406-411).
+int flh_map_download(flh_handle* h, float* xyz, size_t capacity_points) {
+    if (!h) return fail("flh_map_download: null handle");
+    if (capacity_points < h->M) return fail("flh_map_download: buffer too small");
+    if (h->M == 0) return 0;
+    if (!xyz) return fail("flh_map_download: null buffer");
+    HIPC(hipSetDevice(h->device));
+    std::vector<float4> hp(h->M);
+    HIPC(hipMemcpyAsync(hp.data(), h->map_orig.p, h->M * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < h->M; ++i) { xyz[3 * i] = hp[i].x; xyz[3 * i + 1] = hp[i].y; xyz[3 * i + 2] = hp[i].z; }
     return 0;
 }
 
@@ -357,6 +474,7 @@ static int prepare_scan_buffers(flh_handle* h, size_t N, bool full_clear) {
     h->N = N;
     h->have_eval = false;
     h->searched_once = false;
+    h->mi_valid_N = (size_t)-1;
     return 0;
 }
 
@@ -455,6 +573,7 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
                                 h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
                                 h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr, st));
         h->searched_once = true;
+        h->search_state = s;
     }
     if (timed) HIPC(hipEventRecord(h->ev[1], st));
     HIPC(flh::launch_fit(s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
@@ -523,6 +642,72 @@ int flh_eval_device(flh_handle* h, const double x[FLH_NSTATE], int do_search, in
     return enqueue_eval(h, s, do_search, ext, d_gram256, false);
 }
 
+// map_incremental() -- src/laserMapping.cpp:427-474, on the neighbour cache the scan's last search left on the
+// device.  x = the POSTERIOR state (state_point after the update).  apply != 0 also performs the two Add_Points
+// calls (:470-471) and re-indexes the map.
+int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter_size_map, int flg_EKF_inited, int apply,
+                        uint32_t* n_add, uint32_t* n_no_downsample) {
+    if (!h || !x) return fail("flh_map_incremental: null argument");
+    if (!(filter_size_map > 0)) return fail("flh_map_incremental: filter_size_map must be > 0");
+    if (!h->cur_body) return fail("flh_map_incremental: no active scan");
+    if (h->N > 0 && !h->searched_once)
+        return fail("flh_map_incremental: the active scan has not been searched against the current map");
+    HIPC(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const size_t N = h->N;
+    const StateDev s_post = make_state(x + 3, x + 0, x + 7, x + 11);
+    HIPC(h->mi_world.reserve(N ? N : 1)); HIPC(h->mi_cls.reserve(N ? N : 1));
+    HIPC(flh::launch_mi_classify(h->grid, h->grid.hash_mask + 1, (uint32_t)h->M, h->search_state, s_post, h->cur_body,
+                                 h->nn_pts.p, h->nn_cnt.p, (int)N, filter_size_map, flg_EKF_inited, h->mi_world.p,
+                                 h->mi_cls.p, st));
+    uint32_t c1 = 0, c2 = 0;
+    if (N > 0) {
+        HIPC(h->mu_flags.reserve(2 * N)); HIPC(h->mu_incl.reserve(2 * N));
+        HIPC(flh::launch_cls_flags(h->mi_cls.p, (int)N, h->mu_flags.p, st));
+        size_t tb = 0;
+        HIPC(flh::inclusive_sum(nullptr, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)(2 * N), st));
+        HIPC(h->mb_tmp.reserve(tb));
+        tb = h->mb_tmp.cap;
+        HIPC(flh::inclusive_sum(h->mb_tmp.p, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)(2 * N), st));
+        uint32_t e1 = 0, e2 = 0;
+        HIPC(hipMemcpyAsync(&e1, h->mu_incl.p + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPC(hipMemcpyAsync(&e2, h->mu_incl.p + (2 * N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+        c1 = e1;
+        c2 = e2 - e1;
+        HIPC(h->mu_add.reserve((size_t)c1 + c2 + 1));
+        HIPC(flh::launch_cls_compact(h->mi_world.p, h->mi_cls.p, h->mu_incl.p, (int)N, h->mu_add.p, st));
+    }
+    if (n_add) *n_add = c1;
+    if (n_no_downsample) *n_no_downsample = c2;
+    h->mi_valid_N = N;
+    if (!apply) {
+        HIPC(hipStreamSynchronize(st));
+        return 0;
+    }
+    return apply_map_changes(h, h->mu_add.p, c1, c2, filter_size_map, false);
+}
+
+// Per scan point (original order): 0 = not inserted, 1 = PointToAdd, 2 = PointNoNeedDownsample; and the world
+// points map_incremental computed (feats_down_world, :436).  Either pointer may be NULL.
+int flh_fetch_map_incremental(flh_handle* h, uint8_t* cls, float* world_xyz) {
+    if (!h) return fail("flh_fetch_map_incremental: null handle");
+    if (h->mi_valid_N != h->N || !h->cur_body) return fail("flh_fetch_map_incremental: no classification for the active scan");
+    const size_t N = h->N;
+    if (N == 0) return 0;
+    HIPC(hipSetDevice(h->device));
+    if (cls) HIPC(hipMemcpyAsync(cls, h->mi_cls.p, N, hipMemcpyDeviceToHost, h->stream));
+    std::vector<float4> w;
+    if (world_xyz) {
+        w.resize(N);
+        HIPC(hipMemcpyAsync(w.data(), h->mi_world.p, N * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPC(hipStreamSynchronize(h->stream));
+    if (world_xyz)
+        for (size_t i = 0; i < N; ++i) { world_xyz[3 * i] = w[i].x; world_xyz[3 * i + 1] = w[i].y; world_xyz[3 * i + 2] = w[i].z; }
+    return 0;
+}
+
 int flh_last_timing(flh_handle* h, flh_timing* t) {
     if (!h || !t) return fail("flh_last_timing: null argument");
     *t = h->timing;
@@ -555,6 +740,7 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
                                     h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, nullptr, st));
             HIPC(hipMemsetAsync(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t), st));
             h->searched_once = true;
+            h->search_state = s;
         } else {
             HIPC(flh::launch_fit(s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p,
                                  h->normvec.p, h->world.p, h->partials.p, h->part2.p, h->gram.p, h->tickets.p, h->slow_count.p, st));

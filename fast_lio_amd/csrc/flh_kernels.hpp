@@ -38,4 +38,24 @@ hipError_t launch_fit(const StateDev& s, const float4* body, const float4* nn_pt
                       uint8_t* selected, float4* normvec, float4* world, double* partials, double* part2,
                       double* out256, uint32_t* tickets, uint32_t* slow_count, hipStream_t st);
 
+// ---- flh_mapinc.hip: map_incremental and the incremental map ----
+hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t map_points, const StateDev& s_search,
+                              const StateDev& s_post, const float4* body, float4* nn_pts, const uint8_t* nn_cnt, int N,
+                              double fsm, int ekf_inited, float4* world_out, uint8_t* cls, hipStream_t st);
+hipError_t launch_cls_flags(const uint8_t* cls, int N, uint32_t* flags, hipStream_t st);
+hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* incl, int N, float4* out,
+                              hipStream_t st);
+hipError_t launch_aabb(const float4* pts, uint32_t M, uint32_t* out6, hipStream_t st);
+hipError_t launch_add_keys(const float4* add, uint32_t n, double ds, unsigned long long* keys, uint32_t* vals,
+                           hipStream_t st);
+hipError_t sort_vox_pairs(void* tmp, size_t& tmp_bytes, const unsigned long long* kin, unsigned long long* kout,
+                          const uint32_t* vin, uint32_t* vout, uint32_t n, hipStream_t st);
+hipError_t launch_add_resolve(const GridParams& g, const float4* add, const unsigned long long* ks, const uint32_t* vs,
+                              uint32_t n, double ds, uint8_t* dead_old, uint8_t* alive_new, hipStream_t st);
+hipError_t launch_delete_boxes(const float4* pts, uint32_t M, const float* boxes, int nb, uint8_t* dead, hipStream_t st);
+hipError_t launch_alive_flags(const uint8_t* dead_old, uint32_t M, const uint8_t* alive_new, uint32_t n, uint32_t* flags,
+                              hipStream_t st);
+hipError_t launch_compact(const float4* old_pts, uint32_t M, const float4* new_pts, uint32_t n, const uint32_t* flags,
+                          const uint32_t* incl, float4* out, hipStream_t st);
+
 }  // namespace flh

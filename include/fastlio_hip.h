@@ -67,6 +67,33 @@ int flh_device_available(void);
 int flh_map_build(flh_handle* h, const void* xyz, size_t stride_bytes, size_t M);
 size_t flh_map_size(const flh_handle* h);
 
+/* ---- the incremental map around the hot path --------------------------------------
+ * The map keeps an INDEX ORDER: after every change the survivors keep their relative order, points that were
+ * already in the map first, inserted points after them.  flh_fetch_neighbors' indices and the search's
+ * equal-distance tie-break (lower index) refer to that order.  Every change re-indexes the map on the device and
+ * invalidates the active scan's neighbour cache (the next flh_eval must search, as the reference's does). */
+
+/* ikdtree.Add_Points(points, downsample_on) -- src/laserMapping.cpp:470-471, down-sampling length as set by
+ * ikdtree.set_downsample_param(filter_size_map_min) (:868).  downsample != 0: per downsample_size voxel only the
+ * point nearest to the voxel centre survives (an inserted point wins an exact tie against a map point, a later
+ * inserted point against an earlier one); a voxel whose single map point stays nearest is left untouched. */
+int flh_map_add(flh_handle* h, const void* xyz, size_t stride_bytes, size_t n, int downsample, double downsample_size);
+/* ikdtree.Delete_Point_Boxes(cub_needrm) -- src/laserMapping.cpp:275 (lasermap_fov_segment).  boxes = nb x
+ * {min x,y,z, max x,y,z}; a point with min <= p < max on every axis is removed. */
+int flh_map_delete_boxes(flh_handle* h, const float* boxes, size_t nb);
+/* The map in index order, 3 floats per point (what ikdtree.flatten / PCL_Storage hands back, :406-411). */
+int flh_map_download(flh_handle* h, float* xyz, size_t capacity_points);
+/* map_incremental() -- src/laserMapping.cpp:427-474, evaluated on the device from the neighbour cache the active
+ * scan's last search left there (Nearest_Points).  x = the posterior state in the flat layout of flh_eval_device.
+ * Classifies every scan point (skip / PointToAdd / PointNoNeedDownsample), and with apply != 0 performs the two
+ * Add_Points calls.  n_add / n_no_downsample (optional) receive the two list lengths (add_point_size = n_add as
+ * Add_Points counts it before down-sampling). */
+int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter_size_map, int flg_EKF_inited, int apply,
+                        uint32_t* n_add, uint32_t* n_no_downsample);
+/* Results of the last flh_map_incremental in ORIGINAL scan order: cls[i] in {0,1,2}; world_xyz = feats_down_world
+ * (:436).  Either may be NULL. */
+int flh_fetch_map_incremental(flh_handle* h, uint8_t* cls, float* world_xyz);
+
 /* feats_down_body for the coming update -- src/laserMapping.cpp:904-905,935-951.  Resets
  * point_selected_surf to all-true (as memset at :812 leaves it for a fresh search) and clears the
  * neighbour cache. */

@@ -150,6 +150,23 @@ void orc_map_incremental_classify(const orc_scan* sc, const float* map_xyz, size
                                   const double x[ORC_NSTATE], double filter_size_map,
                                   int flg_EKF_inited, float* world_out, uint8_t* cls);
 
+/* ---- incremental map (stand-in for ikd-Tree Add_Points / Delete_Point_Boxes; source absent, semantics
+ * restated from the published ikd-Tree algorithm [recalled-upstream] as used at src/laserMapping.cpp:275,470-471).
+ *
+ * orc_map_add: inserts n points into the map array (cap >= M + n entries of xyz).
+ *   downsample != 0 (Add_Points(PointToAdd, true)): each new point competes inside its filter_size_map
+ *   voxel [floor(x/ds)*ds, +ds)^3: the voxel ends up holding exactly ONE point, the one nearest to the voxel
+ *   centre among the points already there and the new ones (an existing point is displaced only by a strictly
+ *   nearer one... of the NEW points the later wins a tie; a new point wins a tie against an existing one);
+ *   a voxel with a single existing point that stays nearest is left untouched.
+ *   downsample == 0 (Add_Points(PointNoNeedDownsample, false)): plain insert.
+ * The result keeps surviving old points in their old order, followed by surviving new points in input order.
+ * Returns the new size. */
+size_t orc_map_add(float* map_xyz, size_t M, const float* add_xyz, size_t n, int downsample, double ds);
+/* Delete_Point_Boxes: removes every point p with min <= p < max (per axis) for any of the nb boxes
+ * (boxes: nb x 6 floats min xyz, max xyz).  Order preserved.  Returns the new size. */
+size_t orc_map_delete_boxes(float* map_xyz, size_t M, const float* boxes, size_t nb);
+
 #ifdef __cplusplus
 }
 #endif

@@ -711,3 +711,105 @@ void orc_map_incremental_classify(const orc_scan* sc, const float* map_xyz, size
         }
     }
 }
+
+/* =================================================================== incremental map (ikd-Tree stand-in) */
+typedef struct { long long kx, ky, kz; } vox_key;
+static int vox_eq(vox_key a, vox_key b) { return a.kx == b.kx && a.ky == b.ky && a.kz == b.kz; }
+static unsigned long long vox_hash(vox_key k) {
+    unsigned long long h = (unsigned long long)k.kx * 0x9E3779B97F4A7C15ull;
+    h ^= (unsigned long long)k.ky * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2);
+    h ^= (unsigned long long)k.kz * 0x165667B19E3779F9ull + (h << 6) + (h >> 2);
+    return h;
+}
+static vox_key vox_of(const float* p, double ds) {
+    /* Box_of_Point.vertex_min = floor(p/ds)*ds in the reference's float arithmetic is evaluated on doubles here
+       (filter_size_map_min is a double global); the integer voxel index is what matters. */
+    vox_key k;
+    k.kx = (long long)floor((double)p[0] / ds);
+    k.ky = (long long)floor((double)p[1] / ds);
+    k.kz = (long long)floor((double)p[2] / ds);
+    return k;
+}
+static float dist_to_center(const float* p, vox_key k, double ds) {
+    /* calc_dist(point, mid_point) with mid_point (float members) = min + 0.5*ds */
+    float mx = (float)((double)k.kx * ds + 0.5 * ds), my = (float)((double)k.ky * ds + 0.5 * ds), mz = (float)((double)k.kz * ds + 0.5 * ds);
+    float dx = p[0] - mx, dy = p[1] - my, dz = p[2] - mz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+size_t orc_map_add(float* map, size_t M, const float* add, size_t n, int downsample, double ds) {
+    if (!downsample) {
+        memcpy(map + 3 * M, add, sizeof(float) * 3 * n);
+        return M + n;
+    }
+    /* voxel hash over ALL points (old + new): chain heads per bucket */
+    size_t tot = M + n, nb = 1;
+    while (nb < 2 * tot + 16) nb <<= 1;
+    long long* head = (long long*)malloc(sizeof(long long) * nb);
+    long long* next = (long long*)malloc(sizeof(long long) * (tot ? tot : 1));
+    unsigned char* dead = (unsigned char*)calloc(tot ? tot : 1, 1);
+    for (size_t i = 0; i < nb; i++) head[i] = -1;
+    memcpy(map + 3 * M, add, sizeof(float) * 3 * n);
+    for (size_t i = 0; i < M; i++) {
+        vox_key k = vox_of(map + 3 * i, ds);
+        size_t b = (size_t)(vox_hash(k) & (nb - 1));
+        next[i] = head[b];
+        head[b] = (long long)i;
+    }
+    /* sequential semantics of the reference loop, one new point at a time */
+    for (size_t a = 0; a < n; a++) {
+        size_t i = M + a;
+        const float* p = map + 3 * i;
+        vox_key k = vox_of(p, ds);
+        size_t b = (size_t)(vox_hash(k) & (nb - 1));
+        float min_dist = dist_to_center(p, k, ds);
+        long long best = (long long)i;
+        int stored = 0;
+        for (long long j = head[b]; j >= 0; j = next[j]) {
+            if (dead[j] || !vox_eq(vox_of(map + 3 * j, ds), k)) continue;
+            stored++;
+            float d = dist_to_center(map + 3 * j, k, ds);
+            /* strict '<': the new point keeps a tie.  Among EXISTING points at equal distance the reference keeps the
+               first in tree order (arbitrary); pinned here to the lowest index. */
+            if (d < min_dist || (d == min_dist && best != (long long)i && j < best)) { min_dist = d; best = j; }
+        }
+        if (stored > 1 || best == (long long)i) {
+            /* Delete_by_range(box) + Add_by_point(downsample_result) */
+            for (long long j = head[b]; j >= 0; j = next[j])
+                if (!dead[j] && vox_eq(vox_of(map + 3 * j, ds), k) && j != best) dead[j] = 1;
+            if (best == (long long)i) { /* the new point enters the map */
+                next[i] = head[b];
+                head[b] = (long long)i;
+            } else {
+                dead[i] = 1;
+            }
+        } else {
+            dead[i] = 1; /* the single existing point stays; the new one is dropped */
+        }
+    }
+    size_t w = 0;
+    for (size_t i = 0; i < tot; i++)
+        if (!dead[i]) {
+            if (w != i) memmove(map + 3 * w, map + 3 * i, sizeof(float) * 3);
+            w++;
+        }
+    free(head); free(next); free(dead);
+    return w;
+}
+
+size_t orc_map_delete_boxes(float* map, size_t M, const float* boxes, size_t nb) {
+    size_t w = 0;
+    for (size_t i = 0; i < M; i++) {
+        const float* p = map + 3 * i;
+        int del = 0;
+        for (size_t b = 0; b < nb && !del; b++) {
+            const float* bx = boxes + 6 * b;
+            if (p[0] >= bx[0] && p[0] < bx[3] && p[1] >= bx[1] && p[1] < bx[4] && p[2] >= bx[2] && p[2] < bx[5]) del = 1;
+        }
+        if (!del) {
+            if (w != i) memmove(map + 3 * w, p, sizeof(float) * 3);
+            w++;
+        }
+    }
+    return w;
+}

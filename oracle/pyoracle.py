@@ -124,6 +124,10 @@ def lib():
     L.orc_map_incremental_classify.argtypes = [
         C.POINTER(_Scan), _f32p, C.c_size_t, _f64p, C.c_double, C.c_int, _f32p, _u8p,
     ]
+    L.orc_map_add.restype = C.c_size_t
+    L.orc_map_add.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_int, C.c_double]
+    L.orc_map_delete_boxes.restype = C.c_size_t
+    L.orc_map_delete_boxes.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t]
     _lib = L
     return L
 
@@ -408,3 +412,21 @@ def iekf_pass_gain(x, x_prop, P_prop, R, h_x, h):
     dx = np.zeros(NDOF)
     lib().orc_iekf_pass_gain(x, _c64(x_prop), _c64(P_prop), R, hcm, _c64(h), n, P, Kx, dx)
     return x, P, Kx, dx
+
+
+def map_add(map_xyz, add_xyz, downsample=True, ds=0.5):
+    """ikd-Tree Add_Points stand-in: returns the new map array."""
+    m = _c32(map_xyz).reshape(-1, 3)
+    a = _c32(add_xyz).reshape(-1, 3)
+    buf = np.zeros((len(m) + len(a), 3), np.float32)
+    buf[: len(m)] = m
+    n = lib().orc_map_add(buf, len(m), a, len(a), int(downsample), float(ds))
+    return buf[:n].copy()
+
+
+def map_delete_boxes(map_xyz, boxes):
+    """ikd-Tree Delete_Point_Boxes stand-in: boxes (nb x 6: min xyz, max xyz)."""
+    m = _c32(map_xyz).reshape(-1, 3).copy()
+    b = _c32(boxes).reshape(-1, 6)
+    n = lib().orc_map_delete_boxes(m, len(m), b, len(b))
+    return m[:n].copy()

@@ -1,0 +1,243 @@
+"""GPU parity for SURVEY.md 8(f) row 1: map_incremental (src/laserMapping.cpp:427-474) and the incremental map
+(ikdtree.Add_Points / Delete_Point_Boxes) against the oracle's restatement.  Everything here is index / flag /
+fp32-copy work, so the bar is bit-exact: same classes, same surviving points in the same order, and a search on
+the updated map that matches an oracle kd-tree built from the oracle's updated map."""
+import numpy as np
+import pytest
+
+from fast_lio_amd import capi, synth
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+DS = 0.5
+
+
+def same_points(a, b, msg=""):
+    assert a.shape == b.shape, f"{msg}: {a.shape} vs {b.shape}"
+    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32), err_msg=msg)
+
+
+@pytest.fixture(scope="module")
+def prob():
+    pr = synth.make_problem(150000, 12000, "avia", cfg=1)
+    return pr
+
+
+def search_matches(h, map_xyz, body, x):
+    m = po.Map(map_xyz)
+    sc = po.Scan(body, nthreads=8)
+    h.scan_upload(body)
+    HTH, HTh, n_eff, _ = h.eval(x, True, False)
+    sc.h_share_model(m, x, True, False)
+    np.testing.assert_array_equal(h.fetch_selected(), sc.selected)
+    assert n_eff == sc.n_eff
+    idx, d2, cnt = h.fetch_neighbors()
+    gate = (sc.nn_cnt == 5) & (sc.nn_d2[:, 4] <= 5.0)
+    np.testing.assert_array_equal(idx[gate], sc.nn_idx[gate])
+    np.testing.assert_array_equal(d2[gate].view(np.uint32), sc.nn_d2[gate].view(np.uint32))
+    sel = sc.selected.astype(bool)
+    np.testing.assert_array_equal(h.fetch_normvec()[sel].view(np.uint32), sc.normvec[sel].view(np.uint32))
+    return int(gate.sum())
+
+
+def test_download_returns_the_built_map(prob):
+    h = capi.Handle()
+    h.map_build(prob.map_xyz)
+    same_points(h.map_download(), prob.map_xyz.astype(np.float32))
+
+
+@pytest.mark.parametrize("downsample", [True, False])
+def test_map_add_matches_oracle_and_search_stays_exact(prob, downsample):
+    pr = prob
+    rng = np.random.default_rng(11)
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    # new points: jittered copies of map points (crowded voxels), exact duplicates, a block outside the old AABB
+    pick = rng.integers(0, len(pr.map_xyz), 15000)
+    jit = pr.map_xyz[pick] + rng.normal(0, 0.2, (15000, 3)).astype(np.float32)
+    dup = pr.map_xyz[rng.integers(0, len(pr.map_xyz), 500)]
+    far = pr.map_xyz.max(0) + rng.uniform(1.0, 30.0, (800, 3)).astype(np.float32)
+    add = np.vstack([jit, dup, far, jit[:300]]).astype(np.float32)
+    want = po.map_add(pr.map_xyz, add, downsample, DS)
+    h.map_add(add, downsample, DS)
+    assert h.M == len(want)
+    got = h.map_download()
+    same_points(got, want, "map after Add_Points")
+    assert search_matches(h, want, pr.body, pr.x_true) > 1000
+    # a second round on top of the first
+    add2 = (want[rng.integers(0, len(want), 6000)] + rng.normal(0, 0.1, (6000, 3))).astype(np.float32)
+    want2 = po.map_add(want, add2, downsample, DS)
+    h.map_add(add2, downsample, DS)
+    same_points(h.map_download(), want2, "second Add_Points")
+
+
+def test_map_add_exact_ties_on_a_lattice():
+    # every coordinate a multiple of 1/8: distances to the voxel centres tie exactly, all the time
+    rng = np.random.default_rng(5)
+    m = (rng.integers(-40, 40, (4000, 3)) / 8.0).astype(np.float32)
+    add = (rng.integers(-40, 40, (3000, 3)) / 8.0).astype(np.float32)
+    h = capi.Handle()
+    h.map_build(m)
+    want = po.map_add(m, add, True, DS)
+    h.map_add(add, True, DS)
+    same_points(h.map_download(), want, "lattice ties")
+    # and with another voxel size that does not divide the lattice
+    want2 = po.map_add(want, add[::-1].copy(), True, 0.3)
+    h.map_add(add[::-1].copy(), True, 0.3)
+    same_points(h.map_download(), want2, "lattice ties, ds=0.3")
+
+
+def test_map_add_into_empty_and_unbuilt_maps():
+    rng = np.random.default_rng(2)
+    add = rng.uniform(-3, 3, (2000, 3)).astype(np.float32)
+    h = capi.Handle()           # never built
+    h.map_add(add, True, DS)
+    same_points(h.map_download(), po.map_add(np.zeros((0, 3), np.float32), add, True, DS), "unbuilt")
+    h2 = capi.Handle()
+    h2.map_build(np.zeros((0, 3), np.float32))
+    h2.map_add(add, False, DS)
+    same_points(h2.map_download(), add, "empty, no down-sampling")
+    h2.map_add(np.zeros((0, 3), np.float32), True, DS)   # adding nothing changes nothing
+    same_points(h2.map_download(), add)
+
+
+def test_delete_point_boxes(prob):
+    pr = prob
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    c = np.median(pr.map_xyz, axis=0)
+    boxes = np.array([np.r_[c - 6, c + 6], np.r_[c + [10, -3, -50], c + [25, 9, 50]]], np.float32)
+    want = po.map_delete_boxes(pr.map_xyz, boxes)
+    assert 0 < len(want) < len(pr.map_xyz)
+    h.map_delete_boxes(boxes)
+    same_points(h.map_download(), want, "Delete_Point_Boxes")
+    search_matches(h, want, pr.body, pr.x_true)
+    # delete everything
+    big = np.array([[-1e6, -1e6, -1e6, 1e6, 1e6, 1e6]], np.float32)
+    h.map_delete_boxes(big)
+    assert h.M == 0
+    h.scan_upload(pr.body[:100])
+    assert h.eval(pr.x_true, True, False)[2] == 0
+
+
+@pytest.mark.parametrize("fsm", [0.5, 0.3])
+def test_map_incremental_matches_oracle(prob, fsm):
+    pr = prob
+    m = po.Map(pr.map_xyz)
+    xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    # scan with a tail of points nowhere near the map (no neighbour inside the search bound)
+    rng = np.random.default_rng(3)
+    tail = (pr.body[:400] * 0.0 + rng.uniform(150, 400, (400, 3))).astype(np.float32)
+    body = np.vstack([pr.body, tail]).astype(np.float32)
+    h.scan_upload(body)
+    sc = po.Scan(body, nthreads=8)
+    # the passes of one update, driven identically on both sides: search at the prior, two re-linearisations
+    x2 = po.state_boxplus(xp, np.r_[0.02, -0.01, 0.015, 0.002, -0.001, 0.003, np.zeros(17)])
+    for x, s in ((xp, True), (x2, False), (pr.x_true, False)):
+        h.eval(x, s, False)
+        sc.h_share_model(m, x, s, False)
+    x_post = pr.x_true
+    w_ref, c_ref = sc.map_incremental_classify(m, x_post, fsm, True)
+    n1, n2 = h.map_incremental(x_post, fsm, True, apply=False)
+    w, c = h.fetch_map_incremental()
+    same_points(w, w_ref, "feats_down_world")
+    np.testing.assert_array_equal(c, c_ref, err_msg="add / no-downsample / skip classes")
+    assert (n1, n2) == (int((c_ref == 1).sum()), int((c_ref == 2).sum()))
+    assert n1 > 0 and n2 > 0 and int((c_ref == 0).sum()) > 0
+    # apply: Add_Points(PointToAdd, true); Add_Points(PointNoNeedDownsample, false)
+    want = po.map_add(pr.map_xyz, w_ref[c_ref == 1], True, fsm)
+    want = po.map_add(want, w_ref[c_ref == 2], False, fsm)
+    assert h.map_incremental(x_post, fsm, True, apply=True) == (n1, n2)
+    same_points(h.map_download(), want, "map after map_incremental")
+    # the neighbour cache died with the old map
+    with pytest.raises(capi.FlhError):
+        h.eval(x_post, False, False)
+    assert search_matches(h, want, pr.body, pr.x_true) > 1000
+
+
+def test_map_incremental_before_ekf_init_adds_everything(prob):
+    pr = prob
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    h.scan_upload(pr.body)
+    h.eval(pr.x_true, True, False)
+    n1, n2 = h.map_incremental(pr.x_true, DS, False, apply=False)
+    assert (n1, n2) == (len(pr.body), 0)
+    sc = po.Scan(pr.body, nthreads=8)
+    m = po.Map(pr.map_xyz)
+    sc.h_share_model(m, pr.x_true, True, False)
+    w_ref, c_ref = sc.map_incremental_classify(m, pr.x_true, DS, False)
+    w, c = h.fetch_map_incremental()
+    np.testing.assert_array_equal(c, c_ref)
+    same_points(w, w_ref)
+
+
+def test_map_incremental_tiny_maps(prob):
+    # fewer than NUM_MATCH_POINTS map points: points_near.size() < 5 -> the veto loop breaks at once (:454)
+    pr = prob
+    for M in (1, 3, 4, 5, 7):
+        mp = np.ascontiguousarray(pr.map_xyz[:M])
+        m = po.Map(mp)
+        h = capi.Handle()
+        h.map_build(mp)
+        h.scan_upload(pr.body[:3000])
+        sc = po.Scan(pr.body[:3000], nthreads=4)
+        h.eval(pr.x_true, True, False)
+        sc.h_share_model(m, pr.x_true, True, False)
+        w_ref, c_ref = sc.map_incremental_classify(m, pr.x_true, DS, True)
+        h.map_incremental(pr.x_true, DS, True, apply=False)
+        w, c = h.fetch_map_incremental()
+        np.testing.assert_array_equal(c, c_ref, err_msg=f"M={M}")
+
+
+def test_full_scan_cycle_update_then_map_incremental(prob):
+    """One laserMapping loop body (:879-927): iterated update, then map_incremental with the posterior state, then
+    the next scan's update on the grown map -- GPU and oracle side by side."""
+    pr = prob
+    m = po.Map(pr.map_xyz)
+    xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    h.scan_upload(pr.body)
+    kf = capi.Esekf(h, max_iter=3, extrinsic_est_en=False)
+    kf.change_x(xp)
+    kf.change_P(P)
+    kf.update(0.001)
+    x_post = kf.get_x()
+    sc = po.Scan(pr.body, nthreads=8)
+    sc.update_iterated(m, xp, P)
+    w_ref, c_ref = sc.map_incremental_classify(m, x_post, DS, True)
+    n1, n2 = h.map_incremental(x_post, DS, True, apply=True)
+    w, c = h.fetch_map_incremental()
+    np.testing.assert_array_equal(c, c_ref)
+    same_points(w, w_ref)
+    want = po.map_add(po.map_add(pr.map_xyz, w_ref[c_ref == 1], True, DS), w_ref[c_ref == 2], False, DS)
+    same_points(h.map_download(), want)
+    # next scan against the grown map
+    pr2 = synth.make_problem(150000, 12000, "avia", cfg=1, scan_seed=7)
+    m2 = po.Map(want)
+    h.scan_upload(pr2.body)
+    xp2, P2 = synth.propagate_prior_cov(capi.predict_fn, pr2.x_prior)
+    kf.change_x(xp2)
+    kf.change_P(P2)
+    st = kf.update(0.001)
+    sc2 = po.Scan(pr2.body, nthreads=8)
+    x_ref, P_ref, st_ref = sc2.update_iterated(m2, xp2, P2)
+    assert list(st.n_eff)[: st.passes] == list(st_ref.n_eff)[: st.passes]
+    assert np.linalg.norm(kf.get_x()[0:3] - x_ref[0:3]) <= 1e-4
+    np.testing.assert_array_equal(h.fetch_selected(), sc2.selected)
+
+
+def test_map_incremental_requires_a_searched_scan(prob):
+    h = capi.Handle()
+    h.map_build(prob.map_xyz[:1000])
+    with pytest.raises(capi.FlhError):
+        h.map_incremental(prob.x_true, DS)
+    h.scan_upload(prob.body[:100])
+    with pytest.raises(capi.FlhError):
+        h.map_incremental(prob.x_true, DS)
+    with pytest.raises(capi.FlhError):
+        h.map_add(np.array([[np.nan, 0, 0]], np.float32))
