@@ -43,6 +43,35 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic(args):
+    """HBM bytes per search pass from the committed rocprofv3 --pmc summary (profiles/, made by tools/pmc_summary.py
+    from separate FETCH_SIZE and WRITE_SIZE passes of this same command).  FETCH_SIZE/WRITE_SIZE are in KiB;
+    on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled (MI355X_MICROARCH.md, HBM section).
+    Only valid for the default workload the summary was taken on."""
+    import csv
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.csv")
+    if not os.path.exists(path) or args.config != 2 or args.lpq != 4 or args.cell != 1.5:
+        return None
+    fetch, write, calls = {}, {}, {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            k = r["kernel"]
+            if not k.startswith("k_search"):
+                continue
+            if r["counter"] == "FETCH_SIZE":
+                fetch[k] = float(r["sum"])
+                calls[k] = int(r["dispatches"])
+            elif r["counter"] == "WRITE_SIZE":
+                write[k] = float(r["sum"])
+    a1 = [k for k in calls if k.startswith("k_search_ring<4, 1")]
+    if not a1 or not fetch:
+        return None
+    passes = calls[a1[0]]
+    total = (2.0 * sum(fetch.values()) + sum(write.values())) * 1024.0 / passes
+    return {"bytes_per_search_pass": int(total), "source": "profiles/r01_pmc_summary.csv (FETCH_SIZE x2 + WRITE_SIZE, KiB)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,7 +248,8 @@ def main():
         dur_s = ctr["search_ms"] / ctr["n_search"] * 1e-3
         ach = ALG_BYTES_SEARCH * n_pts / dur_s / 1e9
         fit_s = ctr["fit_ms"] / max(ctr["n_fit"], 1) * 1e-3
-        roof = {"bound": "hbm", "kernel": f"k_search_ring<{args.lpq},1> + k_search_exact (5-NN search of one pass)",
+        roof = {"bound": "hbm",
+                "kernel": f"5-NN search of one pass = k_search_ring<{args.lpq},1,false> + k_search_ring<16,2,true> + k_search_exact",
                 "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                 "traffic": None, "avg_kernel_us": round(dur_s * 1e6, 2), "alg_bytes_per_launch": ALG_BYTES_SEARCH * n_pts,
                 "events_sampled": ctr["n_search"], "fit_kernel_us": round(fit_s * 1e6, 2),
@@ -270,6 +300,10 @@ def main():
         "map_build_s": round(t_build, 3),
     }
     if roof is not None:
+        tr = pmc_traffic(args)
+        if tr is not None:
+            roof["traffic"] = tr["bytes_per_search_pass"]
+            roof["traffic_source"] = tr["source"]
         roof["candidates_per_query"] = round(cand_per_query, 2)
         roof["candidate_traffic_GBs"] = round(cand_per_query * 16 * n_pts / (roof["avg_kernel_us"] * 1e-6) / 1e9, 2)
         out["roofline"] = roof
@@ -308,6 +342,34 @@ def main():
                                          f"{args.cpu_threads} threads = the reference's MP_PROC_NUM); host has "
                                          f"{os.cpu_count()} logical cores",
                                "speedup_vs_cpu": round(value / (ncpu / tot), 1)}
+
+    # ---- map_incremental (classification + Add_Points + device re-index) after an update.
+    # Outside the timed region and last, because it grows the map.  t_map = classify + insert + re-index, the
+    # reference's "Incremental Mapping" timer (src/laserMapping.cpp:921-924).
+    if rank == 0 and G == 1 and mode != "shard":
+        h.set_timing_stride(0)
+        t_cls = t_all = 0.0
+        added = 0
+        reps = min(3, S)
+        for s in range(reps):
+            h.scan_activate(s)
+            kf.change_x(priors[s][0])
+            kf.change_P(priors[s][1])
+            kf.update(0.001)
+            xpost = kf.get_x()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            h.map_incremental(xpost, 0.5, True, apply=False)
+            t2 = time.perf_counter()
+            m0 = h.M
+            n1, n2 = h.map_incremental(xpost, 0.5, True, apply=True)
+            t3 = time.perf_counter()
+            t_cls += t2 - t1
+            t_all += t3 - t2
+            added += h.M - m0
+        out["map_incremental"] = {"ms_per_scan": round(t_all / reps * 1e3, 3), "classify_only_ms": round(t_cls / reps * 1e3, 3),
+                                  "net_points_added_per_scan": round(added / reps, 1), "scans": reps,
+                                  "note": "filter_size_map 0.5; full re-index of the map after each change"}
 
     if rank == 0:
         print(json.dumps(out), flush=True)
