@@ -13,6 +13,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -170,28 +171,53 @@ def main():
     def run(step_fn, n_warm, n_steps):
         for i in range(n_warm):
             step_fn(i)
+        # A generation-2 pass of Python's cyclic GC over the synthetic-scene objects costs ~40 ms of pure host time and
+        # landed deterministically inside the timed loop (found with FLH_BENCH_TRACE); collect now, then keep the
+        # collector out of the timed region, as timeit does.
+        gc.collect()
+        gc.disable()
         sync()
         h.counters(reset=True)
         acc = [0, 0]
         t1 = time.perf_counter()
+        trace = [] if os.environ.get("FLH_BENCH_TRACE") else None
         for i in range(n_steps):
+            ta = time.perf_counter()
             st = step_fn(i)
+            if trace is not None:
+                trace.append(time.perf_counter() - ta)
             acc[0] += st.passes
             acc[1] += st.searches
         sync()
         dt_ = time.perf_counter() - t1
+        gc.enable()
+        if trace:
+            order = sorted(range(len(trace)), key=lambda j: -trace[j])[:6]
+            print("[trace] slowest steps:", [(j, round(trace[j] * 1e3, 3)) for j in order], "median ms",
+                  round(sorted(trace)[len(trace) // 2] * 1e3, 4), file=sys.stderr)
         if dist is not None:
             tt = torch.tensor([dt_], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_ = float(tt.item())
         return dt_, acc[0], acc[1], h.counters()
 
+    split = [] if os.environ.get("FLH_BENCH_TRACE") else None
+
     def step_stream(i):
         s = i % S
+        ta = time.perf_counter()
         h.scan_activate(s)
+        tb = time.perf_counter()
         kf.change_x(priors[s][0])
         kf.change_P(priors[s][1])
-        return kf.update(0.001)
+        tc = time.perf_counter()
+        st = kf.update(0.001)
+        if split is not None:
+            td = time.perf_counter()
+            if td - ta > 5e-3:
+                print(f"[trace] slow step {i}: activate {1e3*(tb-ta):.3f} change {1e3*(tc-tb):.3f} update {1e3*(td-tc):.3f} ms",
+                      file=sys.stderr)
+        return st
 
     shard_out = None
     if mode == "shard":

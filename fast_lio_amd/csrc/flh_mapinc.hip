@@ -169,12 +169,20 @@ __global__ void __launch_bounds__(256) k_aabb(const float4* __restrict__ pts, ui
             mn[d] = fminf(mn[d], __shfl_xor(mn[d], o, 64));
             mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o, 64));
         }
+    // one atomic per block and axis: same-address atomics serialise at ~11 ns each
+    __shared__ float smn[4][3], smx[4][3];
+    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            atomicMin(out6 + d, f2ord(mn[d]));
-            atomicMax(out6 + 3 + d, f2ord(mx[d]));
-        }
+        for (int d = 0; d < 3; ++d) { smn[w][d] = mn[d]; smx[w][d] = mx[d]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        const float a = fminf(fminf(smn[0][d], smn[1][d]), fminf(smn[2][d], smn[3][d]));
+        const float b = fmaxf(fmaxf(smx[0][d], smx[1][d]), fmaxf(smx[2][d], smx[3][d]));
+        atomicMin(out6 + d, f2ord(a));
+        atomicMax(out6 + 3 + d, f2ord(b));
     }
 }
 
@@ -340,7 +348,7 @@ hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uin
 hipError_t launch_aabb(const float4* pts, uint32_t M, uint32_t* out6, hipStream_t st) {
     if (M == 0) return hipSuccess;
     int blocks = cdiv2(M, 256 * 8);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(k_aabb, dim3(blocks), dim3(256), 0, st, pts, M, out6);
     return hipGetLastError();
 }
