@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +18,11 @@
 using flh::GridParams;
 using flh::StateDev;
 typedef unsigned long long u64;
+#ifdef FLH_PHASES
+#define FLH_COUNTER_WORDS (128 + 16 * 1024 * 4 * 12)
+#else
+#define FLH_COUNTER_WORDS 1
+#endif
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) {
@@ -96,6 +102,7 @@ struct flh_handle {
     bool searched_once = false;
     int timing_stride = 1;   // record HIP events on every n-th evaluation (0 = never)
     uint64_t eval_no = 0;
+    uint64_t seq = 0;        // sequence number of the last flh_eval (published by k_fit next to the result)
     double acc[6] = {0, 0, 0, 0, 0, 0};
     // staging ring
     struct Slot {
@@ -182,7 +189,8 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
         flh_destroy(h);
         return fail("hipHostMalloc failed");
     }
-    if (h->gram.reserve(256) != hipSuccess || h->counter.reserve(1) != hipSuccess || h->slow_count.reserve(2 * flh::list_stripes()) != hipSuccess ||
+    std::memset(h->h_gram, 0, 256 * sizeof(double));
+    if (h->gram.reserve(256) != hipSuccess || h->counter.reserve(FLH_COUNTER_WORDS) != hipSuccess || h->slow_count.reserve(2 * flh::list_stripes()) != hipSuccess ||
         hipMemset(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t)) != hipSuccess) {
         flh_destroy(h);
         return fail("hipMalloc failed");
@@ -562,13 +570,13 @@ static StateDev make_state(const double rot[4], const double pos[3], const doubl
     return s;
 }
 
-static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext, double* d_out, bool timed) {
+static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext, double* d_out, double seq, bool timed) {
     hipStream_t st = h->stream;
     if (!do_search && !h->searched_once && h->N > 0)
         return fail("flh_eval: do_search == 0 before any search on this scan (the reference always searches on the first pass)");
     if (timed) HIPC(hipEventRecord(h->ev[0], st));
     if (do_search) {
-        if (h->stats) HIPC(hipMemsetAsync(h->counter.p, 0, sizeof(u64), st));
+        if (h->stats) HIPC(hipMemsetAsync(h->counter.p, 0, FLH_COUNTER_WORDS * sizeof(u64), st));
         HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->M,
                                 h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
                                 h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr, st));
@@ -577,7 +585,7 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
     }
     if (timed) HIPC(hipEventRecord(h->ev[1], st));
     HIPC(flh::launch_fit(s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
-                         h->world.p, h->partials.p, h->part2.p, d_out, h->tickets.p, h->slow_count.p, st));
+                         h->world.p, h->partials.p, h->part2.p, d_out, seq, h->tickets.p, h->slow_count.p, st));
     if (timed) HIPC(hipEventRecord(h->ev[2], st));
     h->last_state = s;
     h->last_ext = ext;
@@ -603,11 +611,29 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     // the final reduce kernel writes the 16x16 block straight into pinned, device-mapped host memory:
     // no copy kernel, no extra boundary -- the stream sync below is the only wait
     const bool timed = h->timing_stride > 0 && (h->eval_no++ % (uint64_t)h->timing_stride) == 0;
-    if (enqueue_eval(h, s, do_search, ext, h->h_gram, timed) != 0) return -1;
+    const double seq = (double)(++h->seq);
+    if (enqueue_eval(h, s, do_search, ext, h->h_gram, seq, timed) != 0) return -1;
     hipStream_t st = h->stream;
     if (h->stats && do_search) HIPC(hipMemcpyAsync(h->h_counter, h->counter.p, sizeof(u64), hipMemcpyDeviceToHost, st));
     if (timed) HIPC(hipEventRecord(h->ev[3], st));
-    HIPC(hipStreamSynchronize(st));
+    if (timed || h->stats) {
+        HIPC(hipStreamSynchronize(st));
+    } else {
+        // k_fit publishes the block with system-scope stores and then the sequence word in G[15][15]: poll it instead of
+        // waiting for the kernel to retire and the runtime to notice (saves the completion-signal round trip per pass).
+        const volatile double* flag = h->h_gram + 255;
+        uint64_t spins = 0;
+        while (*flag != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFFu) == 0 && hipStreamQuery(st) != hipErrorNotReady) {  // finished or failed without publishing
+                HIPC(hipStreamSynchronize(st));
+                if (*flag != seq) return fail("flh_eval: kernel retired without publishing its result");
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (h->h_gram[255] != seq) return fail("flh_eval: result sequence mismatch");
+    h->h_gram[255] = 0.0;  // G[15][15] is structurally zero
     flh_unpack_gram(h->h_gram, HTH, HTh, n_eff, total_residual);
     float a = 0, b = 0, c = 0;
     if (timed) {
@@ -619,6 +645,40 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     h->timing.fit_ms = b;
     h->timing.total_ms = c;
     h->timing.candidates = (h->stats && do_search) ? (int64_t)*h->h_counter : 0;
+#ifdef FLH_PHASES
+    if (h->stats && do_search) {  // developer build only (tools/phases.py): per-wave phase stamps, reduced here
+        const size_t kWaves = 16 * 1024 * 4;
+        std::vector<u64> ph(kWaves * 12);
+        HIPC(hipMemcpy(ph.data(), h->counter.p + 128, ph.size() * sizeof(u64), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 2; ++k) {
+            double sum[9] = {0}, waves = 0, maxw = 0;
+            u64 r0 = ~0ull, r1 = 0;
+            std::vector<double> starts, durs;
+            for (size_t w = (size_t)k * 8 * 1024 * 4; w < (size_t)(k + 1) * 8 * 1024 * 4; ++w) {
+                const u64* o = ph.data() + w * 12;
+                if (o[0] == 0 || o[8] == 0) continue;
+                waves += 1;
+                for (int i = 0; i < 8; ++i) sum[i] += (double)(o[i + 1] - o[i]);
+                maxw = std::max(maxw, (double)(o[8] - o[0]));
+                r0 = std::min(r0, o[10]);
+                r1 = std::max(r1, o[11]);
+                starts.push_back((double)o[10]);
+                durs.push_back((double)(o[11] - o[10]) / 100.0);
+            }
+            if (waves == 0) continue;
+            std::fprintf(stderr, "[phases] %s waves=%.0f mean cycles/phase:", k == 0 ? "A1" : "A2", waves);
+            for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %.0f", sum[i] / waves);
+            std::fprintf(stderr, " | max wave cycles %.0f | first start -> last end %.2f us\n", maxw, (double)(r1 - r0) / 100.0);
+            for (auto& v : starts) v = (v - (double)r0) / 100.0;
+            std::sort(starts.begin(), starts.end());
+            std::sort(durs.begin(), durs.end());
+            auto pc = [](const std::vector<double>& v, double p) { return v[(size_t)(p * (v.size() - 1))]; };
+            std::fprintf(stderr, "[phases]    wave start offset us p0/p25/p50/p75/p95/p100: %.2f %.2f %.2f %.2f %.2f %.2f; wave duration us: %.2f %.2f %.2f %.2f %.2f %.2f\n",
+                         pc(starts, 0), pc(starts, .25), pc(starts, .5), pc(starts, .75), pc(starts, .95), pc(starts, 1), pc(durs, 0),
+                         pc(durs, .25), pc(durs, .5), pc(durs, .75), pc(durs, .95), pc(durs, 1));
+        }
+    }
+#endif
     if (timed) {
         if (do_search) { h->acc[0] += a; h->acc[1] += 1; }
         h->acc[2] += b; h->acc[3] += 1;
@@ -639,7 +699,7 @@ int flh_eval_device(flh_handle* h, const double x[FLH_NSTATE], int do_search, in
     if (!h || !x || !d_gram256) return fail("flh_eval_device: null argument");
     HIPC(hipSetDevice(h->device));
     const StateDev s = make_state(x + 3, x + 0, x + 7, x + 11);
-    return enqueue_eval(h, s, do_search, ext, d_gram256, false);
+    return enqueue_eval(h, s, do_search, ext, d_gram256, 0.0, false);
 }
 
 // map_incremental() -- src/laserMapping.cpp:427-474, on the neighbour cache the scan's last search left on the
@@ -743,7 +803,7 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
             h->search_state = s;
         } else {
             HIPC(flh::launch_fit(s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p,
-                                 h->normvec.p, h->world.p, h->partials.p, h->part2.p, h->gram.p, h->tickets.p, h->slow_count.p, st));
+                                 h->normvec.p, h->world.p, h->partials.p, h->part2.p, h->gram.p, 0.0, h->tickets.p, h->slow_count.p, st));
         }
     }
     HIPC(hipEventRecord(h->ev[3], st));

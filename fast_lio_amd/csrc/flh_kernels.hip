@@ -148,70 +148,69 @@ __device__ __forceinline__ u64 make_key(float d, float w) {
     return ((u64)__float_as_uint(d) << 32) | (u64)__float_as_uint(w);
 }
 
-// ---- sorted top-6 of fp32 squared distances carrying the candidate's position in map_sorted.
-// Distances: K0' = min(K0,t), Kj' = med3(K(j-1),Kj,t) (six independent VALU ops); positions follow with the
-// six compares t < Kj.  Strict <: a candidate equal to a kept distance queues behind it, and equal
-// distances are later routed to the general path, so the visiting order never decides a result.
-__device__ __forceinline__ void ins6(float (&K)[6], uint32_t (&I)[6], float t, uint32_t idx) {
-    const bool c0 = t < K[0], c1 = t < K[1], c2 = t < K[2], c3 = t < K[3], c4 = t < K[4], c5 = t < K[5];
-    I[5] = c4 ? I[4] : (c5 ? idx : I[5]);
-    I[4] = c3 ? I[3] : (c4 ? idx : I[4]);
-    I[3] = c2 ? I[2] : (c3 ? idx : I[3]);
-    I[2] = c1 ? I[1] : (c2 ? idx : I[2]);
-    I[1] = c0 ? I[0] : (c1 ? idx : I[1]);
-    I[0] = c0 ? idx : I[0];
-    const float n0 = fminf(K[0], t);
-    const float n1 = __builtin_amdgcn_fmed3f(K[0], K[1], t);
-    const float n2 = __builtin_amdgcn_fmed3f(K[1], K[2], t);
-    const float n3 = __builtin_amdgcn_fmed3f(K[2], K[3], t);
-    const float n4 = __builtin_amdgcn_fmed3f(K[3], K[4], t);
-    const float n5 = __builtin_amdgcn_fmed3f(K[4], K[5], t);
+// ---- sorted top-6 of PACKED keys: the fp32 squared distance with its low PB mantissa bits replaced by the
+// candidate's flat index inside the group's candidate list.  Positive floats order like their bit patterns, so the
+// whole selection is unsigned-integer min / med3 (6 VALU ops per candidate, nothing else rides along):
+// K0' = min(K0,t), Kj' = med3(K(j-1),Kj,t).  Truncation keeps the order of any two candidates whose distances differ
+// above the PB-th bit; a query whose best six contain two neighbours that agree there is not settled by this kernel
+// (the general path orders them by (d2, map index) exactly), so the packing never decides a result.
+constexpr uint32_t kEmptyPacked = 0x7F000000u;  // above every real squared distance, below inf/nan patterns
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ void ins6(uint32_t (&K)[6], uint32_t t) {
+    const uint32_t n0 = min(K[0], t);
+    const uint32_t n1 = umed3(K[0], K[1], t);
+    const uint32_t n2 = umed3(K[1], K[2], t);
+    const uint32_t n3 = umed3(K[2], K[3], t);
+    const uint32_t n4 = umed3(K[3], K[4], t);
+    const uint32_t n5 = umed3(K[4], K[5], t);
     K[0] = n0; K[1] = n1; K[2] = n2; K[3] = n3; K[4] = n4; K[5] = n5;
 }
-__device__ __forceinline__ void cex2(float& ka, uint32_t& ia, float& kb, uint32_t& ib) {  // (ka,ia) <= (kb,ib) after
-    const bool sw = kb < ka;
-    const float lo = sw ? kb : ka, hi = sw ? ka : kb;
-    const uint32_t li = sw ? ib : ia, hi_i = sw ? ia : ib;
-    ka = lo; kb = hi; ia = li; ib = hi_i;
+__device__ __forceinline__ void cex2(uint32_t& a, uint32_t& b) {  // a <= b after
+    const uint32_t lo = min(a, b), hi = max(a, b);
+    a = lo; b = hi;
 }
 template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
 }
 template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+__device__ __forceinline__ uint32_t dpp_u32z(uint32_t v) {  // lanes without a source read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 // lowest six of (mine U partner's), sorted: bitonic half-cleaner, then a 12-comparator network for 6
 // (both verified exhaustively with the 0/1 principle)
 template <int CTRL>
-__device__ __forceinline__ void merge6(float (&K)[6], uint32_t (&I)[6]) {
-    float BK[6];
-    uint32_t BI[6];
+__device__ __forceinline__ void merge6(uint32_t (&K)[6]) {
+    uint32_t B[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { BK[j] = dpp_f32<CTRL>(K[j]); BI[j] = (uint32_t)dpp_i32<CTRL>((int)I[j]); }
+    for (int j = 0; j < 6; ++j) B[j] = dpp_u32<CTRL>(K[j]);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const bool tk = BK[5 - j] < K[j];
-        K[j] = tk ? BK[5 - j] : K[j];
-        I[j] = tk ? BI[5 - j] : I[j];
-    }
-    cex2(K[1], I[1], K[2], I[2]); cex2(K[4], I[4], K[5], I[5]); cex2(K[0], I[0], K[2], I[2]); cex2(K[3], I[3], K[5], I[5]);
-    cex2(K[0], I[0], K[1], I[1]); cex2(K[3], I[3], K[4], I[4]); cex2(K[2], I[2], K[5], I[5]); cex2(K[0], I[0], K[3], I[3]);
-    cex2(K[1], I[1], K[4], I[4]); cex2(K[2], I[2], K[4], I[4]); cex2(K[1], I[1], K[3], I[3]); cex2(K[2], I[2], K[3], I[3]);
+    for (int j = 0; j < 6; ++j) K[j] = min(K[j], B[5 - j]);
+    cex2(K[1], K[2]); cex2(K[4], K[5]); cex2(K[0], K[2]); cex2(K[3], K[5]);
+    cex2(K[0], K[1]); cex2(K[3], K[4]); cex2(K[2], K[5]); cex2(K[0], K[3]);
+    cex2(K[1], K[4]); cex2(K[2], K[4]); cex2(K[1], K[3]); cex2(K[2], K[3]);
 }
 template <int LPQ>
-__device__ __forceinline__ void merge_group6(float (&K)[6], uint32_t (&I)[6]) {
-    if (LPQ >= 2) merge6<0xB1>(K, I);    // quad_perm [1,0,3,2]
-    if (LPQ >= 4) merge6<0x4E>(K, I);    // quad_perm [2,3,0,1]
-    if (LPQ >= 8) merge6<0x141>(K, I);   // row_half_mirror
-    if (LPQ >= 16) merge6<0x140>(K, I);  // row_mirror
+__device__ __forceinline__ void merge_group6(uint32_t (&K)[6]) {
+    if (LPQ >= 2) merge6<0xB1>(K);    // quad_perm [1,0,3,2]
+    if (LPQ >= 4) merge6<0x4E>(K);    // quad_perm [2,3,0,1]
+    if (LPQ >= 8) merge6<0x141>(K);   // row_half_mirror
+    if (LPQ >= 16) merge6<0x140>(K);  // row_mirror
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 load_pt(__amdgpu_buffer_rsrc_t rsrc, uint32_t idx) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx << 4), 0, 0);  // out of range -> zeros
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ u32x3 load_xyz(__amdgpu_buffer_rsrc_t rsrc, uint32_t idx) {  // coordinates only (12 of the 16 B)
+    return __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(idx << 4), 0, 0);
 }
 
 // A query group never spans a wave, so the LDS hand-offs inside k_search_ring only need wave-level ordering:
@@ -221,7 +220,35 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int LPQ, int RING, bool BOUNDED>
+// Developer instrumentation (tools/phases.py builds a separate library with -DFLH_PHASES): per-wave cycle counts
+// of the phases of the first trip, summed into cand_counter[base + i]; compiled out of the product.
+#ifdef FLH_PHASES
+#define PH_DECL u64 ph_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; bool ph_first = true; const u64 ph_r0 = __builtin_amdgcn_s_memrealtime();
+#define PH_MARK(i)                                                      \
+    do {                                                                \
+        if (ph_first) {                                                 \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+            ph_t[i] = __builtin_readcyclecounter();                     \
+        }                                                               \
+    } while (0)
+#define PH_NEXT_TRIP() ph_first = false
+#define PH_DUMP(base)                                                                                          \
+    do {                                                                                                       \
+        if (cand_counter && (threadIdx.x & 63) == 0) {                                                         \
+            u64* o_ = cand_counter + 128 + ((size_t)(base) * 1024 * 4 + (size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 12; \
+            for (int i_ = 0; i_ < 10; ++i_) o_[i_] = ph_t[i_];                                                 \
+            o_[10] = ph_r0;                                                                                    \
+            o_[11] = __builtin_amdgcn_s_memrealtime();                                                         \
+        }                                                                                                      \
+    } while (0)
+#else
+#define PH_DECL
+#define PH_MARK(i)
+#define PH_NEXT_TRIP()
+#define PH_DUMP(base)
+#endif
+
+template <int LPQ, int RING, bool BOUNDED, int PB>
 __global__ void __launch_bounds__(256)
 k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist,
               float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
@@ -254,7 +281,11 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)g.pts, 0, (int)(map_points * 16u), 0x00020000);
     const u64* __restrict__ hash64 = reinterpret_cast<const u64*>(g.hash);
+    PH_DECL
+    PH_MARK(0);  // 0: start
 
+    // A1 (no input list) launches one block per GPB queries and makes a single trip: the state and grid scalars die
+    // after the transform instead of staying pinned in SGPRs around a loop.
     for (uint32_t base = first_base; base < total; base += step_base) {
         const uint32_t gi = base + grp;
         const bool live = gi < total;
@@ -266,12 +297,13 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
         float fx, fy, fz;
         cell_of(g, qx, qy, qz, cx, cy, cz, fx, fy, fz);
         const float minfrac = fminf(fminf(fminf(fx, 1.f - fx), fminf(fy, 1.f - fy)), fminf(fz, 1.f - fz));
+        PH_MARK(1);  // 1: query loaded + transformed
 
         // ---- phase 1: directory probes of this lane's segments
         float ubq = INFINITY;
         if (BOUNDED) ubq = fminf(ub_in[q], max_sqdist) * 1.0001f + 1e-6f;
         const float inv_c2 = g.inv_c * g.inv_c;
-        uint32_t key[SPL], slot[SPL], i0[SPL], i1[SPL];
+        uint32_t key[SPL], i0[SPL], i1[SPL];
         u64 he[SPL];
 #pragma unroll
         for (int u = 0; u < SPL; ++u) {
@@ -301,97 +333,141 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             key[u] = brick_key(xa, y, z);
             i0[u] = cell_local(xa, y, z);
             i1[u] = cell_local(xb, y, z) + 1;
-            slot[u] = hash_slot(key[u], g.hash_shift);
-            he[u] = valid ? hash64[slot[u]] : (u64)kEmptyKey;
+            he[u] = valid ? hash64[hash_slot(key[u], g.hash_shift)] : (u64)kEmptyKey;
         }
-        // ---- phase 2: point ranges -> LDS
+        PH_MARK(2);  // 2: directory entries arrived
+        // ---- phase 2: directory entries -> point ranges.  Collisions first (rare, one branch for all segments), then
+        // every prefix-table read of the lane in one batch: a miss reads brick 0's table and is masked afterwards.
+        {
+            bool coll = false;
 #pragma unroll
-        for (int u = 0; u < SPL; ++u) {
-            const int sl = lane + u * LPQ;
-            u64 e = he[u];
-            while ((uint32_t)e != key[u] && (uint32_t)e != kEmptyKey) {  // collision: linear probing (rare)
-                slot[u] = (slot[u] + 1) & g.hash_mask;
-                e = hash64[slot[u]];
+            for (int u = 0; u < SPL; ++u) coll = coll || ((uint32_t)he[u] != key[u] && (uint32_t)he[u] != kEmptyKey);
+            if (coll) {
+#pragma unroll
+                for (int u = 0; u < SPL; ++u) {
+                    u64 e = he[u];
+                    uint32_t sl_ = hash_slot(key[u], g.hash_shift);
+                    while ((uint32_t)e != key[u] && (uint32_t)e != kEmptyKey) {  // linear probing
+                        sl_ = (sl_ + 1) & g.hash_mask;
+                        e = hash64[sl_];
+                    }
+                    he[u] = e;
+                }
             }
-            uint32_t a = 0, n = 0;
-            if ((uint32_t)e == key[u]) {
-                const uint32_t* st = g.starts + (size_t)(uint32_t)(e >> 32) * kBrickStride;
-                a = st[i0[u]];
-                n = st[i1[u]] - a;
-            }
-            if (sl < NSEG) seg[grp][sl] = make_uint2(a, n);
         }
-        wave_sync();
-        // ---- prefix over the group's segments (every lane runs the same sums; lane s % LPQ rewrites slot s)
+        uint32_t la[SPL], nseg[SPL];
+        {
+            uint32_t lb[SPL];
+#pragma unroll
+            for (int u = 0; u < SPL; ++u) {
+                const bool hit = (uint32_t)he[u] == key[u];
+                const uint32_t* st = g.starts + (size_t)(hit ? (uint32_t)(he[u] >> 32) : 0u) * kBrickStride;
+                la[u] = st[i0[u]];
+                lb[u] = st[i1[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < SPL; ++u) {
+                const bool hit = (uint32_t)he[u] == key[u];
+                nseg[u] = hit ? min(lb[u] - la[u], 1u << 18) : 0u;  // cap: keeps the packed sums below exact (> 2^PB is unsettled anyway)
+            }
+        }
+        PH_MARK(3);  // 3: prefix tables read
+        // ---- flat candidate list of the group: exclusive prefix over its segments in slot order (slot = lane + u*LPQ),
+        // in registers: a DPP scan across the group's lanes per u, running totals across u.  Empty segments are dropped,
+        // so the table holds (first point - flat start, flat end) of the non-empty ones, then a sentinel.
         uint32_t T = 0;
         {
-            uint2 mine[SPL];
+            uint32_t run = 0;  // bits 0..23: candidates so far, 24..31: non-empty segments so far
 #pragma unroll
-            for (int sidx = 0; sidx < NSEG; ++sidx) {
-                const uint2 an = seg[grp][sidx];
-                if ((sidx % LPQ) == lane) mine[sidx / LPQ] = make_uint2(an.x - T, T + an.y);
-                T += an.y;
+            for (int u = 0; u < SPL; ++u) {
+                const uint32_t mine = nseg[u] | (nseg[u] ? (1u << 24) : 0u);
+                uint32_t inc = mine;
+                if (LPQ >= 2) { const uint32_t up = dpp_u32z<0x111>(inc); inc += (lane >= 1) ? up : 0u; }
+                if (LPQ >= 4) { const uint32_t up = dpp_u32z<0x112>(inc); inc += (lane >= 2) ? up : 0u; }
+                if (LPQ >= 8) { const uint32_t up = dpp_u32z<0x114>(inc); inc += (lane >= 4) ? up : 0u; }
+                if (LPQ >= 16) { const uint32_t up = dpp_u32z<0x118>(inc); inc += (lane >= 8) ? up : 0u; }
+                uint32_t tot;
+                if (LPQ == 2) tot = dpp_u32<0xF5>(inc);        // quad_perm [1,1,3,3]
+                else if (LPQ == 4) tot = dpp_u32<0xFF>(inc);   // quad_perm [3,3,3,3]
+                else tot = (uint32_t)__shfl((int)inc, LPQ - 1, LPQ);
+                const uint32_t ex = run + inc - mine;
+                const uint32_t exT = ex & 0xFFFFFFu;
+                if (nseg[u]) seg[grp][ex >> 24] = make_uint2(la[u] - exT, exT + nseg[u]);
+                run += tot;
             }
-            wave_sync();
-#pragma unroll
-            for (int u = 0; u < SPL; ++u)
-                if (lane + u * LPQ < NSEG) seg[grp][lane + u * LPQ] = mine[u];
-            if (lane == 0) seg[grp][NSEG] = make_uint2(0u, 0xFFFFFFFFu);  // sentinel: the walk never runs off the end
+            T = run & 0xFFFFFFu;
+            if (lane == 0) seg[grp][run >> 24] = make_uint2(0u, 0xFFFFFFFFu);  // sentinel: the walk never runs off the end
         }
         wave_sync();
+        PH_MARK(4);  // 4: prefix done
         // ---- one pass over the candidates: the group's T candidates are dealt round-robin to its lanes
-        float K[6];
-        uint32_t I[6];
+        constexpr uint32_t PMASK = (1u << PB) - 1u;
+        uint32_t K[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { K[j] = INFINITY; I[j] = 0xFFFFFFFu; }
+        for (int j = 0; j < 6; ++j) K[j] = kEmptyPacked;
         int cur = 0;
         uint2 sg = seg[grp][0];
         for (uint32_t t0 = lane; t0 < T; t0 += LPQ * UNR) {
-            float4 v[UNR];
-            uint32_t idx[UNR];
+            u32x3 v[UNR];
 #pragma unroll
             for (int w = 0; w < UNR; ++w) {
                 const uint32_t t = t0 + (uint32_t)(w * LPQ);
                 while (t >= sg.y) sg = seg[grp][++cur];
-                idx[w] = (t < T) ? sg.x + t : 0xFFFFFFFu;  // past the end: out-of-range -> zeros, masked below
-                v[w] = load_pt(rsrc, idx[w]);
+                v[w] = load_xyz(rsrc, (t < T) ? sg.x + t : 0xFFFFFFFu);  // past the end: out-of-range -> zeros, masked below
             }
 #pragma unroll
             for (int w = 0; w < UNR; ++w) {
-                float d = dist2(qx, qy, qz, v[w].x, v[w].y, v[w].z);
-                d = (t0 + (uint32_t)(w * LPQ) < T) ? d : INFINITY;
-                ins6(K, I, d, idx[w]);
+                const uint32_t t = t0 + (uint32_t)(w * LPQ);
+                const float d = dist2(qx, qy, qz, __uint_as_float(v[w].x), __uint_as_float(v[w].y), __uint_as_float(v[w].z));
+                const uint32_t key = (__float_as_uint(d) & ~PMASK) | (t & PMASK);
+                ins6(K, (t < T) ? key : kEmptyPacked);
             }
         }
-        merge_group6<LPQ>(K, I);
+        PH_MARK(5);  // 5: candidates
+        merge_group6<LPQ>(K);
         int cnt = 0;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) cnt += (K[j] < INFINITY) ? 1 : 0;
-        bool tie = false;  // equal distances among the best six: the (d2, map index) order needs the general path
+        for (int j = 0; j < 5; ++j) cnt += (K[j] < kEmptyPacked) ? 1 : 0;
+        // two of the best six agree above the packed bits (or the list is longer than the packed index can name):
+        // their order / identity needs the general path
+        bool amb = T > PMASK + 1u;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) tie = tie || (K[j + 1] < INFINITY && K[j] == K[j + 1]);
-        const float d5 = (cnt == 5) ? K[4] : INFINITY;
+        for (int j = 0; j < 5; ++j) amb = amb || (K[j + 1] < kEmptyPacked && (K[j] >> PB) == (K[j + 1] >> PB));
+        const float d5hi = (cnt == 5) ? __uint_as_float(K[4] | PMASK) : INFINITY;  // >= the true 5th distance found
         const float gr = ((float)RING + minfrac) * g.c - 2e-3f * g.c;  // guaranteed-complete radius (fp margin)
         const float gr2 = gr * gr;
-        const bool done = !tie && ((cnt == 5 && d5 <= gr2) || gr2 >= max_sqdist);
+        const bool done = !amb && ((cnt == 5 && d5hi <= gr2) || gr2 >= max_sqdist);
+#ifndef FLH_PHASES
         if (cand_counter && live && lane == 0) atomicAdd(cand_counter, (u64)T);
-        // ---- results: rank j is written by lane j % LPQ (five point loads per query)
+#endif
+        PH_MARK(6);  // 6: merged
+        // ---- results: rank j is written by lane j % LPQ: flat index -> map position -> one point load, and the exact
+        // squared distance recomputed from it (same formula, same bits as the scan saw before packing)
         if (done && live) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
                 if ((j % LPQ) == lane) {
                     const bool has = j < cnt;
                     float4 pv = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-                    if (has) pv = load_pt(rsrc, I[j]);
+                    float dj = INFINITY;
+                    if (has) {
+                        const uint32_t t = K[j] & PMASK;
+                        int c2 = 0;
+                        uint2 s2 = seg[grp][0];
+                        while (t >= s2.y) s2 = seg[grp][++c2];
+                        pv = load_pt(rsrc, s2.x + t);
+                        dj = dist2(qx, qy, qz, pv.x, pv.y, pv.z);
+                    }
                     nn_pts[(size_t)j * N + q] = pv;
-                    nn_d2[(size_t)j * N + q] = has ? K[j] : INFINITY;
+                    nn_d2[(size_t)j * N + q] = dj;
+                    if (j == 4) {
+                        nn_cnt[q] = (uint8_t)cnt;
+                        selected[q] = (cnt == 5 && !(dj > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
+                    }
                 }
             }
-            if (lane == 0) {
-                nn_cnt[q] = (uint8_t)cnt;
-                selected[q] = (cnt == 5 && !(d5 > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
-            }
         }
+        PH_MARK(7);  // 7: results written
         // ---- unsettled queries go to the next stage's list: one global atomic per wave, 64 striped counters
         const bool append = live && !done && lane == 0;
         const u64 bal = __ballot(append);
@@ -403,11 +479,15 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             wbase = __shfl(wbase, leader, 64);
             if (append) {
                 out_list[wbase + (uint32_t)__popcll(bal & ((1ull << wlane) - 1ull))] = (uint32_t)q;
-                ub_out[q] = BOUNDED ? fminf(d5, ub_in[q]) : d5;  // the true 5th distance is <= the one found so far
+                ub_out[q] = BOUNDED ? fminf(d5hi, ub_in[q]) : d5hi;  // the true 5th distance is <= the one found so far
             }
         }
+        PH_MARK(8);  // 8: appended
+        PH_NEXT_TRIP();
+        if (!BOUNDED) break;  // single trip (see above)
         wave_sync();  // seg[] is rewritten by the next trip
     }
+    PH_DUMP(RING == 1 ? 0 : 8);
 }
 
 // A3: general exact path over the queries A1/A2 could not settle; 32 lanes per query, 8 queries per block.
@@ -529,7 +609,7 @@ constexpr int kTileStride = 17;  // doubles per row: 16 + 1 pad (conflict-free d
 __global__ void __launch_bounds__(256)
 k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn_pts, int N, int ext, float thr,
       uint8_t* __restrict__ selected, float4* __restrict__ normvec, float4* __restrict__ world,
-      double* __restrict__ partials, double* __restrict__ part2, double* __restrict__ out256,
+      double* __restrict__ partials, double* __restrict__ part2, double* __restrict__ out256, double seq,
       uint32_t* __restrict__ tickets, uint32_t* __restrict__ slow_count) {
     __shared__ double lds[4 * 64 * kTileStride];
     __shared__ uint32_t s_ticket;
@@ -664,8 +744,13 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
 #pragma unroll
             for (int j = 0; j < kRed2; ++j) sum += v[j];
         }
-        out256[t] = sum;
+        // out256 is pinned host memory on the flh_eval path: system-scope write-through stores, then (below) a
+        // sequence word in the unused G[15][15] slot that the host polls -- it need not wait for the kernel to retire.
+        if (t != 255) __hip_atomic_store(out256 + t, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    __atomic_thread_fence(__ATOMIC_RELEASE);  // system scope
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(out256 + 255, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // re-arm: tickets for the next launch, and the A1 -> A2 work-list counters for the next search pass
     for (int i = t; i < ngroups + 1; i += 256) tickets[i] = 0;
     if (t < 2 * kStripes) slow_count[t] = 0;
@@ -773,7 +858,7 @@ hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const 
     }
     // A1: ring 1, every query
 #define FLH_A1(L)                                                                                                        \
-    hipLaunchKernelGGL((k_search_ring<L, 1, false>), dim3(std::min(cdiv(N, 256 / L), 8192)), blk, 0, st, g, s, body, N, \
+    hipLaunchKernelGGL((k_search_ring<L, 1, false, 8>), dim3(cdiv(N, 256 / L)), blk, 0, st, g, s, body, N, \
                        map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,                \
                        (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, cand_counter)
     switch (lpq) {
@@ -787,7 +872,7 @@ hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const 
     const uint32_t* last_counts = counts;
     if (rmax >= 2) {
         // A2: ring 2 over list 1, inside the ball A1's 5th distance defines
-        hipLaunchKernelGGL((k_search_ring<16, 2, true>), dim3(kStripes * 8), blk, 0, st, g, s, body, N, map_points, max_sqdist,
+        hipLaunchKernelGGL((k_search_ring<16, 2, true, 11>), dim3(kStripes * 16), blk, 0, st, g, s, body, N, map_points, max_sqdist,
                            nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)list1, (const uint32_t*)counts, list2,
                            counts + kStripes, cap, (const float*)ub, ub, cand_counter);
         last_list = list2;
@@ -807,10 +892,10 @@ int reduce1_blocks(int nblk, int* per_out) {
 
 hipError_t launch_fit(const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
                       uint8_t* selected, float4* normvec, float4* world, double* partials, double* part2,
-                      double* out256, uint32_t* tickets, uint32_t* slow_count, hipStream_t st) {
+                      double* out256, double seq, uint32_t* tickets, uint32_t* slow_count, hipStream_t st) {
     const int nblk = fit_blocks(N);
     hipLaunchKernelGGL(k_fit, dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world,
-                       partials, part2, out256, tickets, slow_count);
+                       partials, part2, out256, seq, tickets, slow_count);
     return hipGetLastError();
 }
 
