@@ -19,7 +19,9 @@ HDRS = ["fastlio_hip.h", "fastlio_amd/esekfom.hpp", "fastlio_amd/mtk.hpp", "fast
 # -ffp-contract=off: the reference never fuses a*b+c (baseline x86-64 build); flags must match for
 # bit-exact point_selected_surf.  -fhip-fp32-correctly-rounded-divide-sqrt is hipcc's default; stated.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-result"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-result",
+         # host side (the 23x23 IEKF algebra between two launches): AVX2 without FMA contraction -- same results, wider
+         "-Xarch_host", "-mavx2"]
 
 
 def hipcc() -> str:

@@ -268,7 +268,7 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
     constexpr int UNR = 8;                         // independent point loads in flight per lane
     // seg: (first point, length); after the prefix step: (first point - flat start, flat end), so that flat
     // candidate t of the group lives at pts[seg.x + t] for t < seg.y
-    __shared__ uint2 seg[GPB][NSEG + 1];
+    __shared__ uint2 seg[GPB][NSEG + 2];  // + sentinel + one slot the walk's look-ahead may touch
     const int grp = threadIdx.x / LPQ;
     const int lane = threadIdx.x & (LPQ - 1);
     const uint32_t stripe = blockIdx.x & (kStripes - 1);
@@ -407,12 +407,16 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
         for (int j = 0; j < 6; ++j) K[j] = kEmptyPacked;
         int cur = 0;
         uint2 sg = seg[grp][0];
+        uint2 nx = seg[grp][1];  // the entry after the current one is always in flight before it is needed
         for (uint32_t t0 = lane; t0 < T; t0 += LPQ * UNR) {
             u32x3 v[UNR];
 #pragma unroll
             for (int w = 0; w < UNR; ++w) {
                 const uint32_t t = t0 + (uint32_t)(w * LPQ);
-                while (t >= sg.y) sg = seg[grp][++cur];
+                if (t >= sg.y) {  // one step is the common case; its look-ahead read is not waited for here
+                    sg = nx; ++cur; nx = seg[grp][cur + 1];
+                    while (t >= sg.y) { sg = nx; ++cur; nx = seg[grp][cur + 1]; }
+                }
                 v[w] = load_xyz(rsrc, (t < T) ? sg.x + t : 0xFFFFFFFu);  // past the end: out-of-range -> zeros, masked below
             }
 #pragma unroll
@@ -441,24 +445,35 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
         if (cand_counter && live && lane == 0) atomicAdd(cand_counter, (u64)T);
 #endif
         PH_MARK(6);  // 6: merged
-        // ---- results: rank j is written by lane j % LPQ: flat index -> map position -> one point load, and the exact
-        // squared distance recomputed from it (same formula, same bits as the scan saw before packing)
+        // ---- results: lane l writes ranks l, l + LPQ, ...: flat index -> map position (table walk) -> one point load
+        // each, all issued before the first is consumed; the exact squared distance is recomputed from the point (same
+        // formula, same bits as the scan saw before packing).
         if (done && live) {
+            constexpr int RPL = (5 + LPQ - 1) / LPQ;  // ranks per lane
+            float4 pv[RPL];
+            bool has[RPL];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                if ((j % LPQ) == lane) {
-                    const bool has = j < cnt;
-                    float4 pv = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-                    float dj = INFINITY;
-                    if (has) {
-                        const uint32_t t = K[j] & PMASK;
-                        int c2 = 0;
-                        uint2 s2 = seg[grp][0];
-                        while (t >= s2.y) s2 = seg[grp][++c2];
-                        pv = load_pt(rsrc, s2.x + t);
-                        dj = dist2(qx, qy, qz, pv.x, pv.y, pv.z);
-                    }
-                    nn_pts[(size_t)j * N + q] = pv;
+            for (int r = 0; r < RPL; ++r) {
+                const int j = lane + r * LPQ;
+                uint32_t kj = K[0];
+#pragma unroll
+                for (int jj = 1; jj < 5; ++jj) kj = (j == jj) ? K[jj] : kj;
+                has[r] = j < cnt;  // cnt <= 5
+                pv[r] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+                if (has[r]) {
+                    const uint32_t t = kj & PMASK;
+                    int c2 = 0;
+                    uint2 s2 = seg[grp][0];
+                    while (t >= s2.y) s2 = seg[grp][++c2];
+                    pv[r] = load_pt(rsrc, s2.x + t);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int j = lane + r * LPQ;
+                if (j < 5) {
+                    const float dj = has[r] ? dist2(qx, qy, qz, pv[r].x, pv[r].y, pv[r].z) : INFINITY;
+                    nn_pts[(size_t)j * N + q] = pv[r];
                     nn_d2[(size_t)j * N + q] = dj;
                     if (j == 4) {
                         nn_cnt[q] = (uint8_t)cnt;
