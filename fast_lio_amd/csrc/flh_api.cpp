@@ -646,6 +646,7 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     h->timing.total_ms = c;
     h->timing.candidates = (h->stats && do_search) ? (int64_t)*h->h_counter : 0;
 #ifdef FLH_PHASES
+    if (h->stats) flh::dump_fit_phases();
     if (h->stats && do_search) {  // developer build only (tools/phases.py): per-wave phase stamps, reduced here
         const size_t kWaves = 16 * 1024 * 4;
         std::vector<u64> ph(kWaves * 12);

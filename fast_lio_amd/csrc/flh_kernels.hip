@@ -11,6 +11,8 @@
 #include "flh_kernels.hpp"
 
 #include <hip/hip_runtime.h>
+#include <vector>
+#include <cstdio>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -616,6 +618,15 @@ k_search_exact(GridParams g, StateDev s, const float4* __restrict__ body, int N,
 // v_mfma_f64_16x16x4_f64 takes A[i][k] in lane (i + 16k) and B[k][j] in lane (j + 16k): with A = B^T
 // = the same register, one LDS transpose ([point][16] -> lane (col, point%4)) feeds both operands.
 // ------------------------------------------------------------------------------------------------
+#ifdef FLH_PHASES
+__device__ u64 g_fit_ph[4096 * 4 * 12];
+#define FPH(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); fph[i] = __builtin_readcyclecounter(); } while (0)
+#define FPH_DUMP() do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) { u64* o_ = g_fit_ph + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 12; \
+    for (int i_ = 0; i_ < 10; ++i_) o_[i_] = fph[i_]; o_[10] = fph_r0; o_[11] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define FPH(i)
+#define FPH_DUMP()
+#endif
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int kRed1 = 16;   // blocks per first-level reduction group
 constexpr int kRed2 = 32;   // group sums added per unrolled batch at the top level
@@ -628,6 +639,11 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
       uint32_t* __restrict__ tickets, uint32_t* __restrict__ slow_count) {
     __shared__ double lds[4 * 64 * kTileStride];
     __shared__ uint32_t s_ticket;
+#ifdef FLH_PHASES
+    u64 fph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const u64 fph_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    FPH(0);
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -637,20 +653,27 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
 
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
     float wx = 0.f, wy = 0.f, wz = 0.f;
+    // every load of the thread is issued up front (the flag, the point, its five cached neighbours): one memory round
+    // trip instead of three dependent ones; the ~40 % of neighbour rows fetched for unselected points are cheap next to it
+    const int ic = i < N ? i : (N > 0 ? N - 1 : 0);
+    const uint8_t sel_in = selected[ic];
+    float4 nn[5];
+    b = body[ic];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) nn[j] = nn_pts[(size_t)j * N + ic];
     if (i < N) {  // feats_down_world is rewritten for every point on every pass (laserMapping.cpp:656-661)
-        b = body[i];
         body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
         world[i] = make_float4(wx, wy, wz, 0.f);
     }
-    if (i < N && selected[i]) {  // laserMapping.cpp:674
+    FPH(1);  // point loaded + transformed
+    if (i < N && sel_in) {  // laserMapping.cpp:674
         float P[5][3];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const float4 n = nn_pts[(size_t)j * N + i];
-            P[j][0] = n.x; P[j][1] = n.y; P[j][2] = n.z;
-        }
+        for (int j = 0; j < 5; ++j) { P[j][0] = nn[j].x; P[j][1] = nn[j].y; P[j][2] = nn[j].z; }
         float pabcd[4];
+        FPH(2);  // neighbours loaded
         const bool ok = esti_plane(P, thr, pabcd);  // :678
+        FPH(3);  // plane fit
         bool sel = false;
         float pd2 = 0.f;
         if (ok) {
@@ -690,6 +713,7 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
             v[14] = (double)fabsf(pd2);    // res_last -> total_residual (:702)
         }
     }
+    FPH(4);  // gate + Jacobian row
     double* T = lds + wave * 64 * kTileStride;
 #pragma unroll
     for (int c = 0; c < 16; ++c) T[lane * kTileStride + c] = v[c];
@@ -707,6 +731,7 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
 #pragma unroll
     for (int r = 0; r < 4; ++r) Rb[wave * 256 + (kq + 4 * r) * 16 + col] = acc[r];
     __syncthreads();
+    FPH(5);  // Gram block of the wave in LDS
     const int t = threadIdx.x;
     // ---- R: deterministic two-level cross-block sum inside this launch (no reduce kernels, no extra
     // boundaries).  Blocks are grouped kRed1 at a time; the LAST block of a group to finish sums the group's
@@ -729,7 +754,8 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
     __syncthreads();
     if (t == 0) s_ticket = __hip_atomic_fetch_add(&tickets[1 + group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (s_ticket != (uint32_t)(gsize - 1)) return;  // block-uniform
+    FPH(6);  // partial stored, ticket taken
+    if (s_ticket != (uint32_t)(gsize - 1)) { FPH_DUMP(); return; }  // block-uniform
     {
         const int b0 = group * kRed1;
         double v[kRed1];
@@ -746,7 +772,8 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
     __syncthreads();
     if (t == 0) s_ticket = __hip_atomic_fetch_add(&tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (s_ticket != (uint32_t)(ngroups - 1)) return;
+    FPH(7);  // group summed, second ticket taken
+    if (s_ticket != (uint32_t)(ngroups - 1)) { FPH_DUMP(); return; }
     {
         double sum = 0.0;
         for (int b0 = 0; b0 < ngroups; b0 += kRed2) {
@@ -763,9 +790,13 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
         // sequence word in the unused G[15][15] slot that the host polls -- it need not wait for the kernel to retire.
         if (t != 255) __hip_atomic_store(out256 + t, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __atomic_thread_fence(__ATOMIC_RELEASE);  // system scope
+    // the stores above are write-through to system scope: draining them (vmcnt) orders them before the flag -- no
+    // release fence, whose L2 write-back sweep costs more than the whole publish (MI355X_MICROARCH.md, publish rows)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) __hip_atomic_store(out256 + 255, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 0) __hip_atomic_store(out256 + 255, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    FPH(8);  // result published
+    FPH_DUMP();
     // re-arm: tickets for the next launch, and the A1 -> A2 work-list counters for the next search pass
     for (int i = t; i < ngroups + 1; i += 256) tickets[i] = 0;
     if (t < 2 * kStripes) slow_count[t] = 0;
@@ -898,6 +929,30 @@ hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const 
                        nn_cnt, selected, last_list, last_counts, cap, ub, 0, cand_counter);
     return hipGetLastError();
 }
+
+#ifdef FLH_PHASES
+void dump_fit_phases() {
+    static std::vector<u64> ph(4096 * 4 * 12);
+    if (hipMemcpyFromSymbol(ph.data(), HIP_SYMBOL(g_fit_ph), ph.size() * sizeof(u64)) != hipSuccess) return;
+    double sum[8] = {0}, cnt[8] = {0};
+    u64 r0 = ~0ull, r1 = 0;
+    double longest = 0;
+    for (size_t w = 0; w < 4096 * 4; ++w) {
+        const u64* o = ph.data() + w * 12;
+        if (o[0] == 0) continue;
+        r0 = std::min(r0, o[10]);
+        r1 = std::max(r1, o[11]);
+        longest = std::max(longest, (double)(o[11] - o[10]) / 100.0);
+        for (int i = 0; i < 8; ++i)
+            if (o[i + 1] && o[i]) { sum[i] += (double)(o[i + 1] - o[i]); cnt[i] += 1; }
+    }
+    std::fprintf(stderr, "[phases] k_fit mean cycles/phase (waves that reached it):");
+    for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %.0f(%.0f)", cnt[i] ? sum[i] / cnt[i] : 0.0, cnt[i]);
+    std::fprintf(stderr, " | longest wave %.2f us | first start -> last end %.2f us\n", longest, (double)(r1 - r0) / 100.0);
+    std::vector<u64> z(ph.size(), 0);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fit_ph), z.data(), z.size() * sizeof(u64));
+}
+#endif
 
 int fit_blocks(int N) { return cdiv(N > 0 ? N : 1, 256); }
 int reduce1_blocks(int nblk, int* per_out) {

@@ -32,6 +32,9 @@ hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const 
                          uint32_t* list1, uint32_t* list2, float* ub, uint32_t* counts, unsigned long long* cand_counter,
                          hipStream_t st);
 
+#ifdef FLH_PHASES
+void dump_fit_phases();
+#endif
 int fit_blocks(int N);
 int reduce1_blocks(int nblk, int* per_out);
 hipError_t launch_fit(const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,

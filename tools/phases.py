@@ -37,3 +37,5 @@ for name, x in (("prior", xp), ("truth", pr.x_true)):
     print(f"--- search at the {name} state", file=sys.stderr)
     for _ in range(2):
         h.eval(x, True, False)
+    print("--- no-search pass", file=sys.stderr)
+    h.eval(x, False, False)
