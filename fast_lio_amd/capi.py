@@ -72,9 +72,15 @@ EXPORTS = [
     "flh_esekf_set_meas_model", "flh_esekf_change_x", "flh_esekf_change_P", "flh_esekf_get_x", "flh_esekf_get_P",
     "flh_esekf_predict", "flh_esekf_update",
     "flh_map_add", "flh_map_delete_boxes", "flh_map_download", "flh_map_incremental", "flh_fetch_map_incremental",
+    "flh_fov_segment",
 ]
 
 _lib = None
+
+
+class FlhLocalMap(C.Structure):
+    """LocalMap_Points + Localmap_Initialized (src/laserMapping.cpp:228-229)."""
+    _fields_ = [("vertex_min", C.c_float * 3), ("vertex_max", C.c_float * 3), ("initialized", C.c_int)]
 
 
 class FlhError(RuntimeError):
@@ -105,6 +111,8 @@ def lib():
     L.flh_map_incremental.argtypes = [C.c_void_p, _f64p, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32)]
     L.flh_fetch_map_incremental.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.flh_fov_segment.argtypes = [C.c_void_p, C.POINTER(FlhLocalMap), _f64p, C.c_double, C.c_float, C.c_void_p,
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.flh_scan_size.restype = C.c_size_t
     L.flh_scan_size.argtypes = [C.c_void_p]
     L.flh_scan_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t]
@@ -214,6 +222,14 @@ class Handle:
         world = np.zeros((self.N, 3), np.float32)
         _chk(lib().flh_fetch_map_incremental(self._h, cls.ctypes.data, world.ctypes.data), "flh_fetch_map_incremental")
         return world, cls
+
+    def fov_segment(self, lm: "FlhLocalMap", pos_lid, cube_len: float = 200.0, det_range: float = 300.0):
+        """lasermap_fov_segment() -- src/laserMapping.cpp:230-280.  Returns (boxes nb x 6, points deleted)."""
+        boxes = np.zeros((3, 6), np.float32)
+        nb, ndel = C.c_int(0), C.c_int64(0)
+        _chk(lib().flh_fov_segment(self._h, C.byref(lm), np.ascontiguousarray(pos_lid, dtype=np.float64), float(cube_len),
+                                   float(det_range), boxes.ctypes.data, C.byref(nb), C.byref(ndel)), "flh_fov_segment")
+        return boxes[: nb.value].copy(), int(ndel.value)
 
     def scan_upload(self, body: np.ndarray):
         a = np.ascontiguousarray(body, dtype=np.float32)

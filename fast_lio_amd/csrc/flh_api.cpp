@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/fastlio_hip.h"
+#include "../../include/fastlio_amd/local_map.hpp"
 #include "flh_kernels.hpp"
 
 using flh::GridParams;
@@ -429,6 +430,38 @@ int flh_map_delete_boxes(flh_handle* h, const float* boxes, size_t nb) {
     HIPC(flh::launch_delete_boxes(h->map_orig.p, (uint32_t)h->M, h->mu_boxes.p, (int)nb, h->mu_dead.p, st));
     HIPC(hipStreamSynchronize(st));  // boxes is the caller's
     return apply_map_changes(h, nullptr, 0, 0, 1.0, true);
+}
+
+// lasermap_fov_segment() -- src/laserMapping.cpp:230-280; the cube logic is include/fastlio_amd/local_map.hpp
+int flh_fov_segment(flh_handle* h, flh_local_map* lm, const double pos_lid[3], double cube_len, float det_range,
+                    float* boxes_out, int* n_boxes, int64_t* kdtree_delete_counter) {
+    if (!h || !lm || !pos_lid) return fail("flh_fov_segment: null argument");
+    fastlio_amd::LocalMap cube;
+    cube.cube_len = cube_len;
+    cube.DET_RANGE = det_range;
+    cube.Localmap_Initialized = lm->initialized != 0;
+    for (int a = 0; a < 3; ++a) {
+        cube.LocalMap_Points.vertex_min[a] = lm->vertex_min[a];
+        cube.LocalMap_Points.vertex_max[a] = lm->vertex_max[a];
+    }
+    const std::vector<fastlio_amd::BoxPointType> cub_needrm = cube.lasermap_fov_segment(pos_lid);
+    lm->initialized = cube.Localmap_Initialized ? 1 : 0;
+    for (int a = 0; a < 3; ++a) {
+        lm->vertex_min[a] = cube.LocalMap_Points.vertex_min[a];
+        lm->vertex_max[a] = cube.LocalMap_Points.vertex_max[a];
+    }
+    float boxes[18];
+    for (size_t b = 0; b < cub_needrm.size(); ++b)
+        for (int a = 0; a < 3; ++a) {
+            boxes[6 * b + a] = cub_needrm[b].vertex_min[a];
+            boxes[6 * b + 3 + a] = cub_needrm[b].vertex_max[a];
+        }
+    if (boxes_out) std::memcpy(boxes_out, boxes, sizeof(float) * 6 * cub_needrm.size());
+    if (n_boxes) *n_boxes = (int)cub_needrm.size();
+    const size_t before = h->M;
+    if (!cub_needrm.empty() && flh_map_delete_boxes(h, boxes, cub_needrm.size()) != 0) return -1;
+    if (kdtree_delete_counter) *kdtree_delete_counter = (int64_t)(before - h->M);
+    return 0;
 }
 
 // The map in index order (what PCL_Storage / flatten would hand back, src/laserMapping.cpp:406-411).

@@ -94,6 +94,18 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
  * (:436).  Either may be NULL. */
 int flh_fetch_map_incremental(flh_handle* h, uint8_t* cls, float* world_xyz);
 
+/* lasermap_fov_segment() -- src/laserMapping.cpp:230-280: the local-map cube that follows the LiDAR.  The caller
+ * owns the cube state (zero-initialise it); pos_lid = state.pos + state.rot * state.offset_T_L_I (:890).  When the
+ * sensor comes within 1.5 * det_range of a face the cube shifts and the slabs that fall out are removed from the
+ * device map (ikdtree.Delete_Point_Boxes, :275).  boxes_out (optional, room for 3 x 6 floats) receives the slabs,
+ * n_boxes their number, kdtree_delete_counter (optional) the number of map points removed. */
+typedef struct flh_local_map {
+    float vertex_min[3], vertex_max[3]; /* LocalMap_Points */
+    int initialized;                    /* Localmap_Initialized */
+} flh_local_map;
+int flh_fov_segment(flh_handle* h, flh_local_map* lm, const double pos_lid[3], double cube_len, float det_range,
+                    float* boxes_out, int* n_boxes, int64_t* kdtree_delete_counter);
+
 /* feats_down_body for the coming update -- src/laserMapping.cpp:904-905,935-951.  Resets
  * point_selected_surf to all-true (as memset at :812 leaves it for a fresh search) and clears the
  * neighbour cache. */

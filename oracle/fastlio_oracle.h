@@ -167,6 +167,10 @@ size_t orc_map_add(float* map_xyz, size_t M, const float* add_xyz, size_t n, int
  * (boxes: nb x 6 floats min xyz, max xyz).  Order preserved.  Returns the new size. */
 size_t orc_map_delete_boxes(float* map_xyz, size_t M, const float* boxes, size_t nb);
 
+/* lasermap_fov_segment (src/laserMapping.cpp:230-280): LocalMap_Points + Localmap_Initialized */
+typedef struct { float vertex_min[3], vertex_max[3]; int initialized; } orc_local_map;
+int orc_fov_segment(orc_local_map* lm, const double pos_lid[3], double cube_len, float det_range, float* boxes_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -813,3 +813,54 @@ size_t orc_map_delete_boxes(float* map, size_t M, const float* boxes, size_t nb)
     }
     return w;
 }
+
+/* =================================================================== lasermap_fov_segment (src/laserMapping.cpp:230-280)
+   The local-map cube bookkeeping: float box corners (BoxPointType), float distances, a float mov_dist narrowed from a
+   double max() -- types as declared at :77-78,91.  Returns the number of boxes written to boxes_out (<= 3, each
+   {min xyz, max xyz}) that the caller hands to Delete_Point_Boxes. */
+int orc_fov_segment(orc_local_map* lm, const double pos_lid[3], double cube_len, float det_range, float* boxes_out) {
+    const float MOV_THRESHOLD = 1.5f;
+    if (!lm->initialized) { /* :238-245 */
+        for (int i = 0; i < 3; i++) {
+            lm->vertex_min[i] = (float)(pos_lid[i] - cube_len / 2.0);
+            lm->vertex_max[i] = (float)(pos_lid[i] + cube_len / 2.0);
+        }
+        lm->initialized = 1;
+        return 0;
+    }
+    float dist_to_map_edge[3][2];
+    int need_move = 0;
+    for (int i = 0; i < 3; i++) { /* :248-252 */
+        dist_to_map_edge[i][0] = (float)fabs(pos_lid[i] - (double)lm->vertex_min[i]);
+        dist_to_map_edge[i][1] = (float)fabs(pos_lid[i] - (double)lm->vertex_max[i]);
+        if (dist_to_map_edge[i][0] <= MOV_THRESHOLD * det_range || dist_to_map_edge[i][1] <= MOV_THRESHOLD * det_range) need_move = 1;
+    }
+    if (!need_move) return 0;
+    float nmin[3], nmax[3];
+    for (int i = 0; i < 3; i++) { nmin[i] = lm->vertex_min[i]; nmax[i] = lm->vertex_max[i]; }
+    const double m1 = (cube_len - 2.0 * MOV_THRESHOLD * det_range) * 0.5 * 0.9, m2 = (double)(det_range * (MOV_THRESHOLD - 1));
+    const float mov_dist = (float)(m1 > m2 ? m1 : m2); /* :256 (std::max returns its first argument on ties) */
+    int nb = 0;
+    for (int i = 0; i < 3; i++) { /* :257-270 */
+        float tmin[3], tmax[3];
+        for (int d = 0; d < 3; d++) { tmin[d] = lm->vertex_min[d]; tmax[d] = lm->vertex_max[d]; }
+        int push = 0;
+        if (dist_to_map_edge[i][0] <= MOV_THRESHOLD * det_range) {
+            nmax[i] -= mov_dist;
+            nmin[i] -= mov_dist;
+            tmin[i] = lm->vertex_max[i] - mov_dist;
+            push = 1;
+        } else if (dist_to_map_edge[i][1] <= MOV_THRESHOLD * det_range) {
+            nmax[i] += mov_dist;
+            nmin[i] += mov_dist;
+            tmax[i] = lm->vertex_min[i] + mov_dist;
+            push = 1;
+        }
+        if (push) {
+            for (int d = 0; d < 3; d++) { boxes_out[6 * nb + d] = tmin[d]; boxes_out[6 * nb + 3 + d] = tmax[d]; }
+            nb++;
+        }
+    }
+    for (int i = 0; i < 3; i++) { lm->vertex_min[i] = nmin[i]; lm->vertex_max[i] = nmax[i]; }
+    return nb;
+}

@@ -430,3 +430,19 @@ def map_delete_boxes(map_xyz, boxes):
     b = _c32(boxes).reshape(-1, 6)
     n = lib().orc_map_delete_boxes(m, len(m), b, len(b))
     return m[:n].copy()
+
+
+class LocalMap(C.Structure):
+    """orc_local_map: LocalMap_Points + Localmap_Initialized."""
+    _fields_ = [("vertex_min", C.c_float * 3), ("vertex_max", C.c_float * 3), ("initialized", C.c_int)]
+
+
+def fov_segment(lm: LocalMap, pos_lid, cube_len=200.0, det_range=300.0):
+    """lasermap_fov_segment restated: returns the slabs to delete (nb x 6)."""
+    L = lib()
+    L.orc_fov_segment.restype = C.c_int
+    L.orc_fov_segment.argtypes = [C.POINTER(LocalMap), np.ctypeslib.ndpointer(np.float64), C.c_double, C.c_float,
+                                  np.ctypeslib.ndpointer(np.float32)]
+    boxes = np.zeros((3, 6), np.float32)
+    nb = L.orc_fov_segment(C.byref(lm), _c64(pos_lid), float(cube_len), float(det_range), boxes)
+    return boxes[:nb].copy()

@@ -241,3 +241,28 @@ def test_map_incremental_requires_a_searched_scan(prob):
         h.map_incremental(prob.x_true, DS)
     with pytest.raises(capi.FlhError):
         h.map_add(np.array([[np.nan, 0, 0]], np.float32))
+
+
+def test_fov_segment_moves_cube_and_deletes_slabs(prob):
+    """lasermap_fov_segment (:230-280) through the C ABI: same slabs as the oracle, and the slabs are gone from the map."""
+    pr = prob
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    c = np.median(pr.map_xyz, axis=0).astype(np.float64)
+    lm_g, lm_o = capi.FlhLocalMap(), po.LocalMap()
+    cur = pr.map_xyz.astype(np.float32)
+    ext = float(np.ptp(pr.map_xyz, axis=0).max())
+    cube, det = 0.8 * ext, 0.1 * ext
+    path = [c, c + [0.2 * ext, 0, 0], c + [0.3 * ext, 0.05 * ext, 0], c + [0.3 * ext, -0.3 * ext, 0], c]
+    total = 0
+    for p in path:
+        want = po.fov_segment(lm_o, p, cube, det)
+        boxes, ndel = h.fov_segment(lm_g, p, cube, det)
+        np.testing.assert_array_equal(boxes.view(np.uint32), want.view(np.uint32))
+        assert list(lm_g.vertex_min) == list(lm_o.vertex_min) and list(lm_g.vertex_max) == list(lm_o.vertex_max)
+        new = po.map_delete_boxes(cur, want) if len(want) else cur
+        assert ndel == len(cur) - len(new)
+        cur = new
+        same_points(h.map_download(), cur, "map after lasermap_fov_segment")
+        total += ndel
+    assert total > 0
