@@ -11,7 +11,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfastlio_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-SOURCES = ["flh_kernels.hip", "flh_mapinc.hip", "flh_api.cpp", "flh_esekf.cpp"]
+SOURCES = ["flh_kernels.hip", "flh_mapinc.hip", "flh_scanprep.hip", "flh_api.cpp", "flh_esekf.cpp"]
 DEPS = SOURCES + ["flh_device.hpp", "flh_kernels.hpp"]
 HDRS = ["fastlio_hip.h", "fastlio_amd/esekfom.hpp", "fastlio_amd/mtk.hpp", "fastlio_amd/smallmat.hpp",
         "fastlio_amd/use-ikfom.hpp", "fastlio_amd/h_share_model.hpp"]

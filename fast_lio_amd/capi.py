@@ -72,7 +72,7 @@ EXPORTS = [
     "flh_esekf_set_meas_model", "flh_esekf_change_x", "flh_esekf_change_P", "flh_esekf_get_x", "flh_esekf_get_P",
     "flh_esekf_predict", "flh_esekf_update",
     "flh_map_add", "flh_map_delete_boxes", "flh_map_download", "flh_map_incremental", "flh_fetch_map_incremental",
-    "flh_fov_segment",
+    "flh_fov_segment", "flh_scan_stage_downsampled", "flh_fetch_scan",
 ]
 
 _lib = None
@@ -117,6 +117,9 @@ def lib():
     L.flh_scan_size.argtypes = [C.c_void_p]
     L.flh_scan_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t]
     L.flh_scan_activate.argtypes = [C.c_void_p, C.c_int]
+    L.flh_scan_stage_downsampled.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float,
+                                             C.POINTER(C.c_size_t)]
+    L.flh_fetch_scan.argtypes = [C.c_void_p, C.c_void_p]
     L.flh_get_counters.argtypes = [C.c_void_p, _f64p, C.c_int]
     L.flh_set_timing_stride.argtypes = [C.c_void_p, C.c_int]
     L.flh_eval.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, C.c_int, C.c_int, _f64p, _f64p,
@@ -239,6 +242,19 @@ class Handle:
     def scan_stage(self, slot: int, body: np.ndarray):
         a = np.ascontiguousarray(body, dtype=np.float32)
         _chk(lib().flh_scan_stage(self._h, slot, a.ctypes.data, a.shape[1] * 4, a.shape[0]), "flh_scan_stage")
+
+    def scan_stage_downsampled(self, slot: int, raw: np.ndarray, leaf_size: float = 0.5) -> int:
+        """pcl::VoxelGrid of the raw scan on the device + staging (src/laserMapping.cpp:904-905).  Returns feats_down_size."""
+        a = np.ascontiguousarray(raw, dtype=np.float32)
+        n_out = C.c_size_t(0)
+        _chk(lib().flh_scan_stage_downsampled(self._h, slot, a.ctypes.data, a.shape[1] * 4 if a.ndim == 2 else 12,
+                                              a.shape[0], float(leaf_size), C.byref(n_out)), "flh_scan_stage_downsampled")
+        return int(n_out.value)
+
+    def fetch_scan(self) -> np.ndarray:
+        out = np.zeros((self.N, 3), np.float32)
+        _chk(lib().flh_fetch_scan(self._h, out.ctypes.data), "flh_fetch_scan")
+        return out
 
     def scan_activate(self, slot: int):
         _chk(lib().flh_scan_activate(self._h, slot), "flh_scan_activate")

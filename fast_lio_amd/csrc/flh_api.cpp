@@ -5,7 +5,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -119,7 +121,8 @@ struct flh_handle {
     const float4* cur_body = nullptr;   // the active slot's buffer
     const Slot* cur = nullptr;
     // staging scratch (copy stream)
-    DevBuf<float4> st_raw;
+    DevBuf<float4> st_raw, ds_raw;         // ds_*: voxel-grid down-sampling of a raw scan
+    DevBuf<uint32_t> ds_flags, ds_incl;
     DevBuf<u64> st_k0, st_k1;
     DevBuf<uint32_t> st_v0, st_v1;
     DevBuf<unsigned char> st_tmp;
@@ -218,6 +221,7 @@ void flh_destroy(flh_handle* h) {
         sl.body.release();
         if (sl.ready) (void)hipEventDestroy(sl.ready);
     }
+    h->ds_raw.release(); h->ds_flags.release(); h->ds_incl.release();
     h->st_raw.release(); h->st_k0.release(); h->st_k1.release(); h->st_v0.release(); h->st_v1.release(); h->st_tmp.release();
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->h_gram) (void)hipHostFree(h->h_gram);
@@ -519,31 +523,14 @@ static int prepare_scan_buffers(flh_handle* h, size_t N, bool full_clear) {
     return 0;
 }
 
-// Copies a scan to the device in Morton order of its body-frame coordinates (sort_queries != 0) on the
-// copy stream; returns when the host buffer may be reused.
-static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size_t stride_bytes, size_t N) {
-    if (N > 0 && !pts) return fail("scan staging: null points");
-    if (stride_bytes < 12 && N > 0) return fail("scan staging: stride_bytes < 12");
-    if (N >= (1ull << 26)) return fail("scan staging: N too large");
-    HIPC(hipSetDevice(h->device));
-    if (!h->copy_stream) HIPC(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+// Second half of staging: h->st_raw holds N raw points on the copy stream and sl.h_body their host copy; orders them by
+// the Morton code of their body-frame coordinates (sort_queries != 0) into the slot; returns when the slot is complete.
+static int stage_sorted(flh_handle* h, flh_handle::Slot& sl, size_t N) {
     hipStream_t cs = h->copy_stream;
-    if (!sl.ready) HIPC(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
     const size_t n1 = N ? N : 1;
     HIPC(sl.body.reserve(n1));
-    HIPC(h->st_raw.reserve(n1));
-    sl.h_body.resize(3 * n1);
     sl.h_perm.resize(n1);
-    std::vector<float4> hb(n1);
-    const unsigned char* src = (const unsigned char*)pts;
-    for (size_t i = 0; i < N; ++i) {
-        float p[3];
-        std::memcpy(p, src + i * stride_bytes, 12);
-        hb[i] = make_float4(p[0], p[1], p[2], 0.f);
-        sl.h_body[3 * i] = p[0]; sl.h_body[3 * i + 1] = p[1]; sl.h_body[3 * i + 2] = p[2];
-    }
     const bool do_sort = h->cfg.sort_queries != 0 && N > 1;
-    if (N > 0) HIPC(hipMemcpyAsync(h->st_raw.p, hb.data(), N * sizeof(float4), hipMemcpyHostToDevice, cs));
     if (do_sort) {
         const uint32_t Nu = (uint32_t)N;
         HIPC(h->st_k0.reserve(N)); HIPC(h->st_k1.reserve(N)); HIPC(h->st_v0.reserve(N)); HIPC(h->st_v1.reserve(N));
@@ -560,10 +547,110 @@ static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size
         for (size_t i = 0; i < N; ++i) sl.h_perm[i] = (uint32_t)i;
     }
     HIPC(hipEventRecord(sl.ready, cs));
-    HIPC(hipStreamSynchronize(cs));  // hb is pageable and dies here; h_perm must be complete
+    HIPC(hipStreamSynchronize(cs));  // h_perm must be complete
     sl.N = N;
     sl.used = true;
     return 0;
+}
+
+static int stage_prepare(flh_handle* h, flh_handle::Slot& sl) {
+    HIPC(hipSetDevice(h->device));
+    if (!h->copy_stream) HIPC(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (!sl.ready) HIPC(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+    return 0;
+}
+
+// Copies a scan to the device (copy stream); returns when the host buffer may be reused.
+static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size_t stride_bytes, size_t N) {
+    if (N > 0 && !pts) return fail("scan staging: null points");
+    if (stride_bytes < 12 && N > 0) return fail("scan staging: stride_bytes < 12");
+    if (N >= (1ull << 26)) return fail("scan staging: N too large");
+    if (stage_prepare(h, sl) != 0) return -1;
+    hipStream_t cs = h->copy_stream;
+    const size_t n1 = N ? N : 1;
+    HIPC(h->st_raw.reserve(n1));
+    sl.h_body.resize(3 * n1);
+    std::vector<float4> hb(n1);
+    const unsigned char* src = (const unsigned char*)pts;
+    for (size_t i = 0; i < N; ++i) {
+        float p[3];
+        std::memcpy(p, src + i * stride_bytes, 12);
+        hb[i] = make_float4(p[0], p[1], p[2], 0.f);
+        sl.h_body[3 * i] = p[0]; sl.h_body[3 * i + 1] = p[1]; sl.h_body[3 * i + 2] = p[2];
+    }
+    if (N > 0) HIPC(hipMemcpyAsync(h->st_raw.p, hb.data(), N * sizeof(float4), hipMemcpyHostToDevice, cs));
+    return stage_sorted(h, sl, N);  // synchronises the copy stream before hb (pageable) goes out of scope
+}
+
+// downSizeFilterSurf.filter(*feats_down_body) (src/laserMapping.cpp:904-905) on the device, then staging of the result.
+static int stage_downsampled(flh_handle* h, flh_handle::Slot& sl, const void* pts, size_t stride_bytes, size_t n, float leaf,
+                             size_t* n_out) {
+    if (n > 0 && !pts) return fail("flh_scan_stage_downsampled: null points");
+    if (stride_bytes < 12 && n > 0) return fail("flh_scan_stage_downsampled: stride_bytes < 12");
+    if (n >= (1ull << 26)) return fail("flh_scan_stage_downsampled: n too large");
+    if (!(leaf > 0.f)) return fail("flh_scan_stage_downsampled: leaf size must be > 0");
+    if (stage_prepare(h, sl) != 0) return -1;
+    hipStream_t cs = h->copy_stream;
+    const size_t n1 = n ? n : 1;
+    HIPC(h->ds_raw.reserve(n1));
+    HIPC(h->st_raw.reserve(n1));
+    std::vector<float4> hb(n1);
+    const unsigned char* src = (const unsigned char*)pts;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = 0; i < n; ++i) {
+        float p[3];
+        std::memcpy(p, src + i * stride_bytes, 12);
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2]))
+            return fail("flh_scan_stage_downsampled: non-finite point at index " + std::to_string(i));
+        hb[i] = make_float4(p[0], p[1], p[2], 0.f);
+        for (int d = 0; d < 3; ++d) { mn[d] = std::min(mn[d], p[d]); mx[d] = std::max(mx[d], p[d]); }  // getMinMax3D
+    }
+    size_t m = 0;
+    if (n > 0) {
+        HIPC(hipMemcpyAsync(h->ds_raw.p, hb.data(), n * sizeof(float4), hipMemcpyHostToDevice, cs));
+        const float inv = 1.0f / leaf;  // inverse_leaf_size_
+        long long dxyz[3];
+        for (int d = 0; d < 3; ++d) dxyz[d] = (long long)((mx[d] - mn[d]) * inv) + 1;
+        if (dxyz[0] * dxyz[1] * dxyz[2] > (long long)INT32_MAX) {
+            // "Leaf size is too small for the input dataset": PCL returns the input unchanged
+            HIPC(hipMemcpyAsync(h->st_raw.p, h->ds_raw.p, n * sizeof(float4), hipMemcpyDeviceToDevice, cs));
+            m = n;
+        } else {
+            int min_b[3], div_b[3];
+            for (int d = 0; d < 3; ++d) {
+                min_b[d] = (int)std::floor(mn[d] * inv);
+                div_b[d] = (int)std::floor(mx[d] * inv) - min_b[d] + 1;
+            }
+            const uint32_t nu = (uint32_t)n;
+            HIPC(h->st_k0.reserve(n)); HIPC(h->st_k1.reserve(n)); HIPC(h->st_v0.reserve(n)); HIPC(h->st_v1.reserve(n));
+            HIPC(h->ds_flags.reserve(n)); HIPC(h->ds_incl.reserve(n));
+            HIPC(flh::launch_vg_keys(h->ds_raw.p, nu, inv, min_b, div_b[0], div_b[0] * div_b[1], h->st_k0.p, h->st_v0.p, cs));
+            size_t tb1 = 0, tb2 = 0;
+            HIPC(flh::sort_vg_pairs(nullptr, tb1, h->st_k0.p, h->st_k1.p, h->st_v0.p, h->st_v1.p, nu, cs));
+            HIPC(flh::inclusive_sum(nullptr, tb2, h->ds_flags.p, h->ds_incl.p, nu, cs));
+            HIPC(h->st_tmp.reserve(std::max(tb1, tb2)));
+            size_t tb = h->st_tmp.cap;
+            HIPC(flh::sort_vg_pairs(h->st_tmp.p, tb, h->st_k0.p, h->st_k1.p, h->st_v0.p, h->st_v1.p, nu, cs));
+            HIPC(flh::launch_vg_heads(h->st_k1.p, nu, h->ds_flags.p, cs));
+            tb = h->st_tmp.cap;
+            HIPC(flh::inclusive_sum(h->st_tmp.p, tb, h->ds_flags.p, h->ds_incl.p, nu, cs));
+            uint32_t m32 = 0;
+            HIPC(hipMemcpyAsync(&m32, h->ds_incl.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+            HIPC(flh::launch_vg_reduce(h->ds_raw.p, h->st_k1.p, h->st_v1.p, h->ds_flags.p, h->ds_incl.p, nu, h->st_raw.p, cs));
+            HIPC(hipStreamSynchronize(cs));
+            m = m32;
+        }
+        // feats_down_body back to the host (the node publishes it; flh_fetch_rows / flh_fetch_scan read it)
+        std::vector<float4> out(m ? m : 1);
+        HIPC(hipMemcpyAsync(out.data(), h->st_raw.p, m * sizeof(float4), hipMemcpyDeviceToHost, cs));
+        HIPC(hipStreamSynchronize(cs));
+        sl.h_body.resize(3 * (m ? m : 1));
+        for (size_t i = 0; i < m; ++i) { sl.h_body[3 * i] = out[i].x; sl.h_body[3 * i + 1] = out[i].y; sl.h_body[3 * i + 2] = out[i].z; }
+    } else {
+        sl.h_body.resize(3);
+    }
+    if (n_out) *n_out = m;
+    return stage_sorted(h, sl, m);
 }
 
 static int activate(flh_handle* h, flh_handle::Slot& sl, bool full_clear) {
@@ -588,6 +675,23 @@ int flh_scan_stage(flh_handle* h, int slot, const void* pts, size_t stride_bytes
     if (!h) return fail("flh_scan_stage: null handle");
     if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_stage: bad slot");
     return stage_into(h, h->slots[slot], pts, stride_bytes, N);
+}
+
+// downSizeFilterSurf.setInputCloud(feats_undistort); downSizeFilterSurf.filter(*feats_down_body) -- :904-905
+int flh_scan_stage_downsampled(flh_handle* h, int slot, const void* pts, size_t stride_bytes, size_t n, float leaf_size,
+                               size_t* n_out) {
+    if (!h) return fail("flh_scan_stage_downsampled: null handle");
+    if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_stage_downsampled: bad slot");
+    return stage_downsampled(h, h->slots[slot], pts, stride_bytes, n, leaf_size, n_out);
+}
+
+// feats_down_body of the active scan, original (staging) order
+int flh_fetch_scan(flh_handle* h, float* xyz) {
+    if (!h) return fail("flh_fetch_scan: null handle");
+    if (!h->cur) return fail("flh_fetch_scan: no active scan");
+    if (h->N > 0 && !xyz) return fail("flh_fetch_scan: null buffer");
+    if (h->N > 0) std::memcpy(xyz, h->cur->h_body.data(), sizeof(float) * 3 * h->N);
+    return 0;
 }
 
 int flh_scan_activate(flh_handle* h, int slot) {

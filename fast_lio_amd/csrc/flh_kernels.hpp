@@ -61,4 +61,13 @@ hipError_t launch_alive_flags(const uint8_t* dead_old, uint32_t M, const uint8_t
 hipError_t launch_compact(const float4* old_pts, uint32_t M, const float4* new_pts, uint32_t n, const uint32_t* flags,
                           const uint32_t* incl, float4* out, hipStream_t st);
 
+// ---- flh_scanprep.hip: pcl::VoxelGrid of the scan ----
+hipError_t launch_vg_keys(const float4* raw, uint32_t n, float inv, const int min_b[3], int mul1, int mul2,
+                          unsigned long long* keys, uint32_t* vals, hipStream_t st);
+hipError_t sort_vg_pairs(void* tmp, size_t& tmp_bytes, const unsigned long long* kin, unsigned long long* kout,
+                         const uint32_t* vin, uint32_t* vout, uint32_t n, hipStream_t st);
+hipError_t launch_vg_heads(const unsigned long long* keys_sorted, uint32_t n, uint32_t* flags, hipStream_t st);
+hipError_t launch_vg_reduce(const float4* raw, const unsigned long long* keys_sorted, const uint32_t* vals_sorted,
+                            const uint32_t* flags, const uint32_t* incl, uint32_t n, float4* out, hipStream_t st);
+
 }  // namespace flh

@@ -120,6 +120,17 @@ size_t flh_scan_size(const flh_handle* h);
 int flh_scan_stage(flh_handle* h, int slot, const void* pts, size_t stride_bytes, size_t N);
 int flh_scan_activate(flh_handle* h, int slot);
 
+/* SURVEY.md 8(f) row 2 -- downSizeFilterSurf.setInputCloud(feats_undistort); downSizeFilterSurf.filter(*feats_down_body)
+ * (src/laserMapping.cpp:904-905; pcl::VoxelGrid with leaf = filter_size_surf_min, :813) on the device, and staging of the
+ * result into `slot` exactly as flh_scan_stage does.  One float centroid per occupied leaf, in ascending voxel-index
+ * order (PCL's output order); inside a leaf the float sum runs in ascending input index (PCL's order there is
+ * implementation-defined).  n_out (optional) receives feats_down_size.  A grid that would overflow int32 returns
+ * the input unchanged, as PCL does. */
+int flh_scan_stage_downsampled(flh_handle* h, int slot, const void* pts, size_t stride_bytes, size_t n, float leaf_size,
+                               size_t* n_out);
+/* feats_down_body of the ACTIVE scan (3 floats per point, the order it was staged in). */
+int flh_fetch_scan(flh_handle* h, float* xyz);
+
 /* One evaluation of h_share_model (src/laserMapping.cpp:638-754) at state s:
  *   transform :652-661, 5-NN + gate :667-672 (only if do_search = ekfom_data.converge), plane fit
  *   + residual gate :676-692, then -- instead of materialising h_x/h (:720-752) -- the normal

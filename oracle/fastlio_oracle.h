@@ -171,6 +171,10 @@ size_t orc_map_delete_boxes(float* map_xyz, size_t M, const float* boxes, size_t
 typedef struct { float vertex_min[3], vertex_max[3]; int initialized; } orc_local_map;
 int orc_fov_segment(orc_local_map* lm, const double pos_lid[3], double cube_len, float det_range, float* boxes_out);
 
+/* pcl::VoxelGrid (downSizeFilterSurf, src/laserMapping.cpp:904-905): one float centroid per occupied leaf, output in
+ * ascending voxel-index order; summation order inside a voxel pinned to ascending input index (see oracle_path.c). */
+size_t orc_voxel_grid(const float* in, size_t stride_floats, size_t n, float leaf, float* out_xyz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@
 #include "fastlio_oracle.h"
 
 #include <float.h>
+#include <limits.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -863,4 +864,72 @@ int orc_fov_segment(orc_local_map* lm, const double pos_lid[3], double cube_len,
     }
     for (int i = 0; i < 3; i++) { lm->vertex_min[i] = nmin[i]; lm->vertex_max[i] = nmax[i]; }
     return nb;
+}
+
+/* =================================================================== pcl::VoxelGrid<PointType>::applyFilter
+   (downSizeFilterSurf.filter, src/laserMapping.cpp:904-905; leaf = filter_size_surf_min narrowed to float by
+   setLeafSize, :813).  PCL is an external dependency (README.md:69, PCL >= 1.8); restated from its published
+   algorithm (filters/impl/voxel_grid.hpp): float min/max of the cloud, integer voxel coordinates
+   floor(x * inverse_leaf) - min_b, linear index, sort by index, one centroid per occupied voxel in index order,
+   xyz averaged in float (CentroidPoint / AccumulatorXYZ: running float sum, then sum / n).
+   PCL sorts with an UNSTABLE sort that compares the voxel index only, so the order in which a voxel's points are
+   summed is implementation-defined there; it is pinned here to ascending input index.  Centroids therefore agree
+   with a given PCL build up to the rounding of a different float summation order, not bit for bit.
+   Returns the number of output points; out_xyz needs room for n points.  If the grid would overflow int32 PCL
+   warns and returns the input unchanged -- so does this. */
+typedef struct { unsigned int idx; unsigned int pt; } vg_pair;
+static int vg_cmp(const void* a, const void* b) {
+    const vg_pair* x = (const vg_pair*)a; const vg_pair* y = (const vg_pair*)b;
+    if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
+    return x->pt < y->pt ? -1 : (x->pt > y->pt ? 1 : 0);
+}
+size_t orc_voxel_grid(const float* in, size_t stride, size_t n, float leaf, float* out_xyz) {
+    if (n == 0) return 0;
+    float min_p[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, max_p[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (size_t i = 0; i < n; i++)
+        for (int d = 0; d < 3; d++) {
+            float v = in[i * stride + d];
+            if (v < min_p[d]) min_p[d] = v;
+            if (v > max_p[d]) max_p[d] = v;
+        }
+    const float inv = 1.0f / leaf;
+    long long dxyz[3];
+    for (int d = 0; d < 3; d++) dxyz[d] = (long long)((max_p[d] - min_p[d]) * inv) + 1;
+    if (dxyz[0] * dxyz[1] * dxyz[2] > (long long)INT_MAX) {
+        for (size_t i = 0; i < n; i++)
+            for (int d = 0; d < 3; d++) out_xyz[3 * i + d] = in[i * stride + d];
+        return n;
+    }
+    int min_b[3], max_b[3], div_b[3], mul[3];
+    for (int d = 0; d < 3; d++) {
+        min_b[d] = (int)floorf(min_p[d] * inv);
+        max_b[d] = (int)floorf(max_p[d] * inv);
+        div_b[d] = max_b[d] - min_b[d] + 1;
+    }
+    mul[0] = 1; mul[1] = div_b[0]; mul[2] = div_b[0] * div_b[1];
+    vg_pair* pr = (vg_pair*)malloc(sizeof(vg_pair) * n);
+    for (size_t i = 0; i < n; i++) {
+        int ijk[3];
+        for (int d = 0; d < 3; d++) ijk[d] = (int)(floorf(in[i * stride + d] * inv) - (float)min_b[d]);
+        int idx = ijk[0] * mul[0] + ijk[1] * mul[1] + ijk[2] * mul[2];
+        pr[i].idx = (unsigned int)idx;
+        pr[i].pt = (unsigned int)i;
+    }
+    qsort(pr, n, sizeof(vg_pair), vg_cmp);
+    size_t m = 0, first = 0;
+    while (first < n) {
+        size_t last = first + 1;
+        while (last < n && pr[last].idx == pr[first].idx) last++;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (size_t k = first; k < last; k++) {
+            const float* p = in + (size_t)pr[k].pt * stride;
+            sx = sx + p[0]; sy = sy + p[1]; sz = sz + p[2];
+        }
+        const float cnt = (float)(last - first);
+        out_xyz[3 * m] = sx / cnt; out_xyz[3 * m + 1] = sy / cnt; out_xyz[3 * m + 2] = sz / cnt;
+        m++;
+        first = last;
+    }
+    free(pr);
+    return m;
 }

@@ -446,3 +446,15 @@ def fov_segment(lm: LocalMap, pos_lid, cube_len=200.0, det_range=300.0):
     boxes = np.zeros((3, 6), np.float32)
     nb = L.orc_fov_segment(C.byref(lm), _c64(pos_lid), float(cube_len), float(det_range), boxes)
     return boxes[:nb].copy()
+
+
+def voxel_grid(xyz, leaf=0.5):
+    """pcl::VoxelGrid restated (xyz centroids, ascending voxel index)."""
+    a = _c32(xyz).reshape(-1, 3)
+    L = lib()
+    L.orc_voxel_grid.restype = C.c_size_t
+    L.orc_voxel_grid.argtypes = [np.ctypeslib.ndpointer(np.float32), C.c_size_t, C.c_size_t, C.c_float,
+                                 np.ctypeslib.ndpointer(np.float32)]
+    out = np.zeros((max(len(a), 1), 3), np.float32)
+    m = L.orc_voxel_grid(a, 3, len(a), float(leaf), out)
+    return out[:m].copy()

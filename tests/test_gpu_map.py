@@ -266,3 +266,60 @@ def test_fov_segment_moves_cube_and_deletes_slabs(prob):
         same_points(h.map_download(), cur, "map after lasermap_fov_segment")
         total += ndel
     assert total > 0
+
+
+# ---------------------------------------------------------------------------------------------- 8(f) row 2
+def raw_scan(pr, n, seed):
+    """An un-down-sampled scan: the down-sampled one plus dense clutter around its points (several per leaf)."""
+    rng = np.random.default_rng(seed)
+    base = pr.body[rng.integers(0, len(pr.body), n)]
+    return (base + rng.normal(0, 0.15, (n, 3))).astype(np.float32)
+
+
+@pytest.mark.parametrize("leaf", [0.5, 0.2])
+def test_scan_voxel_grid_matches_oracle_bit_for_bit(prob, leaf):
+    pr = prob
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    raw = raw_scan(pr, 60000, 1)
+    raw[:500] = raw[500:1000]                       # exact duplicates
+    want = po.voxel_grid(raw, leaf)
+    n = h.scan_stage_downsampled(2, raw, leaf)
+    assert n == len(want) and 0 < n < len(raw)
+    h.scan_activate(2)
+    assert h.N == n
+    same_points(h.fetch_scan(), want, "feats_down_body")
+    # the staged scan behaves exactly like the same points handed to flh_scan_upload
+    a = h.eval(pr.x_true, True, False)
+    sel_a = h.fetch_selected()
+    h.scan_upload(want)
+    b = h.eval(pr.x_true, True, False)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(sel_a, h.fetch_selected())
+    assert a[2] == b[2] and a[2] > 100
+
+
+def test_scan_voxel_grid_edge_cases(prob):
+    h = capi.Handle()
+    h.map_build(prob.map_xyz[:1000])
+    assert h.scan_stage_downsampled(0, np.zeros((0, 3), np.float32), 0.5) == 0
+    one = np.array([[1.0, 2.0, 3.0]], np.float32)
+    assert h.scan_stage_downsampled(0, one, 0.5) == 1
+    h.scan_activate(0)
+    same_points(h.fetch_scan(), one)
+    far = np.array([[0, 0, 0], [3000.0, 3000.0, 3000.0], [1.0, 2.0, 3.0]], np.float32)
+    assert h.scan_stage_downsampled(1, far, 0.001) == 3           # leaf too small: input returned unchanged
+    h.scan_activate(1)
+    same_points(h.fetch_scan(), far)
+    with pytest.raises(capi.FlhError):
+        h.scan_stage_downsampled(0, np.array([[np.inf, 0, 0]], np.float32), 0.5)
+    with pytest.raises(capi.FlhError):
+        h.scan_stage_downsampled(0, one, 0.0)
+    # a voxel with thousands of points (dense clutter next to the sensor)
+    rng = np.random.default_rng(9)
+    blob = np.vstack([rng.uniform(0.0, 0.49, (5000, 3)), rng.uniform(-30, 30, (2000, 3))]).astype(np.float32)
+    n = h.scan_stage_downsampled(3, blob, 0.5)
+    h.scan_activate(3)
+    same_points(h.fetch_scan(), po.voxel_grid(blob, 0.5))
+    assert n == h.N
