@@ -73,6 +73,7 @@ EXPORTS = [
     "flh_esekf_predict", "flh_esekf_update",
     "flh_map_add", "flh_map_delete_boxes", "flh_map_download", "flh_map_incremental", "flh_fetch_map_incremental",
     "flh_fov_segment", "flh_scan_stage_downsampled", "flh_fetch_scan",
+    "flh_scan_stage_undistorted",
 ]
 
 _lib = None
@@ -120,6 +121,8 @@ def lib():
     L.flh_scan_stage_downsampled.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float,
                                              C.POINTER(C.c_size_t)]
     L.flh_fetch_scan.argtypes = [C.c_void_p, C.c_void_p]
+    L.flh_scan_stage_undistorted.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                             C.c_int, _f64p, C.c_float, C.c_void_p, C.POINTER(C.c_size_t)]
     L.flh_get_counters.argtypes = [C.c_void_p, _f64p, C.c_int]
     L.flh_set_timing_stride.argtypes = [C.c_void_p, C.c_int]
     L.flh_eval.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, C.c_int, C.c_int, _f64p, _f64p,
@@ -250,6 +253,17 @@ class Handle:
         _chk(lib().flh_scan_stage_downsampled(self._h, slot, a.ctypes.data, a.shape[1] * 4 if a.ndim == 2 else 12,
                                               a.shape[0], float(leaf_size), C.byref(n_out)), "flh_scan_stage_downsampled")
         return int(n_out.value)
+
+    def scan_stage_undistorted(self, slot: int, pts_xyzt: np.ndarray, poses, x_end, leaf_size: float = 0.5):
+        """UndistortPcl's per-point half + VoxelGrid + staging.  pts_xyzt: n x 4 float32 (x, y, z, time offset in ms);
+        poses: a ctypes array of 22-double Pose6D records.  Returns (feats_down_size, feats_undistort n x 3)."""
+        a = np.ascontiguousarray(pts_xyzt, dtype=np.float32).reshape(-1, 4)
+        und = np.zeros((max(len(a), 1), 3), np.float32)
+        n_out = C.c_size_t(0)
+        _chk(lib().flh_scan_stage_undistorted(self._h, slot, a.ctypes.data, 16, 12, a.shape[0], C.cast(poses, C.c_void_p),
+                                              len(poses), np.ascontiguousarray(x_end, dtype=np.float64), float(leaf_size),
+                                              und.ctypes.data, C.byref(n_out)), "flh_scan_stage_undistorted")
+        return int(n_out.value), und[: len(a)].copy()
 
     def fetch_scan(self) -> np.ndarray:
         out = np.zeros((self.N, 3), np.float32)

@@ -121,7 +121,8 @@ struct flh_handle {
     const float4* cur_body = nullptr;   // the active slot's buffer
     const Slot* cur = nullptr;
     // staging scratch (copy stream)
-    DevBuf<float4> st_raw, ds_raw;         // ds_*: voxel-grid down-sampling of a raw scan
+    DevBuf<float4> st_raw, ds_raw, ds_und; // ds_*: undistortion / voxel-grid down-sampling of a raw scan
+    DevBuf<double> ds_poses;
     DevBuf<uint32_t> ds_flags, ds_incl;
     DevBuf<u64> st_k0, st_k1;
     DevBuf<uint32_t> st_v0, st_v1;
@@ -131,6 +132,7 @@ struct flh_handle {
 extern "C" {
 
 static void release_build_scratch(flh_handle* h);
+static StateDev make_state(const double rot[4], const double pos[3], const double offR[4], const double offT[3]);
 
 const char* flh_last_error(void) { return g_err.c_str(); }
 
@@ -221,7 +223,7 @@ void flh_destroy(flh_handle* h) {
         sl.body.release();
         if (sl.ready) (void)hipEventDestroy(sl.ready);
     }
-    h->ds_raw.release(); h->ds_flags.release(); h->ds_incl.release();
+    h->ds_raw.release(); h->ds_und.release(); h->ds_poses.release(); h->ds_flags.release(); h->ds_incl.release();
     h->st_raw.release(); h->st_k0.release(); h->st_k1.release(); h->st_v0.release(); h->st_v1.release(); h->st_tmp.release();
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->h_gram) (void)hipHostFree(h->h_gram);
@@ -582,13 +584,27 @@ static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size
     return stage_sorted(h, sl, N);  // synchronises the copy stream before hb (pageable) goes out of scope
 }
 
-// downSizeFilterSurf.filter(*feats_down_body) (src/laserMapping.cpp:904-905) on the device, then staging of the result.
-static int stage_downsampled(flh_handle* h, flh_handle::Slot& sl, const void* pts, size_t stride_bytes, size_t n, float leaf,
-                             size_t* n_out) {
-    if (n > 0 && !pts) return fail("flh_scan_stage_downsampled: null points");
-    if (stride_bytes < 12 && n > 0) return fail("flh_scan_stage_downsampled: stride_bytes < 12");
-    if (n >= (1ull << 26)) return fail("flh_scan_stage_downsampled: n too large");
-    if (!(leaf > 0.f)) return fail("flh_scan_stage_downsampled: leaf size must be > 0");
+// The raw-scan front end on the device: optional undistortion (UndistortPcl's per-point half, IMU_Processing.hpp:307-349),
+// optional voxel-grid down-sampling (downSizeFilterSurf.filter, src/laserMapping.cpp:904-905), then staging.
+struct UndistortArgs {
+    const flh_pose6d* poses = nullptr;
+    int n_pose = 0;
+    const double* x_end = nullptr;
+    size_t time_offset_bytes = 0;
+    float* undistorted_out = nullptr;
+};
+static int stage_raw(flh_handle* h, flh_handle::Slot& sl, const char* who, const void* pts, size_t stride_bytes, size_t n,
+                     const UndistortArgs* und, float leaf, size_t* n_out) {
+    const std::string w(who);
+    if (n > 0 && !pts) return fail(w + ": null points");
+    if (stride_bytes < 12 && n > 0) return fail(w + ": stride_bytes < 12");
+    if (n >= (1ull << 26)) return fail(w + ": n too large");
+    if (und) {
+        if (!und->poses || und->n_pose < 1 || !und->x_end) return fail(w + ": IMU poses / end state missing");
+        if (n > 0 && und->time_offset_bytes + 4 > stride_bytes) return fail(w + ": time_offset_bytes outside the point record");
+        for (int k = 1; k < und->n_pose; ++k)
+            if (!(und->poses[k].offset_time > und->poses[k - 1].offset_time)) return fail(w + ": IMU pose offset_time must increase");
+    }
     if (stage_prepare(h, sl) != 0) return -1;
     hipStream_t cs = h->copy_stream;
     const size_t n1 = n ? n : 1;
@@ -596,49 +612,87 @@ static int stage_downsampled(flh_handle* h, flh_handle::Slot& sl, const void* pt
     HIPC(h->st_raw.reserve(n1));
     std::vector<float4> hb(n1);
     const unsigned char* src = (const unsigned char*)pts;
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (size_t i = 0; i < n; ++i) {
-        float p[3];
+        float p[3], t = 0.f;
         std::memcpy(p, src + i * stride_bytes, 12);
-        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2]))
-            return fail("flh_scan_stage_downsampled: non-finite point at index " + std::to_string(i));
-        hb[i] = make_float4(p[0], p[1], p[2], 0.f);
-        for (int d = 0; d < 3; ++d) { mn[d] = std::min(mn[d], p[d]); mx[d] = std::max(mx[d], p[d]); }  // getMinMax3D
+        if (und) std::memcpy(&t, src + i * stride_bytes + und->time_offset_bytes, 4);
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2]) || !std::isfinite(t))
+            return fail(w + ": non-finite point at index " + std::to_string(i));
+        hb[i] = make_float4(p[0], p[1], p[2], t);
     }
     size_t m = 0;
     if (n > 0) {
+        const uint32_t nu = (uint32_t)n;
         HIPC(hipMemcpyAsync(h->ds_raw.p, hb.data(), n * sizeof(float4), hipMemcpyHostToDevice, cs));
-        const float inv = 1.0f / leaf;  // inverse_leaf_size_
-        long long dxyz[3];
-        for (int d = 0; d < 3; ++d) dxyz[d] = (long long)((mx[d] - mn[d]) * inv) + 1;
-        if (dxyz[0] * dxyz[1] * dxyz[2] > (long long)INT32_MAX) {
-            // "Leaf size is too small for the input dataset": PCL returns the input unchanged
-            HIPC(hipMemcpyAsync(h->st_raw.p, h->ds_raw.p, n * sizeof(float4), hipMemcpyDeviceToDevice, cs));
-            m = n;
-        } else {
-            int min_b[3], div_b[3];
-            for (int d = 0; d < 3; ++d) {
-                min_b[d] = (int)std::floor(mn[d] * inv);
-                div_b[d] = (int)std::floor(mx[d] * inv) - min_b[d] + 1;
+        const float4* srcd = h->ds_raw.p;
+        if (und) {
+            HIPC(h->ds_und.reserve(n1));
+            HIPC(h->ds_poses.reserve((size_t)22 * und->n_pose));
+            static_assert(sizeof(flh_pose6d) == 22 * sizeof(double), "flh_pose6d must be 22 packed doubles");
+            HIPC(hipMemcpyAsync(h->ds_poses.p, und->poses, sizeof(flh_pose6d) * und->n_pose, hipMemcpyHostToDevice, cs));
+            const StateDev se = make_state(und->x_end + 3, und->x_end + 0, und->x_end + 7, und->x_end + 11);
+            HIPC(flh::launch_undistort(se, h->ds_poses.p, und->n_pose, h->ds_raw.p, nu, h->ds_und.p, cs));
+            srcd = h->ds_und.p;
+            if (und->undistorted_out) {
+                std::vector<float4> uo(n);
+                HIPC(hipMemcpyAsync(uo.data(), h->ds_und.p, n * sizeof(float4), hipMemcpyDeviceToHost, cs));
+                HIPC(hipStreamSynchronize(cs));
+                for (size_t i = 0; i < n; ++i) {
+                    und->undistorted_out[3 * i] = uo[i].x; und->undistorted_out[3 * i + 1] = uo[i].y; und->undistorted_out[3 * i + 2] = uo[i].z;
+                }
             }
-            const uint32_t nu = (uint32_t)n;
-            HIPC(h->st_k0.reserve(n)); HIPC(h->st_k1.reserve(n)); HIPC(h->st_v0.reserve(n)); HIPC(h->st_v1.reserve(n));
-            HIPC(h->ds_flags.reserve(n)); HIPC(h->ds_incl.reserve(n));
-            HIPC(flh::launch_vg_keys(h->ds_raw.p, nu, inv, min_b, div_b[0], div_b[0] * div_b[1], h->st_k0.p, h->st_v0.p, cs));
-            size_t tb1 = 0, tb2 = 0;
-            HIPC(flh::sort_vg_pairs(nullptr, tb1, h->st_k0.p, h->st_k1.p, h->st_v0.p, h->st_v1.p, nu, cs));
-            HIPC(flh::inclusive_sum(nullptr, tb2, h->ds_flags.p, h->ds_incl.p, nu, cs));
-            HIPC(h->st_tmp.reserve(std::max(tb1, tb2)));
-            size_t tb = h->st_tmp.cap;
-            HIPC(flh::sort_vg_pairs(h->st_tmp.p, tb, h->st_k0.p, h->st_k1.p, h->st_v0.p, h->st_v1.p, nu, cs));
-            HIPC(flh::launch_vg_heads(h->st_k1.p, nu, h->ds_flags.p, cs));
-            tb = h->st_tmp.cap;
-            HIPC(flh::inclusive_sum(h->st_tmp.p, tb, h->ds_flags.p, h->ds_incl.p, nu, cs));
-            uint32_t m32 = 0;
-            HIPC(hipMemcpyAsync(&m32, h->ds_incl.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
-            HIPC(flh::launch_vg_reduce(h->ds_raw.p, h->st_k1.p, h->st_v1.p, h->ds_flags.p, h->ds_incl.p, nu, h->st_raw.p, cs));
+        }
+        bool passthrough = !(leaf > 0.f);
+        if (!passthrough) {
+            // getMinMax3D on the device (the points may just have been moved by the undistortion)
+            HIPC(h->mb_aabb.reserve(6));
+            const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+            uint32_t got[6];
+            HIPC(hipMemcpyAsync(h->mb_aabb.p, init, sizeof(init), hipMemcpyHostToDevice, cs));
+            HIPC(flh::launch_aabb(srcd, nu, h->mb_aabb.p, cs));
+            HIPC(hipMemcpyAsync(got, h->mb_aabb.p, sizeof(got), hipMemcpyDeviceToHost, cs));
             HIPC(hipStreamSynchronize(cs));
-            m = m32;
+            float mn[3], mx[3];
+            for (int d = 0; d < 6; ++d) {
+                const uint32_t u = got[d];
+                const uint32_t bits = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+                float f;
+                std::memcpy(&f, &bits, 4);
+                (d < 3 ? mn[d] : mx[d - 3]) = f;
+            }
+            const float inv = 1.0f / leaf;  // inverse_leaf_size_
+            long long dxyz[3];
+            for (int d = 0; d < 3; ++d) dxyz[d] = (long long)((mx[d] - mn[d]) * inv) + 1;
+            if (dxyz[0] * dxyz[1] * dxyz[2] > (long long)INT32_MAX) {
+                passthrough = true;  // "Leaf size is too small for the input dataset": PCL returns the input unchanged
+            } else {
+                int min_b[3], div_b[3];
+                for (int d = 0; d < 3; ++d) {
+                    min_b[d] = (int)std::floor(mn[d] * inv);
+                    div_b[d] = (int)std::floor(mx[d] * inv) - min_b[d] + 1;
+                }
+                HIPC(h->st_k0.reserve(n)); HIPC(h->st_k1.reserve(n)); HIPC(h->st_v0.reserve(n)); HIPC(h->st_v1.reserve(n));
+                HIPC(h->ds_flags.reserve(n)); HIPC(h->ds_incl.reserve(n));
+                HIPC(flh::launch_vg_keys(srcd, nu, inv, min_b, div_b[0], div_b[0] * div_b[1], h->st_k0.p, h->st_v0.p, cs));
+                size_t tb1 = 0, tb2 = 0;
+                HIPC(flh::sort_vg_pairs(nullptr, tb1, h->st_k0.p, h->st_k1.p, h->st_v0.p, h->st_v1.p, nu, cs));
+                HIPC(flh::inclusive_sum(nullptr, tb2, h->ds_flags.p, h->ds_incl.p, nu, cs));
+                HIPC(h->st_tmp.reserve(std::max(tb1, tb2)));
+                size_t tb = h->st_tmp.cap;
+                HIPC(flh::sort_vg_pairs(h->st_tmp.p, tb, h->st_k0.p, h->st_k1.p, h->st_v0.p, h->st_v1.p, nu, cs));
+                HIPC(flh::launch_vg_heads(h->st_k1.p, nu, h->ds_flags.p, cs));
+                tb = h->st_tmp.cap;
+                HIPC(flh::inclusive_sum(h->st_tmp.p, tb, h->ds_flags.p, h->ds_incl.p, nu, cs));
+                uint32_t m32 = 0;
+                HIPC(hipMemcpyAsync(&m32, h->ds_incl.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+                HIPC(flh::launch_vg_reduce(srcd, h->st_k1.p, h->st_v1.p, h->ds_flags.p, h->ds_incl.p, nu, h->st_raw.p, cs));
+                HIPC(hipStreamSynchronize(cs));
+                m = m32;
+            }
+        }
+        if (passthrough) {
+            HIPC(hipMemcpyAsync(h->st_raw.p, srcd, n * sizeof(float4), hipMemcpyDeviceToDevice, cs));
+            m = n;
         }
         // feats_down_body back to the host (the node publishes it; flh_fetch_rows / flh_fetch_scan read it)
         std::vector<float4> out(m ? m : 1);
@@ -682,7 +736,23 @@ int flh_scan_stage_downsampled(flh_handle* h, int slot, const void* pts, size_t 
                                size_t* n_out) {
     if (!h) return fail("flh_scan_stage_downsampled: null handle");
     if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_stage_downsampled: bad slot");
-    return stage_downsampled(h, h->slots[slot], pts, stride_bytes, n, leaf_size, n_out);
+    if (!(leaf_size > 0.f)) return fail("flh_scan_stage_downsampled: leaf size must be > 0");
+    return stage_raw(h, h->slots[slot], "flh_scan_stage_downsampled", pts, stride_bytes, n, nullptr, leaf_size, n_out);
+}
+
+// ImuProcess::UndistortPcl's per-point half (IMU_Processing.hpp:307-349), then :904-905, then staging
+int flh_scan_stage_undistorted(flh_handle* h, int slot, const void* pts, size_t stride_bytes, size_t time_offset_bytes, size_t n,
+                               const flh_pose6d* imu_pose, int n_pose, const double x_end[FLH_NSTATE], float leaf_size,
+                               float* undistorted_xyz, size_t* n_out) {
+    if (!h) return fail("flh_scan_stage_undistorted: null handle");
+    if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_stage_undistorted: bad slot");
+    UndistortArgs u;
+    u.poses = imu_pose;
+    u.n_pose = n_pose;
+    u.x_end = x_end;
+    u.time_offset_bytes = time_offset_bytes;
+    u.undistorted_out = undistorted_xyz;
+    return stage_raw(h, h->slots[slot], "flh_scan_stage_undistorted", pts, stride_bytes, n, &u, leaf_size, n_out);
 }
 
 // feats_down_body of the active scan, original (staging) order

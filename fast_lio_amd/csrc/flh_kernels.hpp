@@ -62,6 +62,8 @@ hipError_t launch_compact(const float4* old_pts, uint32_t M, const float4* new_p
                           const uint32_t* incl, float4* out, hipStream_t st);
 
 // ---- flh_scanprep.hip: pcl::VoxelGrid of the scan ----
+hipError_t launch_undistort(const StateDev& s_end, const double* poses, int n_pose, const float4* raw, uint32_t n, float4* out,
+                            hipStream_t st);
 hipError_t launch_vg_keys(const float4* raw, uint32_t n, float inv, const int min_b[3], int mul1, int mul2,
                           unsigned long long* keys, uint32_t* vals, hipStream_t st);
 hipError_t sort_vg_pairs(void* tmp, size_t& tmp_bytes, const unsigned long long* kin, unsigned long long* kout,

@@ -51,6 +51,85 @@ __global__ void __launch_bounds__(256) k_vg_reduce(const float4* __restrict__ ra
     out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, 0.f);
 }
 
+// ------------------------------------------------------------------------------------------------
+// SURVEY.md 8(f) row 3 -- ImuProcess::UndistortPcl, per-point half (src/IMU_Processing.hpp:307-349): every point is
+// carried from its own sampling time to the scan-end frame.  raw.w = the point's time offset in ms (PointType::curvature).
+// pose rows: 22 doubles each = {offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]} (msg/Pose6D.msg).
+// Segment of a point = the last k <= n_pose-2 with offset_time[k] < t (what the reference's back-to-front sweep over the
+// time-sorted cloud amounts to); points at t <= offset_time[0] stay as they are.  Exp() = so3_math.h:36-58.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_undistort(StateDev s_end, const double* __restrict__ poses, int n_pose,
+                                                   const float4* __restrict__ raw, uint32_t n, float4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = raw[i];
+    float4 o = p;
+    const double t = (double)p.w / (double)1000;
+    int k = -1;
+    for (int j = n_pose - 2; j >= 0; --j)
+        if (t > poses[22 * j]) { k = j; break; }
+    if (k >= 0) {
+        const double* head = poses + 22 * k;
+        const double* tail = head + 22;
+        const double dt = t - head[0];
+        const double* gyr = tail + 4;
+        const double* acc = tail + 1;
+        const double* vel = head + 7;
+        const double* pos = head + 10;
+        const double* Rh = head + 13;
+        double E[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
+        const double nw = sqrt((gyr[0] * gyr[0] + gyr[1] * gyr[1]) + gyr[2] * gyr[2]);
+        if (nw > 0.0000001) {
+            const double a0 = gyr[0] / nw, a1 = gyr[1] / nw, a2 = gyr[2] / nw;
+            const double Kx[9] = {0.0, -a2, a1, a2, 0.0, -a0, -a1, a0, 0.0};
+            const double ang = nw * dt, sn = sin(ang), c1 = 1.0 - cos(ang);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double kk = 0.0;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) kk = kk + (c1 * Kx[3 * r + m]) * Kx[3 * m + c];
+                    E[3 * r + c] = (E[3 * r + c] + sn * Kx[3 * r + c]) + kk;
+                }
+        }
+        double Ri[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double a = 0.0;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) a = a + Rh[3 * r + m] * E[3 * m + c];
+                Ri[3 * r + c] = a;
+            }
+        double Tei[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) Tei[d] = ((pos[d] + vel[d] * dt) + ((0.5 * acc[d]) * dt) * dt) - s_end.pos[d];
+        double q1x, q1y, q1z;
+        quat_rot(s_end.offR, (double)p.x, (double)p.y, (double)p.z, q1x, q1y, q1z);
+        q1x = q1x + s_end.offT[0]; q1y = q1y + s_end.offT[1]; q1z = q1z + s_end.offT[2];
+        const double q2x = ((Ri[0] * q1x + Ri[1] * q1y) + Ri[2] * q1z) + Tei[0];
+        const double q2y = ((Ri[3] * q1x + Ri[4] * q1y) + Ri[5] * q1z) + Tei[1];
+        const double q2z = ((Ri[6] * q1x + Ri[7] * q1y) + Ri[8] * q1z) + Tei[2];
+        const double rotc[4] = {-s_end.rot[0], -s_end.rot[1], -s_end.rot[2], s_end.rot[3]};
+        const double offRc[4] = {-s_end.offR[0], -s_end.offR[1], -s_end.offR[2], s_end.offR[3]};
+        double q3x, q3y, q3z, q4x, q4y, q4z;
+        quat_rot(rotc, q2x, q2y, q2z, q3x, q3y, q3z);
+        q3x = q3x - s_end.offT[0]; q3y = q3y - s_end.offT[1]; q3z = q3z - s_end.offT[2];
+        quat_rot(offRc, q3x, q3y, q3z, q4x, q4y, q4z);
+        o.x = (float)q4x; o.y = (float)q4y; o.z = (float)q4z;
+    }
+    out[i] = o;
+}
+
+hipError_t launch_undistort(const StateDev& s_end, const double* poses, int n_pose, const float4* raw, uint32_t n, float4* out,
+                            hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_undistort, dim3(cdiv3(n, 256)), dim3(256), 0, st, s_end, poses, n_pose, raw, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_vg_keys(const float4* raw, uint32_t n, float inv, const int min_b[3], int mul1, int mul2, u64* keys,
                           uint32_t* vals, hipStream_t st) {
     if (n == 0) return hipSuccess;

@@ -128,6 +128,20 @@ int flh_scan_activate(flh_handle* h, int slot);
  * the input unchanged, as PCL does. */
 int flh_scan_stage_downsampled(flh_handle* h, int slot, const void* pts, size_t stride_bytes, size_t n, float leaf_size,
                                size_t* n_out);
+/* SURVEY.md 8(f) row 3 -- ImuProcess::UndistortPcl's per-point half (src/IMU_Processing.hpp:307-349) on the device, in
+ * front of the down-sampling above.  imu_pose = IMUpose (msg/Pose6D.msg; the forward half, :240-300, is one
+ * esekf::predict per IMU sample on the host), x_end = the propagated state at the scan end (flat layout of
+ * flh_eval_device), time_offset_bytes = where the float time offset in ms (PointType::curvature) sits in a point record.
+ * A point at time t is carried to the scan-end frame with the last segment k <= n_pose-2 whose offset_time is < t
+ * (what the reference's back-to-front sweep over the time-sorted cloud amounts to); points at t <= offset_time[0] are
+ * left as they are.  The cloud is NOT re-ordered by time (the reference's sort only serves its sweep).
+ * leaf_size <= 0 skips the down-sampling; undistorted_xyz (optional, 3*n floats) receives feats_undistort. */
+typedef struct flh_pose6d {
+    double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9];
+} flh_pose6d;
+int flh_scan_stage_undistorted(flh_handle* h, int slot, const void* pts, size_t stride_bytes, size_t time_offset_bytes, size_t n,
+                               const flh_pose6d* imu_pose, int n_pose, const double x_end[FLH_NSTATE], float leaf_size,
+                               float* undistorted_xyz, size_t* n_out);
 /* feats_down_body of the ACTIVE scan (3 floats per point, the order it was staged in). */
 int flh_fetch_scan(flh_handle* h, float* xyz);
 

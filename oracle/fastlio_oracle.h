@@ -175,6 +175,11 @@ int orc_fov_segment(orc_local_map* lm, const double pos_lid[3], double cube_len,
  * ascending voxel-index order; summation order inside a voxel pinned to ascending input index (see oracle_path.c). */
 size_t orc_voxel_grid(const float* in, size_t stride_floats, size_t n, float leaf, float* out_xyz);
 
+/* ImuProcess::UndistortPcl, per-point half (src/IMU_Processing.hpp:307-349); poses = IMUpose (msg/Pose6D.msg). */
+typedef struct { double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]; } orc_pose6d;
+void orc_undistort(const orc_pose6d* poses, int n_pose, const double x_end[ORC_NSTATE], const float* pts, size_t stride_floats,
+                   size_t time_off_floats, size_t n, float* out_xyz);
+
 #ifdef __cplusplus
 }
 #endif

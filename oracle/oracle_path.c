@@ -933,3 +933,70 @@ size_t orc_voxel_grid(const float* in, size_t stride, size_t n, float leaf, floa
     free(pr);
     return m;
 }
+
+/* =================================================================== ImuProcess::UndistortPcl, per-point half
+   (src/IMU_Processing.hpp:307-349): the backward sweep that moves every LiDAR point to the scan-end frame.  The
+   forward half (:240-300, one kf_state.predict per IMU sample) is host work on orc_predict and produces `poses`
+   (IMUpose, msg/Pose6D.msg) and the scan-end state `x_end`.
+   The reference first sorts the cloud by curvature (= time offset in ms, :234) and sweeps segments from the back;
+   since every point is handled independently the sweep reduces to: segment k = the LAST k <= n_pose-2 with
+   poses[k].offset_time < t (points with t <= poses[0].offset_time are left untouched, as the sweep never reaches
+   them).  offset_times are assumed strictly increasing.  The order of the output is the order of the input: the
+   reference's (unstable) sort order is not reproduced.
+   Exp() is so3_math.h:36-58.  Double arithmetic in source order; Eigen's internal evaluation order of the 3x3
+   products is not modelled (it moves results by ~1e-16 before the final narrowing to float). */
+static void und_exp(const double w[3], double dt, double R[9]) {
+    const double n = sqrt((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]);
+    for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    if (n > 0.0000001) {
+        const double a[3] = {w[0] / n, w[1] / n, w[2] / n};
+        const double Kx[9] = {0.0, -a[2], a[1], a[2], 0.0, -a[0], -a[1], a[0], 0.0};
+        const double ang = n * dt, s = sin(ang), c1 = 1.0 - cos(ang);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double kk = 0.0;
+                for (int k = 0; k < 3; k++) kk = kk + (c1 * Kx[3 * i + k]) * Kx[3 * k + j];
+                R[3 * i + j] = (R[3 * i + j] + s * Kx[3 * i + j]) + kk;
+            }
+    }
+}
+void orc_undistort(const orc_pose6d* poses, int n_pose, const double x_end[ORC_NSTATE], const float* pts, size_t stride,
+                   size_t time_off, size_t n, float* out_xyz) {
+    const double* pos_e = x_end + X_POS;
+    const double* rot_e = x_end + X_ROT;
+    const double* offR = x_end + X_OFFR;
+    const double* offT = x_end + X_OFFT;
+    const double rot_c[4] = {-rot_e[0], -rot_e[1], -rot_e[2], rot_e[3]};
+    const double offR_c[4] = {-offR[0], -offR[1], -offR[2], offR[3]};
+    for (size_t i = 0; i < n; i++) {
+        const float* p = pts + i * stride;
+        out_xyz[3 * i] = p[0]; out_xyz[3 * i + 1] = p[1]; out_xyz[3 * i + 2] = p[2];
+        const double t = (double)p[time_off] / (double)1000; /* it_pcl->curvature / double(1000) */
+        int k = -1;
+        for (int j = n_pose - 2; j >= 0; j--)
+            if (t > poses[j].offset_time) { k = j; break; }
+        if (k < 0) continue;
+        const orc_pose6d* head = poses + k;
+        const orc_pose6d* tail = poses + k + 1;
+        const double dt = t - head->offset_time;
+        double E[9], R_i[9];
+        und_exp(tail->gyr, dt, E); /* angvel_avr = tail->gyr */
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) {
+                double a = 0.0;
+                for (int m = 0; m < 3; m++) a = a + head->rot[3 * r + m] * E[3 * m + c];
+                R_i[3 * r + c] = a;
+            }
+        const double P_i[3] = {p[0], p[1], p[2]};
+        double T_ei[3], q1[3], q2[3], q3[3], q4[3];
+        for (int d = 0; d < 3; d++)
+            T_ei[d] = ((head->pos[d] + head->vel[d] * dt) + ((0.5 * tail->acc[d]) * dt) * dt) - pos_e[d];
+        orc_quat_rot(offR, P_i, q1);
+        for (int d = 0; d < 3; d++) q1[d] = q1[d] + offT[d];
+        for (int r = 0; r < 3; r++) q2[r] = ((R_i[3 * r] * q1[0] + R_i[3 * r + 1] * q1[1]) + R_i[3 * r + 2] * q1[2]) + T_ei[r];
+        orc_quat_rot(rot_c, q2, q3);
+        for (int d = 0; d < 3; d++) q3[d] = q3[d] - offT[d];
+        orc_quat_rot(offR_c, q3, q4);
+        for (int d = 0; d < 3; d++) out_xyz[3 * i + d] = (float)q4[d];
+    }
+}

@@ -458,3 +458,33 @@ def voxel_grid(xyz, leaf=0.5):
     out = np.zeros((max(len(a), 1), 3), np.float32)
     m = L.orc_voxel_grid(a, 3, len(a), float(leaf), out)
     return out[:m].copy()
+
+
+class Pose6D(C.Structure):
+    """msg/Pose6D.msg as the reference's IMUpose entries carry it."""
+    _fields_ = [("offset_time", C.c_double), ("acc", C.c_double * 3), ("gyr", C.c_double * 3), ("vel", C.c_double * 3),
+                ("pos", C.c_double * 3), ("rot", C.c_double * 9)]
+
+
+def make_poses(rows):
+    """rows: iterable of (offset_time, acc3, gyr3, vel3, pos3, rot9)."""
+    arr = (Pose6D * len(rows))()
+    for k, (t, a, g, v, p, r) in enumerate(rows):
+        arr[k].offset_time = float(t)
+        for i in range(3):
+            arr[k].acc[i], arr[k].gyr[i], arr[k].vel[i], arr[k].pos[i] = float(a[i]), float(g[i]), float(v[i]), float(p[i])
+        for i in range(9):
+            arr[k].rot[i] = float(np.asarray(r).reshape(9)[i])
+    return arr
+
+
+def undistort(poses, x_end, pts_xyzt):
+    """Per-point half of UndistortPcl: pts_xyzt = n x 4 float32 (x, y, z, time offset in ms)."""
+    a = _c32(pts_xyzt).reshape(-1, 4)
+    L = lib()
+    L.orc_undistort.restype = None
+    L.orc_undistort.argtypes = [C.c_void_p, C.c_int, np.ctypeslib.ndpointer(np.float64), np.ctypeslib.ndpointer(np.float32),
+                                C.c_size_t, C.c_size_t, C.c_size_t, np.ctypeslib.ndpointer(np.float32)]
+    out = np.zeros((max(len(a), 1), 3), np.float32)
+    L.orc_undistort(C.cast(poses, C.c_void_p), len(poses), _c64(x_end), a, 4, 3, len(a), out)
+    return out[: len(a)].copy()

@@ -323,3 +323,64 @@ def test_scan_voxel_grid_edge_cases(prob):
     h.scan_activate(3)
     same_points(h.fetch_scan(), po.voxel_grid(blob, 0.5))
     assert n == h.N
+
+
+# ---------------------------------------------------------------------------------------------- 8(f) row 3
+def imu_poses_for_test(x0, n_imu=21, T=0.1, seed=4):
+    """IMUpose as UndistortPcl's forward half builds it (IMU_Processing.hpp:240-300): one predict per IMU sample."""
+    rng = np.random.default_rng(seed)
+    x = np.array(x0, np.float64)
+    P = po.init_P()
+    Q = po.process_noise_cov()
+    rows = []
+    dt = T / (n_imu - 1)
+    gyro0, acc0 = np.array([0.4, -0.3, 0.9]), np.array([0.8, -0.5, 9.9])
+
+    def rotm(q):
+        return np.array([po.quat_rot(q, e) for e in np.eye(3)]).T
+
+    rows.append((0.0, (0, 0, 0), (0, 0, 0), x[14:17], x[0:3], rotm(x[3:7]).reshape(9)))
+    for k in range(1, n_imu):
+        gyro = gyro0 + rng.normal(0, 0.05, 3)
+        acc = acc0 + rng.normal(0, 0.2, 3)
+        x, P = po.predict(x, P, dt, Q, acc, gyro)
+        R = rotm(x[3:7])
+        acc_s = R @ (acc - x[20:23]) + x[23:26]
+        rows.append((k * dt, acc_s, gyro - x[17:20], x[14:17], x[0:3], R.reshape(9)))
+    return po.make_poses(rows), x
+
+
+def test_undistortion_matches_oracle(prob):
+    pr = prob
+    h = capi.Handle()
+    h.map_build(pr.map_xyz[:1000])
+    x0 = pr.x_true.copy()
+    x0[14:17] = (8.0, -3.0, 0.5)                       # moving fast enough for the correction to matter
+    poses, x_end = imu_poses_for_test(x0)
+    rng = np.random.default_rng(6)
+    raw = raw_scan(pr, 50000, 2)
+    tms = rng.uniform(-2.0, 104.0, len(raw)).astype(np.float32)   # a few before the first / after the last IMU pose
+    tms[:50] = 0.0
+    tms[50:100] = np.float32(50.0)                                # exactly on an IMU sample
+    pts = np.c_[raw, tms].astype(np.float32)
+    want = po.undistort(poses, x_end, pts)
+    n, und = h.scan_stage_undistorted(1, pts, poses, x_end, leaf_size=0.0)
+    assert n == len(pts)
+    moved = np.linalg.norm(want - raw, axis=1)
+    assert moved.max() > 0.2 and (moved[tms <= 0] == 0).all()
+    # double arithmetic in the same order on both sides; sin/cos come from different libms, so a result may differ in
+    # its last float bit: bound the error at float rounding of the coordinates and require near-total bit equality
+    scale = np.abs(want).max()
+    assert np.abs(und - want).max() <= 2.0 * np.spacing(np.float32(scale))
+    assert (und.view(np.uint32) == want.view(np.uint32)).mean() > 0.999
+    h.scan_activate(1)
+    same_points(h.fetch_scan(), und, "leaf_size <= 0 stages feats_undistort as is")
+    # the chain undistort -> voxel grid -> staging
+    n2, und2 = h.scan_stage_undistorted(2, pts, poses, x_end, leaf_size=0.5)
+    same_points(und2, und)
+    h.scan_activate(2)
+    same_points(h.fetch_scan(), po.voxel_grid(und, 0.5), "feats_down_body from the device chain")
+    assert n2 == h.N
+    with pytest.raises(capi.FlhError):
+        bad = po.make_poses([(0.0, (0,) * 3, (0,) * 3, (0,) * 3, (0,) * 3, np.eye(3).reshape(9))] * 2)   # offset_time not increasing
+        h.scan_stage_undistorted(0, pts[:10], bad, x_end)
