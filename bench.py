@@ -397,6 +397,31 @@ def main():
                                   "net_points_added_per_scan": round(added / reps, 1), "scans": reps,
                                   "note": "filter_size_map 0.5; full re-index of the map after each change"}
 
+    # ---- the raw-scan front end (undistortion + VoxelGrid + staging) for one raw scan handed over
+    # as a pageable host buffer: PCIe-inclusive by nature, reported beside the headline, never part of it.
+    if rank == 0 and G == 1 and mode != "shard":
+        rng = np.random.default_rng(11)
+        body = probs[0].body
+        raw = np.repeat(body, 3, axis=0) + rng.normal(0, 0.12, (3 * len(body), 3)).astype(np.float32)
+        tms = rng.uniform(0.0, 100.0, len(raw)).astype(np.float32)
+        pts = np.ascontiguousarray(np.c_[raw, tms].astype(np.float32))
+        from fast_lio_amd import synth as _s
+        poses, x_end = _s.imu_poses(priors[0][0], capi.predict_fn)
+        h.scan_stage_undistorted(0, pts, poses, x_end, 0.5)  # warm-up (allocations)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            n_down, _u = h.scan_stage_undistorted(0, pts, poses, x_end, 0.5)
+        t_fe = (time.perf_counter() - t1) / reps
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            h.scan_stage_downsampled(0, raw, 0.5)
+        t_vg = (time.perf_counter() - t1) / reps
+        out["scan_front_end"] = {"raw_points": int(len(pts)), "feats_down_size": int(n_down),
+                                 "undistort_voxelgrid_stage_ms": round(t_fe * 1e3, 3), "voxelgrid_stage_ms": round(t_vg * 1e3, 3),
+                                 "note": "host buffer in, feats_undistort + feats_down_body copied back; filter_size_surf 0.5"}
+
     if rank == 0:
         print(json.dumps(out), flush=True)
     kf.close()

@@ -391,3 +391,44 @@ def make_problem(M: int, N: int, sensor: str = "avia", cfg: int = 0, scan_seed: 
     body = make_scan(scene, sn, N, xt, seed + 7 + 1000 * scan_seed)
     xp = perturb_prior(xt, seed + 13 + 1000 * scan_seed)
     return Problem(scene=scene, sensor=sn, x_true=xt, x_prior=xp, body=body)
+
+
+def imu_poses(x0, predict_fn, n_imu: int = 21, T: float = 0.1, seed: int = 4):
+    """IMUpose + scan-end state as UndistortPcl's forward half builds them (IMU_Processing.hpp:240-300): one predict
+    per synthetic IMU sample.  Returns (ctypes array of 22-double Pose6D records, x_end)."""
+    import ctypes as C
+
+    class Pose6D(C.Structure):
+        _fields_ = [("offset_time", C.c_double), ("acc", C.c_double * 3), ("gyr", C.c_double * 3), ("vel", C.c_double * 3),
+                    ("pos", C.c_double * 3), ("rot", C.c_double * 9)]
+
+    def rotm(q):
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    rng = np.random.default_rng(seed)
+    x = np.array(x0, np.float64)
+    x[14:17] = (8.0, -3.0, 0.5)
+    P = init_P()
+    Q = process_noise_cov()
+    dt = T / (n_imu - 1)
+    arr = (Pose6D * n_imu)()
+
+    def put(k, t, a, g, xs):
+        arr[k].offset_time = float(t)
+        R = rotm(xs[3:7]).reshape(9)
+        for i in range(3):
+            arr[k].acc[i], arr[k].gyr[i], arr[k].vel[i], arr[k].pos[i] = float(a[i]), float(g[i]), float(xs[14 + i]), float(xs[i])
+        for i in range(9):
+            arr[k].rot[i] = float(R[i])
+
+    put(0, 0.0, (0, 0, 0), (0, 0, 0), x)
+    for k in range(1, n_imu):
+        gyro = np.array([0.4, -0.3, 0.9]) + rng.normal(0, 0.05, 3)
+        acc = np.array([0.8, -0.5, 9.9]) + rng.normal(0, 0.2, 3)
+        x, P = predict_fn(x, P, dt, Q, acc, gyro)
+        acc_s = rotm(x[3:7]) @ (acc - x[20:23]) + x[23:26]
+        put(k, k * dt, acc_s, gyro - x[17:20], x)
+    return arr, x
