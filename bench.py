@@ -402,7 +402,7 @@ def main():
     if rank == 0 and G == 1 and mode != "shard":
         rng = np.random.default_rng(11)
         body = probs[0].body
-        raw = np.repeat(body, 3, axis=0) + rng.normal(0, 0.12, (3 * len(body), 3)).astype(np.float32)
+        raw = np.repeat(body, 3, axis=0) + rng.normal(0, 0.03, (3 * len(body), 3)).astype(np.float32)
         tms = rng.uniform(0.0, 100.0, len(raw)).astype(np.float32)
         pts = np.ascontiguousarray(np.c_[raw, tms].astype(np.float32))
         from fast_lio_amd import synth as _s
