@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--cell", type=float, default=1.5)
     ap.add_argument("--sort", type=int, default=1, help="Morton-order the scan at staging (0 = keep input order)")
     ap.add_argument("--extrinsic-est", type=int, default=0)
-    ap.add_argument("--timing-stride", type=int, default=8,
+    ap.add_argument("--timing-stride", type=int, default=16,
                     help="record the per-kernel HIP events on every n-th evaluation of the timed region")
     ap.add_argument("--cpu-scans", type=int, default=3, help="scans timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=3, help="OpenMP threads (reference MP_PROC_NUM = 3)")
@@ -275,7 +275,7 @@ def main():
         ach = ALG_BYTES_SEARCH * n_pts / dur_s / 1e9
         fit_s = ctr["fit_ms"] / max(ctr["n_fit"], 1) * 1e-3
         roof = {"bound": "hbm",
-                "kernel": f"5-NN search of one pass = k_search_ring<{args.lpq},1,false> + k_search_ring<16,2,true> + k_search_exact",
+                "kernel": f"5-NN search of one pass = k_search_ring<{args.lpq},1> (every query) + k_search_ring<16,2> (the rest, incl. the exact fallback)",
                 "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                 "traffic": None, "avg_kernel_us": round(dur_s * 1e6, 2), "alg_bytes_per_launch": ALG_BYTES_SEARCH * n_pts,
                 "events_sampled": ctr["n_search"], "fit_kernel_us": round(fit_s * 1e6, 2),
@@ -287,7 +287,7 @@ def main():
         s_ms = h.time_kernel(0, x0, ext, 20)
         f_ms = h.time_kernel(1, x0, ext, 20)
         ach = ALG_BYTES_SEARCH * n_pts / (s_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": f"k_search_ring<{args.lpq},1> + k_search_exact", "achieved": round(ach, 2),
+        roof = {"bound": "hbm", "kernel": f"k_search_ring<{args.lpq},1> + k_search_ring<16,2>", "achieved": round(ach, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                 "avg_kernel_us": round(s_ms * 1e3, 2), "alg_bytes_per_launch": ALG_BYTES_SEARCH * n_pts,
                 "fit_kernel_us": round(f_ms * 1e3, 2), "note": "per-rank shard, back-to-back launches"}
@@ -403,7 +403,7 @@ def main():
         rng = np.random.default_rng(11)
         body = probs[0].body
         raw = np.repeat(body, 3, axis=0) + rng.normal(0, 0.03, (3 * len(body), 3)).astype(np.float32)
-        tms = rng.uniform(0.0, 100.0, len(raw)).astype(np.float32)
+        tms = np.repeat(rng.uniform(0.0, 100.0, len(body)), 3).astype(np.float32)  # neighbours in space are neighbours in time
         pts = np.ascontiguousarray(np.c_[raw, tms].astype(np.float32))
         from fast_lio_amd import synth as _s
         poses, x_end = _s.imu_poses(priors[0][0], capi.predict_fn)

@@ -250,13 +250,21 @@ __device__ __forceinline__ void wave_sync() {
 #define PH_DUMP(base)
 #endif
 
-template <int LPQ, int RING, bool BOUNDED, int PB>
+template <int LPQ>
+__device__ __forceinline__ uint32_t exact_query(const GridParams& g, int q, int N, float qx, float qy, float qz, int cx, int cy,
+                                                int cz, float fx, float fy, float fz, float ub, int rmax, float max_sqdist,
+                                                int lane, float4* __restrict__ nn_pts, float* __restrict__ nn_d2,
+                                                uint8_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected);
+
+template <int LPQ, int RING, bool BOUNDED, int PB, bool FINAL>
 __global__ void __launch_bounds__(256)
 k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist,
               float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
               uint8_t* __restrict__ selected, const uint32_t* __restrict__ in_list, const uint32_t* __restrict__ in_count,
               uint32_t* __restrict__ out_list, uint32_t* __restrict__ out_count, uint32_t stripe_cap,
-              const float* ub_in, float* ub_out /* may alias ub_in */, u64* __restrict__ cand_counter) {
+              const float* ub_in, float* ub_out /* may alias ub_in */, int rmax, u64* __restrict__ cand_counter) {
+    // FINAL: a query this stage cannot settle is finished on the spot by its group with the general exact search
+    // (exact_query) instead of being listed for one more kernel -- each extra kernel costs ~6 us of fixed latency per pass.
     // BOUNDED: the query comes with an upper bound ub of its true 5th squared distance (found by a smaller
     // ring); rows and row ends that lie entirely outside that ball are not visited.
     // Work lists are striped kStripes ways (stripe = blockIdx & (kStripes-1)) and appended to with one global
@@ -485,8 +493,16 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             }
         }
         PH_MARK(7);  // 7: results written
+        if (FINAL) {
+            if (live && !done) {
+                const float ubx = fminf(BOUNDED ? fminf(d5hi, ub_in[q]) : d5hi, max_sqdist);
+                const uint32_t nc = exact_query<LPQ>(g, q, N, qx, qy, qz, cx, cy, cz, fx, fy, fz, ubx, rmax, max_sqdist, lane, nn_pts,
+                                                     nn_d2, nn_cnt, selected);
+                if (cand_counter && lane == 0) atomicAdd(cand_counter, (u64)nc);
+            }
+        }
         // ---- unsettled queries go to the next stage's list: one global atomic per wave, 64 striped counters
-        const bool append = live && !done && lane == 0;
+        const bool append = !FINAL && live && !done && lane == 0;
         const u64 bal = __ballot(append);
         if (bal) {
             const int wlane = threadIdx.x & 63;
@@ -507,11 +523,91 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
     PH_DUMP(RING == 1 ? 0 : 8);
 }
 
-// A3: general exact path over the queries A1/A2 could not settle; 32 lanes per query, 8 queries per block.
-// One pass over the cells that intersect the ball of radius sqrt(ub) around the query, where ub is the 5th
-// distance A1/A2 found (an upper bound of the true one) capped by the gate max_sqdist of
-// src/laserMapping.cpp:671 -- beyond the gate a result can never be selected.  64-bit keys
-// (d2 bits << 32 | original map index) give the oracle's (d2, index) order, ties included.
+// The general exact search of ONE query by a group of LPQ lanes: one pass over the cells that intersect the ball of
+// radius sqrt(ub) around the query (ub = an upper bound of its true 5th squared distance, capped by the gate max_sqdist
+// of src/laserMapping.cpp:671 -- beyond the gate a result can never be selected).  64-bit keys
+// (d2 bits << 32 | map index) give the oracle's (d2, index) order, ties included.  Writes the query's result rows.
+template <int LPQ>
+__device__ __forceinline__ uint32_t exact_query(const GridParams& g, int q, int N, float qx, float qy, float qz, int cx, int cy,
+                                                int cz, float fx, float fy, float fz, float ub, int rmax, float max_sqdist,
+                                                int lane, float4* __restrict__ nn_pts, float* __restrict__ nn_d2,
+                                                uint8_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected) {
+    const int wl0 = (threadIdx.x & 63) & ~(LPQ - 1);
+    const u64 gmask = (LPQ == 64 ? ~0ull : ((1ull << LPQ) - 1ull)) << wl0;
+    // cells with |offset| <= R cover the ball; +1 absorbs the position inside the centre cell
+    const int r = min(rmax, (int)(sqrtf(ub) * g.inv_c) + 1);
+    const float ubp = ub * 1.0001f + 1e-6f;
+    Top5 L;
+    L.reset();
+    uint32_t ncand = 0;
+    const int side = 2 * r + 1;
+    const int side2 = side * side;
+    const int ncell = side2 * side;
+    for (int t = lane; t < ncell; t += LPQ) {
+        const int iz = t / side2;
+        const int rem = t - iz * side2;
+        const int iy = rem / side;
+        const int dx = rem - iy * side - r, dy = iy - r, dz = iz - r;
+        // lower bound of the distance from the query to this cell's box; skip cells outside the ball
+        const float gx = dx > 0 ? (float)dx - fx : (dx < 0 ? fx - (float)(dx + 1) : 0.f);
+        const float gy = dy > 0 ? (float)dy - fy : (dy < 0 ? fy - (float)(dy + 1) : 0.f);
+        const float gz = dz > 0 ? (float)dz - fz : (dz < 0 ? fz - (float)(dz + 1) : 0.f);
+        const float lb = ((gx * gx + gy * gy) + gz * gz) * (g.c * g.c) * 0.995f - 1e-5f;
+        if (lb > ubp) continue;
+        const uint2 e = lookup_cell(g, cx + dx, cy + dy, cz + dz);
+        ncand += e.y;
+        for (uint32_t i = e.x; i < e.x + e.y; ++i) {
+            const float4 pv = g.pts[i];
+            L.insert(make_key(dist2(qx, qy, qz, pv.x, pv.y, pv.z), pv.w), i);
+        }
+    }
+    // ---- group merge: 5 x (min butterfly, ballot, pop)
+    u64 rk[5];
+    uint32_t rp[5];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        u64 m = L.k[0];
+#pragma unroll
+        for (int off = LPQ / 2; off >= 1; off >>= 1) {
+            const u64 o = __shfl_xor(m, off, LPQ);
+            m = o < m ? o : m;
+        }
+        const bool win = (L.k[0] == m) && (m != kInfKey);
+        const u64 bal = __ballot(win) & gmask;
+        const int wl = bal ? (__ffsll((long long)bal) - 1) : wl0;
+        const uint32_t wp = __shfl(L.p[0], wl, 64);
+        rk[j] = m;
+        rp[j] = wp;
+        if (m != kInfKey) ++cnt;
+        if (win) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { L.k[t] = L.k[t + 1]; L.p[t] = L.p[t + 1]; }
+            L.k[4] = kInfKey;
+        }
+    }
+    const float d5 = (cnt == 5) ? __uint_as_float((uint32_t)(rk[4] >> 32)) : INFINITY;
+    if (lane < 5) {
+        u64 kk = rk[0];
+        uint32_t pp = rp[0];
+#pragma unroll
+        for (int j = 1; j < 5; ++j)
+            if (lane == j) { kk = rk[j]; pp = rp[j]; }
+        const bool has = lane < cnt;
+        float4 v = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        if (has) v = g.pts[pp];
+        nn_pts[(size_t)lane * N + q] = v;
+        nn_d2[(size_t)lane * N + q] = has ? __uint_as_float((uint32_t)(kk >> 32)) : INFINITY;
+    }
+    if (lane == 0) {
+        nn_cnt[q] = (uint8_t)cnt;
+        selected[q] = (cnt == 5 && !(d5 > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
+    }
+    return ncand;
+}
+
+// A3 as a kernel of its own: every query (lanes_per_query == 0, the tests' cross-check) or the queries of a work list
+// (grids without a ring-2 stage); 32 lanes per query, 8 queries per block.
 __global__ void __launch_bounds__(256)
 k_search_exact(GridParams g, StateDev s, const float4* __restrict__ body, int N, float max_sqdist, int rmax,
                float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
@@ -527,8 +623,6 @@ k_search_exact(GridParams g, StateDev s, const float4* __restrict__ body, int N,
     const uint32_t total = all_queries ? (uint32_t)N : slow_count[stripe];
     const uint32_t gi0 = all_queries ? blockIdx.x * 8 + grp : sub * 8 + grp;
     const uint32_t gstep = all_queries ? gridDim.x * 8 : nsub * 8;
-    const int wl0 = (threadIdx.x & 63) & ~(LPQ - 1);
-    const u64 gmask = ((1ull << LPQ) - 1ull) << wl0;
     for (uint32_t gi = gi0; gi < total; gi += gstep) {
         const int q = all_queries ? (int)gi : (int)slow_list[gi];
         const float4 b = body[q];
@@ -538,75 +632,8 @@ k_search_exact(GridParams g, StateDev s, const float4* __restrict__ body, int N,
         float fx, fy, fz;
         cell_of(g, qx, qy, qz, cx, cy, cz, fx, fy, fz);
         const float ub = all_queries ? max_sqdist : fminf(ub_in[q], max_sqdist);
-        // cells with |offset| <= R cover the ball; +1 absorbs the position inside the centre cell
-        const int r = min(rmax, (int)(sqrtf(ub) * g.inv_c) + 1);
-        const float ubp = ub * 1.0001f + 1e-6f;
-        Top5 L;
-        L.reset();
-        uint32_t ncand = 0;
-        const int side = 2 * r + 1;
-        const int side2 = side * side;
-        const int ncell = side2 * side;
-        for (int t = lane; t < ncell; t += LPQ) {
-            const int iz = t / side2;
-            const int rem = t - iz * side2;
-            const int iy = rem / side;
-            const int dx = rem - iy * side - r, dy = iy - r, dz = iz - r;
-            // lower bound of the distance from the query to this cell's box; skip cells outside the ball
-            const float gx = dx > 0 ? (float)dx - fx : (dx < 0 ? fx - (float)(dx + 1) : 0.f);
-            const float gy = dy > 0 ? (float)dy - fy : (dy < 0 ? fy - (float)(dy + 1) : 0.f);
-            const float gz = dz > 0 ? (float)dz - fz : (dz < 0 ? fz - (float)(dz + 1) : 0.f);
-            const float lb = ((gx * gx + gy * gy) + gz * gz) * (g.c * g.c) * 0.995f - 1e-5f;
-            if (lb > ubp) continue;
-            const uint2 e = lookup_cell(g, cx + dx, cy + dy, cz + dz);
-            ncand += e.y;
-            for (uint32_t i = e.x; i < e.x + e.y; ++i) {
-                const float4 pv = g.pts[i];
-                L.insert(make_key(dist2(qx, qy, qz, pv.x, pv.y, pv.z), pv.w), i);
-            }
-        }
-        // ---- group merge: 5 x (min butterfly, ballot, pop)
-        u64 rk[5];
-        uint32_t rp[5];
-        int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            u64 m = L.k[0];
-#pragma unroll
-            for (int off = LPQ / 2; off >= 1; off >>= 1) {
-                const u64 o = __shfl_xor(m, off, LPQ);
-                m = o < m ? o : m;
-            }
-            const bool win = (L.k[0] == m) && (m != kInfKey);
-            const u64 bal = __ballot(win) & gmask;
-            const int wl = bal ? (__ffsll((long long)bal) - 1) : wl0;
-            const uint32_t wp = __shfl(L.p[0], wl, 64);
-            rk[j] = m;
-            rp[j] = wp;
-            if (m != kInfKey) ++cnt;
-            if (win) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { L.k[t] = L.k[t + 1]; L.p[t] = L.p[t + 1]; }
-                L.k[4] = kInfKey;
-            }
-        }
-        const float d5 = (cnt == 5) ? __uint_as_float((uint32_t)(rk[4] >> 32)) : INFINITY;
-        if (lane < 5) {
-            u64 kk = rk[0];
-            uint32_t pp = rp[0];
-#pragma unroll
-            for (int j = 1; j < 5; ++j)
-                if (lane == j) { kk = rk[j]; pp = rp[j]; }
-            const bool has = lane < cnt;
-            float4 v = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-            if (has) v = g.pts[pp];
-            nn_pts[(size_t)lane * N + q] = v;
-            nn_d2[(size_t)lane * N + q] = has ? __uint_as_float((uint32_t)(kk >> 32)) : INFINITY;
-        }
-        if (lane == 0) {
-            nn_cnt[q] = (uint8_t)cnt;
-            selected[q] = (cnt == 5 && !(d5 > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
-        }
+        const uint32_t ncand = exact_query<LPQ>(g, q, N, qx, qy, qz, cx, cy, cz, fx, fy, fz, ub, rmax, max_sqdist, lane, nn_pts,
+                                                nn_d2, nn_cnt, selected);
         if (cand_counter && ncand) atomicAdd(cand_counter, (u64)ncand);
     }
 }
@@ -904,9 +931,9 @@ hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const 
     }
     // A1: ring 1, every query
 #define FLH_A1(L)                                                                                                        \
-    hipLaunchKernelGGL((k_search_ring<L, 1, false, 8>), dim3(cdiv(N, 256 / L)), blk, 0, st, g, s, body, N, \
+    hipLaunchKernelGGL((k_search_ring<L, 1, false, 8, false>), dim3(cdiv(N, 256 / L)), blk, 0, st, g, s, body, N, \
                        map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,                \
-                       (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, cand_counter)
+                       (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter)
     switch (lpq) {
         case 2: FLH_A1(2); break;
         case 8: FLH_A1(8); break;
@@ -914,19 +941,17 @@ hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const 
         default: FLH_A1(4); break;
     }
 #undef FLH_A1
-    const uint32_t* last_list = list1;
-    const uint32_t* last_counts = counts;
     if (rmax >= 2) {
-        // A2: ring 2 over list 1, inside the ball A1's 5th distance defines
-        hipLaunchKernelGGL((k_search_ring<16, 2, true, 11>), dim3(kStripes * 16), blk, 0, st, g, s, body, N, map_points, max_sqdist,
-                           nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)list1, (const uint32_t*)counts, list2,
-                           counts + kStripes, cap, (const float*)ub, ub, cand_counter);
-        last_list = list2;
-        last_counts = counts + kStripes;
+        // A2: ring 2 over list 1, inside the ball A1's 5th distance defines; whatever it cannot settle (distance ties, a
+        // 5th neighbour beyond the 5x5x5 block) it finishes itself with the general exact search
+        hipLaunchKernelGGL((k_search_ring<16, 2, true, 11, true>), dim3(kStripes * 16), blk, 0, st, g, s, body, N, map_points,
+                           max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)list1, (const uint32_t*)counts, list2,
+                           counts + kStripes, cap, (const float*)ub, ub, rmax, cand_counter);
+    } else {
+        // cells as large as the gate radius: the general search drains list 1 directly
+        hipLaunchKernelGGL(k_search_exact, dim3(kStripes * 8), blk, 0, st, g, s, body, N, max_sqdist, rmax, nn_pts, nn_d2,
+                           nn_cnt, selected, (const uint32_t*)list1, (const uint32_t*)counts, cap, ub, 0, cand_counter);
     }
-    // A3 drains what is left (ties, > 5x5x5); a fixed grid that exits at once when its list is empty
-    hipLaunchKernelGGL(k_search_exact, dim3(kStripes * 8), blk, 0, st, g, s, body, N, max_sqdist, rmax, nn_pts, nn_d2,
-                       nn_cnt, selected, last_list, last_counts, cap, ub, 0, cand_counter);
     return hipGetLastError();
 }
 
