@@ -132,7 +132,8 @@ def main():
 
     def gen(seed_base):
         pr = [synth.make_problem(M, N, sensor, cfg=args.config, scan_seed=seed_base + s, scene=scene) for s in range(S)]
-        return pr, [synth.propagate_prior_cov(capi.predict_fn, p.x_prior) for p in pr]
+        pri = [synth.propagate_prior_cov(capi.predict_fn, p.x_prior) for p in pr]
+        return pr, [(np.ascontiguousarray(x, np.float64), np.ascontiguousarray(P, np.float64)) for x, P in pri]
 
     # streams: every rank follows its own scan stream; the shard leg uses scans common to all ranks
     probs, priors = gen(1000 * rank if G > 1 else 0)
@@ -201,23 +202,9 @@ def main():
             dt_ = float(tt.item())
         return dt_, acc[0], acc[1], h.counters()
 
-    split = [] if os.environ.get("FLH_BENCH_TRACE") else None
-
     def step_stream(i):
         s = i % S
-        ta = time.perf_counter()
-        h.scan_activate(s)
-        tb = time.perf_counter()
-        kf.change_x(priors[s][0])
-        kf.change_P(priors[s][1])
-        tc = time.perf_counter()
-        st = kf.update(0.001)
-        if split is not None:
-            td = time.perf_counter()
-            if td - ta > 5e-3:
-                print(f"[trace] slow step {i}: activate {1e3*(tb-ta):.3f} change {1e3*(tc-tb):.3f} update {1e3*(td-tc):.3f} ms",
-                      file=sys.stderr)
-        return st
+        return kf.update_scan(s, priors[s][0], priors[s][1], 0.001)  # activate staged scan + (x, P) + update, one call
 
     shard_out = None
     if mode == "shard":

@@ -73,7 +73,7 @@ EXPORTS = [
     "flh_esekf_predict", "flh_esekf_update",
     "flh_map_add", "flh_map_delete_boxes", "flh_map_download", "flh_map_incremental", "flh_fetch_map_incremental",
     "flh_fov_segment", "flh_scan_stage_downsampled", "flh_fetch_scan",
-    "flh_scan_stage_undistorted",
+    "flh_scan_stage_undistorted", "flh_esekf_update_scan",
 ]
 
 _lib = None
@@ -147,6 +147,7 @@ def lib():
     L.flh_esekf_get_P.argtypes = [C.c_void_p, _f64p]
     L.flh_esekf_predict.argtypes = [C.c_void_p, C.c_double, _f64p, _f64p, _f64p]
     L.flh_esekf_update.argtypes = [C.c_void_p, C.c_double, C.POINTER(FlhUpdateStats)]
+    L.flh_esekf_update_scan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.POINTER(FlhUpdateStats)]
     _lib = L
     return L
 
@@ -426,6 +427,15 @@ class Esekf:
     def predict(self, dt, Q, acc, gyro):
         lib().flh_esekf_predict(self._e, float(dt), np.ascontiguousarray(Q, np.float64).reshape(-1),
                                 np.ascontiguousarray(acc, np.float64), np.ascontiguousarray(gyro, np.float64))
+
+    def update_scan(self, slot: int, x: np.ndarray, P: np.ndarray, R: float = 0.001):
+        """One loop body of the node: activate the staged scan, set the propagated (x, P), update.  x and P must be
+        C-contiguous float64 arrays that stay alive during the call."""
+        st = FlhUpdateStats()
+        rc = lib().flh_esekf_update_scan(self._e, int(slot), x.ctypes.data, P.ctypes.data, float(R), C.byref(st))
+        if rc != 0:
+            raise FlhError("flh_esekf_update_scan failed: " + lib().flh_last_error().decode())
+        return st
 
     def update(self, R: float = 0.001):
         st = FlhUpdateStats()

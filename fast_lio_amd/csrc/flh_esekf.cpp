@@ -111,4 +111,24 @@ int flh_esekf_update(flh_esekf* e, double R, flh_update_stats* st) {
     return 0;
 }
 
+// One scan of the node's main loop in one call: feats_down_body := staged slot (slot < 0: keep the active scan), the
+// propagated state and covariance from the IMU front end, then update_iterated_dyn_share_modified (:960).
+int flh_esekf_update_scan(flh_esekf* e, int slot, const double x[FLH_NSTATE], const double P[FLH_NDOF * FLH_NDOF], double R,
+                          flh_update_stats* st) {
+    if (!e) return -1;
+    if (slot >= 0) {
+        if (!e->gpu_ctx.handle) {
+            e->err = "flh_esekf_update_scan: filter has no device handle";
+            return -1;
+        }
+        if (flh_scan_activate(e->gpu_ctx.handle, slot) != 0) {
+            e->err = flh_last_error();
+            return -1;
+        }
+    }
+    if (x) flh_esekf_change_x(e, x);
+    if (P) flh_esekf_change_P(e, P);
+    return flh_esekf_update(e, R, st);
+}
+
 }  // extern "C"

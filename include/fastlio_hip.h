@@ -244,6 +244,10 @@ void flh_esekf_get_P(const flh_esekf* kf, double P[FLH_NDOF * FLH_NDOF]);     /*
 void flh_esekf_predict(flh_esekf* kf, double dt, const double Q[144], const double acc[3], const double gyro[3]);
 /* kf.update_iterated_dyn_share_modified(R, solve_time) -- esekfom.hpp:1619-1931. */
 int flh_esekf_update(flh_esekf* kf, double R, flh_update_stats* stats);
+/* The loop body of the node in one call: activate a staged scan (slot < 0: keep the active one), set the propagated
+ * state / covariance handed over by the IMU front end (either may be NULL = keep), run the update (:960). */
+int flh_esekf_update_scan(flh_esekf* e, int slot, const double x[FLH_NSTATE], const double P[FLH_NDOF * FLH_NDOF], double R,
+                          flh_update_stats* st);
 
 #ifdef __cplusplus
 }
