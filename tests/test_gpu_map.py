@@ -384,3 +384,46 @@ def test_undistortion_matches_oracle(prob):
     with pytest.raises(capi.FlhError):
         bad = po.make_poses([(0.0, (0,) * 3, (0,) * 3, (0,) * 3, (0,) * 3, np.eye(3).reshape(9))] * 2)   # offset_time not increasing
         h.scan_stage_undistorted(0, pts[:10], bad, x_end)
+
+
+def test_velodyne_stream_with_incremental_map():
+    """BASELINE configs[2] in miniature: a Velodyne-16 scan stream whose points are inserted into the map after every
+    update (laserMapping.cpp:879-927 loop body, five times over): the device map must stay bit-identical to the
+    oracle's, so that every later search, flag and posterior keeps matching."""
+    M, N = 250000, 9000
+    pr0 = synth.make_problem(M, N, "velodyne", cfg=3)
+    scene = pr0.scene
+    h = capi.Handle()
+    h.map_build(pr0.map_xyz)
+    kf = capi.Esekf(h, max_iter=3, extrinsic_est_en=False)
+    cur = pr0.map_xyz.astype(np.float32)
+    lm_g, lm_o = capi.FlhLocalMap(), po.LocalMap()
+    ext = float(np.ptp(cur, axis=0).max())
+    grown = 0
+    for k in range(5):
+        pr = synth.make_problem(M, N, "velodyne", cfg=3, scan_seed=k, scene=scene)
+        xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
+        # lasermap_fov_segment first (:886), with a cube small enough to bite
+        want_boxes = po.fov_segment(lm_o, xp[0:3], 0.9 * ext, 0.12 * ext)
+        boxes, ndel = h.fov_segment(lm_g, xp[0:3], 0.9 * ext, 0.12 * ext)
+        np.testing.assert_array_equal(boxes.view(np.uint32), want_boxes.view(np.uint32))
+        if len(want_boxes):
+            cur = po.map_delete_boxes(cur, want_boxes)
+        m = po.Map(cur)
+        h.scan_upload(pr.body)
+        st = kf.update_scan(-1, np.ascontiguousarray(xp), np.ascontiguousarray(P), 0.001)
+        sc = po.Scan(pr.body, nthreads=8)
+        x_ref, P_ref, st_ref = sc.update_iterated(m, xp, P)
+        assert list(st.n_eff)[: st.passes] == list(st_ref.n_eff)[: st.passes], f"scan {k}"
+        np.testing.assert_array_equal(h.fetch_selected(), sc.selected, err_msg=f"scan {k}")
+        x_post = kf.get_x()
+        assert np.linalg.norm(x_post[0:3] - x_ref[0:3]) <= 1e-4
+        w_ref, c_ref = sc.map_incremental_classify(m, x_post, DS, True)
+        n1, n2 = h.map_incremental(x_post, DS, True, apply=True)
+        w, c = h.fetch_map_incremental()
+        np.testing.assert_array_equal(c, c_ref, err_msg=f"scan {k}")
+        new = po.map_add(po.map_add(cur, w_ref[c_ref == 1], True, DS), w_ref[c_ref == 2], False, DS)
+        grown += len(new) - len(cur)
+        cur = new
+        same_points(h.map_download(), cur, f"map after scan {k}")
+    assert grown > 0
