@@ -926,8 +926,8 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
     const StateDev s_post = make_state(x + 3, x + 0, x + 7, x + 11);
     HIPC(h->mi_world.reserve(N ? N : 1)); HIPC(h->mi_cls.reserve(N ? N : 1));
     HIPC(flh::launch_mi_classify(h->grid, h->grid.hash_mask + 1, (uint32_t)h->M, h->search_state, s_post, h->cur_body,
-                                 h->nn_pts.p, h->nn_cnt.p, (int)N, filter_size_map, flg_EKF_inited, h->mi_world.p,
-                                 h->mi_cls.p, st));
+                                 h->nn_pts.p, h->nn_cnt.p, h->nn_d2.p, h->cfg.max_sqdist, (int)N, filter_size_map, flg_EKF_inited,
+                                 h->mi_world.p, h->mi_cls.p, st));
     uint32_t c1 = 0, c2 = 0;
     if (N > 0) {
         HIPC(h->mu_flags.reserve(2 * N)); HIPC(h->mu_incl.reserve(2 * N));

@@ -43,8 +43,9 @@ hipError_t launch_fit(const StateDev& s, const float4* body, const float4* nn_pt
 
 // ---- flh_mapinc.hip: map_incremental and the incremental map ----
 hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t map_points, const StateDev& s_search,
-                              const StateDev& s_post, const float4* body, float4* nn_pts, const uint8_t* nn_cnt, int N,
-                              double fsm, int ekf_inited, float4* world_out, uint8_t* cls, hipStream_t st);
+                              const StateDev& s_post, const float4* body, float4* nn_pts, const uint8_t* nn_cnt,
+                              const float* nn_d2, float max_sqdist, int N, double fsm, int ekf_inited, float4* world_out,
+                              uint8_t* cls, hipStream_t st);
 hipError_t launch_cls_flags(const uint8_t* cls, int N, uint32_t* flags, hipStream_t st);
 hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* incl, int N, float4* out,
                               hipStream_t st);

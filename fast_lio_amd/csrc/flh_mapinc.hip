@@ -24,16 +24,18 @@ static inline int cdiv2(long long a, long long b) { return (int)((a + b - 1) / b
 // ------------------------------------------------------------------------------------------------
 // map_incremental: classes 0 = skip, 1 = PointToAdd (down-sampled insert), 2 = PointNoNeedDownsample
 // ------------------------------------------------------------------------------------------------
-// The search that filled the cache is radius-bounded (max_sqdist), the reference's is not; the two agree on every
-// decision below because a neighbour that can veto the insert lies within 2*sqrt(3)*fsm/2 of the point (well inside
-// the bound), and the one case that needs a neighbour outside the bound -- points_near[0] of a point with NO map
-// point inside it -- is served by k_far_nearest first.
+// The search that filled the cache is radius-bounded: entries with d2 <= max_sqdist are the true nearest neighbours in
+// order, entries beyond it are merely some map points (whatever the visited cells held).  The reference's search is
+// unbounded.  The two still agree on every decision below: a neighbour that can veto the insert lies within
+// sqrt(3)*fsm of the point (well inside the bound), and the one case that needs a neighbour outside the bound --
+// points_near[0] of a point with NO map point inside it -- is served by k_far_nearest first.
 __global__ void __launch_bounds__(256)
-k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, const uint8_t* __restrict__ nn_cnt, int N,
-              uint32_t hash_size, float4* __restrict__ nn_pts) {
+k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, const uint8_t* __restrict__ nn_cnt,
+              const float* __restrict__ nn_d2, float max_sqdist, int N, uint32_t hash_size, float4* __restrict__ nn_pts) {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (q >= N || nn_cnt[q] != 0) return;  // wave-uniform
+    if (q >= N) return;
+    if (nn_cnt[q] != 0 && nn_d2[q] <= max_sqdist) return;  // wave-uniform: the cached nearest is the true one
     const float4 b = body[q];
     float wx, wy, wz;
     body_to_world(s_search, b.x, b.y, b.z, wx, wy, wz);  // the world position the last search used
@@ -97,8 +99,8 @@ k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, 
 // Outputs are in ORIGINAL scan order (the body buffer is Morton-ordered; .w carries the original index).
 __global__ void __launch_bounds__(256)
 k_mi_classify(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn_pts,
-              const uint8_t* __restrict__ nn_cnt, int N, uint32_t map_points, double fsm, int ekf_inited,
-              float4* __restrict__ world_out, uint8_t* __restrict__ cls) {
+              const uint8_t* __restrict__ nn_cnt, const float* __restrict__ nn_d2, float max_sqdist, int N, uint32_t map_points,
+              double fsm, int ekf_inited, float4* __restrict__ world_out, uint8_t* __restrict__ cls) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const float4 b = body[i];
@@ -123,6 +125,7 @@ k_mi_classify(StateDev s, const float4* __restrict__ body, const float4* __restr
             bool need_add = true;
             if (true_cnt >= 5) {  // points_near.size() < NUM_MATCH_POINTS -> break (:454)
                 for (int r = 0; r < cnt; ++r) {
+                    if (!(nn_d2[(size_t)r * N + i] <= max_sqdist)) break;  // beyond the bound: not a vetted neighbour, and too far to veto
                     const float4 pn = nn_pts[(size_t)r * N + i];
                     if (dist2(pn.x, pn.y, pn.z, mx, my, mz) < dist) need_add = false;  // :455-459
                 }
@@ -325,13 +328,15 @@ __global__ void __launch_bounds__(256) k_compact(const float4* __restrict__ old_
 
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t map_points, const StateDev& s_search,
-                              const StateDev& s_post, const float4* body, float4* nn_pts, const uint8_t* nn_cnt, int N,
-                              double fsm, int ekf_inited, float4* world_out, uint8_t* cls, hipStream_t st) {
+                              const StateDev& s_post, const float4* body, float4* nn_pts, const uint8_t* nn_cnt,
+                              const float* nn_d2, float max_sqdist, int N, double fsm, int ekf_inited, float4* world_out,
+                              uint8_t* cls, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     if (map_points > 0 && ekf_inited)
-        hipLaunchKernelGGL(k_far_nearest, dim3(cdiv2(N, 4)), dim3(256), 0, st, g, s_search, body, nn_cnt, N, hash_size, nn_pts);
-    hipLaunchKernelGGL(k_mi_classify, dim3(cdiv2(N, 256)), dim3(256), 0, st, s_post, body, nn_pts, nn_cnt, N, map_points, fsm,
-                       ekf_inited, world_out, cls);
+        hipLaunchKernelGGL(k_far_nearest, dim3(cdiv2(N, 4)), dim3(256), 0, st, g, s_search, body, nn_cnt, nn_d2, max_sqdist, N,
+                           hash_size, nn_pts);
+    hipLaunchKernelGGL(k_mi_classify, dim3(cdiv2(N, 256)), dim3(256), 0, st, s_post, body, nn_pts, nn_cnt, nn_d2, max_sqdist, N,
+                       map_points, fsm, ekf_inited, world_out, cls);
     return hipGetLastError();
 }
 hipError_t launch_cls_flags(const uint8_t* cls, int N, uint32_t* flags, hipStream_t st) {
