@@ -256,6 +256,11 @@ __device__ __forceinline__ uint32_t exact_query(const GridParams& g, int q, int 
                                                 int lane, float4* __restrict__ nn_pts, float* __restrict__ nn_d2,
                                                 uint8_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected);
 
+template <int LPQ>
+__device__ __forceinline__ void top5_finish(Top5& L, const GridParams& g, int q, int N, int lane, float max_sqdist,
+                                            float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
+                                            uint8_t* __restrict__ selected);
+
 template <int LPQ, int RING, bool BOUNDED, int PB, bool FINAL>
 __global__ void __launch_bounds__(256)
 k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist,
@@ -493,8 +498,29 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             }
         }
         PH_MARK(7);  // 7: results written
+        // The block provably holds the five nearest (5th distance inside the guaranteed radius) but the packed keys left
+        // their order / identity open (two of the best six agree above the packed bits, equal distances, or a list longer
+        // than the packed index can name): one more pass over the SAME candidates with 64-bit (d2, map index) keys
+        // settles it here -- rare (~0.1 % of the queries), so the divergence is cheap, and it keeps such queries out of
+        // the next kernel, whose fixed latency is paid per pass.
+        const bool covered = (cnt == 5 && d5hi <= gr2) || gr2 >= max_sqdist;
+        bool done2 = done;
+        if (live && !done && covered) {
+            Top5 L;
+            L.reset();
+            int c2 = 0;
+            uint2 s2 = seg[grp][0];
+            for (uint32_t t = lane; t < T; t += LPQ) {
+                while (t >= s2.y) s2 = seg[grp][++c2];
+                const uint32_t pos = s2.x + t;
+                const float4 pv = load_pt(rsrc, pos);
+                L.insert(make_key(dist2(qx, qy, qz, pv.x, pv.y, pv.z), pv.w), pos);
+            }
+            top5_finish<LPQ>(L, g, q, N, lane, max_sqdist, nn_pts, nn_d2, nn_cnt, selected);
+            done2 = true;
+        }
         if (FINAL) {
-            if (live && !done) {
+            if (live && !done2) {
                 const float ubx = fminf(BOUNDED ? fminf(d5hi, ub_in[q]) : d5hi, max_sqdist);
                 const uint32_t nc = exact_query<LPQ>(g, q, N, qx, qy, qz, cx, cy, cz, fx, fy, fz, ubx, rmax, max_sqdist, lane, nn_pts,
                                                      nn_d2, nn_cnt, selected);
@@ -502,7 +528,7 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             }
         }
         // ---- unsettled queries go to the next stage's list: one global atomic per wave, 64 striped counters
-        const bool append = !FINAL && live && !done && lane == 0;
+        const bool append = !FINAL && live && !done2 && lane == 0;
         const u64 bal = __ballot(append);
         if (bal) {
             const int wlane = threadIdx.x & 63;
@@ -523,6 +549,61 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
     PH_DUMP(RING == 1 ? 0 : 8);
 }
 
+// Group-wide merge of the lanes' sorted (d2, map index) lists and the query's result rows: 5 x (min butterfly, ballot, pop).
+template <int LPQ>
+__device__ __forceinline__ void top5_finish(Top5& L, const GridParams& g, int q, int N, int lane, float max_sqdist,
+                                            float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
+                                            uint8_t* __restrict__ selected) {
+    const int wl0 = (threadIdx.x & 63) & ~(LPQ - 1);
+    const u64 gmask = (LPQ == 64 ? ~0ull : ((1ull << LPQ) - 1ull)) << wl0;
+    // ---- group merge: 5 x (min butterfly, ballot, pop)
+    u64 rk[5];
+    uint32_t rp[5];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        u64 m = L.k[0];
+#pragma unroll
+        for (int off = LPQ / 2; off >= 1; off >>= 1) {
+            const u64 o = __shfl_xor(m, off, LPQ);
+            m = o < m ? o : m;
+        }
+        const bool win = (L.k[0] == m) && (m != kInfKey);
+        const u64 bal = __ballot(win) & gmask;
+        const int wl = bal ? (__ffsll((long long)bal) - 1) : wl0;
+        const uint32_t wp = __shfl(L.p[0], wl, 64);
+        rk[j] = m;
+        rp[j] = wp;
+        if (m != kInfKey) ++cnt;
+        if (win) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { L.k[t] = L.k[t + 1]; L.p[t] = L.p[t + 1]; }
+            L.k[4] = kInfKey;
+        }
+    }
+    const float d5 = (cnt == 5) ? __uint_as_float((uint32_t)(rk[4] >> 32)) : INFINITY;
+#pragma unroll
+    for (int r = 0; r < (5 + LPQ - 1) / LPQ; ++r) {  // lane l writes ranks l, l + LPQ, ...
+        const int jr = lane + r * LPQ;
+        if (jr < 5) {
+            u64 kk = rk[0];
+            uint32_t pp = rp[0];
+#pragma unroll
+            for (int j = 1; j < 5; ++j)
+                if (jr == j) { kk = rk[j]; pp = rp[j]; }
+            const bool has = jr < cnt;
+            float4 v = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            if (has) v = g.pts[pp];
+            nn_pts[(size_t)jr * N + q] = v;
+            nn_d2[(size_t)jr * N + q] = has ? __uint_as_float((uint32_t)(kk >> 32)) : INFINITY;
+        }
+    }
+    if (lane == 0) {
+        nn_cnt[q] = (uint8_t)cnt;
+        selected[q] = (cnt == 5 && !(d5 > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
+    }
+}
+
 // The general exact search of ONE query by a group of LPQ lanes: one pass over the cells that intersect the ball of
 // radius sqrt(ub) around the query (ub = an upper bound of its true 5th squared distance, capped by the gate max_sqdist
 // of src/laserMapping.cpp:671 -- beyond the gate a result can never be selected).  64-bit keys
@@ -532,8 +613,6 @@ __device__ __forceinline__ uint32_t exact_query(const GridParams& g, int q, int 
                                                 int cz, float fx, float fy, float fz, float ub, int rmax, float max_sqdist,
                                                 int lane, float4* __restrict__ nn_pts, float* __restrict__ nn_d2,
                                                 uint8_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected) {
-    const int wl0 = (threadIdx.x & 63) & ~(LPQ - 1);
-    const u64 gmask = (LPQ == 64 ? ~0ull : ((1ull << LPQ) - 1ull)) << wl0;
     // cells with |offset| <= R cover the ball; +1 absorbs the position inside the centre cell
     const int r = min(rmax, (int)(sqrtf(ub) * g.inv_c) + 1);
     const float ubp = ub * 1.0001f + 1e-6f;
@@ -561,48 +640,7 @@ __device__ __forceinline__ uint32_t exact_query(const GridParams& g, int q, int 
             L.insert(make_key(dist2(qx, qy, qz, pv.x, pv.y, pv.z), pv.w), i);
         }
     }
-    // ---- group merge: 5 x (min butterfly, ballot, pop)
-    u64 rk[5];
-    uint32_t rp[5];
-    int cnt = 0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        u64 m = L.k[0];
-#pragma unroll
-        for (int off = LPQ / 2; off >= 1; off >>= 1) {
-            const u64 o = __shfl_xor(m, off, LPQ);
-            m = o < m ? o : m;
-        }
-        const bool win = (L.k[0] == m) && (m != kInfKey);
-        const u64 bal = __ballot(win) & gmask;
-        const int wl = bal ? (__ffsll((long long)bal) - 1) : wl0;
-        const uint32_t wp = __shfl(L.p[0], wl, 64);
-        rk[j] = m;
-        rp[j] = wp;
-        if (m != kInfKey) ++cnt;
-        if (win) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { L.k[t] = L.k[t + 1]; L.p[t] = L.p[t + 1]; }
-            L.k[4] = kInfKey;
-        }
-    }
-    const float d5 = (cnt == 5) ? __uint_as_float((uint32_t)(rk[4] >> 32)) : INFINITY;
-    if (lane < 5) {
-        u64 kk = rk[0];
-        uint32_t pp = rp[0];
-#pragma unroll
-        for (int j = 1; j < 5; ++j)
-            if (lane == j) { kk = rk[j]; pp = rp[j]; }
-        const bool has = lane < cnt;
-        float4 v = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-        if (has) v = g.pts[pp];
-        nn_pts[(size_t)lane * N + q] = v;
-        nn_d2[(size_t)lane * N + q] = has ? __uint_as_float((uint32_t)(kk >> 32)) : INFINITY;
-    }
-    if (lane == 0) {
-        nn_cnt[q] = (uint8_t)cnt;
-        selected[q] = (cnt == 5 && !(d5 > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
-    }
+    top5_finish<LPQ>(L, g, q, N, lane, max_sqdist, nn_pts, nn_d2, nn_cnt, selected);
     return ncand;
 }
 
