@@ -510,11 +510,21 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             L.reset();
             int c2 = 0;
             uint2 s2 = seg[grp][0];
-            for (uint32_t t = lane; t < T; t += LPQ) {
-                while (t >= s2.y) s2 = seg[grp][++c2];
-                const uint32_t pos = s2.x + t;
-                const float4 pv = load_pt(rsrc, pos);
-                L.insert(make_key(dist2(qx, qy, qz, pv.x, pv.y, pv.z), pv.w), pos);
+            constexpr int RU = 4;  // loads in flight per lane (the serial version cost ~1 us per candidate)
+            for (uint32_t t0 = lane; t0 < T; t0 += LPQ * RU) {
+                float4 pv[RU];
+                uint32_t pos[RU];
+#pragma unroll
+                for (int w = 0; w < RU; ++w) {
+                    const uint32_t t = t0 + (uint32_t)(w * LPQ);
+                    while (t >= s2.y) s2 = seg[grp][++c2];
+                    pos[w] = (t < T) ? s2.x + t : 0xFFFFFFFu;
+                    pv[w] = load_pt(rsrc, pos[w]);
+                }
+#pragma unroll
+                for (int w = 0; w < RU; ++w)
+                    if (t0 + (uint32_t)(w * LPQ) < T)
+                        L.insert(make_key(dist2(qx, qy, qz, pv[w].x, pv[w].y, pv[w].z), pv[w].w), pos[w]);
             }
             top5_finish<LPQ>(L, g, q, N, lane, max_sqdist, nn_pts, nn_d2, nn_cnt, selected);
             done2 = true;
