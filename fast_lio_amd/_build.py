@@ -14,7 +14,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 SOURCES = ["flh_kernels.hip", "flh_mapinc.hip", "flh_scanprep.hip", "flh_api.cpp", "flh_esekf.cpp"]
 DEPS = SOURCES + ["flh_device.hpp", "flh_kernels.hpp"]
 HDRS = ["fastlio_hip.h", "fastlio_amd/esekfom.hpp", "fastlio_amd/mtk.hpp", "fastlio_amd/smallmat.hpp",
-        "fastlio_amd/use-ikfom.hpp", "fastlio_amd/h_share_model.hpp", "fastlio_amd/local_map.hpp"]
+        "fastlio_amd/use-ikfom.hpp", "fastlio_amd/h_share_model.hpp", "fastlio_amd/local_map.hpp", "fastlio_amd/imu_processing.hpp"]
 
 # -ffp-contract=off: the reference never fuses a*b+c (baseline x86-64 build); flags must match for
 # bit-exact point_selected_surf.  -fhip-fp32-correctly-rounded-divide-sqrt is hipcc's default; stated.

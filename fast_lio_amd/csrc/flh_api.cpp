@@ -602,8 +602,8 @@ static int stage_raw(flh_handle* h, flh_handle::Slot& sl, const char* who, const
     if (und) {
         if (!und->poses || und->n_pose < 1 || !und->x_end) return fail(w + ": IMU poses / end state missing");
         if (n > 0 && und->time_offset_bytes + 4 > stride_bytes) return fail(w + ": time_offset_bytes outside the point record");
-        for (int k = 1; k < und->n_pose; ++k)
-            if (!(und->poses[k].offset_time > und->poses[k - 1].offset_time)) return fail(w + ": IMU pose offset_time must increase");
+        for (int k = 0; k < und->n_pose; ++k)
+            if (!std::isfinite(und->poses[k].offset_time)) return fail(w + ": non-finite IMU pose offset_time");
     }
     if (stage_prepare(h, sl) != 0) return -1;
     hipStream_t cs = h->copy_stream;

@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) k_vg_reduce(const float4* __restrict__ ra
 // carried from its own sampling time to the scan-end frame.  raw.w = the point's time offset in ms (PointType::curvature).
 // pose rows: 22 doubles each = {offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]} (msg/Pose6D.msg).
 // Segment of a point = the last k <= n_pose-2 with offset_time[k] < t (what the reference's back-to-front sweep over the
-// time-sorted cloud amounts to); points at t <= offset_time[0] stay as they are.  Exp() = so3_math.h:36-58.
+// time-sorted cloud amounts to; no ordering of the offset_times is assumed); a point no segment claims stays as it is.  Exp() = so3_math.h:36-58.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_undistort(StateDev s_end, const double* __restrict__ poses, int n_pose,
                                                    const float4* __restrict__ raw, uint32_t n, float4* __restrict__ out) {

@@ -180,6 +180,17 @@ typedef struct { double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]; } o
 void orc_undistort(const orc_pose6d* poses, int n_pose, const double x_end[ORC_NSTATE], const float* pts, size_t stride_floats,
                    size_t time_off_floats, size_t n, float* out_xyz);
 
+/* ImuProcess::UndistortPcl, forward half (src/IMU_Processing.hpp:217-300).  st = the members of ImuProcess that live
+ * from scan to scan; imu = n rows {t, acc[3], gyr[3]}; poses_out needs room for n + 1 entries; returns their number;
+ * x, P end at the scan-end state. */
+typedef struct {
+    double mean_acc[3], cov_acc[3], cov_gyr[3], cov_bias_gyr[3], cov_bias_acc[3], angvel_last[3], acc_s_last[3];
+    double last_imu[7];
+    double last_lidar_end_time;
+} orc_imu_state;
+int orc_imu_forward(orc_imu_state* st, const double* imu, int n, double pcl_beg_time, double pcl_end_time,
+                    double x[ORC_NSTATE], double P[ORC_NDOF * ORC_NDOF], orc_pose6d* poses_out);
+
 #ifdef __cplusplus
 }
 #endif

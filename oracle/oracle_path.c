@@ -940,8 +940,9 @@ size_t orc_voxel_grid(const float* in, size_t stride, size_t n, float leaf, floa
    (IMUpose, msg/Pose6D.msg) and the scan-end state `x_end`.
    The reference first sorts the cloud by curvature (= time offset in ms, :234) and sweeps segments from the back;
    since every point is handled independently the sweep reduces to: segment k = the LAST k <= n_pose-2 with
-   poses[k].offset_time < t (points with t <= poses[0].offset_time are left untouched, as the sweep never reaches
-   them).  offset_times are assumed strictly increasing.  The order of the output is the order of the input: the
+   poses[k].offset_time < t (a segment skipped for a later point has offset_time >= that point's time, hence >= every
+   earlier point's too); a point no segment claims is left untouched, as the sweep never reaches it.  No ordering of the
+   offset_times is assumed: IMUpose[1] precedes IMUpose[0] = 0 whenever the first IMU sample is older than the first point.  The order of the output is the order of the input: the
    reference's (unstable) sort order is not reproduced.
    Exp() is so3_math.h:36-58.  Double arithmetic in source order; Eigen's internal evaluation order of the 3x3
    products is not modelled (it moves results by ~1e-16 before the final narrowing to float). */
@@ -999,4 +1000,66 @@ void orc_undistort(const orc_pose6d* poses, int n_pose, const double x_end[ORC_N
         orc_quat_rot(offR_c, q3, q4);
         for (int d = 0; d < 3; d++) out_xyz[3 * i + d] = (float)q4[d];
     }
+}
+
+/* =================================================================== ImuProcess::UndistortPcl, forward half
+   (src/IMU_Processing.hpp:217-300): one predict per pair of consecutive IMU samples; IMUpose records the state at every
+   IMU sample; the filter ends at the scan end.  imu: n rows of {t, acc[3], gyr[3]} -- this scan's samples; the previous
+   scan's last sample (st->last_imu) is prepended as the reference does (:220). */
+static void q_to_R(const double q[4], double R[9]) { /* Eigen::Quaternion::toRotationMatrix */
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+static void imu_pose(orc_pose6d* kp, double t, const double a[3], const double g[3], const double x[ORC_NSTATE]) {
+    kp->offset_time = t;
+    for (int i = 0; i < 3; i++) { kp->acc[i] = a[i]; kp->gyr[i] = g[i]; kp->vel[i] = x[X_VEL + i]; kp->pos[i] = x[X_POS + i]; }
+    q_to_R(x + X_ROT, kp->rot);
+}
+int orc_imu_forward(orc_imu_state* st, const double* imu, int n, double pcl_beg_time, double pcl_end_time,
+                    double x[ORC_NSTATE], double P[ORC_NDOF * ORC_NDOF], orc_pose6d* poses_out) {
+    const double G_m_s2 = 9.81;
+    const int nv = n + 1;
+    double* v = (double*)malloc(sizeof(double) * 7 * (size_t)nv);
+    memcpy(v, st->last_imu, sizeof(double) * 7);
+    memcpy(v + 7, imu, sizeof(double) * 7 * (size_t)n);
+    const double imu_end_time = v[7 * (nv - 1)];
+    double Q[144];
+    orc_process_noise_cov(Q);
+    int np = 0;
+    imu_pose(poses_out + np++, 0.0, st->acc_s_last, st->angvel_last, x);
+    double acc_avr[3] = {0, 0, 0}, angvel_avr[3] = {0, 0, 0}, dt = 0;
+    const double mnorm = sqrt((st->mean_acc[0] * st->mean_acc[0] + st->mean_acc[1] * st->mean_acc[1]) + st->mean_acc[2] * st->mean_acc[2]);
+    for (int k = 0; k + 1 < nv; k++) {
+        const double* head = v + 7 * k;
+        const double* tail = v + 7 * (k + 1);
+        if (tail[0] < st->last_lidar_end_time) continue;
+        for (int i = 0; i < 3; i++) {
+            angvel_avr[i] = 0.5 * (head[4 + i] + tail[4 + i]);
+            acc_avr[i] = 0.5 * (head[1 + i] + tail[1 + i]);
+        }
+        for (int i = 0; i < 3; i++) acc_avr[i] = acc_avr[i] * G_m_s2 / mnorm;
+        if (head[0] < st->last_lidar_end_time) dt = tail[0] - st->last_lidar_end_time;
+        else dt = tail[0] - head[0];
+        for (int i = 0; i < 3; i++) {
+            Q[(0 + i) * 12 + (0 + i)] = st->cov_gyr[i]; Q[(3 + i) * 12 + (3 + i)] = st->cov_acc[i];
+            Q[(6 + i) * 12 + (6 + i)] = st->cov_bias_gyr[i]; Q[(9 + i) * 12 + (9 + i)] = st->cov_bias_acc[i];
+        }
+        orc_predict(x, P, dt, Q, acc_avr, angvel_avr);
+        double unb[3], as[3];
+        for (int i = 0; i < 3; i++) { st->angvel_last[i] = angvel_avr[i] - x[X_BG + i]; unb[i] = acc_avr[i] - x[X_BA + i]; }
+        orc_quat_rot(x + X_ROT, unb, as);
+        for (int i = 0; i < 3; i++) st->acc_s_last[i] = as[i] + x[X_GRAV + i];
+        imu_pose(poses_out + np++, tail[0] - pcl_beg_time, st->acc_s_last, st->angvel_last, x);
+    }
+    const double note = pcl_end_time > imu_end_time ? 1.0 : -1.0;
+    dt = note * (pcl_end_time - imu_end_time);
+    orc_predict(x, P, dt, Q, acc_avr, angvel_avr);
+    memcpy(st->last_imu, imu + 7 * (size_t)(n - 1), sizeof(double) * 7);
+    st->last_lidar_end_time = pcl_end_time;
+    free(v);
+    return np;
 }

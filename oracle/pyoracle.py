@@ -488,3 +488,34 @@ def undistort(poses, x_end, pts_xyzt):
     out = np.zeros((max(len(a), 1), 3), np.float32)
     L.orc_undistort(C.cast(poses, C.c_void_p), len(poses), _c64(x_end), a, 4, 3, len(a), out)
     return out[: len(a)].copy()
+
+
+class ImuState(C.Structure):
+    """orc_imu_state: ImuProcess members that persist across scans (defaults of the reference's constructor, :115-128)."""
+    _fields_ = [("mean_acc", C.c_double * 3), ("cov_acc", C.c_double * 3), ("cov_gyr", C.c_double * 3), ("cov_bias_gyr", C.c_double * 3),
+                ("cov_bias_acc", C.c_double * 3), ("angvel_last", C.c_double * 3), ("acc_s_last", C.c_double * 3),
+                ("last_imu", C.c_double * 7), ("last_lidar_end_time", C.c_double)]
+
+    def __init__(self):
+        super().__init__()
+        self.mean_acc[:] = [0, 0, -1.0]
+        self.cov_acc[:] = [0.1] * 3
+        self.cov_gyr[:] = [0.1] * 3
+        self.cov_bias_gyr[:] = [0.0001] * 3
+        self.cov_bias_acc[:] = [0.0001] * 3
+
+
+def imu_forward(st: ImuState, imu, pcl_beg_time, pcl_end_time, x, P):
+    """Forward half of UndistortPcl.  imu: n x 7 (t, acc, gyr).  Returns (poses array, x_end, P_end)."""
+    a = _c64(imu).reshape(-1, 7)
+    L = lib()
+    L.orc_imu_forward.restype = C.c_int
+    L.orc_imu_forward.argtypes = [C.POINTER(ImuState), np.ctypeslib.ndpointer(np.float64), C.c_int, C.c_double, C.c_double,
+                                  np.ctypeslib.ndpointer(np.float64), np.ctypeslib.ndpointer(np.float64), C.c_void_p]
+    x = _c64(x).copy()
+    P = _c64(P).reshape(NDOF, NDOF).copy()
+    poses = (Pose6D * (len(a) + 1))()
+    n = L.orc_imu_forward(C.byref(st), a, len(a), float(pcl_beg_time), float(pcl_end_time), x, P, C.cast(poses, C.c_void_p))
+    out = (Pose6D * n)()
+    C.memmove(out, poses, C.sizeof(Pose6D) * n)
+    return out, x, P

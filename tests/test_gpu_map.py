@@ -381,9 +381,16 @@ def test_undistortion_matches_oracle(prob):
     h.scan_activate(2)
     same_points(h.fetch_scan(), po.voxel_grid(und, 0.5), "feats_down_body from the device chain")
     assert n2 == h.N
+    # the first IMU sample older than the first point: IMUpose[1].offset_time < IMUpose[0].offset_time = 0 (a normal case)
+    poses[1].offset_time = -0.002
+    want3 = po.undistort(poses, x_end, pts)
+    _, und3 = h.scan_stage_undistorted(0, pts, poses, x_end, leaf_size=0.0)
+    assert np.abs(und3 - want3).max() <= 2.0 * np.spacing(np.float32(scale))
+    assert (und3.view(np.uint32) == want3.view(np.uint32)).mean() > 0.999
+    assert np.abs(want3 - want).max() > 0      # the early points did change segment
     with pytest.raises(capi.FlhError):
-        bad = po.make_poses([(0.0, (0,) * 3, (0,) * 3, (0,) * 3, (0,) * 3, np.eye(3).reshape(9))] * 2)   # offset_time not increasing
-        h.scan_stage_undistorted(0, pts[:10], bad, x_end)
+        poses[3].offset_time = float("nan")
+        h.scan_stage_undistorted(0, pts[:10], poses, x_end)
 
 
 def test_velodyne_stream_with_incremental_map():

@@ -75,3 +75,17 @@ def test_segment_selection_edges():
     # later than the last IMU pose: the last segment extrapolates
     np.testing.assert_allclose(out[5], rz(-2.0 * (0.13 - 0.05)) @ p, atol=2e-6)
     np.testing.assert_allclose(out[4], rz(-2.0 * 0.05) @ p, atol=2e-6)
+
+
+def test_first_imu_sample_older_than_the_first_point():
+    # IMUpose = [0.0, -0.002, 0.003, ...]: points in (-0.002, 0.003] belong to segment 1, points <= -0.002 to none
+    rows = [(0.0, (0,) * 3, (0, 0, 9.0), (0,) * 3, (0,) * 3, I9), (-0.002, (0,) * 3, (0, 0, 1.0), (0,) * 3, (0,) * 3, I9),
+            (0.003, (0,) * 3, (0, 0, -2.0), (0,) * 3, (0,) * 3, I9), (0.008, (0,) * 3, (0, 0, 3.0), (0,) * 3, (0,) * 3, I9)]
+    poses = po.make_poses(rows)
+    p = np.array([10.0, 0, 0])
+    tms = np.array([-3.0, -1.0, 0.0, 2.0, 5.0], np.float32)
+    out = po.undistort(poses, state(), np.c_[np.tile(p, (5, 1)), tms].astype(np.float32))
+    np.testing.assert_array_equal(out[0], p.astype(np.float32))                       # nobody claims t = -0.003
+    for i in (1, 2, 3):                                                                # segment 1: tail gyr -2 rad/s
+        np.testing.assert_allclose(out[i], rz(-2.0 * (tms[i] / 1000.0 + 0.002)) @ p, atol=2e-6)
+    np.testing.assert_allclose(out[4], rz(3.0 * (0.005 - 0.003)) @ p, atol=2e-6)      # segment 2: tail gyr 3 rad/s
