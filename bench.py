@@ -397,7 +397,7 @@ def main():
                                          f"{os.cpu_count()} logical cores",
                                "speedup_vs_cpu": round(value / (ncpu / tot), 1)}
 
-    # ---- map_incremental (classification + Add_Points + device re-index) after an update.
+    # ---- map_incremental (classification + Add_Points into the device map) after an update.
     # Outside the timed region and last, because it grows the map.  t_map = classify + insert + re-index, the
     # reference's "Incremental Mapping" timer (src/laserMapping.cpp:921-924).
     if rank == 0 and G == 1 and mode != "shard":
@@ -423,7 +423,7 @@ def main():
             added += h.M - m0
         out["map_incremental"] = {"ms_per_scan": round(t_all / reps * 1e3, 3), "classify_only_ms": round(t_cls / reps * 1e3, 3),
                                   "net_points_added_per_scan": round(added / reps, 1), "scans": reps,
-                                  "note": "filter_size_map 0.5; full re-index of the map after each change"}
+                                  "note": "filter_size_map 0.5; only the touched bricks are rewritten (slack-carrying brick storage)"}
 
     # ---- the raw-scan front end (undistortion + VoxelGrid + staging) for one raw scan handed over
     # as a pageable host buffer: PCIe-inclusive by nature, reported beside the headline, never part of it.

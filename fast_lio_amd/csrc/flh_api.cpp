@@ -53,6 +53,20 @@ struct DevBuf {
         if (e == hipSuccess) cap = want;
         return e;
     }
+    // like reserve, but the first `keep` elements survive a reallocation
+    hipError_t grow(size_t n, size_t keep, hipStream_t st) {
+        if (n <= cap) return hipSuccess;
+        T* np = nullptr;
+        const size_t want = n + n / 4 + 64;
+        hipError_t e = hipMalloc((void**)&np, want * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (p && keep) e = hipMemcpyAsync(np, p, keep * sizeof(T), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (p) (void)hipFree(p);
+        p = np;
+        cap = want;
+        return e;
+    }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -69,8 +83,18 @@ struct flh_handle {
     // map
     size_t M = 0;
     GridParams grid{};
-    DevBuf<float4> map_sorted;             // cell-sorted copy the search reads (.w = index)
-    DevBuf<float4> map_orig, map_next;     // the map in index order, and the buffer the next version is built in
+    DevBuf<float4> map_sorted;             // the storage the search reads: per brick its points (cell-sorted, .w = id) + slack
+    DevBuf<float4> map_orig, map_next;     // the points by id (append-only between re-indexings), and a build buffer
+    DevBuf<uint8_t> dead_id;               // 1 = the point with this id has been removed
+    size_t n_ids = 0;                      // ids handed out since the last re-indexing (M = the live ones among them)
+    DevBuf<uint32_t> cap_end, live;        // per brick rank: end of its storage range, live points
+    DevBuf<uint32_t> mb_cap, mb_capincl;
+    DevBuf<uint32_t> ctr;                  // device counters: [0] storage top, [1] bricks, [2] re-index flags, [3] removed
+    uint32_t* h_ctr = nullptr;             // pinned mirror
+    size_t pts_cap = 0, rows_cap = 0, alloc_top = 0;
+    DevBuf<float4> ins;                    // points being inserted, with their ids
+    std::vector<uint32_t> id_pos;          // id -> position among the live points (flh_fetch_neighbors), built on demand
+    bool id_pos_valid = false;
     DevBuf<u64> mb_k0, mb_k1;              // index-build scratch (kept: the map is rebuilt after every change)
     DevBuf<uint32_t> mb_v0, mb_v1, mb_bh, mb_br, mb_bstart, mb_aabb;
     DevBuf<unsigned char> mb_tmp;
@@ -191,7 +215,8 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     }
     for (auto& e : h->ev) (void)hipEventCreate(&e);
     if (hipHostMalloc((void**)&h->h_gram, 256 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_counter, sizeof(u64), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void**)&h->h_counter, sizeof(u64), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_ctr, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
         flh_destroy(h);
         return fail("hipHostMalloc failed");
     }
@@ -213,6 +238,9 @@ void flh_destroy(flh_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     release_build_scratch(h);
+    h->dead_id.release(); h->cap_end.release(); h->live.release(); h->mb_cap.release(); h->mb_capincl.release(); h->ctr.release();
+    h->ins.release();
+    if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     h->map_orig.release(); h->map_next.release(); h->mb_aabb.release(); h->mu_add.release(); h->mi_world.release();
     h->mu_dead.release(); h->mu_alive.release(); h->mi_cls.release(); h->mu_flags.release(); h->mu_incl.release(); h->mu_boxes.release();
     h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_list2.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
@@ -264,7 +292,7 @@ static int rebuild_index(flh_handle* h, DevBuf<float4>& pts, size_t M) {
     GridParams g{};
     g.c = c;
     g.inv_c = 1.0f / c;
-    const int PAD = 4;  // cells of slack on every side, so near-outside queries keep non-negative cells
+    const int PAD = 32;  // cells of slack on every side: room for the map to grow before the grid must be re-laid
     float o[3];
     int dims[3];
     for (int d = 0; d < 3; ++d) {
@@ -276,8 +304,8 @@ static int rebuild_index(flh_handle* h, DevBuf<float4>& pts, size_t M) {
     g.ox = o[0]; g.oy = o[1]; g.oz = o[2];
     g.nx = dims[0]; g.ny = dims[1]; g.nz = dims[2];
 
-    HIPC(h->map_sorted.reserve(M ? M : 1));
-    uint32_t nbricks = 0;
+    // sort by (brick, local cell), find the bricks, give each its range of the storage with slack behind its points
+    uint32_t nbricks = 0, used = 0;
     if (M > 0) {
         HIPC(h->mb_k0.reserve(M)); HIPC(h->mb_k1.reserve(M));
         HIPC(h->mb_v0.reserve(M)); HIPC(h->mb_v1.reserve(M)); HIPC(h->mb_bh.reserve(M)); HIPC(h->mb_br.reserve(M));
@@ -288,26 +316,47 @@ static int rebuild_index(flh_handle* h, DevBuf<float4>& pts, size_t M) {
         HIPC(h->mb_tmp.reserve(std::max(tb1, tb2)));
         size_t tb = h->mb_tmp.cap;
         HIPC(flh::sort_pairs(h->mb_tmp.p, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, Mu, st));
-        HIPC(flh::launch_map_gather(pts.p, h->mb_k1.p, h->mb_v1.p, Mu, h->map_sorted.p, h->mb_bh.p, st));
+        HIPC(flh::launch_brick_heads(h->mb_k1.p, Mu, h->mb_bh.p, st));
         tb = h->mb_tmp.cap;
         HIPC(flh::inclusive_sum(h->mb_tmp.p, tb, h->mb_bh.p, h->mb_br.p, Mu, st));
         HIPC(hipMemcpyAsync(&nbricks, h->mb_br.p + (M - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
-    }
-    // directory + per-brick prefix tables
-    uint32_t hs = 1024;
-    while (hs < 2 * (nbricks + 1)) hs <<= 1;
-    int log2hs = 0;
-    while ((1u << log2hs) < hs) ++log2hs;
-    HIPC(h->hash.reserve(hs));
-    HIPC(h->starts.reserve((size_t)(nbricks ? nbricks : 1) * flh::kBrickStride));
-    HIPC(hipMemsetAsync(h->hash.p, 0xFF, (size_t)hs * sizeof(uint2), st));
-    if (M > 0) {
         HIPC(h->mb_bstart.reserve((size_t)nbricks + 1));
+        HIPC(h->mb_cap.reserve(nbricks)); HIPC(h->mb_capincl.reserve(nbricks));
         HIPC(flh::launch_brick_starts(h->mb_bh.p, h->mb_br.p, Mu, h->mb_bstart.p, st));
         HIPC(hipMemcpyAsync(h->mb_bstart.p + nbricks, &Mu, sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        HIPC(flh::launch_brick_tables(h->mb_k1.p, h->mb_bstart.p, nbricks, h->starts.p, h->hash.p, hs - 1, 32 - log2hs, st));
+        HIPC(flh::launch_brick_caps(h->mb_bstart.p, nbricks, h->mb_cap.p, st));
+        tb = h->mb_tmp.cap;
+        HIPC(flh::inclusive_sum(h->mb_tmp.p, tb, h->mb_cap.p, h->mb_capincl.p, nbricks, st));
+        HIPC(hipMemcpyAsync(&used, h->mb_capincl.p + (nbricks - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
     }
+    // room behind the bricks for relocated / new bricks, table rows and directory slots for new bricks
+    const size_t pts_cap = (size_t)used + std::max<size_t>(M / 4, 65536);
+    if (pts_cap >= (1ull << 27)) return fail("map index: too many points for one storage range");
+    const size_t rows_cap = (size_t)2 * nbricks + 4096;
+    uint32_t hs = 1024;
+    while (hs < 2 * rows_cap) hs <<= 1;
+    int log2hs = 0;
+    while ((1u << log2hs) < hs) ++log2hs;
+    HIPC(h->map_sorted.reserve(pts_cap));
+    HIPC(h->hash.reserve(hs));
+    HIPC(h->starts.reserve(rows_cap * flh::kBrickStride));
+    HIPC(h->cap_end.reserve(rows_cap)); HIPC(h->live.reserve(rows_cap));
+    HIPC(h->ctr.reserve(8));
+    HIPC(hipMemsetAsync(h->hash.p, 0xFF, (size_t)hs * sizeof(uint2), st));
+    HIPC(hipMemsetAsync(h->live.p, 0, rows_cap * sizeof(uint32_t), st));
+    HIPC(flh::launch_fill_tomb(h->map_sorted.p, (uint32_t)pts_cap, st));
+    if (M > 0) {
+        HIPC(flh::launch_map_place(pts.p, h->mb_v1.p, h->mb_br.p, h->mb_bstart.p, h->mb_capincl.p, h->mb_cap.p, Mu, h->map_sorted.p, st));
+        HIPC(flh::launch_brick_tables(h->mb_k1.p, h->mb_bstart.p, nbricks, h->mb_capincl.p, h->mb_cap.p, h->starts.p, h->cap_end.p,
+                                      h->live.p, h->hash.p, hs - 1, 32 - log2hs, st));
+    }
+    const uint32_t ctr0[8] = {used, nbricks, 0u, 0u, 0u, 0u, 0u, 0u};
+    HIPC(hipMemcpyAsync(h->ctr.p, ctr0, sizeof(ctr0), hipMemcpyHostToDevice, st));
+    // identities restart at 0..M-1 = positions in the compacted array
+    HIPC(h->dead_id.reserve(M + M / 4 + 65536));
+    HIPC(hipMemsetAsync(h->dead_id.p, 0, h->dead_id.cap, st));
     HIPC(hipStreamSynchronize(st));
     g.hash_mask = hs - 1;
     g.hash_shift = 32 - log2hs;
@@ -317,6 +366,11 @@ static int rebuild_index(flh_handle* h, DevBuf<float4>& pts, size_t M) {
     h->grid = g;
     h->nbricks = nbricks;
     h->M = M;
+    h->n_ids = M;
+    h->pts_cap = pts_cap;
+    h->rows_cap = rows_cap;
+    h->alloc_top = used;
+    h->id_pos_valid = false;
     if (&pts != &h->map_orig) std::swap(h->map_orig, pts);
     h->searched_once = false;  // cached neighbours refer to the previous map
     return 0;
@@ -364,51 +418,106 @@ int flh_map_build(flh_handle* h, const void* xyz, size_t stride_bytes, size_t M)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Incremental map -- SURVEY.md 8(f) row 1.  d_add holds n1 points to insert WITH down-sampling followed by n2
-// points to append; dead_old (M bytes) may already carry deletions.  Survivors keep their order (old, then new),
-// which is the index order the search's tie-break refers to.
-static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size_t n2, double ds, bool dead_prepared) {
+// Incremental map -- SURVEY.md 8(f) row 1.
+// The points live twice: by id in map_orig (append-only; dead_id marks removals) and in the brick storage the search
+// reads.  A change touches only the bricks it concerns (k_add_resolve tombstones displaced points in place,
+// k_brick_rewrite re-sorts the bricks that receive points, relocating one when it outgrows its slack); when something
+// does not fit -- a point outside the grid, storage / table rows / directory full, a brick beyond the LDS tile -- the
+// index is rebuilt from map_orig, which is always complete, and the ids are renumbered 0..M-1.
+static int reindex_from_ids(flh_handle* h) {
     hipStream_t st = h->stream;
-    const size_t M = h->M, n = n1 + n2, tot = M + n;
-    if (tot >= (1ull << 31)) return fail("map update: too many points");
-    if (!h->grid.hash) {  // no map yet: index an empty one so the voxel lookups have tables to probe
+    const size_t n_ids = h->n_ids;
+    size_t total = 0;
+    if (n_ids > 0) {
+        HIPC(h->mu_flags.reserve(n_ids)); HIPC(h->mu_incl.reserve(n_ids));
+        HIPC(flh::launch_byte_flags(h->dead_id.p, (uint32_t)n_ids, 1, h->mu_flags.p, st));
+        size_t tb = 0;
+        HIPC(flh::inclusive_sum(nullptr, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)n_ids, st));
+        HIPC(h->mb_tmp.reserve(tb));
+        tb = h->mb_tmp.cap;
+        HIPC(flh::inclusive_sum(h->mb_tmp.p, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)n_ids, st));
+        uint32_t t32 = 0;
+        HIPC(hipMemcpyAsync(&t32, h->mu_incl.p + (n_ids - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+        total = t32;
+        HIPC(h->map_next.reserve(total ? total : 1));
+        HIPC(flh::launch_live_compact(h->map_orig.p, h->mu_flags.p, h->mu_incl.p, (uint32_t)n_ids, h->map_next.p, st));
+    } else {
+        HIPC(h->map_next.reserve(1));
+    }
+    return rebuild_index(h, h->map_next, total);
+}
+
+// d_add holds n1 points to insert WITH down-sampling followed by n2 points to insert as they are.
+static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size_t n2, double ds) {
+    hipStream_t st = h->stream;
+    const size_t n = n1 + n2;
+    if (h->n_ids + n >= (1ull << 31)) return fail("map update: too many points");
+    if (!h->grid.hash) {  // no map yet: index an empty one so there are tables to insert into
         if (rebuild_index(h, h->map_orig, 0) != 0) return -1;
     }
-    HIPC(h->mu_dead.reserve(M ? M : 1));
-    HIPC(h->mu_alive.reserve(n ? n : 1));
-    if (!dead_prepared && M > 0) HIPC(hipMemsetAsync(h->mu_dead.p, 0, M, st));
+    if (n == 0) return 0;
+    HIPC(hipMemsetAsync(h->ctr.p + 2, 0, 2 * sizeof(uint32_t), st));
+    HIPC(h->mu_alive.reserve(n));
     if (n1 > 0) HIPC(hipMemsetAsync(h->mu_alive.p, 0, n1, st));
     if (n2 > 0) HIPC(hipMemsetAsync(h->mu_alive.p + n1, 1, n2, st));
     if (n1 > 0) {
         const uint32_t nu = (uint32_t)n1;
-        HIPC(h->mb_k0.reserve(n1)); HIPC(h->mb_k1.reserve(n1)); HIPC(h->mb_v0.reserve(n1)); HIPC(h->mb_v1.reserve(n1));
+        HIPC(h->mb_k0.reserve(n)); HIPC(h->mb_k1.reserve(n)); HIPC(h->mb_v0.reserve(n)); HIPC(h->mb_v1.reserve(n));
         HIPC(flh::launch_add_keys(d_add, nu, ds, h->mb_k0.p, h->mb_v0.p, st));
         size_t tb = 0;
         HIPC(flh::sort_vox_pairs(nullptr, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, nu, st));
         HIPC(h->mb_tmp.reserve(tb));
         tb = h->mb_tmp.cap;
         HIPC(flh::sort_vox_pairs(h->mb_tmp.p, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, nu, st));
-        HIPC(flh::launch_add_resolve(h->grid, d_add, h->mb_k1.p, h->mb_v1.p, nu, ds, h->mu_dead.p, h->mu_alive.p, st));
+        HIPC(flh::launch_add_resolve(h->grid, h->map_sorted.p, d_add, h->mb_k1.p, h->mb_v1.p, nu, ds, h->dead_id.p, h->live.p,
+                                     h->ctr.p, h->mu_alive.p, st));
     }
-    size_t total = 0;
-    if (tot > 0) {
-        HIPC(h->mu_flags.reserve(tot)); HIPC(h->mu_incl.reserve(tot));
-        HIPC(flh::launch_alive_flags(h->mu_dead.p, (uint32_t)M, h->mu_alive.p, (uint32_t)n, h->mu_flags.p, st));
+    // ids of the survivors, in input order
+    HIPC(h->mu_flags.reserve(n)); HIPC(h->mu_incl.reserve(n));
+    HIPC(flh::launch_byte_flags(h->mu_alive.p, (uint32_t)n, 0, h->mu_flags.p, st));
+    {
         size_t tb = 0;
-        HIPC(flh::inclusive_sum(nullptr, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)tot, st));
+        HIPC(flh::inclusive_sum(nullptr, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)n, st));
         HIPC(h->mb_tmp.reserve(tb));
         tb = h->mb_tmp.cap;
-        HIPC(flh::inclusive_sum(h->mb_tmp.p, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)tot, st));
-        uint32_t t32 = 0;
-        HIPC(hipMemcpyAsync(&t32, h->mu_incl.p + (tot - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIPC(hipStreamSynchronize(st));
-        total = t32;
-        HIPC(h->map_next.reserve(total ? total : 1));
-        HIPC(flh::launch_compact(h->map_orig.p, (uint32_t)M, d_add, (uint32_t)n, h->mu_flags.p, h->mu_incl.p, h->map_next.p, st));
-    } else {
-        HIPC(h->map_next.reserve(1));
+        HIPC(flh::inclusive_sum(h->mb_tmp.p, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)n, st));
     }
-    return rebuild_index(h, h->map_next, total);
+    uint32_t n_alive = 0;
+    HIPC(hipMemcpyAsync(&n_alive, h->mu_incl.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    if (n_alive > 0) {
+        HIPC(h->map_orig.grow(h->n_ids + n_alive, h->n_ids, st));
+        {
+            const size_t before = h->dead_id.cap;
+            HIPC(h->dead_id.grow(h->n_ids + n_alive, h->n_ids, st));
+            if (h->dead_id.cap != before) HIPC(hipMemsetAsync(h->dead_id.p + h->n_ids, 0, h->dead_id.cap - h->n_ids, st));
+        }
+        HIPC(h->ins.reserve(n_alive));
+        HIPC(h->mb_k0.reserve(n_alive)); HIPC(h->mb_k1.reserve(n_alive)); HIPC(h->mb_v0.reserve(n_alive)); HIPC(h->mb_v1.reserve(n_alive));
+        HIPC(flh::launch_ins_prepare(h->grid, d_add, h->mu_alive.p, h->mu_incl.p, (uint32_t)n, (uint32_t)h->n_ids, h->map_orig.p,
+                                     h->dead_id.p, h->ins.p, h->mb_k0.p, h->mb_v0.p, h->ctr.p, st));
+        size_t tb = 0;
+        HIPC(flh::sort_vox_pairs(nullptr, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, n_alive, st));
+        HIPC(h->mb_tmp.reserve(tb));
+        tb = h->mb_tmp.cap;
+        HIPC(flh::sort_vox_pairs(h->mb_tmp.p, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, n_alive, st));
+        HIPC(flh::launch_brick_rewrite(h->grid, h->map_sorted.p, h->starts.p, h->hash.p, h->cap_end.p, h->live.p, h->ctr.p, h->ins.p,
+                                       h->mb_k1.p, h->mb_v1.p, n_alive, (uint32_t)h->pts_cap, (uint32_t)h->rows_cap, st));
+    }
+    HIPC(hipMemcpyAsync(h->h_ctr, h->ctr.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    h->n_ids += n_alive;
+    h->M = h->M + n_alive - h->h_ctr[3];
+    h->id_pos_valid = false;
+    h->searched_once = false;  // cached neighbours refer to the previous map
+    if (std::getenv("FLH_TRACE_MAP"))
+        std::fprintf(stderr, "[map] +%u -%u -> M=%zu ids=%zu bricks=%u top=%u/%zu flags=%u%s\n", n_alive, h->h_ctr[3], h->M, h->n_ids,
+                     h->h_ctr[1], h->h_ctr[0], h->pts_cap, h->h_ctr[2], h->h_ctr[2] ? " (re-index)" : "");
+    if (h->h_ctr[2] != 0) return reindex_from_ids(h);
+    h->alloc_top = h->h_ctr[0];
+    h->nbricks = h->h_ctr[1];
+    return 0;
 }
 
 // ikdtree.Add_Points(points, downsample_on) -- src/laserMapping.cpp:470-471 (down-sampling length = the
@@ -418,11 +527,11 @@ int flh_map_add(flh_handle* h, const void* xyz, size_t stride_bytes, size_t n, i
     if (downsample && !(downsample_size > 0)) return fail("flh_map_add: downsample_size must be > 0");
     HIPC(hipSetDevice(h->device));
     if (upload_points(h, "flh_map_add", xyz, stride_bytes, n, h->mu_add) != 0) return -1;
-    return apply_map_changes(h, h->mu_add.p, downsample ? n : 0, downsample ? 0 : n, downsample_size, false);
+    return apply_map_changes(h, h->mu_add.p, downsample ? n : 0, downsample ? 0 : n, downsample_size);
 }
 
 // ikdtree.Delete_Point_Boxes(cub_needrm) -- src/laserMapping.cpp:275.  boxes: nb x {min xyz, max xyz}, a point is
-// removed when min <= p < max on every axis.
+// removed when min <= p < max on every axis: its storage slot becomes a tombstone, its id is marked dead.
 int flh_map_delete_boxes(flh_handle* h, const float* boxes, size_t nb) {
     if (!h) return fail("flh_map_delete_boxes: null handle");
     if (nb > 0 && !boxes) return fail("flh_map_delete_boxes: null boxes");
@@ -430,12 +539,16 @@ int flh_map_delete_boxes(flh_handle* h, const float* boxes, size_t nb) {
     HIPC(hipSetDevice(h->device));
     hipStream_t st = h->stream;
     HIPC(h->mu_boxes.reserve(6 * nb));
-    HIPC(h->mu_dead.reserve(h->M));
     HIPC(hipMemcpyAsync(h->mu_boxes.p, boxes, 6 * nb * sizeof(float), hipMemcpyHostToDevice, st));
-    HIPC(hipMemsetAsync(h->mu_dead.p, 0, h->M, st));
-    HIPC(flh::launch_delete_boxes(h->map_orig.p, (uint32_t)h->M, h->mu_boxes.p, (int)nb, h->mu_dead.p, st));
+    HIPC(hipMemsetAsync(h->ctr.p + 3, 0, sizeof(uint32_t), st));
+    HIPC(flh::launch_delete_boxes(h->grid, h->map_sorted.p, (uint32_t)h->alloc_top, h->mu_boxes.p, (int)nb, h->dead_id.p, h->live.p,
+                                  h->ctr.p, st));
+    HIPC(hipMemcpyAsync(h->h_ctr, h->ctr.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));  // boxes is the caller's
-    return apply_map_changes(h, nullptr, 0, 0, 1.0, true);
+    h->M -= h->h_ctr[3];
+    h->id_pos_valid = false;
+    h->searched_once = false;
+    return 0;
 }
 
 // lasermap_fov_segment() -- src/laserMapping.cpp:230-280; the cube logic is include/fastlio_amd/local_map.hpp
@@ -470,16 +583,31 @@ int flh_fov_segment(flh_handle* h, flh_local_map* lm, const double pos_lid[3], d
     return 0;
 }
 
-// The map in index order (what PCL_Storage / flatten would hand back, src/laserMapping.cpp:406-411).
+// The map in index order (what PCL_Storage / flatten would hand back, src/laserMapping.cpp:406-411): the live points by id.
 int flh_map_download(flh_handle* h, float* xyz, size_t capacity_points) {
     if (!h) return fail("flh_map_download: null handle");
     if (capacity_points < h->M) return fail("flh_map_download: buffer too small");
     if (h->M == 0) return 0;
     if (!xyz) return fail("flh_map_download: null buffer");
     HIPC(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const float4* src = h->map_orig.p;
+    if (h->n_ids != h->M) {  // compact the live ones first
+        const size_t n_ids = h->n_ids;
+        HIPC(h->mu_flags.reserve(n_ids)); HIPC(h->mu_incl.reserve(n_ids));
+        HIPC(flh::launch_byte_flags(h->dead_id.p, (uint32_t)n_ids, 1, h->mu_flags.p, st));
+        size_t tb = 0;
+        HIPC(flh::inclusive_sum(nullptr, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)n_ids, st));
+        HIPC(h->mb_tmp.reserve(tb));
+        tb = h->mb_tmp.cap;
+        HIPC(flh::inclusive_sum(h->mb_tmp.p, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)n_ids, st));
+        HIPC(h->map_next.reserve(h->M));
+        HIPC(flh::launch_live_compact(h->map_orig.p, h->mu_flags.p, h->mu_incl.p, (uint32_t)n_ids, h->map_next.p, st));
+        src = h->map_next.p;
+    }
     std::vector<float4> hp(h->M);
-    HIPC(hipMemcpyAsync(hp.data(), h->map_orig.p, h->M * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
-    HIPC(hipStreamSynchronize(h->stream));
+    HIPC(hipMemcpyAsync(hp.data(), src, h->M * sizeof(float4), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
     for (size_t i = 0; i < h->M; ++i) { xyz[3 * i] = hp[i].x; xyz[3 * i + 1] = hp[i].y; xyz[3 * i + 2] = hp[i].z; }
     return 0;
 }
@@ -784,7 +912,7 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
     if (timed) HIPC(hipEventRecord(h->ev[0], st));
     if (do_search) {
         if (h->stats) HIPC(hipMemsetAsync(h->counter.p, 0, FLH_COUNTER_WORDS * sizeof(u64), st));
-        HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->M,
+        HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
                                 h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
                                 h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr, st));
         h->searched_once = true;
@@ -927,7 +1055,7 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
     HIPC(h->mi_world.reserve(N ? N : 1)); HIPC(h->mi_cls.reserve(N ? N : 1));
     HIPC(flh::launch_mi_classify(h->grid, h->grid.hash_mask + 1, (uint32_t)h->M, h->search_state, s_post, h->cur_body,
                                  h->nn_pts.p, h->nn_cnt.p, h->nn_d2.p, h->cfg.max_sqdist, (int)N, filter_size_map, flg_EKF_inited,
-                                 h->mi_world.p, h->mi_cls.p, st));
+                                 h->live.p, h->mi_world.p, h->mi_cls.p, st));
     uint32_t c1 = 0, c2 = 0;
     if (N > 0) {
         HIPC(h->mu_flags.reserve(2 * N)); HIPC(h->mu_incl.reserve(2 * N));
@@ -953,7 +1081,7 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
         HIPC(hipStreamSynchronize(st));
         return 0;
     }
-    return apply_map_changes(h, h->mu_add.p, c1, c2, filter_size_map, false);
+    return apply_map_changes(h, h->mu_add.p, c1, c2, filter_size_map);
 }
 
 // Per scan point (original order): 0 = not inserted, 1 = PointToAdd, 2 = PointNoNeedDownsample; and the world
@@ -1003,7 +1131,7 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
     HIPC(hipEventRecord(h->ev[0], st));
     for (int it = 0; it < iters; ++it) {
         if (which == 0) {
-            HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->M,
+            HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
                                     h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
                                     h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, nullptr, st));
             HIPC(hipMemsetAsync(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t), st));
@@ -1053,12 +1181,23 @@ int flh_fetch_neighbors(flh_handle* h, int32_t* idx, float* d2, uint8_t* cnt) {
     HIPC(hipMemcpyAsync(dd.data(), h->nn_d2.p, 5 * N * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipMemcpyAsync(cc.data(), h->nn_cnt.p, N, hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
+    // the cache carries point ids; the caller gets positions in the array flh_map_download returns (= rank among the live ids)
+    if (h->n_ids != h->M && !h->id_pos_valid) {
+        std::vector<uint8_t> dead(h->n_ids);
+        HIPC(hipMemcpy(dead.data(), h->dead_id.p, h->n_ids, hipMemcpyDeviceToHost));
+        h->id_pos.resize(h->n_ids);
+        uint32_t r = 0;
+        for (size_t i = 0; i < h->n_ids; ++i) { h->id_pos[i] = r; r += dead[i] ? 0u : 1u; }
+        h->id_pos_valid = true;
+    }
+    const bool translate = h->n_ids != h->M;
     const uint32_t* perm = h->cur->h_perm.data();
     for (size_t i = 0; i < N; ++i) {
         const size_t o = perm[i];
         for (int j = 0; j < 5; ++j) {
             int32_t id;
             std::memcpy(&id, &pts[(size_t)j * N + i].w, 4);
+            if (translate && id >= 0 && (size_t)id < h->n_ids) id = (int32_t)h->id_pos[(size_t)id];
             idx[o * 5 + j] = id;
             d2[o * 5 + j] = id < 0 ? INFINITY : dd[(size_t)j * N + i];
         }

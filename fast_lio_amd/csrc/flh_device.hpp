@@ -251,6 +251,12 @@ __device__ __forceinline__ void cell_of(const GridParams& g, float x, float y, f
 
 constexpr int kBrickStride = 65;  // 64 cells + end sentinel
 
+// A storage slot that holds no map point (slack behind a brick's points, a removed point, a relocated brick's old range):
+// coordinates so large that every squared distance to it overflows to +inf, which no selection accepts; .w = -1.
+constexpr float kTombCoord = 3.0e38f;
+__device__ __forceinline__ float4 tombstone() { return make_float4(kTombCoord, kTombCoord, kTombCoord, __uint_as_float(0xFFFFFFFFu)); }
+__device__ __forceinline__ bool is_tombstone(const float4& p) { return p.x == kTombCoord; }
+
 // rank of a brick in the sorted order, or 0xFFFFFFFF if the brick holds no points
 __device__ __forceinline__ uint32_t lookup_brick(const GridParams& g, uint32_t key) {
     const unsigned long long* __restrict__ hash64 = reinterpret_cast<const unsigned long long*>(g.hash);

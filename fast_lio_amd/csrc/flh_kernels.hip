@@ -44,20 +44,6 @@ __global__ void __launch_bounds__(256) k_map_keys(GridParams g, const float4* __
     vals[i] = i;
 }
 
-// sorted float4 (xyz, original index bits) + head flags of bricks
-__global__ void __launch_bounds__(256) k_map_gather(const float4* __restrict__ pts, const u64* __restrict__ keys_sorted,
-                                                    const uint32_t* __restrict__ vals_sorted, uint32_t M,
-                                                    float4* __restrict__ out, uint32_t* __restrict__ brick_head) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    const uint32_t src = vals_sorted[i];
-    float4 p = pts[src];
-    p.w = __uint_as_float(src);
-    out[i] = p;
-    const u64 k = keys_sorted[i];
-    brick_head[i] = (i == 0 || (keys_sorted[i - 1] >> 6) != (k >> 6)) ? 1u : 0u;
-}
-
 // brick_start[rank] = first sorted position of the brick (brick_start[nbricks] = M is written by the host)
 __global__ void __launch_bounds__(256) k_brick_starts(const uint32_t* __restrict__ brick_head,
                                                       const uint32_t* __restrict__ brick_rank_incl, uint32_t M,
@@ -72,7 +58,9 @@ __global__ void __launch_bounds__(256) k_brick_starts(const uint32_t* __restrict
 // contiguous point range.  Thread l == 0 also inserts (bkey -> rank) into the open-addressing directory.
 __global__ void __launch_bounds__(256) k_brick_tables(const u64* __restrict__ keys_sorted,
                                                       const uint32_t* __restrict__ brick_start, uint32_t nbricks,
-                                                      uint32_t* __restrict__ starts, uint2* __restrict__ hash,
+                                                      const uint32_t* __restrict__ cap_incl, const uint32_t* __restrict__ cap,
+                                                      uint32_t* __restrict__ starts, uint32_t* __restrict__ cap_end,
+                                                      uint32_t* __restrict__ live, uint2* __restrict__ hash,
                                                       uint32_t hash_mask, int hash_shift) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= nbricks * (uint32_t)kBrickStride) return;
@@ -85,8 +73,12 @@ __global__ void __launch_bounds__(256) k_brick_tables(const u64* __restrict__ ke
         const uint32_t mid = (lo + hi) >> 1;
         if (keys_sorted[mid] < target) lo = mid + 1; else hi = mid;
     }
-    starts[t] = lo;
+    // the brick's points live at [base, base + count) of the storage, followed by its slack up to cap_end
+    const uint32_t base = cap_incl[rank] - cap[rank];
+    starts[t] = base + (lo - b0);
     if (l == 0) {
+        cap_end[rank] = base + cap[rank];
+        live[rank] = b1 - b0;
         const uint32_t k32 = (uint32_t)bkey;
         uint32_t slot = hash_slot(k32, hash_shift);
         for (;;) {
@@ -98,6 +90,37 @@ __global__ void __launch_bounds__(256) k_brick_tables(const u64* __restrict__ ke
             slot = (slot + 1) & hash_mask;
         }
     }
+}
+
+// Storage layout with slack: brick r owns [base_r, base_r + cap_r), cap_r = count_r + max(8, count_r / 4), so that points can
+// be inserted into a brick (flh_mapinc.hip: k_brick_rewrite) without moving any other brick.
+__global__ void __launch_bounds__(256) k_brick_heads(const u64* __restrict__ keys_sorted, uint32_t M, uint32_t* __restrict__ bh) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    bh[i] = (i == 0 || (keys_sorted[i - 1] >> 6) != (keys_sorted[i] >> 6)) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k_brick_caps(const uint32_t* __restrict__ brick_start, uint32_t nbricks,
+                                                    uint32_t* __restrict__ cap) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= nbricks) return;
+    const uint32_t cnt = brick_start[r + 1] - brick_start[r];
+    cap[r] = cnt + max(8u, cnt >> 2);
+}
+__global__ void __launch_bounds__(256) k_fill_tomb(float4* __restrict__ pts, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) pts[i] = tombstone();
+}
+__global__ void __launch_bounds__(256) k_map_place(const float4* __restrict__ pts, const uint32_t* __restrict__ vals_sorted,
+                                                   const uint32_t* __restrict__ brick_rank_incl, const uint32_t* __restrict__ brick_start,
+                                                   const uint32_t* __restrict__ cap_incl, const uint32_t* __restrict__ cap, uint32_t M,
+                                                   float4* __restrict__ out) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    const uint32_t src = vals_sorted[j];
+    float4 p = pts[src];
+    p.w = __uint_as_float(src);  // identity of the point = its position in the index-ordered array
+    const uint32_t r = brick_rank_incl[j] - 1;
+    out[(cap_incl[r] - cap[r]) + (j - brick_start[r])] = p;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -132,7 +155,7 @@ struct Top5 {
         for (int j = 0; j < 5; ++j) { k[j] = kInfKey; p[j] = 0; }
     }
     __device__ __forceinline__ void insert(u64 key, uint32_t pos) {
-        if (key < k[4]) {
+        if (key < k[4] && (uint32_t)(key >> 32) < 0x7F800000u) {  // +inf distance = an empty storage slot: never a neighbour
             k[4] = key;
             p[4] = pos;
 #pragma unroll
@@ -929,21 +952,38 @@ hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, c
 hipError_t inclusive_sum(void* tmp, size_t& tmp_bytes, const uint32_t* in, uint32_t* out, uint32_t M, hipStream_t st) {
     return hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, in, out, (int)M, st);
 }
-hipError_t launch_map_gather(const float4* pts, const u64* ks, const uint32_t* vs, uint32_t M, float4* out,
-                             uint32_t* brick_head, hipStream_t st) {
-    hipLaunchKernelGGL(k_map_gather, dim3(cdiv(M, 256)), dim3(256), 0, st, pts, ks, vs, M, out, brick_head);
-    return hipGetLastError();
-}
 hipError_t launch_brick_starts(const uint32_t* brick_head, const uint32_t* rank_incl, uint32_t M, uint32_t* brick_start,
                                hipStream_t st) {
     hipLaunchKernelGGL(k_brick_starts, dim3(cdiv(M, 256)), dim3(256), 0, st, brick_head, rank_incl, M, brick_start);
     return hipGetLastError();
 }
-hipError_t launch_brick_tables(const u64* ks, const uint32_t* brick_start, uint32_t nbricks, uint32_t* starts, uint2* hash,
+hipError_t launch_brick_tables(const u64* ks, const uint32_t* brick_start, uint32_t nbricks, const uint32_t* cap_incl,
+                               const uint32_t* cap, uint32_t* starts, uint32_t* cap_end, uint32_t* live, uint2* hash,
                                uint32_t hash_mask, int hash_shift, hipStream_t st) {
     if (nbricks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_brick_tables, dim3(cdiv((long long)nbricks * kBrickStride, 256)), dim3(256), 0, st, ks,
-                       brick_start, nbricks, starts, hash, hash_mask, hash_shift);
+                       brick_start, nbricks, cap_incl, cap, starts, cap_end, live, hash, hash_mask, hash_shift);
+    return hipGetLastError();
+}
+hipError_t launch_brick_heads(const u64* ks, uint32_t M, uint32_t* bh, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_brick_heads, dim3(cdiv(M, 256)), dim3(256), 0, st, ks, M, bh);
+    return hipGetLastError();
+}
+hipError_t launch_brick_caps(const uint32_t* brick_start, uint32_t nbricks, uint32_t* cap, hipStream_t st) {
+    if (nbricks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_brick_caps, dim3(cdiv(nbricks, 256)), dim3(256), 0, st, brick_start, nbricks, cap);
+    return hipGetLastError();
+}
+hipError_t launch_fill_tomb(float4* pts, uint32_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_tomb, dim3(cdiv(n, 256)), dim3(256), 0, st, pts, n);
+    return hipGetLastError();
+}
+hipError_t launch_map_place(const float4* pts, const uint32_t* vs, const uint32_t* br_incl, const uint32_t* brick_start,
+                            const uint32_t* cap_incl, const uint32_t* cap, uint32_t M, float4* out, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_map_place, dim3(cdiv(M, 256)), dim3(256), 0, st, pts, vs, br_incl, brick_start, cap_incl, cap, M, out);
     return hipGetLastError();
 }
 

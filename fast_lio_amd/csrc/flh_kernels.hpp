@@ -12,12 +12,16 @@ hipError_t launch_map_keys(const GridParams& g, const float4* pts, uint32_t M, u
 hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const unsigned long long* kin, unsigned long long* kout,
                       const uint32_t* vin, uint32_t* vout, uint32_t M, hipStream_t st);
 hipError_t inclusive_sum(void* tmp, size_t& tmp_bytes, const uint32_t* in, uint32_t* out, uint32_t M, hipStream_t st);
-hipError_t launch_map_gather(const float4* pts, const unsigned long long* ks, const uint32_t* vs, uint32_t M,
-                             float4* out, uint32_t* brick_head, hipStream_t st);
+hipError_t launch_brick_heads(const unsigned long long* ks, uint32_t M, uint32_t* bh, hipStream_t st);
 hipError_t launch_brick_starts(const uint32_t* brick_head, const uint32_t* rank_incl, uint32_t M, uint32_t* brick_start,
                                hipStream_t st);
+hipError_t launch_brick_caps(const uint32_t* brick_start, uint32_t nbricks, uint32_t* cap, hipStream_t st);
+hipError_t launch_fill_tomb(float4* pts, uint32_t n, hipStream_t st);
+hipError_t launch_map_place(const float4* pts, const uint32_t* vs, const uint32_t* br_incl, const uint32_t* brick_start,
+                            const uint32_t* cap_incl, const uint32_t* cap, uint32_t M, float4* out, hipStream_t st);
 hipError_t launch_brick_tables(const unsigned long long* ks, const uint32_t* brick_start, uint32_t nbricks,
-                               uint32_t* starts, uint2* hash, uint32_t hash_mask, int hash_shift, hipStream_t st);
+                               const uint32_t* cap_incl, const uint32_t* cap, uint32_t* starts, uint32_t* cap_end, uint32_t* live,
+                               uint2* hash, uint32_t hash_mask, int hash_shift, hipStream_t st);
 
 hipError_t launch_scan_keys(const float4* raw, uint32_t N, float quantum, unsigned long long* keys, uint32_t* vals,
                             hipStream_t st);
@@ -44,8 +48,8 @@ hipError_t launch_fit(const StateDev& s, const float4* body, const float4* nn_pt
 // ---- flh_mapinc.hip: map_incremental and the incremental map ----
 hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t map_points, const StateDev& s_search,
                               const StateDev& s_post, const float4* body, float4* nn_pts, const uint8_t* nn_cnt,
-                              const float* nn_d2, float max_sqdist, int N, double fsm, int ekf_inited, float4* world_out,
-                              uint8_t* cls, hipStream_t st);
+                              const float* nn_d2, float max_sqdist, int N, double fsm, int ekf_inited, const uint32_t* live,
+                              float4* world_out, uint8_t* cls, hipStream_t st);
 hipError_t launch_cls_flags(const uint8_t* cls, int N, uint32_t* flags, hipStream_t st);
 hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* incl, int N, float4* out,
                               hipStream_t st);
@@ -54,13 +58,20 @@ hipError_t launch_add_keys(const float4* add, uint32_t n, double ds, unsigned lo
                            hipStream_t st);
 hipError_t sort_vox_pairs(void* tmp, size_t& tmp_bytes, const unsigned long long* kin, unsigned long long* kout,
                           const uint32_t* vin, uint32_t* vout, uint32_t n, hipStream_t st);
-hipError_t launch_add_resolve(const GridParams& g, const float4* add, const unsigned long long* ks, const uint32_t* vs,
-                              uint32_t n, double ds, uint8_t* dead_old, uint8_t* alive_new, hipStream_t st);
-hipError_t launch_delete_boxes(const float4* pts, uint32_t M, const float* boxes, int nb, uint8_t* dead, hipStream_t st);
-hipError_t launch_alive_flags(const uint8_t* dead_old, uint32_t M, const uint8_t* alive_new, uint32_t n, uint32_t* flags,
-                              hipStream_t st);
-hipError_t launch_compact(const float4* old_pts, uint32_t M, const float4* new_pts, uint32_t n, const uint32_t* flags,
-                          const uint32_t* incl, float4* out, hipStream_t st);
+hipError_t launch_add_resolve(const GridParams& g, float4* pts_rw, const float4* add, const unsigned long long* ks,
+                              const uint32_t* vs, uint32_t n, double ds, uint8_t* dead_id, uint32_t* live, uint32_t* ctr,
+                              uint8_t* alive_new, hipStream_t st);
+hipError_t launch_delete_boxes(const GridParams& g, float4* pts_rw, uint32_t n_slots, const float* boxes, int nb, uint8_t* dead_id,
+                               uint32_t* live, uint32_t* ctr, hipStream_t st);
+hipError_t launch_ins_prepare(const GridParams& g, const float4* add, const uint8_t* alive_new, const uint32_t* incl, uint32_t n,
+                              uint32_t n_ids, float4* map_orig, uint8_t* dead_id, float4* ins, unsigned long long* keys,
+                              uint32_t* vals, uint32_t* ctr, hipStream_t st);
+hipError_t launch_brick_rewrite(const GridParams& g, float4* pts, uint32_t* starts, uint2* hash, uint32_t* cap_end, uint32_t* live,
+                                uint32_t* ctr, const float4* ins, const unsigned long long* ks, const uint32_t* perm, uint32_t n,
+                                uint32_t pts_cap, uint32_t rows_cap, hipStream_t st);
+hipError_t launch_byte_flags(const uint8_t* in, uint32_t n, int invert, uint32_t* flags, hipStream_t st);
+hipError_t launch_live_compact(const float4* map_orig, const uint32_t* flags, const uint32_t* incl, uint32_t n_ids, float4* out,
+                               hipStream_t st);
 
 // ---- flh_scanprep.hip: pcl::VoxelGrid of the scan ----
 hipError_t launch_undistort(const StateDev& s_end, const double* poses, int n_pose, const float4* raw, uint32_t n, float4* out,

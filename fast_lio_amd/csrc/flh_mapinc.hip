@@ -31,7 +31,8 @@ static inline int cdiv2(long long a, long long b) { return (int)((a + b - 1) / b
 // points_near[0] of a point with NO map point inside it -- is served by k_far_nearest first.
 __global__ void __launch_bounds__(256)
 k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, const uint8_t* __restrict__ nn_cnt,
-              const float* __restrict__ nn_d2, float max_sqdist, int N, uint32_t hash_size, float4* __restrict__ nn_pts) {
+              const float* __restrict__ nn_d2, float max_sqdist, int N, uint32_t hash_size, const uint32_t* __restrict__ live,
+              float4* __restrict__ nn_pts) {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= N) return;
@@ -56,11 +57,11 @@ k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, 
             ub2 += dmax * dmax;
         }
     };
-    // pass 1: every brick holds at least one point, so min over bricks of the far-corner distance bounds the answer
+    // pass 1: a brick with a live point holds one within its far corner, so the min over such bricks bounds the answer
     float best_ub = INFINITY;
     for (uint32_t slot = lane; slot < hash_size; slot += 64) {
         const unsigned long long e = hash64[slot];
-        if ((uint32_t)e == kEmptyKey) continue;
+        if ((uint32_t)e == kEmptyKey || live[(uint32_t)(e >> 32)] == 0u) continue;
         float lb2, ub2;
         box((uint32_t)e, lb2, ub2);
         best_ub = fminf(best_ub, ub2);
@@ -81,6 +82,7 @@ k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, 
         const uint32_t i0 = stt[0], i1 = stt[64];
         for (uint32_t i = i0; i < i1; ++i) {
             const float4 p = g.pts[i];
+            if (is_tombstone(p)) continue;
             const float d = dist2(p.x, p.y, p.z, wx, wy, wz);
             const u64 k = ((u64)__float_as_uint(d) << 32) | (u64)__float_as_uint(p.w);
             if (k < best) { best = k; best_p = p; }
@@ -218,14 +220,29 @@ __global__ void __launch_bounds__(256) k_add_keys(const float4* __restrict__ add
     vals[i] = i;
 }
 
+// (start, count) of a cell and the rank of its brick
+__device__ __forceinline__ uint2 lookup_cell_rank(const GridParams& g, int cx, int cy, int cz, uint32_t& rank) {
+    rank = kEmptyKey;
+    if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cy >= (unsigned)g.ny || (unsigned)cz >= (unsigned)g.nz)
+        return make_uint2(0u, 0u);
+    rank = lookup_brick(g, brick_key(cx, cy, cz));
+    if (rank == kEmptyKey) return make_uint2(0u, 0u);
+    const uint32_t* st = g.starts + (size_t)rank * kBrickStride + cell_local(cx, cy, cz);
+    const uint32_t a = st[0], b = st[1];
+    return make_uint2(a, b - a);
+}
+
 // One thread per run of new points sharing a voxel (the radix sort is stable, so a run lists them in input
 // order).  Final state of the voxel = the single point nearest to its centre among {points already in the map}
 // U {new points}; ties: a new point beats an existing one, a later new point beats an earlier one; a voxel whose
 // single existing point stays nearest is left untouched.
+// A displaced map point is removed on the spot: its identity is marked dead (dead_id), its storage slot becomes a
+// tombstone (no search will ever select it), its brick's live count drops.  Threads of other voxels may read that slot
+// while it changes -- either value lies outside THEIR voxel, so it does not matter which they see.
 __global__ void __launch_bounds__(256)
-k_add_resolve(GridParams g, const float4* __restrict__ add, const u64* __restrict__ keys_sorted,
-              const uint32_t* __restrict__ vals_sorted, uint32_t n, double ds, uint8_t* __restrict__ dead_old,
-              uint8_t* __restrict__ alive_new) {
+k_add_resolve(GridParams g, float4* pts_rw /* = g.pts */, const float4* __restrict__ add, const u64* __restrict__ keys_sorted,
+              const uint32_t* __restrict__ vals_sorted, uint32_t n, double ds, uint8_t* __restrict__ dead_id,
+              uint32_t* __restrict__ live, uint32_t* __restrict__ ctr, uint8_t* __restrict__ alive_new) {
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const u64 key = keys_sorted[j];
@@ -261,7 +278,8 @@ k_add_resolve(GridParams g, const float4* __restrict__ add, const u64* __restric
             for (int x = c0x; x <= c1x; ++x) {
                 const uint2 ce = lookup_cell(g, x, y, z);
                 for (uint32_t i = ce.x; i < ce.x + ce.y; ++i) {
-                    const float4 q = g.pts[i];
+                    const float4 q = pts_rw[i];
+                    if (is_tombstone(q)) continue;
                     long long qx, qy, qz;
                     vox_of(q.x, q.y, q.z, ds, qx, qy, qz);
                     if (qx != kx || qy != ky || qz != kz) continue;
@@ -278,50 +296,209 @@ k_add_resolve(GridParams g, const float4* __restrict__ add, const u64* __restric
         for (int z = c0z; z <= c1z; ++z)
             for (int y = c0y; y <= c1y; ++y)
                 for (int x = c0x; x <= c1x; ++x) {
-                    const uint2 ce = lookup_cell(g, x, y, z);
+                    uint32_t rank;
+                    const uint2 ce = lookup_cell_rank(g, x, y, z, rank);
                     for (uint32_t i = ce.x; i < ce.x + ce.y; ++i) {
-                        const float4 q = g.pts[i];
+                        const float4 q = pts_rw[i];
+                        if (is_tombstone(q)) continue;
                         long long qx, qy, qz;
                         vox_of(q.x, q.y, q.z, ds, qx, qy, qz);
                         if (qx != kx || qy != ky || qz != kz) continue;
                         const uint32_t id = __float_as_uint(q.w);
-                        if (new_wins || id != best_e) dead_old[id] = 1;
+                        if (new_wins || id != best_e) {
+                            dead_id[id] = 1;
+                            pts_rw[i] = tombstone();
+                            atomicSub(live + rank, 1u);
+                            atomicAdd(ctr + 3, 1u);
+                        }
                     }
                 }
     }
     if (new_wins) alive_new[best_new] = 1;
 }
 
-__global__ void __launch_bounds__(256) k_delete_boxes(const float4* __restrict__ pts, uint32_t M,
-                                                      const float* __restrict__ boxes, int nb,
-                                                      uint8_t* __restrict__ dead) {
+// Delete_Point_Boxes over the storage: every live slot inside a box becomes a tombstone
+__global__ void __launch_bounds__(256) k_delete_boxes(GridParams g, float4* pts_rw /* = g.pts */, uint32_t n_slots,
+                                                      const float* __restrict__ boxes, int nb, uint8_t* __restrict__ dead_id,
+                                                      uint32_t* __restrict__ live, uint32_t* __restrict__ ctr) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    const float4 p = pts[i];
+    if (i >= n_slots) return;
+    const float4 p = pts_rw[i];
+    if (is_tombstone(p)) return;
     bool del = false;
     for (int b = 0; b < nb; ++b) {
         const float* bx = boxes + 6 * b;
         if (p.x >= bx[0] && p.x < bx[3] && p.y >= bx[1] && p.y < bx[4] && p.z >= bx[2] && p.z < bx[5]) del = true;
     }
-    if (del) dead[i] = 1;
+    if (!del) return;
+    int cx, cy, cz;
+    float fx, fy, fz;
+    cell_of(g, p.x, p.y, p.z, cx, cy, cz, fx, fy, fz);
+    cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);  // as k_map_keys
+    const uint32_t rank = lookup_brick(g, brick_key(cx, cy, cz));
+    dead_id[__float_as_uint(p.w)] = 1;
+    pts_rw[i] = tombstone();
+    if (rank != kEmptyKey) atomicSub(live + rank, 1u);
+    atomicAdd(ctr + 3, 1u);
 }
 
-// alive flags (1 - dead for old points, alive_new for new ones) -> 0/1 words for the prefix sum
-__global__ void __launch_bounds__(256) k_alive_flags(const uint8_t* __restrict__ dead_old, uint32_t M,
-                                                     const uint8_t* __restrict__ alive_new, uint32_t n,
-                                                     uint32_t* __restrict__ flags) {
+// ------------------------------------------------------------------------------------------------
+// Insertion of points into the slack-carrying brick storage.
+// k_ins_prepare: surviving new points get their identity (n_ids + rank), are appended to the index-ordered array and
+//   keyed by the brick they fall into; a point outside the grid raises flag 1 (the caller re-indexes from scratch).
+// k_brick_rewrite: one block per brick that receives points: its live points + the new ones are counting-sorted by local
+//   cell in LDS and written back -- in place while they fit the brick's capacity, else into a freshly bump-allocated range
+//   (the old one becomes tombstones); a brick seen for the first time gets a table row and a directory entry.  Nothing
+//   outside the brick moves.  Anything that does not fit (LDS tile, storage, table rows, directory) raises a flag and leaves
+//   the brick as it was; the caller then rebuilds the index from the index-ordered array, which is always complete.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTile = 2048;  // points of one brick that fit the LDS tile
+
+__global__ void __launch_bounds__(256)
+k_ins_prepare(GridParams g, const float4* __restrict__ add, const uint8_t* __restrict__ alive_new, const uint32_t* __restrict__ incl,
+              uint32_t n, uint32_t n_ids, float4* __restrict__ map_orig, uint8_t* __restrict__ dead_id, float4* __restrict__ ins,
+              u64* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ ctr) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < M) flags[i] = dead_old[i] ? 0u : 1u;
-    else if (i < M + n) flags[i] = alive_new[i - M] ? 1u : 0u;
+    if (i >= n || !alive_new[i]) return;
+    const uint32_t r = incl[i] - 1, id = n_ids + r;
+    float4 p = add[i];
+    p.w = 0.f;
+    map_orig[id] = p;
+    dead_id[id] = 0;
+    int cx, cy, cz;
+    float fx, fy, fz;
+    cell_of(g, p.x, p.y, p.z, cx, cy, cz, fx, fy, fz);
+    if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cy >= (unsigned)g.ny || (unsigned)cz >= (unsigned)g.nz) {
+        atomicOr(ctr + 2, 1u);
+        cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
+    }
+    p.w = __uint_as_float(id);
+    ins[r] = p;
+    keys[r] = (u64)brick_key(cx, cy, cz);
+    vals[r] = r;
 }
-// survivors keep their relative order: old points first, then the new ones
-__global__ void __launch_bounds__(256) k_compact(const float4* __restrict__ old_pts, uint32_t M,
-                                                 const float4* __restrict__ new_pts, uint32_t n,
-                                                 const uint32_t* __restrict__ flags, const uint32_t* __restrict__ incl,
-                                                 float4* __restrict__ out) {
+
+__global__ void __launch_bounds__(128)
+k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g.starts */, uint2* hash /* = g.hash */,
+                uint32_t* __restrict__ cap_end, uint32_t* __restrict__ live, uint32_t* __restrict__ ctr,
+                const float4* __restrict__ ins, const u64* __restrict__ ks, const uint32_t* __restrict__ perm, uint32_t n,
+                uint32_t pts_cap, uint32_t rows_cap) {
+    __shared__ float4 buf[kTile];
+    __shared__ uint32_t hist[64], offs[64];
+    __shared__ uint32_t s_cnt, s_base, s_rank, s_cap_end, s_ok;
+    const uint32_t j = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (j >= n) return;
+    const u64 key = ks[j];
+    if (j > 0 && ks[j - 1] == key) return;  // block-uniform: not the head of its brick's run
+    uint32_t e = j + 1;
+    while (e < n && ks[e] == key) ++e;
+    const uint32_t run = e - j;
+    const uint32_t rank = lookup_brick(g, (uint32_t)key);
+    uint32_t old_base = 0, old_end = 0, old_cap_end = 0;
+    if (rank != kEmptyKey) {
+        old_base = starts[(size_t)rank * kBrickStride];
+        old_end = starts[(size_t)rank * kBrickStride + 64];
+        old_cap_end = cap_end[rank];
+    }
+    if (tid == 0) { s_cnt = 0; s_ok = 1; }
+    if (tid < 64) hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = old_base + tid; i < old_end; i += 128) {
+        const float4 p = pts[i];
+        if (!is_tombstone(p)) {
+            const uint32_t k = atomicAdd(&s_cnt, 1u);
+            if (k < (uint32_t)kTile) buf[k] = p;
+        }
+    }
+    __syncthreads();
+    const uint32_t nold = s_cnt, total = nold + run;
+    if (total > (uint32_t)kTile) {  // block-uniform
+        if (tid == 0) atomicOr(ctr + 2, 2u);
+        return;
+    }
+    for (uint32_t i = tid; i < run; i += 128) buf[nold + i] = ins[perm[j + i]];
+    if (tid == 0) {
+        if (rank != kEmptyKey && old_base + total <= old_cap_end) {
+            s_base = old_base; s_rank = rank; s_cap_end = old_cap_end;
+        } else {
+            const uint32_t newcap = total + max(8u, total >> 2);
+            const uint32_t nb = atomicAdd(ctr + 0, newcap);
+            uint32_t r = rank;
+            if (nb + newcap > pts_cap || nb + newcap < nb) { atomicOr(ctr + 2, 4u); s_ok = 0; }
+            else if (rank == kEmptyKey) {
+                r = atomicAdd(ctr + 1, 1u);
+                if (r >= rows_cap) { atomicOr(ctr + 2, 8u); s_ok = 0; }
+                else {
+                    const uint32_t k32 = (uint32_t)key;
+                    uint32_t slot = hash_slot(k32, g.hash_shift);
+                    bool placed = false;
+                    for (uint32_t tries = 0; tries <= g.hash_mask; ++tries) {
+                        const uint32_t prev = atomicCAS(&hash[slot].x, kEmptyKey, k32);
+                        if (prev == kEmptyKey) { hash[slot].y = r; placed = true; break; }
+                        slot = (slot + 1) & g.hash_mask;
+                    }
+                    if (!placed) { atomicOr(ctr + 2, 16u); s_ok = 0; }
+                }
+            }
+            s_base = nb; s_rank = r; s_cap_end = nb + newcap;
+        }
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    const uint32_t base = s_base, r = s_rank;
+    // counting sort by local cell
+    uint32_t cl[kTile / 128];
+#pragma unroll
+    for (int u = 0; u < kTile / 128; ++u) {
+        const uint32_t i = tid + u * 128;
+        cl[u] = 0;
+        if (i < total) {
+            const float4 p = buf[i];
+            int cx, cy, cz;
+            float fx, fy, fz;
+            cell_of(g, p.x, p.y, p.z, cx, cy, cz, fx, fy, fz);
+            cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
+            cl[u] = cell_local(cx, cy, cz);
+            atomicAdd(&hist[cl[u]], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int c = 0; c < 64; ++c) {
+            offs[c] = acc;
+            starts[(size_t)r * kBrickStride + c] = base + acc;
+            acc += hist[c];
+        }
+        starts[(size_t)r * kBrickStride + 64] = base + acc;
+        cap_end[r] = s_cap_end;
+        live[r] = total;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kTile / 128; ++u) {
+        const uint32_t i = tid + u * 128;
+        if (i < total) pts[base + atomicAdd(&offs[cl[u]], 1u)] = buf[i];
+    }
+    // what the brick no longer uses becomes tombstones: the tail of the old range (in place), or all of it (relocated)
+    if (rank != kEmptyKey) {
+        const uint32_t a = (base == old_base) ? old_base + total : old_base;
+        const uint32_t b = (base == old_base) ? old_end : old_cap_end;
+        for (uint32_t i = a + tid; i < b; i += 128) pts[i] = tombstone();
+    }
+}
+
+// index-ordered array -> contiguous array of the live points, in order (download, full re-index)
+__global__ void __launch_bounds__(256) k_byte_flags(const uint8_t* __restrict__ in, uint32_t n, int invert, uint32_t* __restrict__ flags) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M + n || !flags[i]) return;
-    float4 p = i < M ? old_pts[i] : new_pts[i - M];
+    if (i < n) flags[i] = ((in[i] != 0) != (invert != 0)) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k_live_compact(const float4* __restrict__ map_orig, const uint32_t* __restrict__ flags,
+                                                      const uint32_t* __restrict__ incl, uint32_t n_ids, float4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ids || !flags[i]) return;
+    float4 p = map_orig[i];
     p.w = 0.f;
     out[incl[i] - 1] = p;
 }
@@ -329,12 +506,12 @@ __global__ void __launch_bounds__(256) k_compact(const float4* __restrict__ old_
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t map_points, const StateDev& s_search,
                               const StateDev& s_post, const float4* body, float4* nn_pts, const uint8_t* nn_cnt,
-                              const float* nn_d2, float max_sqdist, int N, double fsm, int ekf_inited, float4* world_out,
-                              uint8_t* cls, hipStream_t st) {
+                              const float* nn_d2, float max_sqdist, int N, double fsm, int ekf_inited, const uint32_t* live,
+                              float4* world_out, uint8_t* cls, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     if (map_points > 0 && ekf_inited)
         hipLaunchKernelGGL(k_far_nearest, dim3(cdiv2(N, 4)), dim3(256), 0, st, g, s_search, body, nn_cnt, nn_d2, max_sqdist, N,
-                           hash_size, nn_pts);
+                           hash_size, live, nn_pts);
     hipLaunchKernelGGL(k_mi_classify, dim3(cdiv2(N, 256)), dim3(256), 0, st, s_post, body, nn_pts, nn_cnt, nn_d2, max_sqdist, N,
                        map_points, fsm, ekf_inited, world_out, cls);
     return hipGetLastError();
@@ -366,28 +543,44 @@ hipError_t sort_vox_pairs(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kou
                           uint32_t n, hipStream_t st) {
     return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kin, kout, vin, vout, (int)n, 0, 63, st);
 }
-hipError_t launch_add_resolve(const GridParams& g, const float4* add, const u64* ks, const uint32_t* vs, uint32_t n,
-                              double ds, uint8_t* dead_old, uint8_t* alive_new, hipStream_t st) {
+hipError_t launch_add_resolve(const GridParams& g, float4* pts_rw, const float4* add, const u64* ks, const uint32_t* vs, uint32_t n,
+                              double ds, uint8_t* dead_id, uint32_t* live, uint32_t* ctr, uint8_t* alive_new, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_add_resolve, dim3(cdiv2(n, 256)), dim3(256), 0, st, g, add, ks, vs, n, ds, dead_old, alive_new);
+    hipLaunchKernelGGL(k_add_resolve, dim3(cdiv2(n, 256)), dim3(256), 0, st, g, pts_rw, add, ks, vs, n, ds, dead_id, live, ctr,
+                       alive_new);
     return hipGetLastError();
 }
-hipError_t launch_delete_boxes(const float4* pts, uint32_t M, const float* boxes, int nb, uint8_t* dead, hipStream_t st) {
-    if (M == 0 || nb == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_delete_boxes, dim3(cdiv2(M, 256)), dim3(256), 0, st, pts, M, boxes, nb, dead);
+hipError_t launch_delete_boxes(const GridParams& g, float4* pts_rw, uint32_t n_slots, const float* boxes, int nb, uint8_t* dead_id,
+                               uint32_t* live, uint32_t* ctr, hipStream_t st) {
+    if (n_slots == 0 || nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_delete_boxes, dim3(cdiv2(n_slots, 256)), dim3(256), 0, st, g, pts_rw, n_slots, boxes, nb, dead_id, live, ctr);
     return hipGetLastError();
 }
-hipError_t launch_alive_flags(const uint8_t* dead_old, uint32_t M, const uint8_t* alive_new, uint32_t n, uint32_t* flags,
-                              hipStream_t st) {
-    if (M + n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_alive_flags, dim3(cdiv2((long long)M + n, 256)), dim3(256), 0, st, dead_old, M, alive_new, n, flags);
+hipError_t launch_ins_prepare(const GridParams& g, const float4* add, const uint8_t* alive_new, const uint32_t* incl, uint32_t n,
+                              uint32_t n_ids, float4* map_orig, uint8_t* dead_id, float4* ins, u64* keys, uint32_t* vals,
+                              uint32_t* ctr, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ins_prepare, dim3(cdiv2(n, 256)), dim3(256), 0, st, g, add, alive_new, incl, n, n_ids, map_orig, dead_id, ins,
+                       keys, vals, ctr);
     return hipGetLastError();
 }
-hipError_t launch_compact(const float4* old_pts, uint32_t M, const float4* new_pts, uint32_t n, const uint32_t* flags,
-                          const uint32_t* incl, float4* out, hipStream_t st) {
-    if (M + n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_compact, dim3(cdiv2((long long)M + n, 256)), dim3(256), 0, st, old_pts, M, new_pts, n, flags, incl,
-                       out);
+hipError_t launch_brick_rewrite(const GridParams& g, float4* pts, uint32_t* starts, uint2* hash, uint32_t* cap_end, uint32_t* live,
+                                uint32_t* ctr, const float4* ins, const u64* ks, const uint32_t* perm, uint32_t n, uint32_t pts_cap,
+                                uint32_t rows_cap, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_brick_rewrite, dim3(n), dim3(128), 0, st, g, pts, starts, hash, cap_end, live, ctr, ins, ks, perm, n, pts_cap,
+                       rows_cap);
+    return hipGetLastError();
+}
+hipError_t launch_byte_flags(const uint8_t* in, uint32_t n, int invert, uint32_t* flags, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_byte_flags, dim3(cdiv2(n, 256)), dim3(256), 0, st, in, n, invert, flags);
+    return hipGetLastError();
+}
+hipError_t launch_live_compact(const float4* map_orig, const uint32_t* flags, const uint32_t* incl, uint32_t n_ids, float4* out,
+                               hipStream_t st) {
+    if (n_ids == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_live_compact, dim3(cdiv2(n_ids, 256)), dim3(256), 0, st, map_orig, flags, incl, n_ids, out);
     return hipGetLastError();
 }
 
