@@ -73,7 +73,7 @@ EXPORTS = [
     "flh_esekf_predict", "flh_esekf_update",
     "flh_map_add", "flh_map_delete_boxes", "flh_map_download", "flh_map_incremental", "flh_fetch_map_incremental",
     "flh_fov_segment", "flh_scan_stage_downsampled", "flh_fetch_scan",
-    "flh_scan_stage_undistorted", "flh_esekf_update_scan",
+    "flh_scan_stage_undistorted", "flh_esekf_update_scan", "flh_map_stats",
 ]
 
 _lib = None
@@ -109,6 +109,7 @@ def lib():
     L.flh_map_add.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_double]
     L.flh_map_delete_boxes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.flh_map_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.flh_map_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.flh_map_incremental.argtypes = [C.c_void_p, _f64p, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32)]
     L.flh_fetch_map_incremental.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -211,6 +212,12 @@ class Handle:
         """ikdtree.Delete_Point_Boxes -- src/laserMapping.cpp:275.  boxes: nb x (min xyz, max xyz)."""
         b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
         _chk(lib().flh_map_delete_boxes(self._h, b.ctypes.data, b.shape[0]), "flh_map_delete_boxes")
+
+    def map_stats(self) -> dict:
+        out = (C.c_uint64 * 6)()
+        _chk(lib().flh_map_stats(self._h, out), "flh_map_stats")
+        return {"reindex": int(out[0]), "brickwise": int(out[1]), "slots_used": int(out[2]), "slots": int(out[3]),
+                "ids": int(out[4]), "bricks": int(out[5])}
 
     def map_download(self) -> np.ndarray:
         out = np.zeros((self.M, 3), np.float32)

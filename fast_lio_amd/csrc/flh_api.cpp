@@ -95,6 +95,7 @@ struct flh_handle {
     DevBuf<float4> ins;                    // points being inserted, with their ids
     std::vector<uint32_t> id_pos;          // id -> position among the live points (flh_fetch_neighbors), built on demand
     bool id_pos_valid = false;
+    uint64_t n_reindex = 0, n_inplace = 0; // full re-indexings / changes applied brick-wise since creation
     DevBuf<u64> mb_k0, mb_k1;              // index-build scratch (kept: the map is rebuilt after every change)
     DevBuf<uint32_t> mb_v0, mb_v1, mb_bh, mb_br, mb_bstart, mb_aabb;
     DevBuf<unsigned char> mb_tmp;
@@ -370,6 +371,7 @@ static int rebuild_index(flh_handle* h, DevBuf<float4>& pts, size_t M) {
     h->pts_cap = pts_cap;
     h->rows_cap = rows_cap;
     h->alloc_top = used;
+    ++h->n_reindex;
     h->id_pos_valid = false;
     if (&pts != &h->map_orig) std::swap(h->map_orig, pts);
     h->searched_once = false;  // cached neighbours refer to the previous map
@@ -515,6 +517,7 @@ static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size
         std::fprintf(stderr, "[map] +%u -%u -> M=%zu ids=%zu bricks=%u top=%u/%zu flags=%u%s\n", n_alive, h->h_ctr[3], h->M, h->n_ids,
                      h->h_ctr[1], h->h_ctr[0], h->pts_cap, h->h_ctr[2], h->h_ctr[2] ? " (re-index)" : "");
     if (h->h_ctr[2] != 0) return reindex_from_ids(h);
+    ++h->n_inplace;
     h->alloc_top = h->h_ctr[0];
     h->nbricks = h->h_ctr[1];
     return 0;
@@ -580,6 +583,14 @@ int flh_fov_segment(flh_handle* h, flh_local_map* lm, const double pos_lid[3], d
     const size_t before = h->M;
     if (!cub_needrm.empty() && flh_map_delete_boxes(h, boxes, cub_needrm.size()) != 0) return -1;
     if (kdtree_delete_counter) *kdtree_delete_counter = (int64_t)(before - h->M);
+    return 0;
+}
+
+// Bookkeeping of the brick storage: {full re-indexings, changes applied brick-wise, storage slots in use, storage slots,
+// ids handed out since the last re-indexing, bricks}.
+int flh_map_stats(const flh_handle* h, uint64_t out[6]) {
+    if (!h || !out) return fail("flh_map_stats: null argument");
+    out[0] = h->n_reindex; out[1] = h->n_inplace; out[2] = h->alloc_top; out[3] = h->pts_cap; out[4] = h->n_ids; out[5] = h->nbricks;
     return 0;
 }
 

@@ -81,6 +81,11 @@ int flh_map_add(flh_handle* h, const void* xyz, size_t stride_bytes, size_t n, i
 /* ikdtree.Delete_Point_Boxes(cub_needrm) -- src/laserMapping.cpp:275 (lasermap_fov_segment).  boxes = nb x
  * {min x,y,z, max x,y,z}; a point with min <= p < max on every axis is removed. */
 int flh_map_delete_boxes(flh_handle* h, const float* boxes, size_t nb);
+/* Bookkeeping of the device map: out = {full re-indexings so far, changes applied brick-wise (no re-indexing), storage slots
+ * in use, storage slots allocated, point ids handed out since the last re-indexing, bricks}.  The map's points sit in
+ * per-brick storage ranges with slack; an insert rewrites only the bricks it touches and a removal tombstones its slot;
+ * the whole index is rebuilt only when something no longer fits (a point outside the grid, storage or tables full). */
+int flh_map_stats(const flh_handle* h, uint64_t out[6]);
 /* The map in index order, 3 floats per point (what ikdtree.flatten / PCL_Storage hands back, :406-411). */
 int flh_map_download(flh_handle* h, float* xyz, size_t capacity_points);
 /* map_incremental() -- src/laserMapping.cpp:427-474, evaluated on the device from the neighbour cache the active

@@ -434,3 +434,69 @@ def test_velodyne_stream_with_incremental_map():
         cur = new
         same_points(h.map_download(), cur, f"map after scan {k}")
     assert grown > 0
+
+
+# ---------------------------------------------------------------------------------------------- brick storage paths
+def test_brickwise_updates_and_every_fallback(prob):
+    """The map index is changed brick by brick; whatever does not fit falls back to a full re-indexing from the id-ordered
+    array.  Each path must leave the same map (bit-exact vs the oracle) and a search that still matches."""
+    pr = prob
+    rng = np.random.default_rng(21)
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    cur = pr.map_xyz.astype(np.float32)
+    s0 = h.map_stats()
+    assert s0["reindex"] == 1 and s0["brickwise"] == 0
+
+    def step(add, downsample, tag, expect_reindex):
+        nonlocal cur
+        before = h.map_stats()
+        cur = po.map_add(cur, add, downsample, DS)
+        h.map_add(add, downsample, DS)
+        after = h.map_stats()
+        assert (after["reindex"] - before["reindex"] == 1) == expect_reindex, (tag, before, after)
+        assert h.M == len(cur), tag
+        same_points(h.map_download(), cur, tag)
+        return after
+
+    # 1. ordinary insert with down-sampling: brick-wise, in place
+    add = (cur[rng.integers(0, len(cur), 8000)] + rng.normal(0, 0.2, (8000, 3))).astype(np.float32)
+    a = step(add, True, "in place", False)
+    assert a["brickwise"] == 1
+    # 2. bricks that outgrow their slack are relocated (storage top moves), new bricks appear next to the map
+    centres = cur[rng.integers(0, len(cur), 40)]
+    crowd = (np.repeat(centres, 80, axis=0) + rng.uniform(-1.0, 1.0, (3200, 3))).astype(np.float32)   # +80 points in ~40 bricks
+    b = step(crowd, False, "relocation", False)
+    assert b["slots_used"] > a["slots_used"]
+    near = (cur.max(0) + rng.uniform(2.0, 25.0, (3000, 3))).astype(np.float32)     # inside the grid's padding
+    c = step(near, True, "new bricks", False)
+    assert c["bricks"] > b["bricks"]
+    search_matches(h, cur, pr.body, pr.x_true)
+    # 3. a point outside the grid forces a re-indexing (ids renumbered)
+    far = (cur.max(0) + rng.uniform(200.0, 260.0, (50, 3))).astype(np.float32)
+    d = step(far, True, "outside the grid", True)
+    assert d["ids"] == h.M
+    # 4. more points in one brick than the rewrite tile holds
+    blob = (cur[123] + rng.uniform(-0.7, 0.7, (2600, 3))).astype(np.float32)
+    step(blob, False, "brick beyond the LDS tile", True)
+    # 5. the storage runs out of slack after enough relocations
+    grew = False
+    for k in range(12):
+        heap = (cur[rng.integers(0, len(cur), 40000)] + rng.normal(0, 0.3, (40000, 3))).astype(np.float32)
+        before = h.map_stats()
+        cur = po.map_add(cur, heap, False, DS)
+        h.map_add(heap, False, DS)
+        grew = grew or h.map_stats()["reindex"] > before["reindex"]
+        if grew:
+            break
+    assert grew, "storage never filled up"
+    same_points(h.map_download(), cur, "after the storage filled up")
+    # 6. deletions are tombstones: ids stay, positions reported to the caller are those of the downloaded array
+    c0 = np.median(cur, axis=0)
+    boxes = np.array([np.r_[c0 - 8, c0 + 8]], np.float32)
+    cur = po.map_delete_boxes(cur, boxes)
+    h.map_delete_boxes(boxes)
+    st = h.map_stats()
+    assert st["ids"] > h.M == len(cur)
+    same_points(h.map_download(), cur, "after Delete_Point_Boxes")
+    assert search_matches(h, cur, pr.body, pr.x_true) > 1000
