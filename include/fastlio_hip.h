@@ -70,8 +70,9 @@ size_t flh_map_size(const flh_handle* h);
 /* ---- the incremental map around the hot path --------------------------------------
  * The map keeps an INDEX ORDER: after every change the survivors keep their relative order, points that were
  * already in the map first, inserted points after them.  flh_fetch_neighbors' indices and the search's
- * equal-distance tie-break (lower index) refer to that order.  Every change re-indexes the map on the device and
- * invalidates the active scan's neighbour cache (the next flh_eval must search, as the reference's does). */
+ * equal-distance tie-break (lower index) refer to that order.  A change rewrites only the bricks of the device index it
+ * touches (see flh_map_stats) and invalidates the active scan's neighbour cache (the next flh_eval must search, as the
+ * reference's does). */
 
 /* ikdtree.Add_Points(points, downsample_on) -- src/laserMapping.cpp:470-471, down-sampling length as set by
  * ikdtree.set_downsample_param(filter_size_map_min) (:868).  downsample != 0: per downsample_size voxel only the
