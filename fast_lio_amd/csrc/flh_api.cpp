@@ -100,7 +100,7 @@ struct flh_handle {
     DevBuf<uint32_t> mb_v0, mb_v1, mb_bh, mb_br, mb_bstart, mb_aabb;
     DevBuf<unsigned char> mb_tmp;
     DevBuf<float4> mu_add, mi_world;       // incremental update: points to insert; map_incremental's world points
-    DevBuf<uint8_t> mu_dead, mu_alive, mi_cls;
+    DevBuf<uint8_t> mu_alive, mi_cls;
     DevBuf<uint32_t> mu_flags, mu_incl;
     DevBuf<float> mu_boxes;
     size_t mi_valid_N = (size_t)-1;        // N of the scan the last classification belongs to
@@ -243,7 +243,7 @@ void flh_destroy(flh_handle* h) {
     h->ins.release();
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     h->map_orig.release(); h->map_next.release(); h->mb_aabb.release(); h->mu_add.release(); h->mi_world.release();
-    h->mu_dead.release(); h->mu_alive.release(); h->mi_cls.release(); h->mu_flags.release(); h->mu_incl.release(); h->mu_boxes.release();
+    h->mu_alive.release(); h->mi_cls.release(); h->mu_flags.release(); h->mu_incl.release(); h->mu_boxes.release();
     h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_list2.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
     h->world.release(); h->nn_pts.release(); h->normvec.release();
     h->nn_d2.release(); h->nn_cnt.release(); h->selected.release();
