@@ -4,11 +4,15 @@
 A "step" is one full update_iterated_dyn_share_modified() of one 100k-point Avia scan against the
 5M-point map (BASELINE.json configs[1]): up to 4 h_share_model evaluations (2 of them with the 5-NN
 search on this workload) plus the host-side 23x23 algebra.  Scans are staged in HBM before the timed
-region (flh_scan_stage); the PCIe-inclusive figure is printed to stderr.
+region (flh_scan_stage).
 
   python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0: the contract fields, `roofline` (HIP events on the handle's stream inside the timed
+region; `traffic` from the committed PMC summary), `cpu_baseline` (the oracle's restated reference path on a bounded
+sample), and -- measured after the timed region, never part of `value` -- `pcie_inclusive_scans_per_s`,
+`two_streams_per_gpu`, `map_incremental`, `scan_front_end`; with N > 1 also `shard_mode` (one scan's points split over
+the ranks, all-reduce of the 16x16 Gram block per pass).
 """
 from __future__ import annotations
 
