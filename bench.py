@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--cell", type=float, default=1.5)
     ap.add_argument("--sort", type=int, default=1, help="Morton-order the scan at staging (0 = keep input order)")
     ap.add_argument("--extrinsic-est", type=int, default=0)
-    ap.add_argument("--timing-stride", type=int, default=16,
+    ap.add_argument("--timing-stride", type=int, default=32,
                     help="record the per-kernel HIP events on every n-th evaluation of the timed region")
     ap.add_argument("--no-overlap-leg", action="store_true", help="skip the two-streams-per-GPU leg")
     ap.add_argument("--cpu-scans", type=int, default=3, help="scans timed on the CPU oracle (0 = skip)")

@@ -176,7 +176,8 @@ class esekf {
                 cov P_temp = fastlio_amd::inverse(P_ / R);
                 for (int a = 0; a < 12; ++a)
                     for (int b = 0; b < 12; ++b) P_temp(a, b) += HTH[a * 12 + b];
-                const cov P_inv = fastlio_amd::inverse(P_temp);
+                // only P_inv.block<n,12>(0,0) is read below (:1803-1806): the first 12 columns of the inverse, bit for bit
+                const Mat<n, 12> P_inv = fastlio_amd::inverse_cols<n, 12>(P_temp);
                 for (int r = 0; r < n; ++r) {
                     double s = 0;
                     for (int c = 0; c < 12; ++c) s += P_inv(r, c) * HTh[c];

@@ -219,6 +219,67 @@ inline bool inverse_lu_fixed(const double* A, double* Ainv) {
     return ok;
 }
 
+// The first NC columns of A^-1 only (the information-form update reads just P_inv.block<23,12>(0,0),
+// esekfom.hpp:1803-1806): same elimination, the identity carried with NC (padded) columns instead of N.  Column j of an
+// inverse depends on no other column, so these are bit for bit the first NC columns of inverse_lu_fixed<N>().
+template <int N, int NC>
+inline bool inverse_lu_fixed_cols(const double* A, double* Acols /* N x NC, row-major */) {
+    constexpr int S = (N + 7) & ~7;
+    constexpr int SC = (NC + 7) & ~7;
+    alignas(64) double LU[N * S];
+    alignas(64) double X[N * SC];
+    for (int i = 0; i < N; ++i) {
+        for (int j = 0; j < N; ++j) LU[i * S + j] = A[i * N + j];
+        for (int j = N; j < S; ++j) LU[i * S + j] = 0.0;
+        for (int j = 0; j < SC; ++j) X[i * SC + j] = 0.0;
+        if (i < NC) X[i * SC + i] = 1.0;
+    }
+    bool ok = true;
+    for (int k = 0; k < N; ++k) {
+        int p = k;
+        double best = std::fabs(LU[k * S + k]);
+        for (int i = k + 1; i < N; ++i) {
+            const double v = std::fabs(LU[i * S + k]);
+            if (v > best) { best = v; p = i; }
+        }
+        if (best == 0.0) ok = false;
+        if (p != k) {
+            for (int j = 0; j < S; ++j) { const double t = LU[k * S + j]; LU[k * S + j] = LU[p * S + j]; LU[p * S + j] = t; }
+            for (int j = 0; j < SC; ++j) { const double t = X[k * SC + j]; X[k * SC + j] = X[p * SC + j]; X[p * SC + j] = t; }
+        }
+        const double piv = LU[k * S + k];
+        const double* rk = LU + k * S;
+        const double* xk = X + k * SC;
+        for (int i = k + 1; i < N; ++i) {
+            const double l = LU[i * S + k] / piv;
+            double* ri = LU + i * S;
+            for (int j = 0; j < S; ++j) ri[j] -= l * rk[j];
+            ri[k] = l;
+            double* xi = X + i * SC;
+            for (int j = 0; j < SC; ++j) xi[j] -= l * xk[j];
+        }
+    }
+    for (int i = N - 1; i >= 0; --i) {
+        double* xi = X + i * SC;
+        for (int r = i + 1; r < N; ++r) {
+            const double u = LU[i * S + r];
+            const double* xr = X + r * SC;
+            for (int j = 0; j < SC; ++j) xi[j] -= u * xr[j];
+        }
+        const double inv = 1.0 / LU[i * S + i];
+        for (int j = 0; j < SC; ++j) xi[j] *= inv;
+    }
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < NC; ++j) Acols[i * NC + j] = X[i * SC + j];
+    return ok;
+}
+template <int N, int NC>
+inline Mat<N, NC> inverse_cols(const Mat<N, N>& A) {
+    Mat<N, NC> r;
+    inverse_lu_fixed_cols<N, NC>(A.a, r.a);
+    return r;
+}
+
 template <int N>
 inline Mat<N, N> inverse(const Mat<N, N>& A) {
     Mat<N, N> r;
