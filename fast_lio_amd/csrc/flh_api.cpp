@@ -96,7 +96,7 @@ struct flh_handle {
     std::vector<uint32_t> id_pos;          // id -> position among the live points (flh_fetch_neighbors), built on demand
     bool id_pos_valid = false;
     uint64_t n_reindex = 0, n_inplace = 0; // full re-indexings / changes applied brick-wise since creation
-    DevBuf<u64> mb_k0, mb_k1;              // index-build scratch (kept: the map is rebuilt after every change)
+    DevBuf<u64> mb_k0, mb_k1;              // sort scratch of the index build and of the map updates (kept allocated)
     DevBuf<uint32_t> mb_v0, mb_v1, mb_bh, mb_br, mb_bstart, mb_aabb;
     DevBuf<unsigned char> mb_tmp;
     DevBuf<float4> mu_add, mi_world;       // incremental update: points to insert; map_incremental's world points
@@ -116,9 +116,9 @@ struct flh_handle {
     DevBuf<uint8_t> nn_cnt, selected;
     DevBuf<double> partials, part2, gram;
     DevBuf<u64> counter;
-    DevBuf<uint32_t> slow_list, slow_list2, slow_count;  // A1 -> A2 -> A3 work lists (striped) and their counters
-    DevBuf<float> slow_ub;
-    DevBuf<uint32_t> tickets;                // arrival tickets of the in-kernel reduction (self re-arming)                   // per-query search radius^2 handed from A1 to A2
+    DevBuf<uint32_t> slow_list, slow_list2, slow_count;  // work lists between the search stages (striped) and their counters
+    DevBuf<float> slow_ub;                   // per-query bound on the 5th squared distance handed from A1 to A2
+    DevBuf<uint32_t> tickets;                // arrival tickets of k_fit's in-kernel reduction (self re-arming)
     double* h_gram = nullptr;  // pinned 256 doubles
     u64* h_counter = nullptr;  // pinned
     // last evaluation
