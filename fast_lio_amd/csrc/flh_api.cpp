@@ -520,6 +520,8 @@ static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size
     ++h->n_inplace;
     h->alloc_top = h->h_ctr[0];
     h->nbricks = h->h_ctr[1];
+    // ids (and the id-ordered array) only grow between re-indexings: renumber once the removed ones outweigh half the map
+    if (h->n_ids > h->M + h->M / 2 + (1u << 20)) return reindex_from_ids(h);
     return 0;
 }
 
