@@ -119,3 +119,27 @@ def test_max_iter_variants(small):
         st = kf.update(0.001)
         assert st.passes == st_ref.passes and st.returned_in_loop == st_ref.returned_in_loop
         np.testing.assert_allclose(kf.get_x(), x_ref, rtol=1e-9, atol=1e-11)
+
+
+def test_update_scan_is_change_x_change_P_update(small):
+    """flh_esekf_update_scan (one call per loop body) with slot < 0 = the three calls it replaces, bit for bit; and it
+    refuses to activate a slot when the filter has no device handle."""
+    pr, m, xp, P = small
+    outs = []
+    for one_call in (False, True):
+        sc = po.Scan(pr.body, nthreads=2)
+        kf = capi.Esekf(None, max_iter=3)
+        kf.set_meas_model(oracle_model(sc, m, False))
+        if one_call:
+            st = kf.update_scan(-1, np.ascontiguousarray(xp, np.float64), np.ascontiguousarray(P, np.float64), 0.001)
+        else:
+            kf.change_x(xp)
+            kf.change_P(P)
+            st = kf.update(0.001)
+        outs.append((kf.get_x(), kf.get_P(), st.passes, list(st.n_eff)[: st.passes]))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2:] == outs[1][2:]
+    kf = capi.Esekf(None, max_iter=3)
+    with pytest.raises(capi.FlhError):
+        kf.update_scan(0, np.ascontiguousarray(xp, np.float64), np.ascontiguousarray(P, np.float64), 0.001)
