@@ -28,6 +28,9 @@ class FlhConfig(C.Structure):
         ("stream", C.c_void_p),
         ("lanes_per_query", C.c_int),
         ("sort_queries", C.c_int),
+        ("first_stage", C.c_int),
+        ("eigen_order", C.c_int),
+        ("plane_fit_dtype", C.c_int),
     ]
 
 
@@ -166,7 +169,8 @@ class Handle:
     """flh_handle: the device-resident map + current scan."""
 
     def __init__(self, cell_size: float = 1.5, lanes_per_query: int = 4, device: int = -1, stream: int | None = None,
-                 plane_threshold: float = 0.1, max_sqdist: float = 5.0, sort_queries: int = -1):
+                 plane_threshold: float = 0.1, max_sqdist: float = 5.0, sort_queries: int = -1, first_stage: int = 0,
+                 eigen_order: int = -1, plane_fit_dtype: int = 0):
         L = lib()
         cfg = FlhConfig()
         L.flh_default_config(C.byref(cfg))
@@ -177,6 +181,9 @@ class Handle:
         cfg.max_sqdist = max_sqdist
         cfg.stream = stream
         cfg.sort_queries = sort_queries
+        cfg.first_stage = first_stage
+        cfg.eigen_order = eigen_order
+        cfg.plane_fit_dtype = plane_fit_dtype
         self._h = C.c_void_p()
         _chk(L.flh_create(C.byref(cfg), C.byref(self._h)), "flh_create")
         self._keep = []

@@ -176,6 +176,9 @@ void flh_default_config(flh_config* c) {
     c->stream = nullptr;
     c->lanes_per_query = 4;
     c->sort_queries = -1;
+    c->first_stage = 0;
+    c->eigen_order = -1;
+    c->plane_fit_dtype = 0;
 }
 
 int flh_create(const flh_config* cfg_in, flh_handle** out) {
@@ -190,9 +193,12 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.plane_threshold <= 0) cfg.plane_threshold = 0.1f;
     if (cfg.max_sqdist <= 0) cfg.max_sqdist = 5.0f;
     if (cfg.sort_queries < 0) cfg.sort_queries = 1;
+    if (cfg.first_stage < 0 || cfg.first_stage > 2) cfg.first_stage = 0;
+    if (cfg.eigen_order < 0 || cfg.eigen_order > 3) cfg.eigen_order = FLH_ORDER_SSE;
+    if (cfg.plane_fit_dtype != 1) cfg.plane_fit_dtype = 0;
     {
         const int l = cfg.lanes_per_query;  // 0 = exact kernel for every query
-        if (l != 0 && l != 2 && l != 8 && l != 16) cfg.lanes_per_query = 4;
+        if (l != 0 && l != 1 && l != 2 && l != 8 && l != 16) cfg.lanes_per_query = 4;
     }
     flh_handle* h = new flh_handle();
     h->cfg = cfg;
@@ -925,14 +931,14 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
     if (timed) HIPC(hipEventRecord(h->ev[0], st));
     if (do_search) {
         if (h->stats) HIPC(hipMemsetAsync(h->counter.p, 0, FLH_COUNTER_WORDS * sizeof(u64), st));
-        HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
+        HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
                                 h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
                                 h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr, st));
         h->searched_once = true;
         h->search_state = s;
     }
     if (timed) HIPC(hipEventRecord(h->ev[1], st));
-    HIPC(flh::launch_fit(s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
+    HIPC(flh::launch_fit(h->cfg.eigen_order, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
                          h->world.p, h->partials.p, h->part2.p, d_out, seq, h->tickets.p, h->slow_count.p, st));
     if (timed) HIPC(hipEventRecord(h->ev[2], st));
     h->last_state = s;
@@ -1144,14 +1150,14 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
     HIPC(hipEventRecord(h->ev[0], st));
     for (int it = 0; it < iters; ++it) {
         if (which == 0) {
-            HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
+            HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
                                     h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
                                     h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, nullptr, st));
             HIPC(hipMemsetAsync(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t), st));
             h->searched_once = true;
             h->search_state = s;
         } else {
-            HIPC(flh::launch_fit(s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p,
+            HIPC(flh::launch_fit(h->cfg.eigen_order, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p,
                                  h->normvec.p, h->world.p, h->partials.p, h->part2.p, h->gram.p, 0.0, h->tickets.p, h->slow_count.p, st));
         }
     }

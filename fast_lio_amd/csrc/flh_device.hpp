@@ -74,12 +74,141 @@ __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, f
 // ---------------------------------------------------------------------------------------------
 // esti_plane<float> (include/common_lib.h:225-257): A (5x3, absolute world coordinates) n = -1 solved
 // with Eigen's ColPivHouseholderQR, restated step by step (column-pivoted Householder QR with
-// LAPACK-style norm down-dating; sequential reductions).  Fully unrolled so everything lives in
-// registers.  Returns true when all five points lie within `threshold` of the fitted plane.
+// LAPACK-style norm down-dating).  Fully unrolled so everything lives in registers.  Returns true when
+// all five points lie within `threshold` of the fitted plane.
+//
+// ORD = the fp32 summation order of Eigen's reductions (flh_config.eigen_order; the same four models as
+// oracle/oracle_math.c "SUMMATION ORDER", which spells out where each comes from):
+//   0 SEQ       ascending loops
+//   1 SSE       Eigen 3.3.x, x86-64 + SSE2 (the reference's build): a 4-packet sums as (a0 + a2) + (a1 + a3); the fixed
+//               5-vector col(k).norm() = packet + e4; dynamic-size reductions (tail norms, reflector dots) use the packet
+//               only at size 4; the fixed 3-vector normvec.norm() = e0 + (e1 + e2)
+//   2 PAIRWISE  the same with (a0 + a1) + (a2 + a3)  (NEON / hadd)
+//   3 NOVEC     EIGEN_DONT_VECTORIZE: fixed 5 = (e0 + e1) + (e2 + (e3 + e4)), fixed 3 = e0 + (e1 + e2), dynamic ascending
 // ---------------------------------------------------------------------------------------------
+template <int ORD>
+__device__ __forceinline__ float ord_sum4(float a0, float a1, float a2, float a3) {
+    if (ORD == 1) return (a0 + a2) + (a1 + a3);
+    if (ORD == 2) return (a0 + a1) + (a2 + a3);
+    return ((a0 + a1) + a2) + a3;
+}
+// dynamic-size reduction of the n = 4 - K addends a[0..n) (K = the Householder step: sizes 4, 3, 2)
+template <int ORD, int K>
+__device__ __forceinline__ float ord_sum_dyn(const float a[4]) {
+    if (K == 0) return (ORD == 1 || ORD == 2) ? ord_sum4<ORD>(a[0], a[1], a[2], a[3]) : ((a[0] + a[1]) + a[2]) + a[3];
+    if (K == 1) return (a[0] + a[1]) + a[2];
+    return a[0] + a[1];
+}
+template <int ORD>
+__device__ __forceinline__ float ord_sum_fixed5(float a0, float a1, float a2, float a3, float a4) {
+    if (ORD == 1 || ORD == 2) return ord_sum4<ORD>(a0, a1, a2, a3) + a4;
+    if (ORD == 3) return (a0 + a1) + (a2 + (a3 + a4));
+    return (((a0 + a1) + a2) + a3) + a4;
+}
+template <int ORD>
+__device__ __forceinline__ float ord_sum_fixed3(float a0, float a1, float a2) {
+    if (ORD == 0) return (a0 + a1) + a2;
+    return a0 + (a1 + a2);
+}
+
+// One Householder step K of the factorisation (column pivot, reflector, trailing update, norm down-date).
+template <int ORD, int K>
+__device__ __forceinline__ void qr_step(float (&qr)[5][3], float (&hC)[3], int (&tr)[3], float (&nU)[3], float (&nD)[3],
+                                        int& nz, float threshold_helper, float downdate_thr) {
+    constexpr float kMin = 1.17549435e-38f;  // numeric_limits<float>::min()
+    constexpr int k = K;
+    int big = k;
+    float bigv = nU[k];
+#pragma unroll
+    for (int j = k + 1; j < 3; ++j)
+        if (nU[j] > bigv) { bigv = nU[j]; big = j; }
+    const float bsq = bigv * bigv;
+    if (nz == 3 && bsq < threshold_helper * (float)(5 - k)) nz = k;
+    tr[k] = big;
+#pragma unroll
+    for (int j = k + 1; j < 3; ++j)
+        if (big == j) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { float t = qr[i][k]; qr[i][k] = qr[i][j]; qr[i][j] = t; }
+            float t = nU[k]; nU[k] = nU[j]; nU[j] = t;
+            t = nD[k]; nD[k] = nD[j]; nD[j] = t;
+        }
+    float sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = k + 1; i < 5; ++i) sq[i - k - 1] = qr[i][k] * qr[i][k];
+    const float tail = ord_sum_dyn<ORD, K>(sq);  // tail.squaredNorm()
+    const float c0 = qr[k][k];
+    float tau, beta;
+    if (tail <= kMin) {
+        tau = 0.f;
+        beta = c0;
+#pragma unroll
+        for (int i = k + 1; i < 5; ++i) qr[i][k] = 0.f;
+    } else {
+        beta = sqrt_rn(c0 * c0 + tail);
+        if (c0 >= 0.f) beta = -beta;
+        const float den = c0 - beta;
+#pragma unroll
+        for (int i = k + 1; i < 5; ++i) qr[i][k] = div_rn(qr[i][k], den);
+        tau = div_rn(beta - c0, beta);
+    }
+    hC[k] = tau;
+    qr[k][k] = beta;
+    if (tau != 0.f) {
+#pragma unroll
+        for (int j = k + 1; j < 3; ++j) {
+            float pr[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = k + 1; i < 5; ++i) pr[i - k - 1] = qr[i][k] * qr[i][j];
+            float tmp = ord_sum_dyn<ORD, K>(pr);  // essential^T * bottom.col(j)
+            tmp = tmp + qr[k][j];
+            qr[k][j] = qr[k][j] - tau * tmp;
+#pragma unroll
+            for (int i = k + 1; i < 5; ++i) qr[i][j] = qr[i][j] - (tau * qr[i][k]) * tmp;
+        }
+    }
+#pragma unroll
+    for (int j = k + 1; j < 3; ++j) {
+        if (nU[j] != 0.f) {
+            float temp = div_rn(fabsf(qr[k][j]), nU[j]);
+            temp = (1.f + temp) * (1.f - temp);
+            temp = temp < 0.f ? 0.f : temp;
+            const float r = div_rn(nU[j], nD[j]);
+            const float temp2 = temp * (r * r);
+            if (temp2 <= downdate_thr) {
+                float s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = k + 1; i < 5; ++i) s2[i - k - 1] = qr[i][j] * qr[i][j];
+                nD[j] = sqrt_rn(ord_sum_dyn<ORD, K>(s2));  // col(j).tail(rows - k - 1).norm()
+                nU[j] = nD[j];
+            } else {
+                nU[j] = nU[j] * sqrt_rn(temp);
+            }
+        }
+    }
+}
+// Q^T c, reflector K (HouseholderSequence::applyThisOnTheLeft, one inner product per reflector)
+template <int ORD, int K>
+__device__ __forceinline__ void qt_step(const float (&qr)[5][3], const float (&hC)[3], int nz, float (&c)[5]) {
+    constexpr int k = K;
+    if (k < nz) {
+        const float tau = hC[k];
+        if (tau != 0.f) {
+            float pr[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = k + 1; i < 5; ++i) pr[i - k - 1] = qr[i][k] * c[i];
+            float tmp = ord_sum_dyn<ORD, K>(pr);
+            tmp = tmp + c[k];
+            c[k] = c[k] - tau * tmp;
+#pragma unroll
+            for (int i = k + 1; i < 5; ++i) c[i] = c[i] - (tau * qr[i][k]) * tmp;
+        }
+    }
+}
+
+template <int ORD>
 __device__ __forceinline__ bool esti_plane(const float P[5][3], float threshold, float pabcd[4]) {
     constexpr float kEps = 1.1920929e-07f;       // NumTraits<float>::epsilon()
-    constexpr float kMin = 1.17549435e-38f;      // numeric_limits<float>::min()
     float qr[5][3];
 #pragma unroll
     for (int i = 0; i < 5; ++i)
@@ -89,11 +218,9 @@ __device__ __forceinline__ bool esti_plane(const float P[5][3], float threshold,
     int tr[3];
     float nU[3], nD[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) s = s + qr[i][k] * qr[i][k];
-        nD[k] = sqrt_rn(s);
+    for (int k = 0; k < 3; ++k) {  // m_qr.col(k).norm(): fixed size 5
+        nD[k] = sqrt_rn(ord_sum_fixed5<ORD>(qr[0][k] * qr[0][k], qr[1][k] * qr[1][k], qr[2][k] * qr[2][k], qr[3][k] * qr[3][k],
+                                            qr[4][k] * qr[4][k]));
         nU[k] = nD[k];
     }
     float maxn = nU[0];
@@ -103,76 +230,9 @@ __device__ __forceinline__ bool esti_plane(const float P[5][3], float threshold,
     const float threshold_helper = (th * th) / 5.0f;
     const float downdate_thr = sqrt_rn(kEps);
     int nz = 3;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        int big = k;
-        float bigv = nU[k];
-#pragma unroll
-        for (int j = k + 1; j < 3; ++j)
-            if (nU[j] > bigv) { bigv = nU[j]; big = j; }
-        const float bsq = bigv * bigv;
-        if (nz == 3 && bsq < threshold_helper * (float)(5 - k)) nz = k;
-        tr[k] = big;
-#pragma unroll
-        for (int j = k + 1; j < 3; ++j)
-            if (big == j) {
-#pragma unroll
-                for (int i = 0; i < 5; ++i) { float t = qr[i][k]; qr[i][k] = qr[i][j]; qr[i][j] = t; }
-                float t = nU[k]; nU[k] = nU[j]; nU[j] = t;
-                t = nD[k]; nD[k] = nD[j]; nD[j] = t;
-            }
-        float tail = 0.f;
-#pragma unroll
-        for (int i = k + 1; i < 5; ++i) tail = tail + qr[i][k] * qr[i][k];
-        const float c0 = qr[k][k];
-        float tau, beta;
-        if (tail <= kMin) {
-            tau = 0.f;
-            beta = c0;
-#pragma unroll
-            for (int i = k + 1; i < 5; ++i) qr[i][k] = 0.f;
-        } else {
-            beta = sqrt_rn(c0 * c0 + tail);
-            if (c0 >= 0.f) beta = -beta;
-            const float den = c0 - beta;
-#pragma unroll
-            for (int i = k + 1; i < 5; ++i) qr[i][k] = div_rn(qr[i][k], den);
-            tau = div_rn(beta - c0, beta);
-        }
-        hC[k] = tau;
-        qr[k][k] = beta;
-        if (tau != 0.f) {
-#pragma unroll
-            for (int j = k + 1; j < 3; ++j) {
-                float tmp = 0.f;
-#pragma unroll
-                for (int i = k + 1; i < 5; ++i) tmp = tmp + qr[i][k] * qr[i][j];
-                tmp = tmp + qr[k][j];
-                qr[k][j] = qr[k][j] - tau * tmp;
-#pragma unroll
-                for (int i = k + 1; i < 5; ++i) qr[i][j] = qr[i][j] - (tau * qr[i][k]) * tmp;
-            }
-        }
-#pragma unroll
-        for (int j = k + 1; j < 3; ++j) {
-            if (nU[j] != 0.f) {
-                float temp = div_rn(fabsf(qr[k][j]), nU[j]);
-                temp = (1.f + temp) * (1.f - temp);
-                temp = temp < 0.f ? 0.f : temp;
-                const float r = div_rn(nU[j], nD[j]);
-                const float temp2 = temp * (r * r);
-                if (temp2 <= downdate_thr) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int i = k + 1; i < 5; ++i) s = s + qr[i][j] * qr[i][j];
-                    nD[j] = sqrt_rn(s);
-                    nU[j] = nD[j];
-                } else {
-                    nU[j] = nU[j] * sqrt_rn(temp);
-                }
-            }
-        }
-    }
+    qr_step<ORD, 0>(qr, hC, tr, nU, nD, nz, threshold_helper, downdate_thr);
+    qr_step<ORD, 1>(qr, hC, tr, nU, nD, nz, threshold_helper, downdate_thr);
+    qr_step<ORD, 2>(qr, hC, tr, nU, nD, nz, threshold_helper, downdate_thr);
     // column permutation from the transpositions
     int perm[3] = {0, 1, 2};
 #pragma unroll
@@ -184,21 +244,9 @@ __device__ __forceinline__ bool esti_plane(const float P[5][3], float threshold,
     float nv[3] = {0.f, 0.f, 0.f};
     if (nz != 0) {
         float c[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (k < nz) {
-                const float tau = hC[k];
-                if (tau != 0.f) {
-                    float tmp = 0.f;
-#pragma unroll
-                    for (int i = k + 1; i < 5; ++i) tmp = tmp + qr[i][k] * c[i];
-                    tmp = tmp + c[k];
-                    c[k] = c[k] - tau * tmp;
-#pragma unroll
-                    for (int i = k + 1; i < 5; ++i) c[i] = c[i] - (tau * qr[i][k]) * tmp;
-                }
-            }
-        }
+        qt_step<ORD, 0>(qr, hC, nz, c);
+        qt_step<ORD, 1>(qr, hC, nz, c);
+        qt_step<ORD, 2>(qr, hC, nz, c);
 #pragma unroll
         for (int i = 2; i >= 0; --i) {
             if (i < nz) {
@@ -215,7 +263,7 @@ __device__ __forceinline__ bool esti_plane(const float P[5][3], float threshold,
                 if (perm[i] == t) nv[t] = v;
         }
     }
-    const float n = sqrt_rn((nv[0] * nv[0] + nv[1] * nv[1]) + nv[2] * nv[2]);
+    const float n = sqrt_rn(ord_sum_fixed3<ORD>(nv[0] * nv[0], nv[1] * nv[1], nv[2] * nv[2]));  // normvec.norm()
     pabcd[0] = div_rn(nv[0], n);
     pabcd[1] = div_rn(nv[1], n);
     pabcd[2] = div_rn(nv[2], n);

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <vector>
 #include <cstdio>
+#include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -227,6 +228,27 @@ __device__ __forceinline__ void merge_group6(uint32_t (&K)[6]) {
     if (LPQ >= 16) merge6<0x140>(K);  // row_mirror
 }
 
+// value of lane `src` of the LPQ-lane query group (src is a compile-time constant at every call site after unrolling)
+template <int LPQ>
+__device__ __forceinline__ float group_bcast(float v, int src) {
+    if (LPQ == 1) return v;
+    if (LPQ == 2) {
+        const int x = __float_as_int(v);
+        const int a = __builtin_amdgcn_update_dpp(0, x, 0xA0, 0xF, 0xF, false);  // quad_perm [0,0,2,2]
+        const int b = __builtin_amdgcn_update_dpp(0, x, 0xF5, 0xF, 0xF, false);  // quad_perm [1,1,3,3]
+        return __int_as_float(src == 0 ? a : b);
+    }
+    if (LPQ == 4) {
+        const int x = __float_as_int(v);
+        const int a = __builtin_amdgcn_update_dpp(0, x, 0x00, 0xF, 0xF, false);  // quad_perm [0,0,0,0]
+        const int b = __builtin_amdgcn_update_dpp(0, x, 0x55, 0xF, 0xF, false);  // [1,1,1,1]
+        const int c = __builtin_amdgcn_update_dpp(0, x, 0xAA, 0xF, 0xF, false);  // [2,2,2,2]
+        const int d = __builtin_amdgcn_update_dpp(0, x, 0xFF, 0xF, 0xF, false);  // [3,3,3,3]
+        return __int_as_float(src == 0 ? a : (src == 1 ? b : (src == 2 ? c : d)));
+    }
+    return __shfl(v, src, LPQ);
+}
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 load_pt(__amdgpu_buffer_rsrc_t rsrc, uint32_t idx) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx << 4), 0, 0);  // out of range -> zeros
@@ -284,7 +306,7 @@ __device__ __forceinline__ void top5_finish(Top5& L, const GridParams& g, int q,
                                             float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
                                             uint8_t* __restrict__ selected);
 
-template <int LPQ, int RING, bool BOUNDED, int PB, bool FINAL>
+template <int LPQ, int RING, bool BOUNDED, int PB, bool FINAL, bool OCT = false>
 __global__ void __launch_bounds__(256)
 k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist,
               float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
@@ -298,7 +320,10 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
     // Work lists are striped kStripes ways (stripe = blockIdx & (kStripes-1)) and appended to with one global
     // atomic per WAVE: thousands of returning atomics on a single word serialise at ~11 ns each and were the
     // whole runtime of an earlier version of this kernel.  No block-level barrier anywhere: waves run free.
-    constexpr int W = 2 * RING + 1;                // block edge in cells
+    // OCT (RING == 1 only): instead of the 3x3x3 block, the 2x2x2 block of cells nearest to the query (per axis the
+    // cell's neighbour on the side of the half the query sits in): 8 cells instead of 27, guaranteed radius
+    // c * min over the axes of max(f, 1 - f) >= c / 2.
+    constexpr int W = OCT ? 2 : 2 * RING + 1;      // block edge in cells
     constexpr int NR = W * W;                      // (y,z) rows: each an x-run of W consecutive cells
     constexpr int NSEG = NR * 2;                   // a run crosses at most one brick boundary -> two segments
     constexpr int SPL = (NSEG + LPQ - 1) / LPQ;    // segments resolved per lane
@@ -348,9 +373,9 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             const int sl = lane + u * LPQ;
             const int half = sl / NR, r = sl - half * NR;  // slots [0,NR): first segments, [NR,2NR): second (split rows)
             const int rz = r / W, ry = r - rz * W;
-            const int dy = ry - RING, dz = rz - RING;
+            const int dy = OCT ? ry - (fy < 0.5f ? 1 : 0) : ry - RING, dz = OCT ? rz - (fz < 0.5f ? 1 : 0) : rz - RING;
             const int y = cy + dy, z = cz + dz;
-            int xlo = cx - RING, xhi = cx + RING;
+            int xlo = OCT ? cx - (fx < 0.5f ? 1 : 0) : cx - RING, xhi = OCT ? xlo + 1 : cx + RING;
             bool inball = true;
             if (BOUNDED) {
                 // distance (in cells) from the query to the row's (y,z) slab; what is left of the ball bounds x
@@ -470,35 +495,37 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < 5; ++j) cnt += (K[j] < kEmptyPacked) ? 1 : 0;
-        // two of the best six agree above the packed bits (or the list is longer than the packed index can name):
-        // their order / identity needs the general path
-        bool amb = T > PMASK + 1u;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) amb = amb || (K[j + 1] < kEmptyPacked && (K[j] >> PB) == (K[j + 1] >> PB));
+        // The packed order decides WHICH five candidates are the nearest as long as the 5th and the 6th differ above the
+        // packed bits (every candidate outside the best six is then farther than all of the best five); the ORDER among
+        // the five is settled below from their exact (d2, map index) once the points are loaded.  A 5th/6th pair that
+        // agrees there (or a list longer than the packed index can name) leaves the set open: next stage / general path.
+        const bool amb = T > PMASK + 1u || (K[5] < kEmptyPacked && (K[4] >> PB) == (K[5] >> PB));
         const float d5hi = (cnt == 5) ? __uint_as_float(K[4] | PMASK) : INFINITY;  // >= the true 5th distance found
-        const float gr = ((float)RING + minfrac) * g.c - 2e-3f * g.c;  // guaranteed-complete radius (fp margin)
+        const float octfrac = fminf(fminf(fmaxf(fx, 1.f - fx), fmaxf(fy, 1.f - fy)), fmaxf(fz, 1.f - fz));
+        const float gr = (OCT ? octfrac : (float)RING + minfrac) * g.c - 2e-3f * g.c;  // guaranteed-complete radius (fp margin)
         const float gr2 = gr * gr;
-        const bool done = !amb && ((cnt == 5 && d5hi <= gr2) || gr2 >= max_sqdist);
+        const bool covered = (cnt == 5 && d5hi <= gr2) || gr2 >= max_sqdist;
+        const bool done = !amb && covered;
 #ifndef FLH_PHASES
         if (cand_counter && live && lane == 0) atomicAdd(cand_counter, (u64)T);
 #endif
         PH_MARK(6);  // 6: merged
-        // ---- results: lane l writes ranks l, l + LPQ, ...: flat index -> map position (table walk) -> one point load
-        // each, all issued before the first is consumed; the exact squared distance is recomputed from the point (same
-        // formula, same bits as the scan saw before packing).
+        // ---- results: lane l loads ranks l, l + LPQ, ...: flat index -> map position (table walk) -> one point load each,
+        // all issued before the first is consumed; the exact squared distance is recomputed from the point (same formula,
+        // same bits as the scan saw before packing).  The group then exchanges the five (d2, map index) pairs and every
+        // lane places its points at their exact rank -- two neighbours closer than the packed bits resolve cost nothing extra.
         if (done && live) {
             constexpr int RPL = (5 + LPQ - 1) / LPQ;  // ranks per lane
             float4 pv[RPL];
-            bool has[RPL];
+            float dv[RPL];
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
                 const int j = lane + r * LPQ;
                 uint32_t kj = K[0];
 #pragma unroll
                 for (int jj = 1; jj < 5; ++jj) kj = (j == jj) ? K[jj] : kj;
-                has[r] = j < cnt;  // cnt <= 5
                 pv[r] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-                if (has[r]) {
+                if (j < cnt) {  // cnt <= 5
                     const uint32_t t = kj & PMASK;
                     int c2 = 0;
                     uint2 s2 = seg[grp][0];
@@ -507,50 +534,71 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
                 }
             }
 #pragma unroll
+            for (int r = 0; r < RPL; ++r)
+                dv[r] = (lane + r * LPQ < cnt) ? dist2(qx, qy, qz, pv[r].x, pv[r].y, pv[r].z) : INFINITY;
+            // every lane sees all five (d2, id): rank i lives in slot i / LPQ of lane i % LPQ
+            float da[5];
+            uint32_t ia[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                da[i] = group_bcast<LPQ>(dv[i / LPQ], i % LPQ);
+                ia[i] = __float_as_uint(group_bcast<LPQ>(pv[i / LPQ].w, i % LPQ));
+            }
+            float d5 = da[0];
+#pragma unroll
+            for (int i = 1; i < 5; ++i) d5 = fmaxf(d5, da[i]);  // +inf when cnt < 5
+#pragma unroll
             for (int r = 0; r < RPL; ++r) {
                 const int j = lane + r * LPQ;
                 if (j < 5) {
-                    const float dj = has[r] ? dist2(qx, qy, qz, pv[r].x, pv[r].y, pv[r].z) : INFINITY;
-                    nn_pts[(size_t)j * N + q] = pv[r];
-                    nn_d2[(size_t)j * N + q] = dj;
-                    if (j == 4) {
-                        nn_cnt[q] = (uint8_t)cnt;
-                        selected[q] = (cnt == 5 && !(dj > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
+                    int e = j;
+                    if (j < cnt) {  // exact rank among the found ones (ids are distinct: a strict total order)
+                        const uint32_t myid = __float_as_uint(pv[r].w);
+                        e = 0;
+#pragma unroll
+                        for (int i = 0; i < 5; ++i)
+                            e += (i < cnt && (da[i] < dv[r] || (da[i] == dv[r] && ia[i] < myid))) ? 1 : 0;
                     }
+                    nn_pts[(size_t)e * N + q] = pv[r];
+                    nn_d2[(size_t)e * N + q] = dv[r];
                 }
+            }
+            if (lane == 0) {
+                nn_cnt[q] = (uint8_t)cnt;
+                selected[q] = (cnt == 5 && !(d5 > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
             }
         }
         PH_MARK(7);  // 7: results written
-        // The block provably holds the five nearest (5th distance inside the guaranteed radius) but the packed keys left
-        // their order / identity open (two of the best six agree above the packed bits, equal distances, or a list longer
-        // than the packed index can name): one more pass over the SAME candidates with 64-bit (d2, map index) keys
-        // settles it here -- rare (~0.1 % of the queries), so the divergence is cheap, and it keeps such queries out of
-        // the next kernel, whose fixed latency is paid per pass.
-        const bool covered = (cnt == 5 && d5hi <= gr2) || gr2 >= max_sqdist;
         bool done2 = done;
-        if (live && !done && covered) {
-            Top5 L;
-            L.reset();
-            int c2 = 0;
-            uint2 s2 = seg[grp][0];
-            constexpr int RU = 4;  // loads in flight per lane (the serial version cost ~1 us per candidate)
-            for (uint32_t t0 = lane; t0 < T; t0 += LPQ * RU) {
-                float4 pv[RU];
-                uint32_t pos[RU];
+        if (FINAL) {
+            // Last stage only.  The block provably holds the five nearest (5th distance inside the guaranteed radius) but
+            // the packed keys left the set open (5th and 6th agree above the packed bits -- equal distances included -- or
+            // the list is longer than the packed index can name): one more pass over the SAME candidates with 64-bit
+            // (d2, map index) keys settles it.
+            if (live && !done && covered) {
+                Top5 L;
+                L.reset();
+                int c2 = 0;
+                uint2 s2 = seg[grp][0];
+                constexpr int RU = 8;  // loads in flight per lane
+                for (uint32_t t0 = lane; t0 < T; t0 += LPQ * RU) {
+                    float4 pv[RU];
+                    uint32_t pos[RU];
 #pragma unroll
-                for (int w = 0; w < RU; ++w) {
-                    const uint32_t t = t0 + (uint32_t)(w * LPQ);
-                    while (t >= s2.y) s2 = seg[grp][++c2];
-                    pos[w] = (t < T) ? s2.x + t : 0xFFFFFFFu;
-                    pv[w] = load_pt(rsrc, pos[w]);
+                    for (int w = 0; w < RU; ++w) {
+                        const uint32_t t = t0 + (uint32_t)(w * LPQ);
+                        while (t >= s2.y) s2 = seg[grp][++c2];
+                        pos[w] = (t < T) ? s2.x + t : 0xFFFFFFFu;
+                        pv[w] = load_pt(rsrc, pos[w]);
+                    }
+#pragma unroll
+                    for (int w = 0; w < RU; ++w)
+                        if (t0 + (uint32_t)(w * LPQ) < T)
+                            L.insert(make_key(dist2(qx, qy, qz, pv[w].x, pv[w].y, pv[w].z), pv[w].w), pos[w]);
                 }
-#pragma unroll
-                for (int w = 0; w < RU; ++w)
-                    if (t0 + (uint32_t)(w * LPQ) < T)
-                        L.insert(make_key(dist2(qx, qy, qz, pv[w].x, pv[w].y, pv[w].z), pv[w].w), pos[w]);
+                top5_finish<LPQ>(L, g, q, N, lane, max_sqdist, nn_pts, nn_d2, nn_cnt, selected);
+                done2 = true;
             }
-            top5_finish<LPQ>(L, g, q, N, lane, max_sqdist, nn_pts, nn_d2, nn_cnt, selected);
-            done2 = true;
         }
         if (FINAL) {
             if (live && !done2) {
@@ -730,6 +778,7 @@ constexpr int kRed1 = 16;   // blocks per first-level reduction group
 constexpr int kRed2 = 32;   // group sums added per unrolled batch at the top level
 constexpr int kTileStride = 17;  // doubles per row: 16 + 1 pad (conflict-free ds_write_b64 / ds_read_b64)
 
+template <int ORD>
 __global__ void __launch_bounds__(256)
 k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn_pts, int N, int ext, float thr,
       uint8_t* __restrict__ selected, float4* __restrict__ normvec, float4* __restrict__ world,
@@ -770,7 +819,7 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
         for (int j = 0; j < 5; ++j) { P[j][0] = nn[j].x; P[j][1] = nn[j].y; P[j][2] = nn[j].z; }
         float pabcd[4];
         FPH(2);  // neighbours loaded
-        const bool ok = esti_plane(P, thr, pabcd);  // :678
+        const bool ok = esti_plane<ORD>(P, thr, pabcd);  // :678
         FPH(3);  // plane fit
         bool sel = false;
         float pd2 = 0.f;
@@ -1005,7 +1054,7 @@ hipError_t launch_scan_gather(const float4* raw, const uint32_t* perm, uint32_t 
 int list_stripes() { return kStripes; }
 uint32_t list_stripe_cap(int N) { return (uint32_t)(cdiv(cdiv(N > 0 ? N : 1, 16), kStripes) + 1) * 128u; }
 
-hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points,
+hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points,
                          float max_sqdist, int rmax, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
                          uint32_t* list1, uint32_t* list2, float* ub, uint32_t* counts /* [2 * kStripes] */,
                          u64* cand_counter, hipStream_t st) {
@@ -1018,15 +1067,24 @@ hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const 
         return hipGetLastError();
     }
     // A1: ring 1, every query
-#define FLH_A1(L)                                                                                                        \
-    hipLaunchKernelGGL((k_search_ring<L, 1, false, 8, false>), dim3(cdiv(N, 256 / L)), blk, 0, st, g, s, body, N, \
+#define FLH_A1(L, O)                                                                                                     \
+    hipLaunchKernelGGL((k_search_ring<L, 1, false, 8, false, O>), dim3(cdiv(N, 256 / L)), blk, 0, st, g, s, body, N, \
                        map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,                \
                        (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter)
-    switch (lpq) {
-        case 2: FLH_A1(2); break;
-        case 8: FLH_A1(8); break;
-        case 16: FLH_A1(16); break;
-        default: FLH_A1(4); break;
+    if (first_stage == 2 && rmax >= 2) {
+        switch (lpq) {
+            case 1: FLH_A1(1, true); break;
+            case 2: FLH_A1(2, true); break;
+            default: FLH_A1(4, true); break;
+        }
+    } else {
+        switch (lpq) {
+            case 1: FLH_A1(1, false); break;
+            case 2: FLH_A1(2, false); break;
+            case 8: FLH_A1(8, false); break;
+            case 16: FLH_A1(16, false); break;
+            default: FLH_A1(4, false); break;
+        }
     }
 #undef FLH_A1
     if (rmax >= 2) {
@@ -1073,12 +1131,20 @@ int reduce1_blocks(int nblk, int* per_out) {
     return cdiv(nblk, kRed1);
 }
 
-hipError_t launch_fit(const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
+hipError_t launch_fit(int order, const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
                       uint8_t* selected, float4* normvec, float4* world, double* partials, double* part2,
                       double* out256, double seq, uint32_t* tickets, uint32_t* slow_count, hipStream_t st) {
     const int nblk = fit_blocks(N);
-    hipLaunchKernelGGL(k_fit, dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world,
-                       partials, part2, out256, seq, tickets, slow_count);
+#define FLH_FIT(O)                                                                                                      \
+    hipLaunchKernelGGL(k_fit<O>, dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world, \
+                       partials, part2, out256, seq, tickets, slow_count)
+    switch (order) {
+        case 0: FLH_FIT(0); break;
+        case 2: FLH_FIT(2); break;
+        case 3: FLH_FIT(3); break;
+        default: FLH_FIT(1); break;
+    }
+#undef FLH_FIT
     return hipGetLastError();
 }
 

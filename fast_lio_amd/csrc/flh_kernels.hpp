@@ -31,7 +31,7 @@ hipError_t launch_scan_gather(const float4* raw, const uint32_t* perm, uint32_t 
 
 int list_stripes();
 uint32_t list_stripe_cap(int N);
-hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points,
+hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points,
                          float max_sqdist, int rmax, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
                          uint32_t* list1, uint32_t* list2, float* ub, uint32_t* counts, unsigned long long* cand_counter,
                          hipStream_t st);
@@ -41,7 +41,7 @@ void dump_fit_phases();
 #endif
 int fit_blocks(int N);
 int reduce1_blocks(int nblk, int* per_out);
-hipError_t launch_fit(const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
+hipError_t launch_fit(int order, const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
                       uint8_t* selected, float4* normvec, float4* world, double* partials, double* part2,
                       double* out256, double seq, uint32_t* tickets, uint32_t* slow_count, hipStream_t st);
 

@@ -52,7 +52,17 @@ typedef struct flh_config {
     int lanes_per_query;    /* fast search kernel: lanes cooperating on one query, 2/4/8/16 (default 4);
                                0 = run the general exact kernel for every query */
     int sort_queries;       /* 1: Morton-sort scan points at upload for cache locality (default 1 if <0) */
+    int first_stage;        /* block of cells the first search stage scans: 1 = the 3x3x3 block around the query's cell,
+                               2 = the 2x2x2 block nearest to the query (8 cells instead of 27; more queries go on to the
+                               second stage), 0 = default.  Performance only: every setting returns the same exact 5-NN */
+    int eigen_order;        /* fp32 summation order of esti_plane's reductions (include/common_lib.h:241 runs Eigen's
+                               ColPivHouseholderQR, whose reduction order depends on how Eigen was vectorised):
+                               FLH_ORDER_SEQ / _SSE / _PAIRWISE / _NOVEC; <0 -> FLH_ORDER_SSE (Eigen 3.3.x, x86-64 + SSE2:
+                               the reference's own build).  See DESIGN.md "Eigen summation order" */
+    int plane_fit_dtype;    /* 0 = fp32, exactly as the reference (esti_plane<float>); 1 = ABLATION ONLY: the plane fit in
+                               fp16 on query-centred coordinates (BASELINE configs[4]); not bit-exact, never the default */
 } flh_config;
+enum { FLH_ORDER_SEQ = 0, FLH_ORDER_SSE = 1, FLH_ORDER_PAIRWISE = 2, FLH_ORDER_NOVEC = 3 };
 
 void flh_default_config(flh_config* cfg);
 int flh_create(const flh_config* cfg, flh_handle** out);

@@ -50,6 +50,11 @@ void orc_knn5_batch(const orc_kdtree* t, const float* q_xyz, size_t N, int32_t* 
 /* ---- esti_plane<float> (include/common_lib.h:225-257) ---- */
 /* pts: 5x3 fp32 row-major.  Returns 1 if all 5 points are within `threshold` of the plane. */
 int orc_esti_plane(const float pts[15], float threshold, float pabcd[4]);
+/* Which fp32 summation order the restated Eigen reductions use (oracle_math.c, "SUMMATION ORDER"); process-wide, set it
+ * before any fit.  Default ORC_ORDER_SSE = Eigen 3.3.x on x86-64 with SSE2, the reference's own build. */
+enum { ORC_ORDER_SEQ = 0, ORC_ORDER_SSE = 1, ORC_ORDER_PAIRWISE = 2, ORC_ORDER_NOVEC = 3 };
+void orc_set_eigen_order(int order);
+int orc_get_eigen_order(void);
 /* The restated Eigen ColPivHouseholderQR 5x3 solve of A x = b (b = -1), exposed for KATs. */
 void orc_qr_solve_5x3(const float A[15], const float b[5], float x[3]);
 

@@ -337,8 +337,62 @@ int orc_inverse(const double* A, int n, double* Ainv) {
 /* ------------------------------------------------------------------ ColPivHouseholderQR 5x3 fp32 */
 /* Restated from Eigen's ColPivHouseholderQR::computeInPlace / _solve_impl and
    MatrixBase::makeHouseholder / applyHouseholderOnTheLeft (Eigen 3.3.x) [recalled-upstream].
-   All reductions are sequential (ascending index); fp32 throughout; no FMA. */
+   fp32 throughout; no FMA (the reference is built for baseline x86-64, CMakeLists.txt:8,14).
+
+   SUMMATION ORDER.  Eigen's fp32 reductions are not sequential loops: which adds happen in which order depends on
+   the vectorisation Eigen compiles in, and the reference ships no test that pins it.  Every reduction of the fit goes
+   through the four helpers below, switched by orc_set_eigen_order():
+
+     ORC_ORDER_SEQ     0  plain ascending loops (what a reader of the algorithm would write; round 1's only model)
+     ORC_ORDER_SSE     1  Eigen 3.3.x as the reference builds it: x86-64, SSE2 on, EIGEN_UNALIGNED_VECTORIZE = 1 (default)
+                          - fixed-size 5-vector (col(k).norm(), redux LinearVectorizedTraversal + CompleteUnrolling):
+                            predux(packet 0..3) + e4, predux<Packet4f> = (a0 + a2) + (a1 + a3)  (movehl + add, shuffle + add_ss)
+                          - dynamic-size vectors (tail.squaredNorm(), the lazy-product / inner-product dots of
+                            applyHouseholderOnTheLeft, the down-date's tail norm; redux LinearVectorizedTraversal +
+                            NoUnrolling with alignedStart = 0 because the cwise expression has no direct access):
+                            size 4 -> one packet, predux as above; size < 4 -> ascending scalar loop
+                          - fixed-size 3-vector (normvec.norm(): VectorizedSize = 0 -> redux_novec_unroller, a binary
+                            tree): e0 + (e1 + e2)
+     ORC_ORDER_PAIRWISE 2 the same structure with a pairwise predux (a0 + a1) + (a2 + a3) (NEON vpadd; SSE3 hadd builds)
+     ORC_ORDER_NOVEC   3  Eigen with EIGEN_DONT_VECTORIZE: fixed sizes go through redux_novec_unroller's binary tree
+                          (5: (e0 + e1) + (e2 + (e3 + e4)); 3: e0 + (e1 + e2)), dynamic sizes are ascending loops
+
+   The default is ORC_ORDER_SSE (the reference's own build: Ubuntu + ROS, Eigen >= 3.3.4, -O3 without -march).
+   The product's device code (fast_lio_amd/csrc/flh_device.hpp: esti_plane<ORD>) implements the same four orders and
+   is compared bit for bit against whichever is selected; tests/test_eigen_order.py + DESIGN.md quantify how many
+   plane fits / point_selected_surf flags / how much pose change the choice is worth.  oracle/ref/ holds the recipe
+   that dumps the real Eigen's bits on a box that has Eigen, and tells which order (if any) it matches. */
+static int g_eigen_order = ORC_ORDER_SSE;
+void orc_set_eigen_order(int order) { g_eigen_order = (order >= 0 && order <= 3) ? order : ORC_ORDER_SSE; }
+int orc_get_eigen_order(void) { return g_eigen_order; }
+
+/* sum of a packet's four lanes */
+static inline float ord_sum4(int ord, float a0, float a1, float a2, float a3) {
+    if (ord == ORC_ORDER_SSE) return (a0 + a2) + (a1 + a3);
+    if (ord == ORC_ORDER_PAIRWISE) return (a0 + a1) + (a2 + a3);
+    return ((a0 + a1) + a2) + a3;
+}
+/* reduction of a DYNAMIC-size vector of n <= 4 addends (redux_impl<..., LinearVectorizedTraversal, NoUnrolling>) */
+static inline float ord_sum_dyn(int ord, const float* a, int n) {
+    if (n == 4 && (ord == ORC_ORDER_SSE || ord == ORC_ORDER_PAIRWISE)) return ord_sum4(ord, a[0], a[1], a[2], a[3]);
+    float s = a[0];
+    for (int i = 1; i < n; i++) s = s + a[i];
+    return s;
+}
+/* reduction of a FIXED-size 5-vector (col(k).squaredNorm()) */
+static inline float ord_sum_fixed5(int ord, const float a[5]) {
+    if (ord == ORC_ORDER_SSE || ord == ORC_ORDER_PAIRWISE) return ord_sum4(ord, a[0], a[1], a[2], a[3]) + a[4];
+    if (ord == ORC_ORDER_NOVEC) return (a[0] + a[1]) + (a[2] + (a[3] + a[4]));
+    return (((a[0] + a[1]) + a[2]) + a[3]) + a[4];
+}
+/* reduction of a FIXED-size 3-vector (normvec.squaredNorm()) */
+static inline float ord_sum_fixed3(int ord, float a0, float a1, float a2) {
+    if (ord == ORC_ORDER_SEQ) return (a0 + a1) + a2;
+    return a0 + (a1 + a2);
+}
+
 void orc_qr_solve_5x3(const float Ain[15], const float bin[5], float x[3]) {
+    const int ord = g_eigen_order;
     enum { ROWS = 5, COLS = 3, SIZE = 3 };
     float qr[ROWS][COLS];
     for (int i = 0; i < ROWS; i++)
@@ -346,10 +400,10 @@ void orc_qr_solve_5x3(const float Ain[15], const float bin[5], float x[3]) {
     float hCoeffs[SIZE];
     int transp[SIZE];
     float normsUpdated[COLS], normsDirect[COLS];
-    for (int k = 0; k < COLS; k++) {
-        float s = 0.f;
-        for (int i = 0; i < ROWS; i++) s = s + qr[i][k] * qr[i][k];
-        normsDirect[k] = sqrtf(s);
+    for (int k = 0; k < COLS; k++) { /* m_qr.col(k).norm(): fixed size 5 */
+        float sq[ROWS];
+        for (int i = 0; i < ROWS; i++) sq[i] = qr[i][k] * qr[i][k];
+        normsDirect[k] = sqrtf(ord_sum_fixed5(ord, sq));
         normsUpdated[k] = normsDirect[k];
     }
     float maxn = normsUpdated[0];
@@ -377,8 +431,12 @@ void orc_qr_solve_5x3(const float Ain[15], const float bin[5], float x[3]) {
             t = normsDirect[k]; normsDirect[k] = normsDirect[big]; normsDirect[big] = t;
         }
         /* makeHouseholderInPlace on qr[k..4][k] */
-        float tailSqNorm = 0.f;
-        for (int i = k + 1; i < ROWS; i++) tailSqNorm = tailSqNorm + qr[i][k] * qr[i][k];
+        float tailSqNorm; /* tail.squaredNorm(): dynamic size ROWS - k - 1 */
+        {
+            float sq[ROWS];
+            for (int i = k + 1; i < ROWS; i++) sq[i - k - 1] = qr[i][k] * qr[i][k];
+            tailSqNorm = ord_sum_dyn(ord, sq, ROWS - k - 1);
+        }
         float c0 = qr[k][k];
         float tau, beta;
         if (tailSqNorm <= FLT_MIN) {
@@ -397,8 +455,9 @@ void orc_qr_solve_5x3(const float Ain[15], const float bin[5], float x[3]) {
         /* apply H_k to the trailing block rows k..4, cols k+1..2 */
         if (tau != 0.f) {
             for (int j = k + 1; j < COLS; j++) {
-                float tmp = 0.f;
-                for (int i = k + 1; i < ROWS; i++) tmp = tmp + qr[i][k] * qr[i][j];
+                float pr[ROWS]; /* tmp = essential.adjoint() * bottom: lazy product, one dynamic-size dot per column */
+                for (int i = k + 1; i < ROWS; i++) pr[i - k - 1] = qr[i][k] * qr[i][j];
+                float tmp = ord_sum_dyn(ord, pr, ROWS - k - 1);
                 tmp = tmp + qr[k][j];
                 qr[k][j] = qr[k][j] - tau * tmp;
                 for (int i = k + 1; i < ROWS; i++) qr[i][j] = qr[i][j] - (tau * qr[i][k]) * tmp;
@@ -412,9 +471,10 @@ void orc_qr_solve_5x3(const float Ain[15], const float bin[5], float x[3]) {
                 temp = temp < 0.f ? 0.f : temp;
                 float r = normsUpdated[j] / normsDirect[j];
                 float temp2 = temp * (r * r);
-                if (temp2 <= norm_downdate_threshold) {
-                    float s = 0.f;
-                    for (int i = k + 1; i < ROWS; i++) s = s + qr[i][j] * qr[i][j];
+                if (temp2 <= norm_downdate_threshold) { /* m_qr.col(j).tail(rows - k - 1).norm(): dynamic size */
+                    float sq[ROWS];
+                    for (int i = k + 1; i < ROWS; i++) sq[i - k - 1] = qr[i][j] * qr[i][j];
+                    float s = ord_sum_dyn(ord, sq, ROWS - k - 1);
                     normsDirect[j] = sqrtf(s);
                     normsUpdated[j] = normsDirect[j];
                 } else {
@@ -437,8 +497,9 @@ void orc_qr_solve_5x3(const float Ain[15], const float bin[5], float x[3]) {
     for (int k = 0; k < nonzero_pivots; k++) { /* Q^T c = H_{nz-1} ... H_1 H_0 c */
         float tau = hCoeffs[k];
         if (tau != 0.f) {
-            float tmp = 0.f;
-            for (int i = k + 1; i < ROWS; i++) tmp = tmp + qr[i][k] * c[i];
+            float pr[ROWS]; /* inner product essential^T * c.bottomRows: dynamic size */
+            for (int i = k + 1; i < ROWS; i++) pr[i - k - 1] = qr[i][k] * c[i];
+            float tmp = ord_sum_dyn(ord, pr, ROWS - k - 1);
             tmp = tmp + c[k];
             c[k] = c[k] - tau * tmp;
             for (int i = k + 1; i < ROWS; i++) c[i] = c[i] - (tau * qr[i][k]) * tmp;
@@ -458,7 +519,7 @@ int orc_esti_plane(const float pts[15], float threshold, float pabcd[4]) {
     float b[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};
     float nv[3];
     orc_qr_solve_5x3(pts, b, nv);
-    float n = sqrtf((nv[0] * nv[0] + nv[1] * nv[1]) + nv[2] * nv[2]);
+    float n = sqrtf(ord_sum_fixed3(g_eigen_order, nv[0] * nv[0], nv[1] * nv[1], nv[2] * nv[2])); /* normvec.norm() */
     pabcd[0] = nv[0] / n;
     pabcd[1] = nv[1] / n;
     pabcd[2] = nv[2] / n;

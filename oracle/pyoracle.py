@@ -91,6 +91,8 @@ def lib():
     L.orc_esti_plane.restype = C.c_int
     L.orc_esti_plane.argtypes = [_f32p, C.c_float, _f32p]
     L.orc_qr_solve_5x3.argtypes = [_f32p, _f32p, _f32p]
+    L.orc_set_eigen_order.argtypes = [C.c_int]
+    L.orc_get_eigen_order.restype = C.c_int
     L.orc_A_matrix.argtypes = [_f64p, _f64p]
     L.orc_so3_exp.argtypes = [_f64p, C.c_double, _f64p]
     L.orc_so3_log.argtypes = [_f64p, _f64p]
@@ -281,6 +283,19 @@ class Scan:
 
 
 # ---- thin functional wrappers for the KATs ----
+ORDER_SEQ, ORDER_SSE, ORDER_PAIRWISE, ORDER_NOVEC = 0, 1, 2, 3
+ORDER_NAMES = {0: "seq", 1: "sse", 2: "pairwise", 3: "novec"}
+
+
+def set_eigen_order(order: int) -> None:
+    """Process-wide fp32 summation order of the restated Eigen reductions (oracle_math.c "SUMMATION ORDER")."""
+    lib().orc_set_eigen_order(int(order))
+
+
+def get_eigen_order() -> int:
+    return int(lib().orc_get_eigen_order())
+
+
 def esti_plane(pts, threshold=0.1):
     out = np.zeros(4, np.float32)
     ok = lib().orc_esti_plane(_c32(pts).reshape(15), threshold, out)

@@ -23,6 +23,17 @@ def main():
     m = po.Map(pr.map_xyz)
     xp, P = synth.propagate_prior_cov(po.predict, pr.x_prior)
     out = {"map_xyz": pr.map_xyz, "body": pr.body, "x_prior": xp, "P_prior": P, "x_true": pr.x_true}
+    # the fixtures under the plain keys are made with the DEFAULT summation order (ORDER_SSE, oracle_math.c); the plane
+    # coefficients and flags of the other three orders ride along under o{order}_* so that every order of the device
+    # code has an anchor
+    for order in (0, 2, 3):
+        po.set_eigen_order(order)
+        sc = po.Scan(pr.body, nthreads=1)
+        assert sc.h_share_model(m, xp, True, False)
+        out[f"o{order}_selected"] = sc.selected
+        out[f"o{order}_normvec"] = sc.normvec
+    po.set_eigen_order(po.ORDER_SSE)
+    out["eigen_order"] = np.int64(po.get_eigen_order())
     for ext in (0, 1):
         sc = po.Scan(pr.body, nthreads=1)
         assert sc.h_share_model(m, xp, True, bool(ext))

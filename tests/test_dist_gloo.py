@@ -83,7 +83,9 @@ def test_sharded_update_matches_single_process(tmp_path, n_scan, ext):
     x_ref, P_ref, st_ref = sc.update_iterated(m, xp, P, extrinsic_est_en=ext)
     assert int(got["passes"]) == st_ref.passes and int(got["searches"]) == st_ref.searches
     assert list(got["n_eff"])[: st_ref.passes] == list(st_ref.n_eff)[: st_ref.passes]
-    np.testing.assert_allclose(got["x"], x_ref, rtol=1e-9, atol=1e-11)
+    # the shards' fp64 partial sums add up in a different order than the single-process sum; with extrinsic estimation on,
+    # the 12-column system is poorly conditioned and that last-bit difference shows at ~1e-10 absolute in the state
+    np.testing.assert_allclose(got["x"], x_ref, rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(got["P"], P_ref, rtol=0, atol=1e-6 * np.abs(P_ref).max())
 
 

@@ -6,7 +6,7 @@ import sys
 import pandas as pd
 
 df = pd.read_csv(sys.argv[1])
-pat = re.compile(r"(k_[a-z_0-9]+(?:<[0-9, ]+>)?)")
+pat = re.compile(r"(k_[a-z_0-9]+(?:<[0-9a-z, ]+>)?)")
 rows = []
 for _, r in df.iterrows():
     m = pat.search(r["Name"])
