@@ -77,6 +77,8 @@ EXPORTS = [
     "flh_map_add", "flh_map_delete_boxes", "flh_map_download", "flh_map_incremental", "flh_fetch_map_incremental",
     "flh_fov_segment", "flh_scan_stage_downsampled", "flh_fetch_scan",
     "flh_scan_stage_undistorted", "flh_esekf_update_scan", "flh_map_stats",
+    "flh_scan_stage_async", "flh_scan_wait", "flh_host_alloc", "flh_host_free", "flh_frame_world", "flh_points_body_to_world",
+    "flh_esekf_last_error",
 ]
 
 _lib = None
@@ -122,6 +124,15 @@ def lib():
     L.flh_scan_size.argtypes = [C.c_void_p]
     L.flh_scan_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t]
     L.flh_scan_activate.argtypes = [C.c_void_p, C.c_int]
+    L.flh_scan_stage_async.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t]
+    L.flh_scan_wait.argtypes = [C.c_void_p, C.c_int]
+    L.flh_host_alloc.restype = C.c_void_p
+    L.flh_host_alloc.argtypes = [C.c_size_t]
+    L.flh_host_free.argtypes = [C.c_void_p]
+    L.flh_frame_world.argtypes = [C.c_void_p, C.c_int, _f64p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.flh_points_body_to_world.argtypes = [C.c_void_p, _f64p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    L.flh_esekf_last_error.restype = C.c_char_p
+    L.flh_esekf_last_error.argtypes = [C.c_void_p]
     L.flh_scan_stage_downsampled.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float,
                                              C.POINTER(C.c_size_t)]
     L.flh_fetch_scan.argtypes = [C.c_void_p, C.c_void_p]
@@ -260,6 +271,37 @@ class Handle:
     def scan_stage(self, slot: int, body: np.ndarray):
         a = np.ascontiguousarray(body, dtype=np.float32)
         _chk(lib().flh_scan_stage(self._h, slot, a.ctypes.data, a.shape[1] * 4, a.shape[0]), "flh_scan_stage")
+
+    def scan_stage_async(self, slot: int, body: np.ndarray):
+        """Staging by the handle's staging thread; `body` (float32, C-contiguous, N x 3/4/12) is kept alive here until
+        scan_wait / scan_activate / update_scan of that slot."""
+        a = body
+        assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and a.ndim == 2
+        self._pending = getattr(self, "_pending", {})
+        self._pending[slot] = a
+        _chk(lib().flh_scan_stage_async(self._h, slot, a.ctypes.data, a.shape[1] * 4, a.shape[0]), "flh_scan_stage_async")
+
+    def scan_wait(self, slot: int):
+        _chk(lib().flh_scan_wait(self._h, slot), "flh_scan_wait")
+        getattr(self, "_pending", {}).pop(slot, None)
+
+    def frame_world(self, x, slot: int = -1, dense: bool = True) -> np.ndarray:
+        """publish_frame_world's cloud (src/laserMapping.cpp:478-530): feats_undistort (dense) or feats_down_body of
+        `slot` (-1 = the active scan) carried to the world frame at state x."""
+        n = C.c_size_t(0)
+        xx = np.ascontiguousarray(x, np.float64)
+        _chk(lib().flh_frame_world(self._h, slot, xx, int(dense), None, 0, C.byref(n)), "flh_frame_world")
+        out = np.empty((n.value, 3), np.float32)
+        if n.value:
+            _chk(lib().flh_frame_world(self._h, slot, xx, int(dense), out.ctypes.data, n.value, C.byref(n)), "flh_frame_world")
+        return out
+
+    def points_body_to_world(self, x, pts: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(pts, dtype=np.float32)
+        out = np.empty((a.shape[0], 3), np.float32)
+        _chk(lib().flh_points_body_to_world(self._h, np.ascontiguousarray(x, np.float64), a.ctypes.data, a.shape[1] * 4,
+                                            a.shape[0], out.ctypes.data), "flh_points_body_to_world")
+        return out
 
     def scan_stage_downsampled(self, slot: int, raw: np.ndarray, leaf_size: float = 0.5) -> int:
         """pcl::VoxelGrid of the raw scan on the device + staging (src/laserMapping.cpp:904-905).  Returns feats_down_size."""
@@ -448,14 +490,14 @@ class Esekf:
         st = FlhUpdateStats()
         rc = lib().flh_esekf_update_scan(self._e, int(slot), x.ctypes.data, P.ctypes.data, float(R), C.byref(st))
         if rc != 0:
-            raise FlhError("flh_esekf_update_scan failed: " + lib().flh_last_error().decode())
+            raise FlhError("flh_esekf_update_scan failed: " + lib().flh_esekf_last_error(self._e).decode())
         return st
 
     def update(self, R: float = 0.001):
         st = FlhUpdateStats()
         rc = lib().flh_esekf_update(self._e, float(R), C.byref(st))
         if rc != 0:
-            raise FlhError("flh_esekf_update failed: " + lib().flh_last_error().decode())
+            raise FlhError("flh_esekf_update failed: " + lib().flh_esekf_last_error(self._e).decode())
         return st
 
 

@@ -11,7 +11,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fastlio_hip.h"
@@ -135,16 +139,37 @@ struct flh_handle {
     // staging ring
     struct Slot {
         DevBuf<float4> body;            // Morton-ordered (internal order); .w = original index
-        std::vector<float> h_body;      // host copy, original order (flh_fetch_rows)
-        std::vector<uint32_t> h_perm;   // internal index -> original index
+        DevBuf<float4> dense;           // the cloud a raw-scan staging started from (feats_undistort), original order
+        size_t n_dense = 0;
+        std::vector<float> h_body;      // host copy, original order (lazy: ensure_host_copy)
+        std::vector<uint32_t> h_perm;   // internal index -> original index (lazy)
+        bool host_valid = false;
         size_t N = 0;
-        hipEvent_t ready = nullptr;
+        hipEvent_t ready = nullptr, h2d_done = nullptr;
         bool used = false;
+        unsigned char* pin = nullptr;   // pinned staging buffer (pageable caller memory goes through it)
+        size_t pin_cap = 0;
+        bool pending = false;           // handed to the staging thread, not finished yet (guarded by st_mu)
+        int async_rc = 0;
+        std::string async_err;
     };
+    struct StageJob { int slot; const void* pts; size_t stride; size_t N; };
+    std::thread stager;                 // flh_scan_stage_async's worker
+    std::mutex st_mu;
+    std::condition_variable st_cv, st_done;
+    std::deque<StageJob> st_queue;
+    bool st_quit = false;
+    unsigned char* pin_in = nullptr;    // pinned scratch of the synchronous entry points
+    size_t pin_in_cap = 0;
+    unsigned char* pin_out = nullptr;
+    size_t pin_out_cap = 0;
+    uint32_t* h_small = nullptr;        // pinned: a few words read back by the staging paths
+    DevBuf<unsigned char> st_bytes, fw_bytes;  // the caller's records as they came over PCIe
+    DevBuf<float4> fw_in, fw_out;       // flh_frame_world / flh_points_body_to_world
     Slot slots[FLH_MAX_SLOTS + 1];      // [FLH_MAX_SLOTS] backs flh_scan_upload
     hipStream_t copy_stream = nullptr;
     const float4* cur_body = nullptr;   // the active slot's buffer
-    const Slot* cur = nullptr;
+    Slot* cur = nullptr;
     // staging scratch (copy stream)
     DevBuf<float4> st_raw, ds_raw, ds_und; // ds_*: undistortion / voxel-grid down-sampling of a raw scan
     DevBuf<double> ds_poses;
@@ -157,6 +182,7 @@ struct flh_handle {
 extern "C" {
 
 static void release_build_scratch(flh_handle* h);
+static void stop_stager(flh_handle* h);
 static StateDev make_state(const double rot[4], const double pos[3], const double offR[4], const double offT[3]);
 
 const char* flh_last_error(void) { return g_err.c_str(); }
@@ -223,7 +249,8 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     for (auto& e : h->ev) (void)hipEventCreate(&e);
     if (hipHostMalloc((void**)&h->h_gram, 256 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_counter, sizeof(u64), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_ctr, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void**)&h->h_ctr, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_small, 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
         flh_destroy(h);
         return fail("hipHostMalloc failed");
     }
@@ -242,7 +269,9 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
 
 void flh_destroy(flh_handle* h) {
     if (!h) return;
+    stop_stager(h);
     (void)hipSetDevice(h->device);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     release_build_scratch(h);
     h->dead_id.release(); h->cap_end.release(); h->live.release(); h->mb_cap.release(); h->mb_capincl.release(); h->ctr.release();
@@ -256,8 +285,15 @@ void flh_destroy(flh_handle* h) {
     h->partials.release(); h->part2.release(); h->gram.release(); h->counter.release();
     for (auto& sl : h->slots) {
         sl.body.release();
+        sl.dense.release();
         if (sl.ready) (void)hipEventDestroy(sl.ready);
+        if (sl.h2d_done) (void)hipEventDestroy(sl.h2d_done);
+        if (sl.pin) (void)hipHostFree(sl.pin);
     }
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
+    if (h->h_small) (void)hipHostFree(h->h_small);
+    h->st_bytes.release(); h->fw_bytes.release(); h->fw_in.release(); h->fw_out.release();
     h->ds_raw.release(); h->ds_und.release(); h->ds_poses.release(); h->ds_flags.release(); h->ds_incl.release();
     h->st_raw.release(); h->st_k0.release(); h->st_k1.release(); h->st_v0.release(); h->st_v1.release(); h->st_tmp.release();
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -274,8 +310,25 @@ size_t flh_scan_size(const flh_handle* h) { return h ? h->N : 0; }
 
 // ---------------------------------------------------------------------------------------------
 // Map index (re)build from a device array of points in INDEX order.  `pts` is h->map_orig or h->map_next; on
-// success it becomes h->map_orig.  On failure the previous map stays in place.
+// success it becomes h->map_orig.  A failure before the tables are touched (extent / size checks) leaves the previous map
+// in place; a later one (allocation, a launch) leaves the handle without a map.
+static int rebuild_index_impl(flh_handle* h, DevBuf<float4>& pts, size_t M, bool& touched);
+// Map index (re)build.  The new index is written over the old one's buffers, so a failure after that point leaves no
+// usable map: the handle is then marked map-less (flh_eval refuses) instead of pointing at half-written tables.
 static int rebuild_index(flh_handle* h, DevBuf<float4>& pts, size_t M) {
+    bool touched = false;
+    const int rc = rebuild_index_impl(h, pts, M, touched);
+    if (rc != 0 && touched) {
+        h->M = 0;
+        h->n_ids = 0;
+        h->nbricks = 0;
+        h->grid = GridParams{};
+        h->searched_once = false;
+        h->id_pos_valid = false;
+    }
+    return rc;
+}
+static int rebuild_index_impl(flh_handle* h, DevBuf<float4>& pts, size_t M, bool& touched) {
     hipStream_t st = h->stream;
     const float c = h->cfg.cell_size;
     const uint32_t Mu = (uint32_t)M;
@@ -346,6 +399,7 @@ static int rebuild_index(flh_handle* h, DevBuf<float4>& pts, size_t M) {
     while (hs < 2 * rows_cap) hs <<= 1;
     int log2hs = 0;
     while ((1u << log2hs) < hs) ++log2hs;
+    touched = true;  // from here on the previous index is being overwritten
     HIPC(h->map_sorted.reserve(pts_cap));
     HIPC(h->hash.reserve(hs));
     HIPC(h->starts.reserve(rows_cap * flh::kBrickStride));
@@ -672,67 +726,102 @@ static int prepare_scan_buffers(flh_handle* h, size_t N, bool full_clear) {
     return 0;
 }
 
-// Second half of staging: h->st_raw holds N raw points on the copy stream and sl.h_body their host copy; orders them by
-// the Morton code of their body-frame coordinates (sort_queries != 0) into the slot; returns when the slot is complete.
-static int stage_sorted(flh_handle* h, flh_handle::Slot& sl, size_t N) {
-    hipStream_t cs = h->copy_stream;
-    const size_t n1 = N ? N : 1;
-    HIPC(sl.body.reserve(n1));
-    sl.h_perm.resize(n1);
-    const bool do_sort = h->cfg.sort_queries != 0 && N > 1;
-    if (do_sort) {
-        const uint32_t Nu = (uint32_t)N;
-        HIPC(h->st_k0.reserve(N)); HIPC(h->st_k1.reserve(N)); HIPC(h->st_v0.reserve(N)); HIPC(h->st_v1.reserve(N));
-        HIPC(flh::launch_scan_keys(h->st_raw.p, Nu, 0.25f, h->st_k0.p, h->st_v0.p, cs));
-        size_t tb = 0;
-        HIPC(flh::sort_scan_pairs(nullptr, tb, h->st_k0.p, h->st_k1.p, h->st_v0.p, h->st_v1.p, Nu, cs));
-        HIPC(h->st_tmp.reserve(tb));
-        tb = h->st_tmp.cap;
-        HIPC(flh::sort_scan_pairs(h->st_tmp.p, tb, h->st_k0.p, h->st_k1.p, h->st_v0.p, h->st_v1.p, Nu, cs));
-        HIPC(flh::launch_scan_gather(h->st_raw.p, h->st_v1.p, Nu, sl.body.p, cs));
-        HIPC(hipMemcpyAsync(sl.h_perm.data(), h->st_v1.p, N * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
-    } else {
-        HIPC(flh::launch_scan_gather(h->st_raw.p, nullptr, (uint32_t)N, sl.body.p, cs));
-        for (size_t i = 0; i < N; ++i) sl.h_perm[i] = (uint32_t)i;
-    }
-    HIPC(hipEventRecord(sl.ready, cs));
-    HIPC(hipStreamSynchronize(cs));  // h_perm must be complete
-    sl.N = N;
-    sl.used = true;
+// ---------------------------------------------------------------------------------------------
+// Scan staging.  A scan travels: caller's buffer -> pinned host memory (skipped when the caller's buffer is itself
+// pinned, flh_host_alloc) -> one H2D copy of the records as they are -> k_scan_restride (float4 + Morton key of the
+// body-frame coordinates) -> radix sort -> gather into the slot.  Everything runs on the copy stream; nothing comes back
+// to the host (the permutation and the host copy of feats_down_body are fetched lazily, flh_fetch_* / flh_fetch_rows
+// need them, the hot path does not).  flh_scan_stage_async hands the whole sequence to the handle's staging thread so
+// that the caller's thread goes straight on with the update of the previous scan.
+// ---------------------------------------------------------------------------------------------
+static int ensure_pinned(unsigned char*& p, size_t& cap, size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIPC(hipHostMalloc((void**)&p, want, hipHostMallocDefault));
+    cap = want;
     return 0;
+}
+static bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // plain malloc'd memory: not an error
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
 }
 
 static int stage_prepare(flh_handle* h, flh_handle::Slot& sl) {
     HIPC(hipSetDevice(h->device));
     if (!h->copy_stream) HIPC(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     if (!sl.ready) HIPC(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+    if (!sl.h2d_done) HIPC(hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
+    sl.host_valid = false;
     return 0;
 }
 
-// Copies a scan to the device (copy stream); returns when the host buffer may be reused.
-static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size_t stride_bytes, size_t N) {
+// Device side of the plain staging: st_raw (N float4, original order) + keys/vals are in place on the copy stream.
+static int stage_sorted(flh_handle* h, flh_handle::Slot& sl, size_t N, bool have_keys) {
+    hipStream_t cs = h->copy_stream;
+    const size_t n1 = N ? N : 1;
+    HIPC(sl.body.reserve(n1));
+    const bool do_sort = h->cfg.sort_queries != 0 && N > 1;
+    if (do_sort) {
+        const uint32_t Nu = (uint32_t)N;
+        HIPC(h->st_k0.reserve(N)); HIPC(h->st_k1.reserve(N)); HIPC(h->st_v0.reserve(N)); HIPC(h->st_v1.reserve(N));
+        if (!have_keys) HIPC(flh::launch_scan_keys(h->st_raw.p, Nu, 0.25f, h->st_k0.p, h->st_v0.p, cs));
+        size_t tb = 0;
+        HIPC(flh::sort_scan_pairs(nullptr, tb, h->st_k0.p, h->st_k1.p, h->st_v0.p, h->st_v1.p, Nu, cs));
+        HIPC(h->st_tmp.reserve(tb));
+        tb = h->st_tmp.cap;
+        HIPC(flh::sort_scan_pairs(h->st_tmp.p, tb, h->st_k0.p, h->st_k1.p, h->st_v0.p, h->st_v1.p, Nu, cs));
+        HIPC(flh::launch_scan_gather(h->st_raw.p, h->st_v1.p, Nu, sl.body.p, cs));
+    } else {
+        HIPC(flh::launch_scan_gather(h->st_raw.p, nullptr, (uint32_t)N, sl.body.p, cs));
+    }
+    HIPC(hipEventRecord(sl.ready, cs));
+    sl.N = N;
+    sl.used = true;
+    return 0;
+}
+
+// Copies a scan to the device (copy stream).  wait_reusable: return only when the caller's buffer may be overwritten.
+static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size_t stride_bytes, size_t N, bool wait_reusable) {
     if (N > 0 && !pts) return fail("scan staging: null points");
-    if (stride_bytes < 12 && N > 0) return fail("scan staging: stride_bytes < 12");
+    if ((stride_bytes < 12 || (stride_bytes & 3)) && N > 0) return fail("scan staging: stride_bytes must be a multiple of 4 and >= 12");
     if (N >= (1ull << 26)) return fail("scan staging: N too large");
     if (stage_prepare(h, sl) != 0) return -1;
     hipStream_t cs = h->copy_stream;
     const size_t n1 = N ? N : 1;
+    const size_t bytes = N * stride_bytes;
     HIPC(h->st_raw.reserve(n1));
-    sl.h_body.resize(3 * n1);
-    std::vector<float4> hb(n1);
-    const unsigned char* src = (const unsigned char*)pts;
-    for (size_t i = 0; i < N; ++i) {
-        float p[3];
-        std::memcpy(p, src + i * stride_bytes, 12);
-        hb[i] = make_float4(p[0], p[1], p[2], 0.f);
-        sl.h_body[3 * i] = p[0]; sl.h_body[3 * i + 1] = p[1]; sl.h_body[3 * i + 2] = p[2];
+    HIPC(h->st_bytes.reserve(bytes ? bytes : 4));
+    bool direct = false;
+    if (N > 0) {
+        direct = is_pinned_host(pts);
+        const void* src = pts;
+        if (!direct) {  // pageable memory cannot be DMA'd: through the slot's pinned buffer (the caller's is free at once)
+            if (ensure_pinned(sl.pin, sl.pin_cap, bytes) != 0) return -1;
+            std::memcpy(sl.pin, pts, bytes);
+            src = sl.pin;
+        }
+        HIPC(hipMemcpyAsync(h->st_bytes.p, src, bytes, hipMemcpyHostToDevice, cs));
+        HIPC(hipEventRecord(sl.h2d_done, cs));
     }
-    if (N > 0) HIPC(hipMemcpyAsync(h->st_raw.p, hb.data(), N * sizeof(float4), hipMemcpyHostToDevice, cs));
-    return stage_sorted(h, sl, N);  // synchronises the copy stream before hb (pageable) goes out of scope
+    const bool do_sort = h->cfg.sort_queries != 0 && N > 1;
+    if (do_sort) { HIPC(h->st_k0.reserve(N)); HIPC(h->st_v0.reserve(N)); }
+    HIPC(flh::launch_scan_restride(h->st_bytes.p, (uint32_t)stride_bytes, 0, 0, (uint32_t)N, 0.25f, h->st_raw.p,
+                                   do_sort ? h->st_k0.p : nullptr, do_sort ? h->st_v0.p : nullptr, nullptr, cs));
+    if (stage_sorted(h, sl, N, do_sort) != 0) return -1;
+    if (direct && wait_reusable && N > 0) HIPC(hipEventSynchronize(sl.h2d_done));
+    return 0;
 }
 
 // The raw-scan front end on the device: optional undistortion (UndistortPcl's per-point half, IMU_Processing.hpp:307-349),
-// optional voxel-grid down-sampling (downSizeFilterSurf.filter, src/laserMapping.cpp:904-905), then staging.
+// optional voxel-grid down-sampling (downSizeFilterSurf.filter, src/laserMapping.cpp:904-905), then staging.  The cloud the
+// down-sampling starts from (feats_undistort) stays in the slot for flh_frame_world.
 struct UndistortArgs {
     const flh_pose6d* poses = nullptr;
     int n_pose = 0;
@@ -740,73 +829,77 @@ struct UndistortArgs {
     size_t time_offset_bytes = 0;
     float* undistorted_out = nullptr;
 };
+static int read_aabb(flh_handle* h, const float4* pts, uint32_t n, hipStream_t cs, float mn[3], float mx[3], uint32_t* bad_out) {
+    HIPC(h->mb_aabb.reserve(8));
+    const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    HIPC(hipMemcpyAsync(h->mb_aabb.p, init, sizeof(init), hipMemcpyHostToDevice, cs));
+    HIPC(flh::launch_aabb(pts, n, h->mb_aabb.p, cs));
+    HIPC(hipMemcpyAsync(h->h_small, h->mb_aabb.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+    HIPC(hipStreamSynchronize(cs));
+    for (int d = 0; d < 6; ++d) {
+        const uint32_t u = h->h_small[d];
+        const uint32_t bits = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+        float f;
+        std::memcpy(&f, &bits, 4);
+        (d < 3 ? mn[d] : mx[d - 3]) = f;
+    }
+    if (bad_out) *bad_out = h->h_small[6];
+    return 0;
+}
 static int stage_raw(flh_handle* h, flh_handle::Slot& sl, const char* who, const void* pts, size_t stride_bytes, size_t n,
                      const UndistortArgs* und, float leaf, size_t* n_out) {
     const std::string w(who);
     if (n > 0 && !pts) return fail(w + ": null points");
-    if (stride_bytes < 12 && n > 0) return fail(w + ": stride_bytes < 12");
+    if ((stride_bytes < 12 || (stride_bytes & 3)) && n > 0) return fail(w + ": stride_bytes must be a multiple of 4 and >= 12");
     if (n >= (1ull << 26)) return fail(w + ": n too large");
     if (und) {
         if (!und->poses || und->n_pose < 1 || !und->x_end) return fail(w + ": IMU poses / end state missing");
-        if (n > 0 && und->time_offset_bytes + 4 > stride_bytes) return fail(w + ": time_offset_bytes outside the point record");
+        if (n > 0 && (und->time_offset_bytes + 4 > stride_bytes || (und->time_offset_bytes & 3)))
+            return fail(w + ": time_offset_bytes outside the point record (or not a multiple of 4)");
         for (int k = 0; k < und->n_pose; ++k)
             if (!std::isfinite(und->poses[k].offset_time)) return fail(w + ": non-finite IMU pose offset_time");
     }
     if (stage_prepare(h, sl) != 0) return -1;
     hipStream_t cs = h->copy_stream;
     const size_t n1 = n ? n : 1;
-    HIPC(h->ds_raw.reserve(n1));
     HIPC(h->st_raw.reserve(n1));
-    std::vector<float4> hb(n1);
-    const unsigned char* src = (const unsigned char*)pts;
-    for (size_t i = 0; i < n; ++i) {
-        float p[3], t = 0.f;
-        std::memcpy(p, src + i * stride_bytes, 12);
-        if (und) std::memcpy(&t, src + i * stride_bytes + und->time_offset_bytes, 4);
-        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2]) || !std::isfinite(t))
-            return fail(w + ": non-finite point at index " + std::to_string(i));
-        hb[i] = make_float4(p[0], p[1], p[2], t);
-    }
+    HIPC(sl.dense.reserve(n1));
+    sl.n_dense = 0;
     size_t m = 0;
     if (n > 0) {
         const uint32_t nu = (uint32_t)n;
-        HIPC(hipMemcpyAsync(h->ds_raw.p, hb.data(), n * sizeof(float4), hipMemcpyHostToDevice, cs));
-        const float4* srcd = h->ds_raw.p;
+        const size_t bytes = n * stride_bytes;
+        HIPC(h->st_bytes.reserve(bytes));
+        const void* src = pts;
+        const bool direct = is_pinned_host(pts);
+        if (!direct) {
+            if (ensure_pinned(sl.pin, sl.pin_cap, bytes) != 0) return -1;
+            std::memcpy(sl.pin, pts, bytes);
+            src = sl.pin;
+        }
+        HIPC(hipMemcpyAsync(h->st_bytes.p, src, bytes, hipMemcpyHostToDevice, cs));
+        HIPC(h->mb_aabb.reserve(8));
+        HIPC(hipMemsetAsync(h->mb_aabb.p + 6, 0, sizeof(uint32_t), cs));  // non-finite counter
+        // records -> float4 (x, y, z, time offset); with undistortion into scratch, else straight into the slot's dense cloud
+        if (und) HIPC(h->ds_raw.reserve(n1));
+        float4* first = und ? h->ds_raw.p : sl.dense.p;
+        HIPC(flh::launch_scan_restride(h->st_bytes.p, (uint32_t)stride_bytes, und ? (uint32_t)und->time_offset_bytes : 0u, und ? 1 : 0,
+                                       nu, 0.25f, first, nullptr, nullptr, h->mb_aabb.p + 6, cs));
         if (und) {
-            HIPC(h->ds_und.reserve(n1));
             HIPC(h->ds_poses.reserve((size_t)22 * und->n_pose));
             static_assert(sizeof(flh_pose6d) == 22 * sizeof(double), "flh_pose6d must be 22 packed doubles");
             HIPC(hipMemcpyAsync(h->ds_poses.p, und->poses, sizeof(flh_pose6d) * und->n_pose, hipMemcpyHostToDevice, cs));
             const StateDev se = make_state(und->x_end + 3, und->x_end + 0, und->x_end + 7, und->x_end + 11);
-            HIPC(flh::launch_undistort(se, h->ds_poses.p, und->n_pose, h->ds_raw.p, nu, h->ds_und.p, cs));
-            srcd = h->ds_und.p;
-            if (und->undistorted_out) {
-                std::vector<float4> uo(n);
-                HIPC(hipMemcpyAsync(uo.data(), h->ds_und.p, n * sizeof(float4), hipMemcpyDeviceToHost, cs));
-                HIPC(hipStreamSynchronize(cs));
-                for (size_t i = 0; i < n; ++i) {
-                    und->undistorted_out[3 * i] = uo[i].x; und->undistorted_out[3 * i + 1] = uo[i].y; und->undistorted_out[3 * i + 2] = uo[i].z;
-                }
-            }
+            HIPC(flh::launch_undistort(se, h->ds_poses.p, und->n_pose, h->ds_raw.p, nu, sl.dense.p, cs));
         }
+        sl.n_dense = n;
+        const float4* srcd = sl.dense.p;
         bool passthrough = !(leaf > 0.f);
+        uint32_t bad = 0;
         if (!passthrough) {
-            // getMinMax3D on the device (the points may just have been moved by the undistortion)
-            HIPC(h->mb_aabb.reserve(6));
-            const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-            uint32_t got[6];
-            HIPC(hipMemcpyAsync(h->mb_aabb.p, init, sizeof(init), hipMemcpyHostToDevice, cs));
-            HIPC(flh::launch_aabb(srcd, nu, h->mb_aabb.p, cs));
-            HIPC(hipMemcpyAsync(got, h->mb_aabb.p, sizeof(got), hipMemcpyDeviceToHost, cs));
-            HIPC(hipStreamSynchronize(cs));
-            float mn[3], mx[3];
-            for (int d = 0; d < 6; ++d) {
-                const uint32_t u = got[d];
-                const uint32_t bits = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
-                float f;
-                std::memcpy(&f, &bits, 4);
-                (d < 3 ? mn[d] : mx[d - 3]) = f;
-            }
+            float mn[3], mx[3];  // getMinMax3D on the device (the points may just have been moved by the undistortion)
+            if (read_aabb(h, srcd, nu, cs, mn, mx, &bad) != 0) return -1;
+            if (bad) return fail(w + ": " + std::to_string(bad) + " non-finite point record(s)");
             const float inv = 1.0f / leaf;  // inverse_leaf_size_
             long long dxyz[3];
             for (int d = 0; d < 3; ++d) dxyz[d] = (long long)((mx[d] - mn[d]) * inv) + 1;
@@ -830,32 +923,102 @@ static int stage_raw(flh_handle* h, flh_handle::Slot& sl, const char* who, const
                 HIPC(flh::launch_vg_heads(h->st_k1.p, nu, h->ds_flags.p, cs));
                 tb = h->st_tmp.cap;
                 HIPC(flh::inclusive_sum(h->st_tmp.p, tb, h->ds_flags.p, h->ds_incl.p, nu, cs));
-                uint32_t m32 = 0;
-                HIPC(hipMemcpyAsync(&m32, h->ds_incl.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+                HIPC(hipMemcpyAsync(h->h_small, h->ds_incl.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
                 HIPC(flh::launch_vg_reduce(srcd, h->st_k1.p, h->st_v1.p, h->ds_flags.p, h->ds_incl.p, nu, h->st_raw.p, cs));
                 HIPC(hipStreamSynchronize(cs));
-                m = m32;
+                m = h->h_small[0];
             }
         }
         if (passthrough) {
             HIPC(hipMemcpyAsync(h->st_raw.p, srcd, n * sizeof(float4), hipMemcpyDeviceToDevice, cs));
+            HIPC(hipMemcpyAsync(h->h_small, h->mb_aabb.p + 6, sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+            HIPC(hipStreamSynchronize(cs));
+            if (h->h_small[0]) return fail(w + ": " + std::to_string(h->h_small[0]) + " non-finite point record(s)");
             m = n;
         }
-        // feats_down_body back to the host (the node publishes it; flh_fetch_rows / flh_fetch_scan read it)
-        std::vector<float4> out(m ? m : 1);
-        HIPC(hipMemcpyAsync(out.data(), h->st_raw.p, m * sizeof(float4), hipMemcpyDeviceToHost, cs));
-        HIPC(hipStreamSynchronize(cs));
-        sl.h_body.resize(3 * (m ? m : 1));
-        for (size_t i = 0; i < m; ++i) { sl.h_body[3 * i] = out[i].x; sl.h_body[3 * i + 1] = out[i].y; sl.h_body[3 * i + 2] = out[i].z; }
-    } else {
-        sl.h_body.resize(3);
+        if (und && und->undistorted_out) {  // feats_undistort for the caller: only when asked for
+            if (ensure_pinned(h->pin_out, h->pin_out_cap, n * sizeof(float4)) != 0) return -1;
+            HIPC(hipMemcpyAsync(h->pin_out, sl.dense.p, n * sizeof(float4), hipMemcpyDeviceToHost, cs));
+            HIPC(hipStreamSynchronize(cs));
+            const float4* uo = (const float4*)h->pin_out;
+            for (size_t i = 0; i < n; ++i) {
+                und->undistorted_out[3 * i] = uo[i].x; und->undistorted_out[3 * i + 1] = uo[i].y; und->undistorted_out[3 * i + 2] = uo[i].z;
+            }
+        }
     }
     if (n_out) *n_out = m;
-    return stage_sorted(h, sl, m);
+    return stage_sorted(h, sl, m, false);
+}
+
+// The slot's scan on the host (feats_down_body in the order it was staged + the permutation of the device order): one D2H
+// of the Morton-ordered cloud, whose .w carries each point's original index.  Only the lazy fetches need it.
+static int ensure_host_copy(flh_handle* h, flh_handle::Slot& sl) {
+    if (sl.host_valid) return 0;
+    const size_t N = sl.N;
+    sl.h_perm.assign(N ? N : 1, 0u);
+    sl.h_body.assign(3 * (N ? N : 1), 0.f);
+    if (N > 0) {
+        HIPC(hipSetDevice(h->device));
+        if (ensure_pinned(h->pin_out, h->pin_out_cap, N * sizeof(float4)) != 0) return -1;
+        HIPC(hipEventSynchronize(sl.ready));
+        HIPC(hipMemcpy(h->pin_out, sl.body.p, N * sizeof(float4), hipMemcpyDeviceToHost));
+        const float4* b = (const float4*)h->pin_out;
+        for (size_t i = 0; i < N; ++i) {
+            uint32_t o;
+            std::memcpy(&o, &b[i].w, 4);
+            if (o >= N) return fail("scan slot: corrupt permutation");
+            sl.h_perm[i] = o;
+            sl.h_body[3 * (size_t)o] = b[i].x; sl.h_body[3 * (size_t)o + 1] = b[i].y; sl.h_body[3 * (size_t)o + 2] = b[i].z;
+        }
+    }
+    sl.host_valid = true;
+    return 0;
+}
+
+// ---- the staging thread (flh_scan_stage_async) ----
+static void stager_main(flh_handle* h) {
+    (void)hipSetDevice(h->device);
+    std::unique_lock<std::mutex> lk(h->st_mu);
+    for (;;) {
+        h->st_cv.wait(lk, [&] { return h->st_quit || !h->st_queue.empty(); });
+        if (h->st_queue.empty()) return;  // quit
+        flh_handle::StageJob job = h->st_queue.front();
+        h->st_queue.pop_front();
+        lk.unlock();
+        flh_handle::Slot& sl = h->slots[job.slot];
+        g_err.clear();
+        const int rc = stage_into(h, sl, job.pts, job.stride, job.N, true);
+        lk.lock();
+        sl.async_rc = rc;
+        sl.async_err = rc ? g_err : std::string();
+        sl.pending = false;
+        h->st_done.notify_all();
+    }
+}
+static int wait_slot(flh_handle* h, flh_handle::Slot& sl) {
+    if (!h->stager.joinable()) return 0;
+    std::unique_lock<std::mutex> lk(h->st_mu);
+    h->st_done.wait(lk, [&] { return !sl.pending; });
+    if (sl.async_rc != 0) {
+        const std::string e = sl.async_err;
+        sl.async_rc = 0;
+        return fail("flh_scan_stage_async: " + e);
+    }
+    return 0;
+}
+static void stop_stager(flh_handle* h) {
+    if (!h->stager.joinable()) return;
+    {
+        std::lock_guard<std::mutex> lk(h->st_mu);
+        h->st_quit = true;
+    }
+    h->st_cv.notify_all();
+    h->stager.join();
 }
 
 static int activate(flh_handle* h, flh_handle::Slot& sl, bool full_clear) {
     HIPC(hipSetDevice(h->device));
+    if (wait_slot(h, sl) != 0) return -1;
     HIPC(hipStreamWaitEvent(h->stream, sl.ready, 0));
     if (prepare_scan_buffers(h, sl.N, full_clear) != 0) return -1;
     h->cur_body = sl.body.p;
@@ -866,7 +1029,7 @@ static int activate(flh_handle* h, flh_handle::Slot& sl, bool full_clear) {
 int flh_scan_upload(flh_handle* h, const void* pts, size_t stride_bytes, size_t N) {
     if (!h) return fail("flh_scan_upload: null handle");
     flh_handle::Slot& sl = h->slots[FLH_MAX_SLOTS];
-    if (stage_into(h, sl, pts, stride_bytes, N) != 0) return -1;
+    if (stage_into(h, sl, pts, stride_bytes, N, true) != 0) return -1;
     if (activate(h, sl, true) != 0) return -1;
     HIPC(hipStreamSynchronize(h->stream));
     return 0;
@@ -875,7 +1038,40 @@ int flh_scan_upload(flh_handle* h, const void* pts, size_t stride_bytes, size_t 
 int flh_scan_stage(flh_handle* h, int slot, const void* pts, size_t stride_bytes, size_t N) {
     if (!h) return fail("flh_scan_stage: null handle");
     if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_stage: bad slot");
-    return stage_into(h, h->slots[slot], pts, stride_bytes, N);
+    if (wait_slot(h, h->slots[slot]) != 0) return -1;
+    return stage_into(h, h->slots[slot], pts, stride_bytes, N, true);
+}
+
+int flh_scan_stage_async(flh_handle* h, int slot, const void* pts, size_t stride_bytes, size_t N) {
+    if (!h) return fail("flh_scan_stage_async: null handle");
+    if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_stage_async: bad slot");
+    if (N > 0 && !pts) return fail("flh_scan_stage_async: null points");
+    if (h->cur == &h->slots[slot]) return fail("flh_scan_stage_async: the slot holds the active scan");
+    std::lock_guard<std::mutex> lk(h->st_mu);
+    if (h->slots[slot].pending) return fail("flh_scan_stage_async: the slot is still being staged");
+    if (!h->stager.joinable()) h->stager = std::thread(stager_main, h);
+    h->slots[slot].pending = true;
+    h->st_queue.push_back({slot, pts, stride_bytes, N});
+    h->st_cv.notify_one();
+    return 0;
+}
+
+int flh_scan_wait(flh_handle* h, int slot) {
+    if (!h) return fail("flh_scan_wait: null handle");
+    if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_wait: bad slot");
+    return wait_slot(h, h->slots[slot]);
+}
+
+void* flh_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)fail("flh_host_alloc: hipHostMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+void flh_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 // downSizeFilterSurf.setInputCloud(feats_undistort); downSizeFilterSurf.filter(*feats_down_body) -- :904-905
@@ -884,6 +1080,7 @@ int flh_scan_stage_downsampled(flh_handle* h, int slot, const void* pts, size_t 
     if (!h) return fail("flh_scan_stage_downsampled: null handle");
     if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_stage_downsampled: bad slot");
     if (!(leaf_size > 0.f)) return fail("flh_scan_stage_downsampled: leaf size must be > 0");
+    if (wait_slot(h, h->slots[slot]) != 0) return -1;
     return stage_raw(h, h->slots[slot], "flh_scan_stage_downsampled", pts, stride_bytes, n, nullptr, leaf_size, n_out);
 }
 
@@ -893,6 +1090,7 @@ int flh_scan_stage_undistorted(flh_handle* h, int slot, const void* pts, size_t 
                                float* undistorted_xyz, size_t* n_out) {
     if (!h) return fail("flh_scan_stage_undistorted: null handle");
     if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_stage_undistorted: bad slot");
+    if (wait_slot(h, h->slots[slot]) != 0) return -1;
     UndistortArgs u;
     u.poses = imu_pose;
     u.n_pose = n_pose;
@@ -902,18 +1100,91 @@ int flh_scan_stage_undistorted(flh_handle* h, int slot, const void* pts, size_t 
     return stage_raw(h, h->slots[slot], "flh_scan_stage_undistorted", pts, stride_bytes, n, &u, leaf_size, n_out);
 }
 
-// feats_down_body of the active scan, original (staging) order
+// feats_down_body of the ACTIVE scan, original (staging) order
 int flh_fetch_scan(flh_handle* h, float* xyz) {
     if (!h) return fail("flh_fetch_scan: null handle");
     if (!h->cur) return fail("flh_fetch_scan: no active scan");
     if (h->N > 0 && !xyz) return fail("flh_fetch_scan: null buffer");
+    if (ensure_host_copy(h, *h->cur) != 0) return -1;
     if (h->N > 0) std::memcpy(xyz, h->cur->h_body.data(), sizeof(float) * 3 * h->N);
+    return 0;
+}
+
+// SURVEY.md 8(f) row 4 -- publish_frame_world (src/laserMapping.cpp:478-530): RGBpointBodyToWorld (:200-211) over
+// feats_undistort (dense != 0: the cloud `slot` was down-sampled from, still on the device) or feats_down_body (dense == 0).
+int flh_frame_world(flh_handle* h, int slot, const double x[FLH_NSTATE], int dense, float* world_xyz, size_t capacity_points,
+                    size_t* n_points) {
+    if (!h || !x) return fail("flh_frame_world: null argument");
+    flh_handle::Slot* sl = nullptr;
+    if (slot < 0) sl = h->cur;
+    else if (slot <= FLH_MAX_SLOTS) sl = &h->slots[slot];
+    if (!sl || !sl->used) return fail("flh_frame_world: slot not staged");
+    if (wait_slot(h, *sl) != 0) return -1;
+    if (dense && sl->n_dense == 0 && sl->N > 0)
+        return fail("flh_frame_world: the slot was not staged from a raw scan (no feats_undistort on the device)");
+    HIPC(hipSetDevice(h->device));
+    const size_t n = dense ? sl->n_dense : sl->N;
+    if (n_points) *n_points = n;
+    if (n == 0 || (!world_xyz && capacity_points == 0)) return 0;  // size query
+    if (!world_xyz) return fail("flh_frame_world: null buffer");
+    if (capacity_points < n) return fail("flh_frame_world: buffer too small");
+    hipStream_t st = h->stream;
+    HIPC(hipStreamWaitEvent(st, sl->ready, 0));
+    HIPC(h->fw_out.reserve(n));
+    if (ensure_pinned(h->pin_out, h->pin_out_cap, n * sizeof(float4)) != 0) return -1;
+    const StateDev s = make_state(x + 3, x + 0, x + 7, x + 11);
+    HIPC(flh::launch_cloud_body_to_world(s, dense ? sl->dense.p : sl->body.p, (uint32_t)n, h->fw_out.p, st));
+    HIPC(hipMemcpyAsync(h->pin_out, h->fw_out.p, n * sizeof(float4), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    const float4* o = (const float4*)h->pin_out;
+    if (dense) {
+        for (size_t i = 0; i < n; ++i) { world_xyz[3 * i] = o[i].x; world_xyz[3 * i + 1] = o[i].y; world_xyz[3 * i + 2] = o[i].z; }
+    } else {  // the slot's cloud is Morton-ordered; .w = original index
+        for (size_t i = 0; i < n; ++i) {
+            uint32_t k;
+            std::memcpy(&k, &o[i].w, 4);
+            if (k >= n) return fail("flh_frame_world: corrupt permutation");
+            world_xyz[3 * (size_t)k] = o[i].x; world_xyz[3 * (size_t)k + 1] = o[i].y; world_xyz[3 * (size_t)k + 2] = o[i].z;
+        }
+    }
+    return 0;
+}
+
+// RGBpointBodyToWorld over any host cloud (e.g. pcl_wait_save's input, :505-512)
+int flh_points_body_to_world(flh_handle* h, const double x[FLH_NSTATE], const void* pts, size_t stride_bytes, size_t n,
+                             float* world_xyz) {
+    if (!h || !x) return fail("flh_points_body_to_world: null argument");
+    if (n == 0) return 0;
+    if (!pts || !world_xyz) return fail("flh_points_body_to_world: null buffer");
+    if (stride_bytes < 12 || (stride_bytes & 3)) return fail("flh_points_body_to_world: stride_bytes must be a multiple of 4 and >= 12");
+    if (n >= (1ull << 28)) return fail("flh_points_body_to_world: n too large");
+    HIPC(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const size_t bytes = n * stride_bytes;
+    HIPC(h->fw_bytes.reserve(bytes)); HIPC(h->fw_in.reserve(n)); HIPC(h->fw_out.reserve(n));
+    const void* src = pts;
+    if (!is_pinned_host(pts)) {
+        if (ensure_pinned(h->pin_in, h->pin_in_cap, bytes) != 0) return -1;
+        std::memcpy(h->pin_in, pts, bytes);
+        src = h->pin_in;
+    }
+    if (ensure_pinned(h->pin_out, h->pin_out_cap, n * sizeof(float4)) != 0) return -1;
+    HIPC(hipMemcpyAsync(h->fw_bytes.p, src, bytes, hipMemcpyHostToDevice, st));
+    HIPC(flh::launch_scan_restride(h->fw_bytes.p, (uint32_t)stride_bytes, 0, 0, (uint32_t)n, 0.25f, h->fw_in.p, nullptr, nullptr, nullptr, st));
+    const StateDev s = make_state(x + 3, x + 0, x + 7, x + 11);
+    HIPC(flh::launch_cloud_body_to_world(s, h->fw_in.p, (uint32_t)n, h->fw_out.p, st));
+    HIPC(hipMemcpyAsync(h->pin_out, h->fw_out.p, n * sizeof(float4), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    const float4* o = (const float4*)h->pin_out;
+    for (size_t i = 0; i < n; ++i) { world_xyz[3 * i] = o[i].x; world_xyz[3 * i + 1] = o[i].y; world_xyz[3 * i + 2] = o[i].z; }
     return 0;
 }
 
 int flh_scan_activate(flh_handle* h, int slot) {
     if (!h) return fail("flh_scan_activate: null handle");
-    if (slot < 0 || slot >= FLH_MAX_SLOTS || !h->slots[slot].used) return fail("flh_scan_activate: slot not staged");
+    if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_activate: bad slot");
+    if (wait_slot(h, h->slots[slot]) != 0) return -1;  // an asynchronous staging of the slot finishes first
+    if (!h->slots[slot].used) return fail("flh_scan_activate: slot not staged");
     return activate(h, h->slots[slot], false);
 }
 
@@ -926,6 +1197,8 @@ static StateDev make_state(const double rot[4], const double pos[3], const doubl
 
 static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext, double* d_out, double seq, bool timed) {
     hipStream_t st = h->stream;
+    if (!h->cur_body || !h->selected.p) return fail("flh_eval: no active scan (flh_scan_upload / flh_scan_activate first)");
+    if (!h->grid.hash && h->N > 0) return fail("flh_eval: no map (flh_map_build / flh_map_add first)");
     if (!do_search && !h->searched_once && h->N > 0)
         return fail("flh_eval: do_search == 0 before any search on this scan (the reference always searches on the first pass)");
     if (timed) HIPC(hipEventRecord(h->ev[0], st));
@@ -1177,12 +1450,14 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
 // ---------------------------------------------------------------------------------------------
 int flh_fetch_selected(flh_handle* h, uint8_t* flags) {
     if (!h || !flags) return fail("flh_fetch_selected: null argument");
+    if (!h->cur) return fail("flh_fetch_selected: no active scan");
     const size_t N = h->N;
     if (N == 0) return 0;
     HIPC(hipSetDevice(h->device));
     std::vector<uint8_t> tmp(N);
     HIPC(hipMemcpyAsync(tmp.data(), h->selected.p, N, hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
+    if (ensure_host_copy(h, *h->cur) != 0) return -1;
     const uint32_t* perm = h->cur->h_perm.data();
     for (size_t i = 0; i < N; ++i) flags[perm[i]] = tmp[i];
     return 0;
@@ -1190,6 +1465,7 @@ int flh_fetch_selected(flh_handle* h, uint8_t* flags) {
 
 int flh_fetch_neighbors(flh_handle* h, int32_t* idx, float* d2, uint8_t* cnt) {
     if (!h || !idx || !d2) return fail("flh_fetch_neighbors: null argument");
+    if (!h->cur) return fail("flh_fetch_neighbors: no active scan");
     const size_t N = h->N;
     if (N == 0) return 0;
     HIPC(hipSetDevice(h->device));
@@ -1210,6 +1486,7 @@ int flh_fetch_neighbors(flh_handle* h, int32_t* idx, float* d2, uint8_t* cnt) {
         h->id_pos_valid = true;
     }
     const bool translate = h->n_ids != h->M;
+    if (ensure_host_copy(h, *h->cur) != 0) return -1;
     const uint32_t* perm = h->cur->h_perm.data();
     for (size_t i = 0; i < N; ++i) {
         const size_t o = perm[i];
@@ -1227,12 +1504,14 @@ int flh_fetch_neighbors(flh_handle* h, int32_t* idx, float* d2, uint8_t* cnt) {
 
 int flh_fetch_world(flh_handle* h, float* xyz) {
     if (!h || !xyz) return fail("flh_fetch_world: null argument");
+    if (!h->cur) return fail("flh_fetch_world: no active scan");
     const size_t N = h->N;
     if (N == 0) return 0;
     HIPC(hipSetDevice(h->device));
     std::vector<float4> w(N);
     HIPC(hipMemcpyAsync(w.data(), h->world.p, N * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
+    if (ensure_host_copy(h, *h->cur) != 0) return -1;
     const uint32_t* perm = h->cur->h_perm.data();
     for (size_t i = 0; i < N; ++i) {
         const size_t o = perm[i];
@@ -1243,12 +1522,14 @@ int flh_fetch_world(flh_handle* h, float* xyz) {
 
 int flh_fetch_normvec(flh_handle* h, float* out) {
     if (!h || !out) return fail("flh_fetch_normvec: null argument");
+    if (!h->cur) return fail("flh_fetch_normvec: no active scan");
     const size_t N = h->N;
     if (N == 0) return 0;
     HIPC(hipSetDevice(h->device));
     std::vector<float4> nv(N);
     HIPC(hipMemcpyAsync(nv.data(), h->normvec.p, N * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
+    if (ensure_host_copy(h, *h->cur) != 0) return -1;
     const uint32_t* perm = h->cur->h_perm.data();
     for (size_t i = 0; i < N; ++i) std::memcpy(out + 4 * (size_t)perm[i], &nv[i], 16);
     return 0;
@@ -1283,6 +1564,7 @@ int flh_fetch_rows(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* 
     *n_rows = n;
     if (!hx || !hv) return 0;
     if (cap < n) return fail("flh_fetch_rows: buffers too small");
+    if (ensure_host_copy(h, *h->cur) != 0) return -1;
     std::vector<uint32_t> inv(N ? N : 1);
     for (size_t i = 0; i < N; ++i) inv[h->cur->h_perm[i]] = (uint32_t)i;
     const std::vector<float>& hbody = h->cur->h_body;

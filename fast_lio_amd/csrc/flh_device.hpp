@@ -25,7 +25,7 @@ struct GridParams {
     uint32_t hash_mask;
     int hash_shift;          // 32 - log2(hash size)
     const uint2* hash;       // (brick_key, brick_rank); empty = 0xFFFFFFFF
-    const uint32_t* starts;  // [nbricks * 65] prefix table: cell i of brick b holds pts[starts[b*65+i] .. starts[b*65+i+1])
+    const uint32_t* starts;  // [nbricks * kBrickStride] prefix table: cell i of brick b holds pts[starts[b*S+i] .. starts[b*S+i+1])
     const float4* pts;       // map points sorted by (brick, cell); .w = original map index (bits)
 };
 
@@ -297,7 +297,7 @@ __device__ __forceinline__ void cell_of(const GridParams& g, float x, float y, f
     fx -= flx; fy -= fly; fz -= flz;
 }
 
-constexpr int kBrickStride = 65;  // 64 cells + end sentinel
+constexpr int kBrickStride = 80;  // 64 cells + end sentinel, padded so that every z-slab of 16 cells starts a 64-byte line
 
 // A storage slot that holds no map point (slack behind a brick's points, a removed point, a relocated brick's old range):
 // coordinates so large that every squared distance to it overflows to +inf, which no selection accepts; .w = -1.

@@ -92,6 +92,7 @@ void flh_esekf_predict(flh_esekf* e, double dt, const double Q[144], const doubl
 }
 int flh_esekf_update(flh_esekf* e, double R, flh_update_stats* st) {
     if (!e) return -1;
+    e->err.clear();
     double solve_time = 0;
     try {
         e->kf.update_iterated_dyn_share_modified(R, solve_time);
@@ -111,6 +112,8 @@ int flh_esekf_update(flh_esekf* e, double R, flh_update_stats* st) {
     return 0;
 }
 
+const char* flh_esekf_last_error(const flh_esekf* e) { return e ? e->err.c_str() : "null filter"; }
+
 // One scan of the node's main loop in one call: feats_down_body := staged slot (slot < 0: keep the active scan), the
 // propagated state and covariance from the IMU front end, then update_iterated_dyn_share_modified (:960).
 int flh_esekf_update_scan(flh_esekf* e, int slot, const double x[FLH_NSTATE], const double P[FLH_NDOF * FLH_NDOF], double R,
@@ -122,7 +125,7 @@ int flh_esekf_update_scan(flh_esekf* e, int slot, const double x[FLH_NSTATE], co
             return -1;
         }
         if (flh_scan_activate(e->gpu_ctx.handle, slot) != 0) {
-            e->err = flh_last_error();
+            e->err = std::string("flh_scan_activate: ") + flh_last_error();
             return -1;
         }
     }

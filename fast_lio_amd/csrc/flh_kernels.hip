@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(256) k_brick_tables(const u64* __restrict__ ke
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= nbricks * (uint32_t)kBrickStride) return;
     const uint32_t rank = t / kBrickStride, l = t - rank * kBrickStride;
+    if (l > 64) return;  // padding of the row
     const uint32_t b0 = brick_start[rank], b1 = brick_start[rank + 1];
     const u64 bkey = keys_sorted[b0] >> 6;
     const u64 target = (bkey << 6) + l;  // l == 64 -> first key of the next brick value
@@ -186,14 +187,17 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ void ins6(uint32_t (&K)[6], uint32_t t) {
+constexpr int kTop = 8;  // packed keys kept per lane / per group: the five wanted + three to see ties at the boundary
+__device__ __forceinline__ void ins8(uint32_t (&K)[kTop], uint32_t t) {
     const uint32_t n0 = min(K[0], t);
     const uint32_t n1 = umed3(K[0], K[1], t);
     const uint32_t n2 = umed3(K[1], K[2], t);
     const uint32_t n3 = umed3(K[2], K[3], t);
     const uint32_t n4 = umed3(K[3], K[4], t);
     const uint32_t n5 = umed3(K[4], K[5], t);
-    K[0] = n0; K[1] = n1; K[2] = n2; K[3] = n3; K[4] = n4; K[5] = n5;
+    const uint32_t n6 = umed3(K[5], K[6], t);
+    const uint32_t n7 = umed3(K[6], K[7], t);
+    K[0] = n0; K[1] = n1; K[2] = n2; K[3] = n3; K[4] = n4; K[5] = n5; K[6] = n6; K[7] = n7;
 }
 __device__ __forceinline__ void cex2(uint32_t& a, uint32_t& b) {  // a <= b after
     const uint32_t lo = min(a, b), hi = max(a, b);
@@ -207,25 +211,26 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u32z(uint32_t v) {  // lanes without a source read 0
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
-// lowest six of (mine U partner's), sorted: bitonic half-cleaner, then a 12-comparator network for 6
-// (both verified exhaustively with the 0/1 principle)
+// lowest eight of (mine U partner's), sorted: min(mine[j], partner's[7 - j]) are the eight smallest of the sixteen and
+// form a bitonic sequence, which the three-stage bitonic merge sorts (tools/check_networks.py verifies it exhaustively
+// with the 0/1 principle)
 template <int CTRL>
-__device__ __forceinline__ void merge6(uint32_t (&K)[6]) {
-    uint32_t B[6];
+__device__ __forceinline__ void merge8(uint32_t (&K)[kTop]) {
+    uint32_t B[kTop];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) B[j] = dpp_u32<CTRL>(K[j]);
+    for (int j = 0; j < kTop; ++j) B[j] = dpp_u32<CTRL>(K[j]);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) K[j] = min(K[j], B[5 - j]);
-    cex2(K[1], K[2]); cex2(K[4], K[5]); cex2(K[0], K[2]); cex2(K[3], K[5]);
-    cex2(K[0], K[1]); cex2(K[3], K[4]); cex2(K[2], K[5]); cex2(K[0], K[3]);
-    cex2(K[1], K[4]); cex2(K[2], K[4]); cex2(K[1], K[3]); cex2(K[2], K[3]);
+    for (int j = 0; j < kTop; ++j) K[j] = min(K[j], B[kTop - 1 - j]);
+    cex2(K[0], K[4]); cex2(K[1], K[5]); cex2(K[2], K[6]); cex2(K[3], K[7]);
+    cex2(K[0], K[2]); cex2(K[1], K[3]); cex2(K[4], K[6]); cex2(K[5], K[7]);
+    cex2(K[0], K[1]); cex2(K[2], K[3]); cex2(K[4], K[5]); cex2(K[6], K[7]);
 }
 template <int LPQ>
-__device__ __forceinline__ void merge_group6(uint32_t (&K)[6]) {
-    if (LPQ >= 2) merge6<0xB1>(K);    // quad_perm [1,0,3,2]
-    if (LPQ >= 4) merge6<0x4E>(K);    // quad_perm [2,3,0,1]
-    if (LPQ >= 8) merge6<0x141>(K);   // row_half_mirror
-    if (LPQ >= 16) merge6<0x140>(K);  // row_mirror
+__device__ __forceinline__ void merge_group8(uint32_t (&K)[kTop]) {
+    if (LPQ >= 2) merge8<0xB1>(K);    // quad_perm [1,0,3,2]
+    if (LPQ >= 4) merge8<0x4E>(K);    // quad_perm [2,3,0,1]
+    if (LPQ >= 8) merge8<0x141>(K);   // row_half_mirror
+    if (LPQ >= 16) merge8<0x140>(K);  // row_mirror
 }
 
 // value of lane `src` of the LPQ-lane query group (src is a compile-time constant at every call site after unrolling)
@@ -419,7 +424,27 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             }
         }
         uint32_t la[SPL], nseg[SPL];
-        {
+        if (RING == 1) {
+            // a ring-1 run covers at most three cells of one brick row, so its start and its end sit within four consecutive
+            // table entries: ONE 16-byte load per segment (the table rows are padded so that a z-slab's 16 entries share
+            // a 64-byte line -- the three rows of one z that neighbouring lanes resolve hit the same line)
+            typedef u32x4 __attribute__((aligned(4))) u32x4_u;
+            u32x4 tb[SPL];
+#pragma unroll
+            for (int u = 0; u < SPL; ++u) {
+                const bool hit = (uint32_t)he[u] == key[u];
+                const uint32_t* st = g.starts + (size_t)(hit ? (uint32_t)(he[u] >> 32) : 0u) * kBrickStride + i0[u];
+                tb[u] = *reinterpret_cast<const u32x4_u*>(st);
+            }
+#pragma unroll
+            for (int u = 0; u < SPL; ++u) {
+                const bool hit = (uint32_t)he[u] == key[u];
+                const uint32_t len = i1[u] - i0[u];  // 1..3 cells
+                la[u] = tb[u].x;
+                const uint32_t lb = len == 1 ? tb[u].y : (len == 2 ? tb[u].z : tb[u].w);
+                nseg[u] = hit ? min(lb - la[u], 1u << 18) : 0u;  // cap: keeps the packed sums below exact (> 2^PB is unsettled anyway)
+            }
+        } else {
             uint32_t lb[SPL];
 #pragma unroll
             for (int u = 0; u < SPL; ++u) {
@@ -431,7 +456,7 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
 #pragma unroll
             for (int u = 0; u < SPL; ++u) {
                 const bool hit = (uint32_t)he[u] == key[u];
-                nseg[u] = hit ? min(lb[u] - la[u], 1u << 18) : 0u;  // cap: keeps the packed sums below exact (> 2^PB is unsettled anyway)
+                nseg[u] = hit ? min(lb[u] - la[u], 1u << 18) : 0u;
             }
         }
         PH_MARK(3);  // 3: prefix tables read
@@ -465,9 +490,9 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
         PH_MARK(4);  // 4: prefix done
         // ---- one pass over the candidates: the group's T candidates are dealt round-robin to its lanes
         constexpr uint32_t PMASK = (1u << PB) - 1u;
-        uint32_t K[6];
+        uint32_t K[kTop];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) K[j] = kEmptyPacked;
+        for (int j = 0; j < kTop; ++j) K[j] = kEmptyPacked;
         int cur = 0;
         uint2 sg = seg[grp][0];
         uint2 nx = seg[grp][1];  // the entry after the current one is always in flight before it is needed
@@ -487,20 +512,25 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
                 const uint32_t t = t0 + (uint32_t)(w * LPQ);
                 const float d = dist2(qx, qy, qz, __uint_as_float(v[w].x), __uint_as_float(v[w].y), __uint_as_float(v[w].z));
                 const uint32_t key = (__float_as_uint(d) & ~PMASK) | (t & PMASK);
-                ins6(K, (t < T) ? key : kEmptyPacked);
+                ins8(K, (t < T) ? key : kEmptyPacked);
             }
         }
         PH_MARK(5);  // 5: candidates
-        merge_group6<LPQ>(K);
+        merge_group8<LPQ>(K);
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < 5; ++j) cnt += (K[j] < kEmptyPacked) ? 1 : 0;
-        // The packed order decides WHICH five candidates are the nearest as long as the 5th and the 6th differ above the
-        // packed bits (every candidate outside the best six is then farther than all of the best five); the ORDER among
-        // the five is settled below from their exact (d2, map index) once the points are loaded.  A 5th/6th pair that
-        // agrees there (or a list longer than the packed index can name) leaves the set open: next stage / general path.
-        const bool amb = T > PMASK + 1u || (K[5] < kEmptyPacked && (K[4] >> PB) == (K[5] >> PB));
-        const float d5hi = (cnt == 5) ? __uint_as_float(K[4] | PMASK) : INFINITY;  // >= the true 5th distance found
+        // The packed order decides WHICH candidates can be among the five nearest: with v = the 5th key above the packed
+        // bits, every candidate whose key exceeds v there is farther than five others, and those at or below v are all
+        // among the best eight as long as the 8th key is above v.  Their exact (d2, map index) -- known once their points
+        // are loaded -- then picks and orders the five.  Only an 8th key at v (four neighbours within 2^-15 relative, or
+        // equal distances) or a list longer than the packed index can name leaves the set open: next stage / general path.
+        const uint32_t v5 = K[4] >> PB;
+        int m = cnt;  // candidates to load: the found ones among the first five + the ties of the fifth
+#pragma unroll
+        for (int j = 5; j < kTop - 1; ++j) m += (cnt == 5 && K[j] < kEmptyPacked && (K[j] >> PB) == v5) ? 1 : 0;
+        const bool amb = T > PMASK + 1u || (cnt == 5 && K[kTop - 1] < kEmptyPacked && (K[kTop - 1] >> PB) == v5);
+        const float d5hi = (cnt == 5) ? __uint_as_float(K[4] | PMASK) : INFINITY;  // >= the true 5th distance
         const float octfrac = fminf(fminf(fmaxf(fx, 1.f - fx), fmaxf(fy, 1.f - fy)), fmaxf(fz, 1.f - fz));
         const float gr = (OCT ? octfrac : (float)RING + minfrac) * g.c - 2e-3f * g.c;  // guaranteed-complete radius (fp margin)
         const float gr2 = gr * gr;
@@ -510,12 +540,13 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
         if (cand_counter && live && lane == 0) atomicAdd(cand_counter, (u64)T);
 #endif
         PH_MARK(6);  // 6: merged
-        // ---- results: lane l loads ranks l, l + LPQ, ...: flat index -> map position (table walk) -> one point load each,
-        // all issued before the first is consumed; the exact squared distance is recomputed from the point (same formula,
-        // same bits as the scan saw before packing).  The group then exchanges the five (d2, map index) pairs and every
-        // lane places its points at their exact rank -- two neighbours closer than the packed bits resolve cost nothing extra.
+        // ---- results: lane l loads ranks l, l + LPQ, ... (< m): flat index -> map position (table walk) -> one point load
+        // each, all issued before the first is consumed; the exact squared distance is recomputed from the point (same
+        // formula, same bits as the scan saw before packing).  The group then exchanges the (d2, map index) pairs and every
+        // lane places its points at their exact rank; ranks beyond the fifth are dropped.
         if (done && live) {
-            constexpr int RPL = (5 + LPQ - 1) / LPQ;  // ranks per lane
+            constexpr int NL = kTop - 1;                 // at most seven candidates are loaded
+            constexpr int RPL = (NL + LPQ - 1) / LPQ;    // per lane
             float4 pv[RPL];
             float dv[RPL];
 #pragma unroll
@@ -523,9 +554,9 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
                 const int j = lane + r * LPQ;
                 uint32_t kj = K[0];
 #pragma unroll
-                for (int jj = 1; jj < 5; ++jj) kj = (j == jj) ? K[jj] : kj;
+                for (int jj = 1; jj < NL; ++jj) kj = (j == jj) ? K[jj] : kj;
                 pv[r] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-                if (j < cnt) {  // cnt <= 5
+                if (j < m) {
                     const uint32_t t = kj & PMASK;
                     int c2 = 0;
                     uint2 s2 = seg[grp][0];
@@ -535,38 +566,35 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             }
 #pragma unroll
             for (int r = 0; r < RPL; ++r)
-                dv[r] = (lane + r * LPQ < cnt) ? dist2(qx, qy, qz, pv[r].x, pv[r].y, pv[r].z) : INFINITY;
-            // every lane sees all five (d2, id): rank i lives in slot i / LPQ of lane i % LPQ
-            float da[5];
-            uint32_t ia[5];
+                dv[r] = (lane + r * LPQ < m) ? dist2(qx, qy, qz, pv[r].x, pv[r].y, pv[r].z) : INFINITY;
+            // every lane sees all (d2, id): candidate i lives in slot i / LPQ of lane i % LPQ
+            float da[NL];
+            uint32_t ia[NL];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
+            for (int i = 0; i < NL; ++i) {
                 da[i] = group_bcast<LPQ>(dv[i / LPQ], i % LPQ);
                 ia[i] = __float_as_uint(group_bcast<LPQ>(pv[i / LPQ].w, i % LPQ));
             }
-            float d5 = da[0];
-#pragma unroll
-            for (int i = 1; i < 5; ++i) d5 = fmaxf(d5, da[i]);  // +inf when cnt < 5
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
                 const int j = lane + r * LPQ;
-                if (j < 5) {
-                    int e = j;
-                    if (j < cnt) {  // exact rank among the found ones (ids are distinct: a strict total order)
+                if (j < NL) {
+                    int e = j;  // rows past the found ones (j >= m, only when fewer than five were found) are written empty
+                    if (j < m) {  // exact rank among the loaded ones (ids are distinct: a strict total order)
                         const uint32_t myid = __float_as_uint(pv[r].w);
                         e = 0;
 #pragma unroll
-                        for (int i = 0; i < 5; ++i)
-                            e += (i < cnt && (da[i] < dv[r] || (da[i] == dv[r] && ia[i] < myid))) ? 1 : 0;
+                        for (int i = 0; i < NL; ++i)
+                            e += (i < m && (da[i] < dv[r] || (da[i] == dv[r] && ia[i] < myid))) ? 1 : 0;
                     }
-                    nn_pts[(size_t)e * N + q] = pv[r];
-                    nn_d2[(size_t)e * N + q] = dv[r];
+                    if (e < 5) {
+                        nn_pts[(size_t)e * N + q] = pv[r];
+                        nn_d2[(size_t)e * N + q] = dv[r];
+                        if (e == 4) selected[q] = (j < m && !(dv[r] > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
+                    }
                 }
             }
-            if (lane == 0) {
-                nn_cnt[q] = (uint8_t)cnt;
-                selected[q] = (cnt == 5 && !(d5 > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
-            }
+            if (lane == 0) nn_cnt[q] = (uint8_t)cnt;
         }
         PH_MARK(7);  // 7: results written
         bool done2 = done;
@@ -962,17 +990,43 @@ __device__ __forceinline__ u64 spread3(uint32_t v) {  // 14 bits -> every third 
     x = (x | (x << 2)) & 0x249249249249ull;
     return x;
 }
+__device__ __forceinline__ u64 scan_morton(float x, float y, float z, float inv_q) {
+    const float lim = 16383.f;
+    const uint32_t ix = (uint32_t)fminf(fmaxf(x * inv_q + 8192.f, 0.f), lim);
+    const uint32_t iy = (uint32_t)fminf(fmaxf(y * inv_q + 8192.f, 0.f), lim);
+    const uint32_t iz = (uint32_t)fminf(fmaxf(z * inv_q + 8192.f, 0.f), lim);
+    return spread3(ix) | (spread3(iy) << 1) | (spread3(iz) << 2);
+}
 __global__ void __launch_bounds__(256) k_scan_keys(const float4* __restrict__ raw, uint32_t N, float inv_q,
                                                    u64* __restrict__ keys, uint32_t* __restrict__ vals) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const float4 p = raw[i];
-    const float lim = 16383.f;
-    const uint32_t x = (uint32_t)fminf(fmaxf(p.x * inv_q + 8192.f, 0.f), lim);
-    const uint32_t y = (uint32_t)fminf(fmaxf(p.y * inv_q + 8192.f, 0.f), lim);
-    const uint32_t z = (uint32_t)fminf(fmaxf(p.z * inv_q + 8192.f, 0.f), lim);
-    keys[i] = spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
+    keys[i] = scan_morton(p.x, p.y, p.z, inv_q);
     vals[i] = i;
+}
+// The caller's point records exactly as they came over PCIe (xyz first, any stride that is a multiple of 4 -- 12 packed,
+// 16 float4, 48 pcl::PointXYZINormal): re-strided to float4 on the device (the host used to do this in a per-point loop),
+// optionally with a fourth float picked from inside the record (the time offset the undistortion needs), and -- for the
+// plain staging path -- the Morton key in the same pass.  bad (optional) counts non-finite input.
+__global__ void __launch_bounds__(256) k_scan_restride(const uint32_t* __restrict__ words, uint32_t stride_words, uint32_t w_off,
+                                                       int has_w, uint32_t N, float inv_q, float4* __restrict__ raw,
+                                                       u64* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                       uint32_t* __restrict__ bad) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t* r = words + (size_t)i * stride_words;
+    float4 p;
+    p.x = __uint_as_float(r[0]);
+    p.y = __uint_as_float(r[1]);
+    p.z = __uint_as_float(r[2]);
+    p.w = has_w ? __uint_as_float(r[w_off]) : 0.f;
+    raw[i] = p;
+    if (keys) {
+        keys[i] = scan_morton(p.x, p.y, p.z, inv_q);
+        vals[i] = i;
+    }
+    if (bad && !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(p.w))) atomicAdd(bad, 1u);
 }
 // body[i] = raw[perm[i]] with .w = original index; perm == nullptr -> identity
 __global__ void __launch_bounds__(256) k_scan_gather(const float4* __restrict__ raw, const uint32_t* __restrict__ perm,
@@ -1039,6 +1093,13 @@ hipError_t launch_map_place(const float4* pts, const uint32_t* vs, const uint32_
 hipError_t launch_scan_keys(const float4* raw, uint32_t N, float quantum, u64* keys, uint32_t* vals, hipStream_t st) {
     if (N == 0) return hipSuccess;
     hipLaunchKernelGGL(k_scan_keys, dim3(cdiv(N, 256)), dim3(256), 0, st, raw, N, 1.0f / quantum, keys, vals);
+    return hipGetLastError();
+}
+hipError_t launch_scan_restride(const void* bytes, uint32_t stride_bytes, uint32_t w_off_bytes, int has_w, uint32_t N, float quantum,
+                                float4* raw, u64* keys, uint32_t* vals, uint32_t* bad, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scan_restride, dim3(cdiv(N, 256)), dim3(256), 0, st, (const uint32_t*)bytes, stride_bytes / 4u,
+                       w_off_bytes / 4u, has_w, N, 1.0f / quantum, raw, keys, vals, bad);
     return hipGetLastError();
 }
 hipError_t sort_scan_pairs(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, const uint32_t* vin, uint32_t* vout,

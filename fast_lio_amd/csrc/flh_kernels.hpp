@@ -25,6 +25,8 @@ hipError_t launch_brick_tables(const unsigned long long* ks, const uint32_t* bri
 
 hipError_t launch_scan_keys(const float4* raw, uint32_t N, float quantum, unsigned long long* keys, uint32_t* vals,
                             hipStream_t st);
+hipError_t launch_scan_restride(const void* bytes, uint32_t stride_bytes, uint32_t w_off_bytes, int has_w, uint32_t N, float quantum,
+                                float4* raw, unsigned long long* keys, uint32_t* vals, uint32_t* bad, hipStream_t st);
 hipError_t sort_scan_pairs(void* tmp, size_t& tmp_bytes, const unsigned long long* kin, unsigned long long* kout,
                            const uint32_t* vin, uint32_t* vout, uint32_t N, hipStream_t st);
 hipError_t launch_scan_gather(const float4* raw, const uint32_t* perm, uint32_t N, float4* body, hipStream_t st);
@@ -76,6 +78,7 @@ hipError_t launch_live_compact(const float4* map_orig, const uint32_t* flags, co
 // ---- flh_scanprep.hip: pcl::VoxelGrid of the scan ----
 hipError_t launch_undistort(const StateDev& s_end, const double* poses, int n_pose, const float4* raw, uint32_t n, float4* out,
                             hipStream_t st);
+hipError_t launch_cloud_body_to_world(const StateDev& s, const float4* in, uint32_t n, float4* out, hipStream_t st);
 hipError_t launch_vg_keys(const float4* raw, uint32_t n, float inv, const int min_b[3], int mul1, int mul2,
                           unsigned long long* keys, uint32_t* vals, hipStream_t st);
 hipError_t sort_vg_pairs(void* tmp, size_t& tmp_bytes, const unsigned long long* kin, unsigned long long* kout,

@@ -123,6 +123,27 @@ __global__ void __launch_bounds__(256) k_undistort(StateDev s_end, const double*
     out[i] = o;
 }
 
+// ------------------------------------------------------------------------------------------------
+// SURVEY.md 8(f) row 4 -- publish_frame_world's loop (src/laserMapping.cpp:478-530): RGBpointBodyToWorld (:200-211) over a
+// whole cloud (feats_undistort when dense_pub_en, else feats_down_body): the same fp64 transform as the hot path's first
+// step, narrowed to float.  in.w is carried through (intensity / original index).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cloud_body_to_world(StateDev s, const float4* __restrict__ in, uint32_t n,
+                                                             float4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    float4 o;
+    body_to_world(s, p.x, p.y, p.z, o.x, o.y, o.z);
+    o.w = p.w;
+    out[i] = o;
+}
+hipError_t launch_cloud_body_to_world(const StateDev& s, const float4* in, uint32_t n, float4* out, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cloud_body_to_world, dim3(cdiv3(n, 256)), dim3(256), 0, st, s, in, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_undistort(const StateDev& s_end, const double* poses, int n_pose, const float4* raw, uint32_t n, float4* out,
                             hipStream_t st) {
     if (n == 0) return hipSuccess;

@@ -135,6 +135,16 @@ size_t flh_scan_size(const flh_handle* h);
 #define FLH_MAX_SLOTS 64
 int flh_scan_stage(flh_handle* h, int slot, const void* pts, size_t stride_bytes, size_t N);
 int flh_scan_activate(flh_handle* h, int slot);
+/* The same staging, performed by the handle's staging thread: the call returns at once and the caller's thread goes on
+ * with the update of the previous scan (the node's main loop, src/laserMapping.cpp:865-969, would hand over scan k+1
+ * from its LiDAR callback).  `pts` must stay valid and unchanged until flh_scan_wait(slot) or flh_scan_activate(slot)
+ * returns; a staging error is reported there.  Pageable memory is copied through a pinned buffer; memory from
+ * flh_host_alloc is DMA'd from where it lies. */
+int flh_scan_stage_async(flh_handle* h, int slot, const void* pts, size_t stride_bytes, size_t N);
+int flh_scan_wait(flh_handle* h, int slot);
+/* Page-locked host memory for scan / cloud buffers handed to this library (saves the copy through the staging buffer). */
+void* flh_host_alloc(size_t bytes);
+void flh_host_free(void* p);
 
 /* SURVEY.md 8(f) row 2 -- downSizeFilterSurf.setInputCloud(feats_undistort); downSizeFilterSurf.filter(*feats_down_body)
  * (src/laserMapping.cpp:904-905; pcl::VoxelGrid with leaf = filter_size_surf_min, :813) on the device, and staging of the
@@ -160,6 +170,18 @@ int flh_scan_stage_undistorted(flh_handle* h, int slot, const void* pts, size_t 
                                float* undistorted_xyz, size_t* n_out);
 /* feats_down_body of the ACTIVE scan (3 floats per point, the order it was staged in). */
 int flh_fetch_scan(flh_handle* h, float* xyz);
+
+/* SURVEY.md 8(f) row 4 -- publish_frame_world()'s loops (src/laserMapping.cpp:478-530): RGBpointBodyToWorld (:200-211), i.e.
+ * p_world = rot * (offset_R_L_I * p_body + offset_T_L_I) + pos in double narrowed to float, over a whole cloud.
+ * flh_frame_world: the cloud already on the device -- dense != 0: feats_undistort, the cloud `slot` was staged from by
+ * flh_scan_stage_undistorted / _downsampled (dense_pub_en, and the pcd_save_en loop); dense == 0: the slot's feats_down_body.
+ * slot < 0 = the active scan.  x = state_point (the posterior), flat layout.  Output in the cloud's original order;
+ * world_xyz == NULL with capacity_points == 0 only reports the size in *n_points.
+ * flh_points_body_to_world: the same for any host cloud. */
+int flh_frame_world(flh_handle* h, int slot, const double x[FLH_NSTATE], int dense, float* world_xyz, size_t capacity_points,
+                    size_t* n_points);
+int flh_points_body_to_world(flh_handle* h, const double x[FLH_NSTATE], const void* pts, size_t stride_bytes, size_t n,
+                             float* world_xyz);
 
 /* One evaluation of h_share_model (src/laserMapping.cpp:638-754) at state s:
  *   transform :652-661, 5-NN + gate :667-672 (only if do_search = ekfom_data.converge), plane fit
@@ -264,6 +286,8 @@ int flh_esekf_update(flh_esekf* kf, double R, flh_update_stats* stats);
  * state / covariance handed over by the IMU front end (either may be NULL = keep), run the update (:960). */
 int flh_esekf_update_scan(flh_esekf* e, int slot, const double x[FLH_NSTATE], const double P[FLH_NDOF * FLH_NDOF], double R,
                           flh_update_stats* st);
+/* Text of the last error a flh_esekf_* call on this filter returned (failures inside the measurement model included). */
+const char* flh_esekf_last_error(const flh_esekf* kf);
 
 #ifdef __cplusplus
 }

@@ -115,6 +115,8 @@ void orc_scan_reset(orc_scan* s); /* selected[] = 1, timers = 0 */
 int orc_h_share_model(orc_scan* sc, const orc_kdtree* map, const float* map_xyz,
                       size_t map_stride_floats, const double x[ORC_NSTATE], int converge,
                       int extrinsic_est_en);
+/* publish_frame_world's loop (src/laserMapping.cpp:478-530): RGBpointBodyToWorld (:200-211) over n points. */
+void orc_points_body_to_world(const double x[ORC_NSTATE], const float* pts, size_t stride_floats, size_t n, float* out_xyz);
 /* Convenience: HTH (12x12 row-major) and HTh (12) from the last h call's h_x/h. */
 void orc_normal_equations(const orc_scan* sc, double HTH[144], double HTh[12]);
 

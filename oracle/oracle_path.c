@@ -252,6 +252,25 @@ void orc_scan_free(orc_scan* s) {
 }
 
 /* =================================================================== h_share_model */
+/* RGBpointBodyToWorld (src/laserMapping.cpp:200-211) over a whole cloud, as publish_frame_world does for
+   feats_undistort / feats_down_body (:478-530): p_global = rot * (offset_R_L_I * p_body + offset_T_L_I) + pos in double,
+   stored as float. */
+void orc_points_body_to_world(const double x[ORC_NSTATE], const float* pts, size_t stride_floats, size_t n, float* out_xyz) {
+    const double* rot = x + X_ROT;
+    const double* offR = x + X_OFFR;
+    const double* offT = x + X_OFFT;
+    const double* pos = x + X_POS;
+    for (size_t i = 0; i < n; i++) {
+        const float* pb = pts + stride_floats * i;
+        double p_body[3] = {pb[0], pb[1], pb[2]};
+        double t1[3], t2[3];
+        orc_quat_rot(offR, p_body, t1);
+        for (int d = 0; d < 3; d++) t1[d] = t1[d] + offT[d];
+        orc_quat_rot(rot, t1, t2);
+        for (int d = 0; d < 3; d++) out_xyz[3 * i + d] = (float)(t2[d] + pos[d]);
+    }
+}
+
 int orc_h_share_model(orc_scan* sc, const orc_kdtree* map, const float* map_xyz, size_t mstride,
                       const double x[ORC_NSTATE], int converge, int extrinsic_est_en) {
     double match_start = now_s();

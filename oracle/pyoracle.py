@@ -91,6 +91,7 @@ def lib():
     L.orc_esti_plane.restype = C.c_int
     L.orc_esti_plane.argtypes = [_f32p, C.c_float, _f32p]
     L.orc_qr_solve_5x3.argtypes = [_f32p, _f32p, _f32p]
+    L.orc_points_body_to_world.argtypes = [_f64p, _f32p, C.c_size_t, C.c_size_t, _f32p]
     L.orc_set_eigen_order.argtypes = [C.c_int]
     L.orc_get_eigen_order.restype = C.c_int
     L.orc_A_matrix.argtypes = [_f64p, _f64p]
@@ -283,6 +284,14 @@ class Scan:
 
 
 # ---- thin functional wrappers for the KATs ----
+def points_body_to_world(x, pts):
+    """RGBpointBodyToWorld over a cloud (src/laserMapping.cpp:200-211, 478-530)."""
+    a = _c32(pts)
+    out = np.empty((a.shape[0], 3), np.float32)
+    lib().orc_points_body_to_world(np.ascontiguousarray(x, np.float64), a.reshape(-1), a.shape[1], a.shape[0], out.reshape(-1))
+    return out
+
+
 ORDER_SEQ, ORDER_SSE, ORDER_PAIRWISE, ORDER_NOVEC = 0, 1, 2, 3
 ORDER_NAMES = {0: "seq", 1: "sse", 2: "pairwise", 3: "novec"}
 

@@ -80,10 +80,11 @@ def test_eval_search_and_nosearch_passes(prob, ext):
     check_neighbors(h, sc)
 
 
-@pytest.mark.parametrize("lpq,sort", [(0, 1), (2, 1), (4, 0), (8, 1), (16, 0)])
-def test_search_kernel_variants(prob, lpq, sort):
+@pytest.mark.parametrize("lpq,sort,stage", [(0, 1, 0), (2, 1, 0), (4, 0, 0), (8, 1, 0), (16, 0, 0), (1, 1, 1), (1, 1, 2), (2, 1, 2),
+                                            (4, 1, 2)])
+def test_search_kernel_variants(prob, lpq, sort, stage):
     pr, m, xp, P, _ = prob
-    h = capi.Handle(lanes_per_query=lpq, sort_queries=sort)
+    h = capi.Handle(lanes_per_query=lpq, sort_queries=sort, first_stage=stage)
     h.map_build(pr.map_xyz)
     h.scan_upload(pr.body[:5000])
     sc = po.Scan(pr.body[:5000], nthreads=8)
@@ -306,3 +307,78 @@ def test_cell_size_variants(prob):
         check_eval(h, sc, m, xp, True, False, f"cell={c}")
         check_neighbors(h, sc)
         h.close()
+
+
+def test_eval_without_scan_or_map_fails_loudly(prob):
+    """flh_eval before a scan / a map must return an error, not fault on the device."""
+    pr, m, xp, P, _ = prob
+    h = capi.Handle()
+    with pytest.raises(capi.FlhError, match="no active scan"):
+        h.eval(xp, True, False)
+    h.scan_upload(pr.body[:100])
+    with pytest.raises(capi.FlhError, match="no map"):
+        h.eval(xp, True, False)
+    h.map_build(pr.map_xyz)
+    h.eval(xp, True, False)
+    kf = capi.Esekf(None)
+    kf.change_x(xp)
+    kf.change_P(P)
+    with pytest.raises(capi.FlhError, match="no flh_handle|no device handle"):
+        kf.update(0.001)
+    h.close()
+
+
+def test_async_staging_equals_synchronous_staging(prob):
+    pr, m, xp, P, _ = prob
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    bodies = [np.ascontiguousarray(pr.body[i::3][:4000]) for i in range(3)]
+    ref = []
+    for b in bodies:
+        h.scan_upload(b)
+        ref.append((h.eval(xp, True, False), h.fetch_selected(), h.fetch_neighbors()[0]))
+    for s, b in enumerate(bodies):          # all three in flight on the staging thread at once
+        h.scan_stage_async(s, b)
+    for s in (2, 0, 1):
+        h.scan_activate(s)
+        got = h.eval(xp, True, False)
+        np.testing.assert_array_equal(got[0], ref[s][0][0])
+        np.testing.assert_array_equal(got[1], ref[s][0][1])
+        assert got[2] == ref[s][0][2]
+        np.testing.assert_array_equal(h.fetch_selected(), ref[s][1])
+        np.testing.assert_array_equal(h.fetch_neighbors()[0], ref[s][2])
+        np.testing.assert_array_equal(h.fetch_scan().view(np.uint32), bodies[s].view(np.uint32))
+    h.scan_stage_async(5, bodies[0])
+    h.scan_wait(5)
+    with pytest.raises(capi.FlhError):
+        h.scan_stage(3, np.zeros((4, 3), np.float32)[:, :2])  # stride < 12
+    h.close()
+
+
+def test_frame_world_and_points_body_to_world(prob):
+    """publish_frame_world's RGBpointBodyToWorld loops (src/laserMapping.cpp:478-530, :200-211)."""
+    pr, m, xp, P, _ = prob
+    h = capi.Handle()
+    x = pr.x_true.copy()
+    x[7:11] = (0.01, -0.02, 0.03, 0.9993)
+    x[7:11] /= np.linalg.norm(x[7:11])
+    rng = np.random.default_rng(3)
+    cloud = (np.repeat(pr.body[:15000], 2, axis=0) + rng.normal(0, 0.05, (30000, 3))).astype(np.float32)
+    want = po.points_body_to_world(x, cloud)
+    np.testing.assert_array_equal(h.points_body_to_world(x, cloud).view(np.uint32), want.view(np.uint32))
+    wide = np.zeros((len(cloud), 12), np.float32)   # pcl::PointXYZINormal records
+    wide[:, :3] = cloud
+    wide[:, 4:] = 7.0
+    np.testing.assert_array_equal(h.points_body_to_world(x, wide).view(np.uint32), want.view(np.uint32))
+    # the device-resident clouds of a staged raw scan: feats_undistort (dense) and feats_down_body
+    n = h.scan_stage_downsampled(2, cloud, 0.5)
+    np.testing.assert_array_equal(h.frame_world(x, slot=2, dense=True).view(np.uint32), want.view(np.uint32))
+    down = po.voxel_grid(cloud, 0.5)
+    assert n == len(down)
+    np.testing.assert_array_equal(h.frame_world(x, slot=2, dense=False).view(np.uint32),
+                                  po.points_body_to_world(x, down).view(np.uint32))
+    h.scan_stage(3, cloud[:100])
+    with pytest.raises(capi.FlhError, match="not staged from a raw scan"):
+        h.frame_world(x, slot=3, dense=True)
+    assert h.points_body_to_world(x, cloud[:0]).shape == (0, 3)
+    h.close()
