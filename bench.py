@@ -1,18 +1,22 @@
 #!/usr/bin/env python
 """bench.py -- scans/s of the FAST-LIO2 measurement update (h_share_model + iterated ESKF) on MI355X.
 
-A "step" is one full update_iterated_dyn_share_modified() of one 100k-point Avia scan against the
-5M-point map (BASELINE.json configs[1]): up to 4 h_share_model evaluations (2 of them with the 5-NN
-search on this workload) plus the host-side 23x23 algebra.  Scans are staged in HBM before the timed
-region (flh_scan_stage).
+A "step" is what the node does per scan between receiving feats_down_body and having the posterior
+(src/laserMapping.cpp:904-969): the scan is handed over as a HOST buffer (page-locked, flh_host_alloc), staged to
+the device (H2D + re-stride + Morton sort, flh_scan_stage_async on the handle's staging thread) WHILE the previous
+scan's update runs, then one full update_iterated_dyn_share_modified(): up to 4 h_share_model evaluations (2 of them
+with the 5-NN search on this workload) plus the host-side 23x23 algebra.  `value` is the steady-state rate of that
+pipeline over >= 100 distinct scans (BASELINE.json configs[1]: 100k-point Avia scan vs 5M-point map); the rate with
+the scans already resident in HBM is reported beside it as `device_resident_scans_per_s`.  For --config 3 (scan
+stream with incremental map inserts) a step also runs map_incremental (src/laserMapping.cpp:427-474) on the device map.
 
   python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
 
 Prints ONE JSON line on rank 0: the contract fields, `roofline` (HIP events on the handle's stream inside the timed
-region; `traffic` from the committed PMC summary), `cpu_baseline` (the oracle's restated reference path on a bounded
-sample), and -- measured after the timed region, never part of `value` -- `pcie_inclusive_scans_per_s`,
-`two_streams_per_gpu`, `map_incremental`, `scan_front_end`; with N > 1 also `shard_mode` (one scan's points split over
-the ranks, all-reduce of the 16x16 Gram block per pass).
+region; `traffic` from the committed PMC summary of the same command), `cpu_baseline` (the oracle's restated
+reference path on a bounded sample, at the reference's 3 OpenMP threads and at all host cores), and -- measured after
+the timed region, never part of `value` -- `two_streams_per_gpu`, `map_incremental`, `scan_front_end`; with N > 1 also
+`shard_mode` (one scan's points split over the ranks, all-reduce of the 16x16 Gram block per pass).
 """
 from __future__ import annotations
 
@@ -42,6 +46,7 @@ CONFIGS = {
 ALG_BYTES_SEARCH = 117  # 16 (query) + 5*16 (neighbours) + 5*4 (index write) + 1 (flag)
 ALG_BYTES_NOSEARCH = 97  # 16 + 5*16 (cached neighbours) + 1
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
+RING = 4                 # staging slots cycled by the pipelined loop
 
 
 def log(*a):
@@ -49,14 +54,14 @@ def log(*a):
 
 
 def pmc_traffic(args):
-    """HBM bytes per search pass from the committed rocprofv3 --pmc summary (profiles/, made by tools/pmc_summary.py
-    from separate FETCH_SIZE and WRITE_SIZE passes of this same command).  FETCH_SIZE/WRITE_SIZE are in KiB;
-    on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled (MI355X_MICROARCH.md, HBM section).
-    Only valid for the default workload the summary was taken on."""
+    """HBM bytes per search pass from the committed rocprofv3 --pmc summary of this round (profiles/, made by
+    tools/pmc_summary.py from separate FETCH_SIZE and WRITE_SIZE passes of this same command).  FETCH_SIZE/WRITE_SIZE
+    are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled (MI355X_MICROARCH.md, HBM
+    section).  Only valid for the workload the summary was taken on (default kernel settings)."""
     import csv
 
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.csv")
-    if not os.path.exists(path) or args.config != 2 or args.lpq != 4 or args.cell != 1.5:
+    path = os.path.join(ROOT, "profiles", f"r02_pmc_summary_config{args.config}.csv")
+    if not os.path.exists(path) or args.lpq != 4 or args.cell != 1.5 or args.first_stage != 0:
         return None
     fetch, write, calls = {}, {}, {}
     with open(path) as f:
@@ -74,7 +79,7 @@ def pmc_traffic(args):
         return None
     passes = calls[a1[0]]
     total = (2.0 * sum(fetch.values()) + sum(write.values())) * 1024.0 / passes
-    return {"bytes_per_search_pass": int(total), "source": "profiles/r01_pmc_summary.csv (FETCH_SIZE x2 + WRITE_SIZE, KiB)"}
+    return {"bytes_per_search_pass": int(total), "source": os.path.relpath(path, ROOT) + " (FETCH_SIZE x2 + WRITE_SIZE, KiB)"}
 
 
 def main():
@@ -83,7 +88,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--config", type=int, default=2)
-    ap.add_argument("--scans", type=int, default=8, help="distinct seeded scans cycled through")
+    ap.add_argument("--scans", type=int, default=128, help="distinct seeded scans cycled through (>= 100 by default)")
     ap.add_argument("--mode", default="auto", choices=["auto", "streams", "shard"],
                     help="multi-GPU: streams = one independent scan stream per rank, replicated map, no collective "
                          "(weak scaling; the headline value); shard = ONE scan's points split over the ranks + RCCL "
@@ -91,12 +96,13 @@ def main():
                          "plus a short shard-mode leg reported under \"shard_mode\"")
     ap.add_argument("--lpq", type=int, default=4)
     ap.add_argument("--cell", type=float, default=1.5)
+    ap.add_argument("--first-stage", type=int, default=0)
     ap.add_argument("--sort", type=int, default=1, help="Morton-order the scan at staging (0 = keep input order)")
     ap.add_argument("--extrinsic-est", type=int, default=0)
-    ap.add_argument("--timing-stride", type=int, default=32,
-                    help="record the per-kernel HIP events on every n-th evaluation of the timed region")
-    ap.add_argument("--no-overlap-leg", action="store_true", help="skip the two-streams-per-GPU leg")
-    ap.add_argument("--cpu-scans", type=int, default=3, help="scans timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--timing-samples", type=int, default=24,
+                    help="evaluations of the timed region whose kernels are bracketed by HIP events (>= 16)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="only the headline + roofline (profiling runs)")
+    ap.add_argument("--cpu-scans", type=int, default=3, help="scans timed on the CPU oracle per thread count (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=3, help="OpenMP threads (reference MP_PROC_NUM = 3)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo for debugging")
     ap.add_argument("--single-device", type=int, default=0, help="debug: every rank uses cuda:0 (needs --backend gloo)")
@@ -131,18 +137,26 @@ def main():
 
     M, N, sensor = CONFIGS[args.config]
     ext = bool(args.extrinsic_est)
+    with_map_inserts = args.config == 3  # "Velodyne scan stream ... incremental map inserts"
     t0 = time.time()
     scene = synth.make_scene(M, synth.CONFIG_SEED_BASE + args.config)
-    S = max(1, min(args.scans, 28))
+    S = max(1, min(args.scans, args.steps + args.warmup))
 
-    def gen(seed_base):
-        pr = [synth.make_problem(M, N, sensor, cfg=args.config, scan_seed=seed_base + s, scene=scene) for s in range(S)]
+    def gen(seed_base, count):
+        pr = [synth.make_problem(M, N, sensor, cfg=args.config, scan_seed=seed_base + s, scene=scene) for s in range(count)]
         pri = [synth.propagate_prior_cov(capi.predict_fn, p.x_prior) for p in pr]
         return pr, [(np.ascontiguousarray(x, np.float64), np.ascontiguousarray(P, np.float64)) for x, P in pri]
 
     # streams: every rank follows its own scan stream; the shard leg uses scans common to all ranks
-    probs, priors = gen(1000 * rank if G > 1 else 0)
-    sh_probs, sh_priors = (gen(0) if run_shard_leg and rank != 0 else (probs, priors)) if run_shard_leg else (None, None)
+    probs, priors = gen(1000 * rank if G > 1 else 0, S)
+    S_sh = min(S, 8)
+    sh_probs, sh_priors = (gen(0, S_sh) if rank != 0 else (probs[:S_sh], priors[:S_sh])) if run_shard_leg else (None, None)
+    # the scans as the node would hold them: host buffers (page-locked so that the DMA engine reads them where they lie)
+    bodies = []
+    for p in probs:
+        a = capi.pinned_empty((N, 3), np.float32)
+        a[:] = p.body
+        bodies.append(a)
     if rank == 0:
         log(f"[bench] config {args.config}: M={M} N={N} sensor={sensor} scans={S} ranks={G} mode={args.mode} "
             f"gen {time.time() - t0:.1f}s")
@@ -155,18 +169,12 @@ def main():
         torch.cuda.set_stream(ts)
         stream_ptr = ts.cuda_stream
     h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, stream=stream_ptr,
-                    sort_queries=args.sort)
+                    sort_queries=args.sort, first_stage=args.first_stage)
     t0 = time.time()
     h.map_build(scene.map_xyz)
     t_build = time.time() - t0
-    for s, p in enumerate(probs):
-        h.scan_stage(s, p.body)
     lo, hi = fdist.shard_bounds(N, rank, G)
-    if run_shard_leg:
-        for s, p in enumerate(sh_probs):
-            h.scan_stage(S + s, p.body[lo:hi])
     kf = capi.Esekf(h, max_iter=3, extrinsic_est_en=ext)
-    h.set_timing_stride(args.timing_stride)
 
     def sync():
         torch.cuda.synchronize()
@@ -174,29 +182,49 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run(step_fn, n_warm, n_steps):
+    class Acc:
+        def __init__(self):
+            self.passes = self.searches = 0
+            self.ms_s = self.ms_n = 0.0
+            self.n_s = self.n_n = 0
+
+        def add(self, st):
+            self.passes += st.passes
+            self.searches += st.searches
+            for k in range(min(st.passes, 8)):
+                if st.pass_search[k]:
+                    self.ms_s += st.pass_ms[k]
+                    self.n_s += 1
+                else:
+                    self.ms_n += st.pass_ms[k]
+                    self.n_n += 1
+
+    def run(step_fn, n_warm, n_steps, prologue=None):
+        if prologue:
+            prologue(0)
         for i in range(n_warm):
-            step_fn(i)
+            step_fn(i, n_warm + n_steps)
         # A generation-2 pass of Python's cyclic GC over the synthetic-scene objects costs ~40 ms of pure host time and
         # landed deterministically inside the timed loop (found with FLH_BENCH_TRACE); collect now, then keep the
         # collector out of the timed region, as timeit does.
         gc.collect()
         gc.disable()
         sync()
+        h.set_timing_stride(max(1, (n_steps * 4) // max(args.timing_samples, 16)))
         h.counters(reset=True)
-        acc = [0, 0]
+        acc = Acc()
         t1 = time.perf_counter()
         trace = [] if os.environ.get("FLH_BENCH_TRACE") else None
-        for i in range(n_steps):
+        for i in range(n_warm, n_warm + n_steps):
             ta = time.perf_counter()
-            st = step_fn(i)
+            st = step_fn(i, n_warm + n_steps)
             if trace is not None:
                 trace.append(time.perf_counter() - ta)
-            acc[0] += st.passes
-            acc[1] += st.searches
+            acc.add(st)
         sync()
         dt_ = time.perf_counter() - t1
         gc.enable()
+        h.set_timing_stride(0)
         if trace:
             order = sorted(range(len(trace)), key=lambda j: -trace[j])[:6]
             print("[trace] slowest steps:", [(j, round(trace[j] * 1e3, 3)) for j in order], "median ms",
@@ -205,22 +233,34 @@ def main():
             tt = torch.tensor([dt_], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_ = float(tt.item())
-        return dt_, acc[0], acc[1], h.counters()
+        return dt_, acc, h.counters()
 
-    def step_stream(i):
+    # ---------------- headline leg: the pipelined loop.  Scan i+1 is handed to the staging thread (host buffer -> H2D ->
+    # re-stride + Morton sort on the copy stream) before the update of scan i starts; update_scan(i) waits for ITS
+    # staging only.  Every scan of the timed region crosses PCIe inside the timed region.
+    def stage(i):
+        h.scan_stage_async(i % RING, bodies[i % S])
+
+    def step_pipelined(i, n_total):
+        if i + 1 < n_total:
+            stage(i + 1)
         s = i % S
-        return kf.update_scan(s, priors[s][0], priors[s][1], 0.001)  # activate staged scan + (x, P) + update, one call
+        st = kf.update_scan(i % RING, priors[s][0], priors[s][1], 0.001)  # activate staged scan + (x, P) + update
+        if with_map_inserts:
+            h.map_incremental(kf.get_x(), 0.5, True, apply=True)
+        return st
 
     shard_out = None
     if mode == "shard":
         run_shard_leg = True
-    # ---------------- headline leg
     if mode == "streams" or G == 1:
-        dt, passes, searches, ctr = run(step_stream, args.warmup, args.steps)
+        dt, acc, ctr = run(step_pipelined, args.warmup, args.steps, prologue=stage)
         units = args.steps * G
         n_pts = N
     # ---------------- sharded leg: ONE scan's points over all ranks + all-reduce of the Gram block (C1)
     if run_shard_leg:
+        for s, p in enumerate(sh_probs):
+            h.scan_stage(8 + s, p.body[lo:hi])
         gram = torch.zeros(256, dtype=torch.float64, device="cuda")
 
         def eval_partial(x, converge):
@@ -235,26 +275,26 @@ def main():
 
         kf.set_meas_model(fdist.make_sharded_model(eval_partial, lambda t: fdist.torch_allreduce(dist, t), gather_rows))
 
-        def step_shard(i):
-            s = i % S
-            h.scan_activate(S + s)
+        def step_shard(i, n_total):
+            s = i % S_sh
+            h.scan_activate(8 + s)
             kf.change_x(sh_priors[s][0])
             kf.change_P(sh_priors[s][1])
             return kf.update(0.001)
 
         k2 = args.steps if mode == "shard" else max(10, min(60, args.steps // 4))
-        dt2, p2, s2, _ = run(step_shard, max(3, args.warmup // 4), k2)
+        dt2, acc2, _ = run(step_shard, max(3, args.warmup // 4), k2)
         # every rank must have produced the same posterior
         xs = [None] * G
         dist.all_gather_object(xs, kf.get_x())
         agree = float(max(np.abs(np.asarray(x_) - np.asarray(xs[0])).max() for x_ in xs))
         shard_out = {"value": round(k2 / dt2, 3), "unit": "scans/s", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 4),
-                     "ms_per_iekf_pass": round(dt2 / max(p2, 1) * 1e3, 4), "points_per_rank": hi - lo,
+                     "ms_per_iekf_pass": round(dt2 / max(acc2.passes, 1) * 1e3, 4), "points_per_rank": hi - lo,
                      "collective": f"all_reduce(sum) of 256 f64 per pass over {args.backend}",
                      "max_abs_state_disagreement_across_ranks": agree, "scaling": "strong"}
         kf.set_meas_model(None)
         if mode == "shard":
-            dt, passes, searches, ctr = dt2, p2, s2, h.counters()
+            dt, acc, ctr = dt2, acc2, h.counters()
             units = args.steps
             n_pts = hi - lo
     value = units / dt
@@ -270,27 +310,11 @@ def main():
                 "kernel": f"5-NN search of one pass = k_search_ring<{args.lpq},1> (every query) + k_search_ring<16,2> (the rest, incl. the exact fallback)",
                 "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                 "traffic": None, "avg_kernel_us": round(dur_s * 1e6, 2), "alg_bytes_per_launch": ALG_BYTES_SEARCH * n_pts,
-                "events_sampled": ctr["n_search"], "fit_kernel_us": round(fit_s * 1e6, 2),
+                "events_sampled": int(ctr["n_search"]), "fit_kernel_us": round(fit_s * 1e6, 2),
+                "fit_events_sampled": int(ctr["n_fit"]),
+                "fit_alg_bytes_per_launch": ALG_BYTES_NOSEARCH * n_pts,
                 "fit_achieved_GBs": round(ALG_BYTES_NOSEARCH * n_pts / fit_s / 1e9, 2),
                 "fit_frac": round(ALG_BYTES_NOSEARCH * n_pts / fit_s / 1e9 / HBM_PEAK_GBS, 5)}
-    elif mode == "shard":
-        x0 = sh_priors[0][0]
-        h.scan_activate(S)
-        s_ms = h.time_kernel(0, x0, ext, 20)
-        f_ms = h.time_kernel(1, x0, ext, 20)
-        ach = ALG_BYTES_SEARCH * n_pts / (s_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": f"k_search_ring<{args.lpq},1> + k_search_ring<16,2>", "achieved": round(ach, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
-                "avg_kernel_us": round(s_ms * 1e3, 2), "alg_bytes_per_launch": ALG_BYTES_SEARCH * n_pts,
-                "fit_kernel_us": round(f_ms * 1e3, 2), "note": "per-rank shard, back-to-back launches"}
-
-    # companion figure (SURVEY 8d): mean map points examined per query by one search pass
-    h.enable_stats(True)
-    h.set_timing_stride(1)
-    h.scan_activate(0)
-    h.eval(priors[0][0], True, ext)
-    cand_per_query = h.timing()["candidates"] / max(N, 1)
-    h.enable_stats(False)
 
     out = {
         "metric": "scans/sec + ms/IEKF-iter, 100k-pt scan vs 5M-pt map, 1/2/4/8 MI355X",
@@ -306,17 +330,53 @@ def main():
         "dtype": "f32 (kNN, plane fit) + f64 (transform, Jacobian, normal equations)",
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {sensor} {N}-pt scan vs {M}-pt box-city map, "
-                               f"max_iteration=3, R=0.001, extrinsic_est_en={int(ext)}",
+                               f"max_iteration=3, R=0.001, extrinsic_est_en={int(ext)}"
+                               + (", map_incremental after every update" if with_map_inserts else ""),
+                   "timed_region": ("scan handed over as a page-locked host buffer, staged (H2D + re-stride + Morton sort) on the "
+                                    "copy stream while the previous scan updates, then the full iterated update"
+                                    if mode != "shard" else "scan shards resident in HBM, full iterated update"),
                    "parallelism": ("1 GPU" if G == 1 else
                                    (f"scan points sharded over {G} ranks + all-reduce of the 16x16 normal-equation block "
                                     f"per pass" if mode == "shard" else
                                     f"{G} independent scan streams (one per rank), replicated map, no collective in the data path")),
-                   "distinct_scans": S, "cell_size_m": args.cell, "lanes_per_query": args.lpq},
-        "ms_per_iekf_pass": round(dt / max(passes, 1) * 1e3, 4),
-        "passes_per_scan": round(passes / args.steps, 3),
-        "searches_per_scan": round(searches / args.steps, 3),
+                   "distinct_scans": S, "cell_size_m": args.cell, "lanes_per_query": args.lpq, "first_stage": args.first_stage},
+        "ms_per_iekf_pass": round(dt / max(acc.passes, 1) * 1e3, 4),
+        "ms_search_pass": round(acc.ms_s / max(acc.n_s, 1), 4),
+        "ms_nosearch_pass": round(acc.ms_n / max(acc.n_n, 1), 4),
+        "passes_per_scan": round(acc.passes / args.steps, 3),
+        "searches_per_scan": round(acc.searches / args.steps, 3),
         "map_build_s": round(t_build, 3),
     }
+    if G > 1 and dist is not None:
+        out["ranks_seen_by_collective"] = int(dist.get_world_size())
+
+    # ---- the same update with the scans already resident in HBM (staged before the timed loop): what round 1 reported
+    # as `value`.  Not PCIe-inclusive, hence a sub-field.
+    extra = rank == 0 and G == 1 and mode != "shard" and not args.no_extra_legs
+    if rank == 0 and G == 1 and mode != "shard":
+        Sd = min(S, 32)
+        for s in range(Sd):
+            h.scan_stage(16 + s, bodies[s])
+
+        def step_resident(i, n_total):
+            s = i % Sd
+            st = kf.update_scan(16 + s, priors[s][0], priors[s][1], 0.001)
+            if with_map_inserts:
+                h.map_incremental(kf.get_x(), 0.5, True, apply=True)
+            return st
+
+        dtr, accr, _ = run(step_resident, max(4, args.warmup // 2), args.steps)
+        out["device_resident_scans_per_s"] = round(args.steps / dtr, 3)
+        out["device_resident_ms_per_step"] = round(dtr / args.steps * 1e3, 4)
+
+    # companion figure (SURVEY 8d): mean map points examined per query by one search pass
+    h.enable_stats(True)
+    h.set_timing_stride(1)
+    h.scan_upload(bodies[0])
+    h.eval(priors[0][0], True, ext)
+    cand_per_query = h.timing()["candidates"] / max(N, 1)
+    h.enable_stats(False)
+    h.set_timing_stride(0)
     if roof is not None:
         tr = pmc_traffic(args)
         if tr is not None:
@@ -328,46 +388,33 @@ def main():
     if shard_out is not None and mode != "shard":
         out["shard_mode"] = shard_out
 
-    # ---- PCIe-inclusive rate (scan handed over as a host buffer every step): never `value`
-    if rank == 0 and G == 1:
-        h.set_timing_stride(0)
-        t1 = time.perf_counter()
-        reps = max(5, min(50, args.steps // 4))
-        for i in range(reps):
-            s = i % S
-            h.scan_upload(probs[s].body)
-            kf.change_x(priors[s][0])
-            kf.change_P(priors[s][1])
-            kf.update(0.001)
-        torch.cuda.synchronize()
-        out["pcie_inclusive_scans_per_s"] = round(reps / (time.perf_counter() - t1), 3)
-
     # ---- two independent scan streams in flight on this GPU (two handles, two host threads): while one stream's host
     # solves its 23x23 system the other's kernels run.  Same work per scan, so this is the GPU's throughput with the host
     # turn-around hidden; the headline `value` stays one stream per GPU (the latency a single LiDAR stream sees).
-    if rank == 0 and G == 1 and mode != "shard" and not args.no_overlap_leg:
+    if extra and not with_map_inserts:
         import threading
 
-        h2 = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort)
+        h2 = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
+                         first_stage=args.first_stage)
         h2.map_build(scene.map_xyz)
-        for s, p in enumerate(probs):
-            h2.scan_stage(s, p.body)
+        Sd = min(S, 32)
+        for s in range(Sd):
+            h2.scan_stage(16 + s, bodies[s])
         kf2 = capi.Esekf(h2, max_iter=3, extrinsic_est_en=ext)
-        h.set_timing_stride(0)
         h2.set_timing_stride(0)
         per = max(args.steps // 2, 8)
 
         def worker(kfx, off):
             for i in range(per):
-                s = (i + off) % S
-                kfx.update_scan(s, priors[s][0], priors[s][1], 0.001)
+                s = (i + off) % Sd
+                kfx.update_scan(16 + s, priors[s][0], priors[s][1], 0.001)
 
         for kfx in (kf, kf2):  # warm-up
             worker(kfx, 0)
         torch.cuda.synchronize()
         gc.collect()
         gc.disable()
-        th = [threading.Thread(target=worker, args=(kf, 0)), threading.Thread(target=worker, args=(kf2, S // 2))]
+        th = [threading.Thread(target=worker, args=(kf, 0)), threading.Thread(target=worker, args=(kf2, Sd // 2))]
         t1 = time.perf_counter()
         for t in th:
             t.start()
@@ -377,43 +424,47 @@ def main():
         dt2 = time.perf_counter() - t1
         gc.enable()
         out["two_streams_per_gpu"] = {"scans_per_s": round(2 * per / dt2, 3), "scans": 2 * per,
-                                      "note": "two independent scan streams, one handle + one host thread each, same GPU"}
+                                      "note": "two independent scan streams (device-resident scans), one handle + one host thread each, same GPU"}
         kf2.close()
         h2.close()
-        h.set_timing_stride(args.timing_stride)
 
-    # ---- CPU baseline: the oracle's restated reference path on this box's host cores (rank 0, N=1 only)
+    # ---- CPU baseline: the oracle's restated reference path on this box's host cores (rank 0, N=1 only), at the
+    # reference's own thread count (MP_PROC_NUM = 3, CMakeLists.txt:21-24) and at all host cores
     if rank == 0 and G == 1 and args.cpu_scans > 0:
         from oracle import pyoracle as po
 
         m = po.Map(scene.map_xyz)  # k-d tree build is outside the reference's t_update window too
-        tot = 0.0
         ncpu = min(args.cpu_scans, S)
-        for s in range(ncpu):
-            sc = po.Scan(probs[s].body, nthreads=args.cpu_threads)
-            t1 = time.perf_counter()
-            sc.update_iterated(m, priors[s][0], priors[s][1], extrinsic_est_en=ext)
-            tot += time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": round(ncpu / tot, 4), "unit": "scans/s", "cores": args.cpu_threads, "kind": "port",
+
+        def cpu_rate(threads):
+            tot = 0.0
+            for s in range(ncpu):
+                sc = po.Scan(probs[s].body, nthreads=threads)
+                t1 = time.perf_counter()
+                sc.update_iterated(m, priors[s][0], priors[s][1], extrinsic_est_en=ext)
+                tot += time.perf_counter() - t1
+            return ncpu / tot
+
+        r3 = cpu_rate(args.cpu_threads)
+        ncores = os.cpu_count() or 1
+        rall = cpu_rate(ncores)
+        out["cpu_baseline"] = {"value": round(r3, 4), "unit": "scans/s", "cores": args.cpu_threads, "kind": "port",
                                "sample": f"{ncpu} full updates of the same {N}-pt scans vs the same {M}-pt map "
                                          f"(restated reference path: k-d tree 5-NN + plane fit + IEKF, OpenMP "
                                          f"{args.cpu_threads} threads = the reference's MP_PROC_NUM); host has "
-                                         f"{os.cpu_count()} logical cores",
-                               "speedup_vs_cpu": round(value / (ncpu / tot), 1)}
+                                         f"{ncores} logical cores",
+                               "speedup_vs_cpu": round(value / r3, 1),
+                               "all_cores": {"value": round(rall, 4), "cores": ncores, "speedup_vs_cpu": round(value / rall, 1)}}
 
     # ---- map_incremental (classification + Add_Points into the device map) after an update.
     # Outside the timed region and last, because it grows the map.  t_map = classify + insert + re-index, the
     # reference's "Incremental Mapping" timer (src/laserMapping.cpp:921-924).
-    if rank == 0 and G == 1 and mode != "shard":
-        h.set_timing_stride(0)
+    if extra:
         t_cls = t_all = 0.0
         added = 0
         reps = min(3, S)
         for s in range(reps):
-            h.scan_activate(s)
-            kf.change_x(priors[s][0])
-            kf.change_P(priors[s][1])
-            kf.update(0.001)
+            kf.update_scan(16 + s, priors[s][0], priors[s][1], 0.001)
             xpost = kf.get_x()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -429,30 +480,41 @@ def main():
                                   "net_points_added_per_scan": round(added / reps, 1), "scans": reps,
                                   "note": "filter_size_map 0.5; only the touched bricks are rewritten (slack-carrying brick storage)"}
 
-    # ---- SURVEY 8(f) rows 2-3: the raw-scan front end (undistortion + VoxelGrid + staging) for one raw scan handed over
-    # as a pageable host buffer: PCIe-inclusive by nature, reported beside the headline, never part of it.
-    if rank == 0 and G == 1 and mode != "shard":
+    # ---- SURVEY 8(f) rows 2-4: the raw-scan front end (undistortion + VoxelGrid + staging) for one raw scan handed over
+    # as a host buffer, and publish_frame_world's dense cloud: PCIe-inclusive by nature, reported beside the headline.
+    if extra:
         rng = np.random.default_rng(11)
         body = probs[0].body
         raw = np.repeat(body, 3, axis=0) + rng.normal(0, 0.03, (3 * len(body), 3)).astype(np.float32)
         tms = np.repeat(rng.uniform(0.0, 100.0, len(body)), 3).astype(np.float32)  # neighbours in space are neighbours in time
-        pts = np.ascontiguousarray(np.c_[raw, tms].astype(np.float32))
-        from fast_lio_amd import synth as _s
-        poses, x_end = _s.imu_poses(priors[0][0], capi.predict_fn)
-        h.scan_stage_undistorted(0, pts, poses, x_end, 0.5)  # warm-up (allocations)
+        pts = capi.pinned_empty((len(raw), 4), np.float32)
+        pts[:, :3] = raw
+        pts[:, 3] = tms
+        poses, x_end = synth.imu_poses(priors[0][0], capi.predict_fn)
+        h.scan_stage_undistorted(0, pts, poses, x_end, 0.5, want_undistorted=False)  # warm-up (allocations)
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
         reps = 5
+        t1 = time.perf_counter()
         for _ in range(reps):
-            n_down, _u = h.scan_stage_undistorted(0, pts, poses, x_end, 0.5)
+            n_down, _u = h.scan_stage_undistorted(0, pts, poses, x_end, 0.5, want_undistorted=False)
+        h.scan_wait(0)
+        torch.cuda.synchronize()
         t_fe = (time.perf_counter() - t1) / reps
         t1 = time.perf_counter()
         for _ in range(reps):
-            h.scan_stage_downsampled(0, raw, 0.5)
-        t_vg = (time.perf_counter() - t1) / reps
+            h.scan_stage_undistorted(0, pts, poses, x_end, 0.5, want_undistorted=True)
+        t_fe_back = (time.perf_counter() - t1) / reps
+        h.frame_world(x_end, slot=0, dense=True)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            h.frame_world(x_end, slot=0, dense=True)
+        t_fw = (time.perf_counter() - t1) / reps
         out["scan_front_end"] = {"raw_points": int(len(pts)), "feats_down_size": int(n_down),
-                                 "undistort_voxelgrid_stage_ms": round(t_fe * 1e3, 3), "voxelgrid_stage_ms": round(t_vg * 1e3, 3),
-                                 "note": "host buffer in, feats_undistort + feats_down_body copied back; filter_size_surf 0.5"}
+                                 "undistort_voxelgrid_stage_ms": round(t_fe * 1e3, 3),
+                                 "same_with_feats_undistort_copied_back_ms": round(t_fe_back * 1e3, 3),
+                                 "frame_world_dense_ms": round(t_fw * 1e3, 3),
+                                 "note": "page-locked host buffer in; filter_size_surf 0.5; frame_world = RGBpointBodyToWorld over "
+                                         "the device-resident feats_undistort + D2H (publish_frame_world, dense_pub_en)"}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -58,6 +58,7 @@ class FlhUpdateStats(C.Structure):
         ("returned_in_loop", C.c_int),
         ("n_eff", C.c_int * 8),
         ("pass_search", C.c_int * 8),
+        ("pass_ms", C.c_double * 8),
         ("h_ms", C.c_double),
         ("solve_ms", C.c_double),
     ]
@@ -91,6 +92,22 @@ class FlhLocalMap(C.Structure):
 
 class FlhError(RuntimeError):
     pass
+
+
+_pinned = []
+
+
+def pinned_empty(shape, dtype=np.float32) -> np.ndarray:
+    """A numpy array in page-locked host memory (flh_host_alloc): the DMA engine reads scans from it where they lie.
+    The memory lives until the process ends (the arrays handed out here are few and long-lived)."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    p = lib().flh_host_alloc(max(n, 1))
+    if not p:
+        raise FlhError("flh_host_alloc: " + lib().flh_last_error().decode())
+    buf = (C.c_char * max(n, 1)).from_address(p)
+    _pinned.append(buf)
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
 
 def lib():
@@ -311,16 +328,20 @@ class Handle:
                                               a.shape[0], float(leaf_size), C.byref(n_out)), "flh_scan_stage_downsampled")
         return int(n_out.value)
 
-    def scan_stage_undistorted(self, slot: int, pts_xyzt: np.ndarray, poses, x_end, leaf_size: float = 0.5):
+    def scan_stage_undistorted(self, slot: int, pts_xyzt: np.ndarray, poses, x_end, leaf_size: float = 0.5,
+                               want_undistorted: bool = True):
         """UndistortPcl's per-point half + VoxelGrid + staging.  pts_xyzt: n x 4 float32 (x, y, z, time offset in ms);
-        poses: a ctypes array of 22-double Pose6D records.  Returns (feats_down_size, feats_undistort n x 3)."""
-        a = np.ascontiguousarray(pts_xyzt, dtype=np.float32).reshape(-1, 4)
-        und = np.zeros((max(len(a), 1), 3), np.float32)
+        poses: a ctypes array of 22-double Pose6D records.  Returns (feats_down_size, feats_undistort n x 3 or None --
+        the cloud stays on the device either way, see frame_world)."""
+        a = pts_xyzt if (pts_xyzt.dtype == np.float32 and pts_xyzt.flags["C_CONTIGUOUS"]) else np.ascontiguousarray(pts_xyzt, dtype=np.float32)
+        a = a.reshape(-1, 4)
+        und = np.zeros((max(len(a), 1), 3), np.float32) if want_undistorted else None
         n_out = C.c_size_t(0)
         _chk(lib().flh_scan_stage_undistorted(self._h, slot, a.ctypes.data, 16, 12, a.shape[0], C.cast(poses, C.c_void_p),
                                               len(poses), np.ascontiguousarray(x_end, dtype=np.float64), float(leaf_size),
-                                              und.ctypes.data, C.byref(n_out)), "flh_scan_stage_undistorted")
-        return int(n_out.value), und[: len(a)].copy()
+                                              und.ctypes.data if want_undistorted else None, C.byref(n_out)),
+             "flh_scan_stage_undistorted")
+        return int(n_out.value), (und[: len(a)].copy() if want_undistorted else None)
 
     def fetch_scan(self) -> np.ndarray:
         out = np.zeros((self.N, 3), np.float32)

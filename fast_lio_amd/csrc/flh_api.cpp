@@ -1242,8 +1242,7 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     if (enqueue_eval(h, s, do_search, ext, h->h_gram, seq, timed) != 0) return -1;
     hipStream_t st = h->stream;
     if (h->stats && do_search) HIPC(hipMemcpyAsync(h->h_counter, h->counter.p, sizeof(u64), hipMemcpyDeviceToHost, st));
-    if (timed) HIPC(hipEventRecord(h->ev[3], st));
-    if (timed || h->stats) {
+    if (h->stats) {
         HIPC(hipStreamSynchronize(st));
     } else {
         // k_fit publishes the block with system-scope stores and then the sequence word in G[15][15]: poll it instead of
@@ -1259,6 +1258,9 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
+    // timed evaluations: three event records on the stream (before the first launch, after the search kernels, after the
+    // fit kernel); the last one completes when k_fit retires, a moment after the flag
+    if (timed) HIPC(hipEventSynchronize(h->ev[2]));
     if (h->h_gram[255] != seq) return fail("flh_eval: result sequence mismatch");
     h->h_gram[255] = 0.0;  // G[15][15] is structurally zero
     flh_unpack_gram(h->h_gram, HTH, HTh, n_eff, total_residual);
@@ -1266,7 +1268,7 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     if (timed) {
         (void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
         (void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
-        (void)hipEventElapsedTime(&c, h->ev[0], h->ev[3]);
+        (void)hipEventElapsedTime(&c, h->ev[0], h->ev[2]);
     }
     h->timing.search_ms = do_search ? a : 0.f;
     h->timing.fit_ms = b;

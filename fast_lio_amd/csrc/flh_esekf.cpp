@@ -105,7 +105,7 @@ int flh_esekf_update(flh_esekf* e, double R, flh_update_stats* st) {
         st->passes = s.passes;
         st->searches = s.searches;
         st->returned_in_loop = s.returned_in_loop;
-        for (int i = 0; i < 8; ++i) { st->n_eff[i] = s.n_eff[i]; st->pass_search[i] = s.pass_search[i]; }
+        for (int i = 0; i < 8; ++i) { st->n_eff[i] = s.n_eff[i]; st->pass_search[i] = s.pass_search[i]; st->pass_ms[i] = s.pass_ms[i]; }
         st->h_ms = s.h_ms;
         st->solve_ms = s.solve_ms;
     }

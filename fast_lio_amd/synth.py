@@ -33,6 +33,7 @@ class Sensor:
     extrinsic_T: tuple
     extrinsic_R: tuple = (1, 0, 0, 0, 1, 0, 0, 0, 1)
     height: float = 2.0  # sensor height above ground used by the default true pose
+    voxel: float = 0.5   # leaf of the scan down-sampling the generated scan stands for (filter_size_surf)
 
 
 SENSORS = {
@@ -45,7 +46,9 @@ SENSORS = {
     # config/ouster64.yaml (det_range 150, blind 4), 360 x +-22.5 deg
     "ouster64": Sensor("ouster64", (-180.0, 180.0), (-22.5, 22.5), 4.0, 150.0, (0.0, 0.0, 0.0), height=2.5),
     # config/mid360.yaml (extrinsic_T [-0.011,-0.02329,0.04412], det_range 100, blind 0.5), 360 x 59 deg
-    "mid360": Sensor("mid360", (-180.0, 180.0), (-7.0, 52.0), 0.5, 100.0, (-0.011, -0.02329, 0.04412), height=1.5),
+    # BASELINE configs[4] asks for DENSE 200k-point MID-360 scans: within det_range 100 m the scene shows < 100k distinct
+    # 0.5 m voxels, so the dense scan is the one a 0.25 m leaf leaves (filter_size_surf 0.25)
+    "mid360": Sensor("mid360", (-180.0, 180.0), (-7.0, 52.0), 0.5, 100.0, (-0.011, -0.02329, 0.04412), height=1.5, voxel=0.25),
 }
 
 
@@ -217,9 +220,11 @@ def _raycast(scene: Scene, o: np.ndarray, d: np.ndarray, rmin: float, rmax: floa
     return best
 
 
-def make_scan(scene: Scene, sensor: Sensor, N: int, x_true: np.ndarray, seed: int, voxel: float = 0.5,
+def make_scan(scene: Scene, sensor: Sensor, N: int, x_true: np.ndarray, seed: int, voxel: float | None = None,
               range_noise: float = 0.02) -> np.ndarray:
     """N post-downsample LiDAR-frame points (float32 N x 3) seen from the true state x_true."""
+    if voxel is None:
+        voxel = sensor.voxel
     rng = np.random.default_rng(seed)
     R = quat_to_R(x_true[X_ROT:X_ROT + 4])
     R_LI = quat_to_R(x_true[X_OFFR:X_OFFR + 4])
@@ -230,6 +235,7 @@ def make_scan(scene: Scene, sensor: Sensor, N: int, x_true: np.ndarray, seed: in
     all_pts = np.zeros((0, 3))
     all_keys = np.zeros((0,), np.int64)
     batch = max(4 * N, 20000)
+    stalled = 0
     for _ in range(64):
         az = np.deg2rad(rng.uniform(sensor.az_deg[0], sensor.az_deg[1], batch))
         # 40 % of the rays uniform in elevation (walls, near field); 60 % aimed so that their ground
@@ -251,13 +257,18 @@ def make_scan(scene: Scene, sensor: Sensor, N: int, x_true: np.ndarray, seed: in
         # keep the first sample that lands in each voxel
         key = np.floor(pl / voxel).astype(np.int64) + (1 << 20)
         k1 = (key[:, 0] << 42) | (key[:, 1] << 21) | key[:, 2]
+        all_keys_before = all_keys.shape[0]
         all_pts = np.concatenate([all_pts, pl], axis=0)
         all_keys = np.concatenate([all_keys, k1], axis=0)
         _, first = np.unique(all_keys, return_index=True)
         first.sort()
+        grew = len(first) - all_keys_before
         all_pts = all_pts[first]
         all_keys = all_keys[first]
         if all_pts.shape[0] >= N:
+            break
+        stalled = stalled + 1 if grew < max(N // 500, 1) else 0
+        if stalled >= 3:  # the visible surface is exhausted: more rays will not find new voxels
             break
     pts = all_pts
     if pts.shape[0] < N:

@@ -127,6 +127,7 @@ class esekf {
         int passes = 0, searches = 0, returned_in_loop = 0;
         int n_eff[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
         int pass_search[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double pass_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wall time of each pass: measurement model + host algebra
         double h_ms = 0, solve_ms = 0;
     };
     const update_stats& last_stats() const { return stats_; }
@@ -152,13 +153,17 @@ class esekf {
             const bool searched = dyn_share.converge;
             h_dyn_share(x_, dyn_share, h_ctx_);
             stats_.h_ms += std::chrono::duration<double, std::milli>(clk::now() - t_h0).count();
+            const int pass_no = stats_.passes;
             if (stats_.passes < 8) {
                 stats_.pass_search[stats_.passes] = searched ? 1 : 0;
                 stats_.n_eff[stats_.passes] = dyn_share.valid ? (int)meas_rows(dyn_share) : 0;
             }
             stats_.passes++;
             stats_.searches += searched ? 1 : 0;
-            if (!dyn_share.valid) continue;  // :1638-1641
+            if (!dyn_share.valid) {  // :1638-1641
+                if (pass_no < 8) stats_.pass_ms[pass_no] = std::chrono::duration<double, std::milli>(clk::now() - t_h0).count();
+                continue;
+            }
 
             const auto solve_start = clk::now();
             dof_Measurement = (int)meas_rows(dyn_share);
@@ -209,11 +214,13 @@ class esekf {
                 const double ms = std::chrono::duration<double, std::milli>(clk::now() - solve_start).count();
                 stats_.solve_ms += ms;
                 solve_time += ms * 1e-3;
+                if (pass_no < 8) stats_.pass_ms[pass_no] = std::chrono::duration<double, std::milli>(clk::now() - t_h0).count();
                 return;
             }
             const double ms = std::chrono::duration<double, std::milli>(clk::now() - solve_start).count();
             stats_.solve_ms += ms;
             solve_time += ms * 1e-3;
+            if (pass_no < 8) stats_.pass_ms[pass_no] = std::chrono::duration<double, std::milli>(clk::now() - t_h0).count();
         }
     }
 

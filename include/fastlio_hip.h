@@ -263,6 +263,8 @@ typedef struct flh_update_stats {
     int returned_in_loop;  /* final-covariance branch taken (esekfom.hpp:1834) */
     int n_eff[8];
     int pass_search[8];
+    double pass_ms[8];     /* wall time of each pass (measurement model + host algebra): "ms/IEKF-iter", search and
+                              no-search passes apart (pass_search) */
     double h_ms;           /* wall time inside the measurement model */
     double solve_ms;       /* wall time of the host algebra (solve_H_time, esekfom.hpp:1649,1926) */
 } flh_update_stats;
