@@ -137,6 +137,13 @@ void orc_update_iterated(orc_scan* sc, const orc_kdtree* map, const float* map_x
                          const double limit[ORC_NDOF], int extrinsic_est_en,
                          orc_update_stats* stats);
 
+/* Hook for oracle/ref (record-replay against the real esekfom.hpp): after every pass of orc_update_iterated the callback
+ * receives (pass number, the converge flag the pass was given, ekfom_data.valid, n_eff, h_x n_eff x 12 column-major, h,
+ * the state after the pass).  NULL removes it. */
+typedef void (*orc_pass_recorder)(void* ctx, int pass, int converge, int valid, int n_eff, const double* h_x,
+                                  const double* h, const double x_after[ORC_NSTATE]);
+void orc_set_pass_recorder(orc_pass_recorder cb, void* ctx);
+
 /* One IEKF pass's host algebra given precomputed normal equations (information form,
  * esekfom.hpp:1651-1817 with HTH/HTh substituted).  Used to check the product's host solver and the
  * info-form/gain-form equivalence KAT.  Returns dx_ (23). x is updated in place (x boxplus dx_). */
@@ -170,6 +177,9 @@ void orc_map_incremental_classify(const orc_scan* sc, const float* map_xyz, size
  * The result keeps surviving old points in their old order, followed by surviving new points in input order.
  * Returns the new size. */
 size_t orc_map_add(float* map_xyz, size_t M, const float* add_xyz, size_t n, int downsample, double ds);
+/* Sensitivity variant (oracle_path.c): the same insert with ikd-Tree's own FLOAT box arithmetic; equal to orc_map_add at
+ * downsample_size 0.5, not at 0.3.  Used by tools/eigen_order_study.py only. */
+size_t orc_map_add_floatbox(float* map_xyz, size_t M, const float* add_xyz, size_t n, float ds);
 /* Delete_Point_Boxes: removes every point p with min <= p < max (per axis) for any of the nb boxes
  * (boxes: nb x 6 floats min xyz, max xyz).  Order preserved.  Returns the new size. */
 size_t orc_map_delete_boxes(float* map_xyz, size_t M, const float* boxes, size_t nb);

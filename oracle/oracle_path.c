@@ -633,6 +633,12 @@ void orc_iekf_pass_gain(double x[ORC_NSTATE], const double x_prop[ORC_NSTATE], c
     finish_pass(x, K_h, K_x_out, dx_new, dx_out);
 }
 
+/* Recorder for oracle/ref (record-replay against the real esekfom.hpp): called after every pass of orc_update_iterated
+   with the rows h_share_model produced and the state the pass ended in. */
+static orc_pass_recorder g_recorder = NULL;
+static void* g_recorder_ctx = NULL;
+void orc_set_pass_recorder(orc_pass_recorder cb, void* ctx) { g_recorder = cb; g_recorder_ctx = ctx; }
+
 void orc_update_iterated(orc_scan* sc, const orc_kdtree* map, const float* map_xyz, size_t mstride, double x[ORC_NSTATE],
                          double P[NDOF * NDOF], double R, int maximum_iter, const double limit[NDOF], int extrinsic_est_en,
                          orc_update_stats* st) {
@@ -658,7 +664,11 @@ void orc_update_iterated(orc_scan* sc, const orc_kdtree* map, const float* map_x
         }
         st->passes++;
         st->searches += converge ? 1 : 0;
-        if (!valid) continue; /* :1638-1641 */
+        if (!valid) {
+            if (g_recorder) g_recorder(g_recorder_ctx, st->passes - 1, converge, 0, 0, NULL, NULL, x);
+            continue; /* :1638-1641 */
+        }
+        const int rec_converge = converge;
         double solve_start = now_s();
         int dof_Measurement = sc->effct_feat_num;
         double dx[NDOF];
@@ -680,6 +690,7 @@ void orc_update_iterated(orc_scan* sc, const orc_kdtree* map, const float* map_x
             if (fabs(dx_[j]) > limit[j]) { converge = 0; break; }
         if (converge) t++;
         if (!t && i == maximum_iter - 2) converge = 1; /* :1829-1832 */
+        if (g_recorder) g_recorder(g_recorder_ctx, st->passes - 1, rec_converge, 1, sc->effct_feat_num, sc->h_x, sc->h, x);
         if (t > 1 || i == maximum_iter - 1) {          /* :1834 */
             final_cov(P, K_x, x, x_prop, dx_);
             st->returned_in_loop = 1;
@@ -805,6 +816,90 @@ size_t orc_map_add(float* map, size_t M, const float* add, size_t n, int downsam
             }
         } else {
             dead[i] = 1; /* the single existing point stays; the new one is dropped */
+        }
+    }
+    size_t w = 0;
+    for (size_t i = 0; i < tot; i++)
+        if (!dead[i]) {
+            if (w != i) memmove(map + 3 * w, map + 3 * i, sizeof(float) * 3);
+            w++;
+        }
+    free(head); free(next); free(dead);
+    return w;
+}
+
+/* SENSITIVITY VARIANT of orc_map_add (downsample = true), not used by any parity test: the box arithmetic as ikd-Tree
+   itself carries it [recalled-upstream: KD_TREE::Add_Points; source absent, .gitmodules:1-4] -- `float downsample_size`,
+   Box_of_Point.vertex_min = floor(p / downsample_size) * downsample_size and vertex_max = vertex_min + downsample_size in
+   FLOAT, membership by Search_by_range's  vertex_min <= p < vertex_max  on those float corners, mid_point =
+   min + (max - min) / 2.0.  At downsample_size = 0.5 (every launch file but marsim) the float corners equal the double
+   voxel grid of orc_map_add exactly; at marsim's 0.3 they do not, and a box can reach into a neighbouring voxel.
+   tools/eigen_order_study.py reports how many surviving points differ between the two. */
+size_t orc_map_add_floatbox(float* map, size_t M, const float* add, size_t n, float dsf) {
+    const double ds = (double)dsf;
+    size_t tot = M + n, nb = 1;
+    while (nb < 2 * tot + 16) nb <<= 1;
+    long long* head = (long long*)malloc(sizeof(long long) * nb);
+    long long* next = (long long*)malloc(sizeof(long long) * (tot ? tot : 1));
+    unsigned char* dead = (unsigned char*)calloc(tot ? tot : 1, 1);
+    for (size_t i = 0; i < nb; i++) head[i] = -1;
+    memcpy(map + 3 * M, add, sizeof(float) * 3 * n);
+    for (size_t i = 0; i < M; i++) { /* coarse buckets (double grid): a float box overlaps at most 3 of them per axis */
+        vox_key k = vox_of(map + 3 * i, ds);
+        size_t b = (size_t)(vox_hash(k) & (nb - 1));
+        next[i] = head[b];
+        head[b] = (long long)i;
+    }
+    for (size_t a = 0; a < n; a++) {
+        size_t i = M + a;
+        const float* p = map + 3 * i;
+        float bmin[3], bmax[3], mid[3];
+        for (int d = 0; d < 3; d++) {
+            bmin[d] = floorf(p[d] / dsf) * dsf;
+            bmax[d] = bmin[d] + dsf;
+            mid[d] = (float)((double)bmin[d] + (double)(bmax[d] - bmin[d]) / 2.0);
+        }
+        float dx = p[0] - mid[0], dy = p[1] - mid[1], dz = p[2] - mid[2];
+        float min_dist = (dx * dx + dy * dy) + dz * dz;
+        long long best = (long long)i;
+        int stored = 0;
+        vox_key kc = vox_of(p, ds);
+        for (long long oz = -1; oz <= 1; oz++)
+            for (long long oy = -1; oy <= 1; oy++)
+                for (long long ox = -1; ox <= 1; ox++) {
+                    vox_key k = {kc.kx + ox, kc.ky + oy, kc.kz + oz};
+                    size_t b = (size_t)(vox_hash(k) & (nb - 1));
+                    for (long long j = head[b]; j >= 0; j = next[j]) {
+                        const float* q = map + 3 * j;
+                        if (dead[j] || !vox_eq(vox_of(q, ds), k)) continue;
+                        if (!(q[0] >= bmin[0] && q[0] < bmax[0] && q[1] >= bmin[1] && q[1] < bmax[1] && q[2] >= bmin[2] && q[2] < bmax[2])) continue;
+                        stored++;
+                        float ex = q[0] - mid[0], ey = q[1] - mid[1], ez = q[2] - mid[2];
+                        float d = (ex * ex + ey * ey) + ez * ez;
+                        if (d < min_dist || (d == min_dist && best != (long long)i && j < best)) { min_dist = d; best = j; }
+                    }
+                }
+        if (stored > 1 || best == (long long)i) {
+            for (long long oz = -1; oz <= 1; oz++)
+                for (long long oy = -1; oy <= 1; oy++)
+                    for (long long ox = -1; ox <= 1; ox++) {
+                        vox_key k = {kc.kx + ox, kc.ky + oy, kc.kz + oz};
+                        size_t b = (size_t)(vox_hash(k) & (nb - 1));
+                        for (long long j = head[b]; j >= 0; j = next[j]) {
+                            const float* q = map + 3 * j;
+                            if (dead[j] || j == best || !vox_eq(vox_of(q, ds), k)) continue;
+                            if (q[0] >= bmin[0] && q[0] < bmax[0] && q[1] >= bmin[1] && q[1] < bmax[1] && q[2] >= bmin[2] && q[2] < bmax[2]) dead[j] = 1;
+                        }
+                    }
+            if (best == (long long)i) {
+                size_t b = (size_t)(vox_hash(kc) & (nb - 1));
+                next[i] = head[b];
+                head[b] = (long long)i;
+            } else {
+                dead[i] = 1;
+            }
+        } else {
+            dead[i] = 1;
         }
     }
     size_t w = 0;

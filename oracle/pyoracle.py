@@ -129,6 +129,8 @@ def lib():
     ]
     L.orc_map_add.restype = C.c_size_t
     L.orc_map_add.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_int, C.c_double]
+    L.orc_map_add_floatbox.restype = C.c_size_t
+    L.orc_map_add_floatbox.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float]
     L.orc_map_delete_boxes.restype = C.c_size_t
     L.orc_map_delete_boxes.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t]
     _lib = L
@@ -445,6 +447,16 @@ def map_add(map_xyz, add_xyz, downsample=True, ds=0.5):
     buf = np.zeros((len(m) + len(a), 3), np.float32)
     buf[: len(m)] = m
     n = lib().orc_map_add(buf, len(m), a, len(a), int(downsample), float(ds))
+    return buf[:n].copy()
+
+
+def map_add_floatbox(map_xyz, add_xyz, ds=0.5):
+    """Sensitivity variant of map_add(downsample=True): ikd-Tree's float box arithmetic (oracle_path.c)."""
+    m = _c32(map_xyz).reshape(-1, 3)
+    a = _c32(add_xyz).reshape(-1, 3)
+    buf = np.zeros((len(m) + len(a), 3), np.float32)
+    buf[: len(m)] = m
+    n = lib().orc_map_add_floatbox(buf, len(m), a, len(a), float(ds))
     return buf[:n].copy()
 
 
