@@ -68,7 +68,8 @@ int main() {
     kf_t kf;
     double epsi[23];
     for (double& e : epsi) e = 0.001;
-    kf.init_dyn_share(get_f, df_dx, df_dw, fastlio_amd::h_share_model, 3, epsi, &hctx);  // laserMapping.cpp:828
+    kf.init_dyn_share(get_f, df_dx, df_dw, static_cast<kf_t::measurementModel_dyn_share_ctx*>(fastlio_amd::h_share_model), 3, epsi,
+                      &hctx);  // laserMapping.cpp:828 with an explicit context (examples/node_lines.cpp: the line as it stands)
 
     state_ikfom st = kf.get_x();
     st.pos[0] = 0; st.pos[1] = 0; st.pos[2] = 2.0;

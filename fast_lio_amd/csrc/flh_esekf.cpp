@@ -61,7 +61,7 @@ flh_esekf* flh_esekf_create(flh_handle* handle, int maximum_iter, const double l
     e->gpu_ctx.extrinsic_est_en = extrinsic_est_en != 0;
     double lim[FLH_NDOF];
     for (int i = 0; i < FLH_NDOF; ++i) lim[i] = limit ? limit[i] : 0.001;  // epsi, laserMapping.cpp:826-827
-    e->kf.init_dyn_share(get_f, df_dx, df_dw, gpu_model_adapter, maximum_iter, lim, e);
+    e->kf.init_dyn_share(get_f, df_dx, df_dw, static_cast<kf_t::measurementModel_dyn_share_ctx*>(gpu_model_adapter), maximum_iter, lim, e);
     return e;
 }
 void flh_esekf_destroy(flh_esekf* e) { delete e; }
@@ -69,7 +69,7 @@ void flh_esekf_set_meas_model(flh_esekf* e, flh_meas_fn h, void* ctx) {
     if (!e) return;
     e->user_h = h;
     e->user_ctx = ctx;
-    e->kf.set_meas_model(h ? user_model_adapter : gpu_model_adapter, e);
+    e->kf.set_meas_model(static_cast<kf_t::measurementModel_dyn_share_ctx*>(h ? user_model_adapter : gpu_model_adapter), e);
 }
 void flh_esekf_change_x(flh_esekf* e, const double x[FLH_NSTATE]) {
     state_ikfom s = e->kf.get_x();

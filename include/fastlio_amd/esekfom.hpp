@@ -50,28 +50,33 @@ class esekf {
     typedef Mat<m, n> processMatrix1(state&, const input&);
     typedef Mat<m, process_noise_dof> processMatrix2(state&, const input&);
     typedef Mat<process_noise_dof, process_noise_dof> processnoisecovariance;
-    // measurementModel_dyn_share (esekfom.hpp:129) with an opaque context pointer so that a C caller
-    // can bind one (the reference registers a plain function that reads globals).
-    typedef void measurementModel_dyn_share(state&, dyn_share_datastruct<scalar_type>&, void* ctx);
+    // measurementModel_dyn_share exactly as the reference declares it (esekfom.hpp:129): a plain function that reads
+    // its inputs from globals.  The _ctx form carries an opaque context pointer instead (C callers, several filters in one
+    // process); either can be registered.
+    typedef void measurementModel_dyn_share(state&, dyn_share_datastruct<scalar_type>&);
+    typedef void measurementModel_dyn_share_ctx(state&, dyn_share_datastruct<scalar_type>&, void* ctx);
 
     esekf(const state& x = state(), const cov& P = cov::Identity()) : x_(x), P_(P) {}
 
-    // esekfom.hpp:238-254
+    // esekfom.hpp:238-254 -- the reference's own signature: laserMapping.cpp:828 compiles against it unchanged
     void init_dyn_share(processModel f_in, processMatrix1 f_x_in, processMatrix2 f_w_in,
-                        measurementModel_dyn_share h_dyn_share_in, int maximum_iteration, const scalar_type limit_vector[n],
-                        void* h_ctx = nullptr) {
-        f = f_in;
-        f_x = f_x_in;
-        f_w = f_w_in;
+                        measurementModel_dyn_share h_dyn_share_in, int maximum_iteration, scalar_type limit_vector[n]) {
+        init_common(f_in, f_x_in, f_w_in, maximum_iteration, limit_vector);
         h_dyn_share = h_dyn_share_in;
-        h_ctx_ = h_ctx;
-        maximum_iter = maximum_iteration;
-        for (int i = 0; i < n; i++) limit[i] = limit_vector[i];
-        x_.build_S2_state();
-        x_.build_SO3_state();
-        x_.build_vect_state();
+        h_dyn_share_ctx = nullptr;
+        h_ctx_ = nullptr;
     }
-    void set_meas_model(measurementModel_dyn_share h, void* ctx) { h_dyn_share = h; h_ctx_ = ctx; }
+    // the same with a context pointer handed to the measurement model
+    void init_dyn_share(processModel f_in, processMatrix1 f_x_in, processMatrix2 f_w_in,
+                        measurementModel_dyn_share_ctx h_dyn_share_in, int maximum_iteration, const scalar_type limit_vector[n],
+                        void* h_ctx) {
+        init_common(f_in, f_x_in, f_w_in, maximum_iteration, limit_vector);
+        h_dyn_share = nullptr;
+        h_dyn_share_ctx = h_dyn_share_in;
+        h_ctx_ = h_ctx;
+    }
+    void set_meas_model(measurementModel_dyn_share_ctx h, void* ctx) { h_dyn_share = nullptr; h_dyn_share_ctx = h; h_ctx_ = ctx; }
+    void set_meas_model(measurementModel_dyn_share h) { h_dyn_share = h; h_dyn_share_ctx = nullptr; h_ctx_ = nullptr; }
 
     // esekfom.hpp:279-383 (dense path)
     void predict(double& dt, processnoisecovariance& Q, const input& i_in) {
@@ -151,7 +156,8 @@ class esekf {
             dyn_share.has_normal_eq = false;
             const auto t_h0 = clk::now();
             const bool searched = dyn_share.converge;
-            h_dyn_share(x_, dyn_share, h_ctx_);
+            if (h_dyn_share_ctx) h_dyn_share_ctx(x_, dyn_share, h_ctx_);
+            else h_dyn_share(x_, dyn_share);
             stats_.h_ms += std::chrono::duration<double, std::milli>(clk::now() - t_h0).count();
             const int pass_no = stats_.passes;
             if (stats_.passes < 8) {
@@ -237,6 +243,17 @@ class esekf {
     const cov& get_P() const { return P_; }
 
    private:
+    void init_common(processModel f_in, processMatrix1 f_x_in, processMatrix2 f_w_in, int maximum_iteration,
+                     const scalar_type* limit_vector) {
+        f = f_in;
+        f_x = f_x_in;
+        f_w = f_w_in;
+        maximum_iter = maximum_iteration;
+        for (int i = 0; i < n; i++) limit[i] = limit_vector[i];
+        x_.build_S2_state();
+        x_.build_SO3_state();
+        x_.build_vect_state();
+    }
     static int64_t meas_rows(const dyn_share_datastruct<scalar_type>& d) {
         return d.has_normal_eq ? d.n_eff : (int64_t)d.h.size();
     }
@@ -367,6 +384,7 @@ class esekf {
     processMatrix1* f_x = nullptr;
     processMatrix2* f_w = nullptr;
     measurementModel_dyn_share* h_dyn_share = nullptr;
+    measurementModel_dyn_share_ctx* h_dyn_share_ctx = nullptr;
     void* h_ctx_ = nullptr;
     int maximum_iter = 0;
     scalar_type limit[n];

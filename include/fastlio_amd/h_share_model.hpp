@@ -1,7 +1,10 @@
 // h_share_model.hpp -- the measurement model of FAST-LIO2 (src/laserMapping.cpp:638-754) as a thin host
 // wrapper over the HIP library: one flh_eval per call, normal equations straight into the extended
-// dyn_share_datastruct.  Registered with kf.init_dyn_share(get_f, df_dx, df_dw, fastlio_amd::h_share_model,
-// NUM_MAX_ITERATIONS, epsi, &ctx) exactly where the reference registers its own (laserMapping.cpp:828).
+// dyn_share_datastruct.  Two forms:
+//   void h_share_model(state_ikfom&, esekfom::dyn_share_datastruct<double>&)          the reference's signature (:638): reads
+//        its inputs from the global context fastlio_amd::g_hshare, as the reference's reads its globals (:69-114); with
+//        `using fastlio_amd::h_share_model;` the node's line :828 registers it unchanged
+//   void h_share_model(state_ikfom&, esekfom::dyn_share_datastruct<double>&, void* ctx)  the same with an explicit context
 #pragma once
 #include <stdexcept>
 #include <string>
@@ -22,6 +25,13 @@ struct HShareContext {
     double res_mean_last = 0.05;    // :86
     double match_ms = 0.0;          // wall time inside flh_eval (match_time + solve_time buckets, :640,716-717,753)
 };
+
+inline HShareContext g_hshare;  // the globals of laserMapping.cpp:69-114 that the two-argument form reads
+
+inline void h_share_model(state_ikfom& s, esekfom::dyn_share_datastruct<double>& ekfom_data, void* ctx_);
+inline void h_share_model(state_ikfom& s, esekfom::dyn_share_datastruct<double>& ekfom_data) {  // :638
+    h_share_model(s, ekfom_data, &g_hshare);
+}
 
 inline void h_share_model(state_ikfom& s, esekfom::dyn_share_datastruct<double>& ekfom_data, void* ctx_) {
     HShareContext* ctx = static_cast<HShareContext*>(ctx_);

@@ -22,3 +22,24 @@ def test_mapping_loop_example_links_and_fails_loudly_without_a_device(tmp_path):
         assert r.returncode == 0 and "map initialised" in out and "effct_feat_num" in out, out
     else:
         assert r.returncode == 2 and "no HIP device visible" in out, out
+
+
+def test_node_lines_compile_verbatim_against_the_mirror(tmp_path):
+    """The reference's own registration and update lines (src/laserMapping.cpp:826-828, 960-961) compile unchanged against
+    the mirrored esekf / h_share_model (the 3-argument model of round 1 did not)."""
+    lib = _build.build()
+    src = open(os.path.join(ROOT, "examples", "node_lines.cpp")).read()
+    for line in ("kf.init_dyn_share(get_f, df_dx, df_dw, h_share_model, NUM_MAX_ITERATIONS, epsi);",
+                 "kf.update_iterated_dyn_share_modified(LASER_POINT_COV, solve_H_time);", "state_point = kf.get_x();",
+                 "fill(epsi, epsi+23, 0.001);"):
+        assert line in src
+    exe = tmp_path / "node_lines"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "node_lines.cpp"), "-L", os.path.dirname(lib), "-lfastlio_hip",
+                           "-Wl,-rpath," + os.path.dirname(lib), "-o", str(exe)])
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    out = r.stdout.decode()
+    if capi.device_available():
+        assert r.returncode == 0 and "node lines compiled and registered" in out, out
+    else:
+        assert r.returncode == 2 and "no HIP device visible" in out, out
