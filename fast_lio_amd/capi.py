@@ -79,7 +79,8 @@ EXPORTS = [
     "flh_fov_segment", "flh_scan_stage_downsampled", "flh_fetch_scan",
     "flh_scan_stage_undistorted", "flh_esekf_update_scan", "flh_map_stats",
     "flh_scan_stage_async", "flh_scan_wait", "flh_host_alloc", "flh_host_free", "flh_frame_world", "flh_points_body_to_world",
-    "flh_esekf_last_error",
+    "flh_esekf_last_error", "flh_rccl_unique_id", "flh_rccl_init_rank", "flh_rccl_init_all", "flh_rccl_destroy", "flh_rccl_size",
+    "flh_rccl_rank", "flh_eval_group", "flh_set_owned_interval",
 ]
 
 _lib = None
@@ -92,6 +93,29 @@ class FlhLocalMap(C.Structure):
 
 class FlhError(RuntimeError):
     pass
+
+
+def rccl_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    _chk(lib().flh_rccl_unique_id(buf), "flh_rccl_unique_id")
+    return buf.raw
+
+
+def rccl_init_all(handles):
+    """One process, one Handle per device: a common communicator (ncclCommInitAll); use eval_group afterwards."""
+    arr = (C.c_void_p * len(handles))(*[h.ptr for h in handles])
+    _chk(lib().flh_rccl_init_all(arr, len(handles)), "flh_rccl_init_all")
+
+
+def eval_group(handles, x, do_search: bool, ext: bool = False):
+    arr = (C.c_void_p * len(handles))(*[h.ptr for h in handles])
+    HTH = np.zeros(144)
+    HTh = np.zeros(12)
+    n = C.c_int64()
+    tr = C.c_double()
+    _chk(lib().flh_eval_group(arr, len(handles), np.ascontiguousarray(x, np.float64), int(do_search), int(ext), HTH, HTh,
+                              C.byref(n), C.byref(tr)), "flh_eval_group")
+    return HTH.reshape(12, 12), HTh, int(n.value), float(tr.value)
 
 
 _pinned = []
@@ -148,6 +172,16 @@ def lib():
     L.flh_host_free.argtypes = [C.c_void_p]
     L.flh_frame_world.argtypes = [C.c_void_p, C.c_int, _f64p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.flh_points_body_to_world.argtypes = [C.c_void_p, _f64p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    L.flh_rccl_unique_id.argtypes = [C.c_char_p]
+    L.flh_rccl_init_rank.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+    L.flh_rccl_init_all.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.flh_rccl_destroy.argtypes = [C.c_void_p]
+    L.flh_rccl_destroy.restype = None
+    L.flh_rccl_size.argtypes = [C.c_void_p]
+    L.flh_rccl_rank.argtypes = [C.c_void_p]
+    L.flh_eval_group.argtypes = [C.POINTER(C.c_void_p), C.c_int, _f64p, C.c_int, C.c_int, _f64p, _f64p, C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_double)]
+    L.flh_set_owned_interval.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float]
     L.flh_esekf_last_error.restype = C.c_char_p
     L.flh_esekf_last_error.argtypes = [C.c_void_p]
     L.flh_scan_stage_downsampled.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float,
@@ -288,6 +322,19 @@ class Handle:
     def scan_stage(self, slot: int, body: np.ndarray):
         a = np.ascontiguousarray(body, dtype=np.float32)
         _chk(lib().flh_scan_stage(self._h, slot, a.ctypes.data, a.shape[1] * 4, a.shape[0]), "flh_scan_stage")
+
+    # ---- multi-GPU ----
+    def rccl_init_rank(self, nranks: int, unique_id: bytes, rank: int):
+        """Join the RCCL communicator (one process per GPU); afterwards eval / Esekf.update all-reduce every pass."""
+        assert len(unique_id) == 128
+        _chk(lib().flh_rccl_init_rank(self._h, nranks, unique_id, rank), "flh_rccl_init_rank")
+
+    def rccl_size(self) -> int:
+        return int(lib().flh_rccl_size(self._h))
+
+    def set_owned_interval(self, axis: int, lo: float = 0.0, hi: float = 0.0):
+        """Map partitioned over ranks: search only the queries whose world coordinate `axis` lies in [lo, hi); axis < 0 = all."""
+        _chk(lib().flh_set_owned_interval(self._h, axis, float(lo), float(hi)), "flh_set_owned_interval")
 
     def scan_stage_async(self, slot: int, body: np.ndarray):
         """Staging by the handle's staging thread; `body` (float32, C-contiguous, N x 3/4/12) is kept alive here until

@@ -2,6 +2,8 @@
 // upload, one h_share_model evaluation per call, lazy fetches.  Host side only; kernels live in
 // flh_kernels.hip.  There is NO CPU fallback: without a HIP device every entry point fails loudly.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <atomic>
@@ -123,6 +125,12 @@ struct flh_handle {
     DevBuf<uint32_t> slow_list, slow_list2, slow_count;  // work lists between the search stages (striped) and their counters
     DevBuf<float> slow_ub;                   // per-query bound on the 5th squared distance handed from A1 to A2
     DevBuf<uint32_t> tickets;                // arrival tickets of k_fit's in-kernel reduction (self re-arming)
+    // multi-GPU (flh_rccl_*): the communicator this handle's rank belongs to; flh_eval all-reduces the Gram block over it
+    ncclComm_t comm = nullptr;
+    int comm_size = 1, comm_rank = 0;
+    // map partitioned over the ranks: only queries whose world coordinate own_axis lies in [own_lo, own_hi) are searched here
+    int own_axis = -1;
+    float own_lo = -INFINITY, own_hi = INFINITY;
     double* h_gram = nullptr;  // pinned 256 doubles
     u64* h_counter = nullptr;  // pinned
     // last evaluation
@@ -183,6 +191,7 @@ extern "C" {
 
 static void release_build_scratch(flh_handle* h);
 static void stop_stager(flh_handle* h);
+static int rccl_allreduce_publish(flh_handle* h, double seq);
 static StateDev make_state(const double rot[4], const double pos[3], const double offR[4], const double offT[3]);
 
 const char* flh_last_error(void) { return g_err.c_str(); }
@@ -271,6 +280,7 @@ void flh_destroy(flh_handle* h) {
     if (!h) return;
     stop_stager(h);
     (void)hipSetDevice(h->device);
+    flh_rccl_destroy(h);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     release_build_scratch(h);
@@ -1206,7 +1216,8 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
         if (h->stats) HIPC(hipMemsetAsync(h->counter.p, 0, FLH_COUNTER_WORDS * sizeof(u64), st));
         HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
                                 h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
-                                h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr, st));
+                                h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr,
+                                h->own_axis, h->own_lo, h->own_hi, st));
         h->searched_once = true;
         h->search_state = s;
     }
@@ -1239,8 +1250,15 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     // no copy kernel, no extra boundary -- the stream sync below is the only wait
     const bool timed = h->timing_stride > 0 && (h->eval_no++ % (uint64_t)h->timing_stride) == 0;
     const double seq = (double)(++h->seq);
-    if (enqueue_eval(h, s, do_search, ext, h->h_gram, seq, timed) != 0) return -1;
     hipStream_t st = h->stream;
+    if (h->comm) {
+        // this rank's partial block stays in device memory, RCCL sums the ranks' blocks in place (256 doubles: latency-bound,
+        // xGMI bandwidth is irrelevant), then one small kernel publishes the sum + sequence word to pinned host memory
+        if (enqueue_eval(h, s, do_search, ext, h->gram.p, 0.0, timed) != 0) return -1;
+        if (rccl_allreduce_publish(h, seq) != 0) return -1;
+    } else if (enqueue_eval(h, s, do_search, ext, h->h_gram, seq, timed) != 0) {
+        return -1;
+    }
     if (h->stats && do_search) HIPC(hipMemcpyAsync(h->h_counter, h->counter.p, sizeof(u64), hipMemcpyDeviceToHost, st));
     if (h->stats) {
         HIPC(hipStreamSynchronize(st));
@@ -1427,7 +1445,7 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
         if (which == 0) {
             HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
                                     h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
-                                    h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, nullptr, st));
+                                    h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, nullptr, h->own_axis, h->own_lo, h->own_hi, st));
             HIPC(hipMemsetAsync(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t), st));
             h->searched_once = true;
             h->search_state = s;
@@ -1598,6 +1616,172 @@ int flh_fetch_rows(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* 
         hv[k] = -(double)nv[i].w;
         ++k;
     }
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU: RCCL all-reduce of the normal equations (BASELINE north_star).  RCCL is loaded on first use
+// (dlopen), so a single-GPU process never pays for it and the library has no link-time dependency on it.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mu;
+int rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return 0;
+    void* l = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!l) l = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!l) return fail(std::string("RCCL not available: ") + dlerror());
+#define RSYM(field, name)                                                         \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(l, name));      \
+    if (!g_rccl.field) return fail(std::string("RCCL symbol missing: ") + name)
+    RSYM(GetUniqueId, "ncclGetUniqueId");
+    RSYM(CommInitRank, "ncclCommInitRank");
+    RSYM(CommInitAll, "ncclCommInitAll");
+    RSYM(CommDestroy, "ncclCommDestroy");
+    RSYM(AllReduce, "ncclAllReduce");
+    RSYM(AllGather, "ncclAllGather");
+    RSYM(GroupStart, "ncclGroupStart");
+    RSYM(GroupEnd, "ncclGroupEnd");
+    RSYM(GetErrorString, "ncclGetErrorString");
+#undef RSYM
+    g_rccl.lib = l;
+    return 0;
+}
+}  // namespace
+#define NCCLC(expr)                                                                                          \
+    do {                                                                                                     \
+        ncclResult_t r_ = (expr);                                                                            \
+        if (r_ != ncclSuccess) return fail(std::string(#expr) + ": " + g_rccl.GetErrorString(r_));           \
+    } while (0)
+
+int flh_rccl_unique_id(char id[FLH_RCCL_ID_BYTES]) {
+    if (!id) return fail("flh_rccl_unique_id: null argument");
+    if (rccl_load() != 0) return -1;
+    static_assert(FLH_RCCL_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    ncclUniqueId u;
+    NCCLC(g_rccl.GetUniqueId(&u));
+    std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return 0;
+}
+
+// one process per GPU: every rank calls this with the id rank 0 generated (handed around by whatever launched the ranks)
+int flh_rccl_init_rank(flh_handle* h, int nranks, const char id[FLH_RCCL_ID_BYTES], int rank) {
+    if (!h || !id) return fail("flh_rccl_init_rank: null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("flh_rccl_init_rank: bad rank / nranks");
+    if (h->comm) return fail("flh_rccl_init_rank: the handle already has a communicator");
+    if (rccl_load() != 0) return -1;
+    HIPC(hipSetDevice(h->device));
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    NCCLC(g_rccl.CommInitRank(&h->comm, nranks, u, rank));
+    h->comm_size = nranks;
+    h->comm_rank = rank;
+    return 0;
+}
+
+// one process, one handle per device (ncclCommInitAll): drive them with flh_eval_group
+int flh_rccl_init_all(flh_handle* const* handles, int n) {
+    if (!handles || n < 1) return fail("flh_rccl_init_all: bad arguments");
+    if (rccl_load() != 0) return -1;
+    std::vector<int> devs(n);
+    std::vector<ncclComm_t> comms(n);
+    for (int i = 0; i < n; ++i) {
+        if (!handles[i]) return fail("flh_rccl_init_all: null handle");
+        if (handles[i]->comm) return fail("flh_rccl_init_all: a handle already has a communicator");
+        devs[i] = handles[i]->device;
+    }
+    NCCLC(g_rccl.CommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; ++i) {
+        handles[i]->comm = comms[i];
+        handles[i]->comm_size = n;
+        handles[i]->comm_rank = i;
+    }
+    return 0;
+}
+
+void flh_rccl_destroy(flh_handle* h) {
+    if (!h || !h->comm) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr;
+    h->comm_size = 1;
+    h->comm_rank = 0;
+}
+int flh_rccl_size(const flh_handle* h) { return h ? h->comm_size : 0; }
+int flh_rccl_rank(const flh_handle* h) { return h ? h->comm_rank : -1; }
+
+static int rccl_allreduce_publish(flh_handle* h, double seq) {
+    NCCLC(g_rccl.AllReduce(h->gram.p, h->gram.p, 256, ncclDouble, ncclSum, h->comm, h->stream));
+    HIPC(flh::launch_publish256(h->gram.p, h->h_gram, seq, h->stream));
+    return 0;
+}
+
+// Single process, several devices: one h_share_model evaluation at `state` on every handle (each holds its shard of the
+// scan / its slab of the map), the partial Gram blocks summed by RCCL, the result unpacked once.  Enqueues on all devices
+// first (inside one RCCL group), then waits for rank 0's published block.
+int flh_eval_group(flh_handle* const* handles, int n, const double state[FLH_NSTATE], int do_search, int ext, double HTH[144],
+                   double HTh[12], int64_t* n_eff, double* total_residual) {
+    if (!handles || n < 1 || !state || !HTH || !HTh) return fail("flh_eval_group: bad arguments");
+    for (int i = 0; i < n; ++i)
+        if (!handles[i] || !handles[i]->comm || handles[i]->comm_size != n) return fail("flh_eval_group: handles lack a common communicator (flh_rccl_init_all)");
+    const StateDev s = make_state(state + 3, state + 0, state + 7, state + 11);
+    for (int i = 0; i < n; ++i) {
+        flh_handle* h = handles[i];
+        HIPC(hipSetDevice(h->device));
+        if (enqueue_eval(h, s, do_search, ext, h->gram.p, 0.0, false) != 0) return -1;
+    }
+    flh_handle* h0 = handles[0];
+    const double seq = (double)(++h0->seq);
+    NCCLC(g_rccl.GroupStart());
+    for (int i = 0; i < n; ++i) {
+        flh_handle* h = handles[i];
+        NCCLC(g_rccl.AllReduce(h->gram.p, h->gram.p, 256, ncclDouble, ncclSum, h->comm, h->stream));
+    }
+    NCCLC(g_rccl.GroupEnd());
+    HIPC(hipSetDevice(h0->device));
+    HIPC(flh::launch_publish256(h0->gram.p, h0->h_gram, seq, h0->stream));
+    const volatile double* flag = h0->h_gram + 255;
+    uint64_t spins = 0;
+    while (*flag != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFFu) == 0 && hipStreamQuery(h0->stream) != hipErrorNotReady) {
+            HIPC(hipStreamSynchronize(h0->stream));
+            if (*flag != seq) return fail("flh_eval_group: result not published");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    h0->h_gram[255] = 0.0;
+    flh_unpack_gram(h0->h_gram, HTH, HTh, n_eff, total_residual);
+    return 0;
+}
+
+// Map partitioned over the ranks (BASELINE configs[4]): this handle's map holds one slab of the world plus a halo of at least
+// sqrt(max_sqdist) on either side, every rank holds the whole scan, and a query is searched -- and thereafter fitted -- only
+// by the rank whose half-open interval [lo, hi) of world coordinate `axis` contains it; the others leave its flag at 0.
+// Every query has exactly one owner when the ranks' intervals tile the axis.  axis < 0 switches the restriction off.
+int flh_set_owned_interval(flh_handle* h, int axis, float lo, float hi) {
+    if (!h) return fail("flh_set_owned_interval: null handle");
+    if (axis > 2) return fail("flh_set_owned_interval: axis must be 0, 1, 2 or negative");
+    if (axis >= 0 && !(lo < hi)) return fail("flh_set_owned_interval: empty interval");
+    h->own_axis = axis;
+    h->own_lo = axis < 0 ? -INFINITY : lo;
+    h->own_hi = axis < 0 ? INFINITY : hi;
+    h->searched_once = false;
     return 0;
 }
 

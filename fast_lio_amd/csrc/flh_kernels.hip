@@ -317,7 +317,10 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
               float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
               uint8_t* __restrict__ selected, const uint32_t* __restrict__ in_list, const uint32_t* __restrict__ in_count,
               uint32_t* __restrict__ out_list, uint32_t* __restrict__ out_count, uint32_t stripe_cap,
-              const float* ub_in, float* ub_out /* may alias ub_in */, int rmax, u64* __restrict__ cand_counter) {
+              const float* ub_in, float* ub_out /* may alias ub_in */, int rmax, u64* __restrict__ cand_counter, int own_axis,
+              float own_lo, float own_hi) {
+    // own_axis >= 0 (map partitioned over ranks, flh_set_owned_interval): a query whose world coordinate lies outside
+    // [own_lo, own_hi) belongs to another rank: its flag is cleared and it is not searched here.
     // FINAL: a query this stage cannot settle is finished on the spot by its group with the general exact search
     // (exact_query) instead of being listed for one more kernel -- each extra kernel costs ~6 us of fixed latency per pass.
     // BOUNDED: the query comes with an upper bound ub of its true 5th squared distance (found by a smaller
@@ -356,11 +359,18 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
     // after the transform instead of staying pinned in SGPRs around a loop.
     for (uint32_t base = first_base; base < total; base += step_base) {
         const uint32_t gi = base + grp;
-        const bool live = gi < total;
+        bool live = gi < total;
         const int q = in_list ? (int)in_list[live ? gi : total - 1] : (int)(live ? gi : total - 1);
         const float4 b = body[q];
         float qx, qy, qz;
         body_to_world(s, b.x, b.y, b.z, qx, qy, qz);
+        if (!in_list && own_axis >= 0) {
+            const float oc = own_axis == 0 ? qx : (own_axis == 1 ? qy : qz);
+            if (live && !(oc >= own_lo && oc < own_hi)) {
+                if (lane == 0) { selected[q] = 0; nn_cnt[q] = 0; }
+                live = false;
+            }
+        }
         int cx, cy, cz;
         float fx, fy, fz;
         cell_of(g, qx, qy, qz, cx, cy, cz, fx, fy, fz);
@@ -760,7 +770,7 @@ k_search_exact(GridParams g, StateDev s, const float4* __restrict__ body, int N,
                float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
                uint8_t* __restrict__ selected, const uint32_t* __restrict__ slow_list,
                const uint32_t* __restrict__ slow_count, uint32_t stripe_cap, const float* __restrict__ ub_in,
-               int all_queries, u64* __restrict__ cand_counter) {
+               int all_queries, u64* __restrict__ cand_counter, int own_axis, float own_lo, float own_hi) {
     constexpr int LPQ = 32;
     const int lane = threadIdx.x & (LPQ - 1);
     const int grp = threadIdx.x / LPQ;
@@ -775,6 +785,13 @@ k_search_exact(GridParams g, StateDev s, const float4* __restrict__ body, int N,
         const float4 b = body[q];
         float qx, qy, qz;
         body_to_world(s, b.x, b.y, b.z, qx, qy, qz);
+        if (all_queries && own_axis >= 0) {
+            const float oc = own_axis == 0 ? qx : (own_axis == 1 ? qy : qz);
+            if (!(oc >= own_lo && oc < own_hi)) {
+                if (lane == 0) { selected[q] = 0; nn_cnt[q] = 0; }
+                continue;
+            }
+        }
         int cx, cy, cz;
         float fx, fy, fz;
         cell_of(g, qx, qy, qz, cx, cy, cz, fx, fy, fz);
@@ -1118,20 +1135,21 @@ uint32_t list_stripe_cap(int N) { return (uint32_t)(cdiv(cdiv(N > 0 ? N : 1, 16)
 hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points,
                          float max_sqdist, int rmax, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
                          uint32_t* list1, uint32_t* list2, float* ub, uint32_t* counts /* [2 * kStripes] */,
-                         u64* cand_counter, hipStream_t st) {
+                         u64* cand_counter, int own_axis, float own_lo, float own_hi, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     const dim3 blk(256);
     const uint32_t cap = list_stripe_cap(N);
     if (lpq == 0) {  // exact path for every query (validation / fallback)
         hipLaunchKernelGGL(k_search_exact, dim3(std::min(cdiv(N, 8), 4096)), blk, 0, st, g, s, body, N, max_sqdist, rmax,
-                           nn_pts, nn_d2, nn_cnt, selected, list1, counts, cap, ub, 1, cand_counter);
+                           nn_pts, nn_d2, nn_cnt, selected, list1, counts, cap, ub, 1, cand_counter, own_axis, own_lo, own_hi);
         return hipGetLastError();
     }
     // A1: ring 1, every query
 #define FLH_A1(L, O)                                                                                                     \
     hipLaunchKernelGGL((k_search_ring<L, 1, false, 8, false, O>), dim3(cdiv(N, 256 / L)), blk, 0, st, g, s, body, N, \
                        map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,                \
-                       (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter)
+                       (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter, own_axis,     \
+                       own_lo, own_hi)
     if (first_stage == 2 && rmax >= 2) {
         switch (lpq) {
             case 1: FLH_A1(1, true); break;
@@ -1153,11 +1171,11 @@ hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const St
         // 5th neighbour beyond the 5x5x5 block) it finishes itself with the general exact search
         hipLaunchKernelGGL((k_search_ring<16, 2, true, 11, true>), dim3(kStripes * 16), blk, 0, st, g, s, body, N, map_points,
                            max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)list1, (const uint32_t*)counts, list2,
-                           counts + kStripes, cap, (const float*)ub, ub, rmax, cand_counter);
+                           counts + kStripes, cap, (const float*)ub, ub, rmax, cand_counter, -1, 0.f, 0.f);
     } else {
         // cells as large as the gate radius: the general search drains list 1 directly
         hipLaunchKernelGGL(k_search_exact, dim3(kStripes * 8), blk, 0, st, g, s, body, N, max_sqdist, rmax, nn_pts, nn_d2,
-                           nn_cnt, selected, (const uint32_t*)list1, (const uint32_t*)counts, cap, ub, 0, cand_counter);
+                           nn_cnt, selected, (const uint32_t*)list1, (const uint32_t*)counts, cap, ub, 0, cand_counter, -1, 0.f, 0.f);
     }
     return hipGetLastError();
 }
@@ -1185,6 +1203,21 @@ void dump_fit_phases() {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fit_ph), z.data(), z.size() * sizeof(u64));
 }
 #endif
+
+// After an all-reduce: the summed 16x16 block from device memory to pinned host memory, then the sequence word (the same
+// publish protocol as k_fit's last block).
+__global__ void __launch_bounds__(256) k_publish256(const double* __restrict__ src, double* __restrict__ out256, double seq) {
+    const int t = threadIdx.x;
+    const double v = src[t];
+    if (t != 255) __hip_atomic_store(out256 + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(out256 + 255, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_publish256(const double* src, double* out256, double seq, hipStream_t st) {
+    hipLaunchKernelGGL(k_publish256, dim3(1), dim3(256), 0, st, src, out256, seq);
+    return hipGetLastError();
+}
 
 int fit_blocks(int N) { return cdiv(N > 0 ? N : 1, 256); }
 int reduce1_blocks(int nblk, int* per_out) {

@@ -203,6 +203,30 @@ int flh_eval_device(flh_handle* h, const double state[FLH_NSTATE], int do_search
 void flh_unpack_gram(const double gram256[256], double HTH[144], double HTh[12], int64_t* n_eff,
                      double* total_residual);
 
+/* ---- multi-GPU: RCCL all-reduce of the normal equations over xGMI ---------------------------------------
+ * The scan's points are sharded over the GPUs (map replicated), or the map is partitioned (flh_set_owned_interval); either
+ * way a pass's only exchange is the sum of the ranks' 16x16 Gram blocks.  Once a handle has a communicator, flh_eval (and
+ * with it the mirrored h_share_model / esekf) all-reduces before it returns: every rank gets the same normal equations
+ * and runs the same 23x23 solve.  RCCL is loaded on first use.
+ *   one process per GPU: rank 0 calls flh_rccl_unique_id, hands the 128 bytes to the others by any means (MPI, a file,
+ *     torch.distributed), every rank calls flh_rccl_init_rank.
+ *   one process, several GPUs: flh_rccl_init_all over one handle per device, then flh_eval_group (enqueues on every device
+ *     inside one RCCL group, waits once) instead of flh_eval. */
+#define FLH_RCCL_ID_BYTES 128
+int flh_rccl_unique_id(char id[FLH_RCCL_ID_BYTES]);
+int flh_rccl_init_rank(flh_handle* h, int nranks, const char id[FLH_RCCL_ID_BYTES], int rank);
+int flh_rccl_init_all(flh_handle* const* handles, int n);
+void flh_rccl_destroy(flh_handle* h);
+int flh_rccl_size(const flh_handle* h);
+int flh_rccl_rank(const flh_handle* h);
+int flh_eval_group(flh_handle* const* handles, int n, const double state[FLH_NSTATE], int do_search, int extrinsic_est_en,
+                   double HTH[144], double HTh[12], int64_t* n_eff, double* total_residual);
+/* Map partitioned over the ranks (BASELINE configs[4]): this handle's map is one slab of the world plus a halo of at least
+ * sqrt(max_sqdist) on either side; every rank holds the whole scan; a query is searched (and then fitted) only by the
+ * rank whose half-open interval [lo, hi) of world coordinate `axis` (0/1/2) contains it.  The ranks' intervals must tile
+ * the axis.  axis < 0 removes the restriction. */
+int flh_set_owned_interval(flh_handle* h, int axis, float lo, float hi);
+
 /* Lazy D2H fetches of the globals later reference code reads (SURVEY.md 8b "Data passed implicitly"). */
 int flh_fetch_selected(flh_handle* h, uint8_t* flags /* N: point_selected_surf */);
 int flh_fetch_neighbors(flh_handle* h, int32_t* idx /* N x 5 map indices, -1 = none */,

@@ -108,3 +108,104 @@ def test_pack_unpack_gram_roundtrip():
     np.testing.assert_array_equal(HTH, A.T @ A)
     np.testing.assert_array_equal(HTh, A.T @ h)
     assert n == 30 and tr == 1.25
+
+
+# ---------------------------------------------------------------------------------------------- Morton-first sharding
+def test_morton_shards_partition_the_scan_and_are_compact():
+    pr = synth.make_problem(60000, 6000, "avia", cfg=103)
+    for w in (2, 3, 8):
+        shards = [fdist.morton_shard(pr.body, r, w) for r in range(w)]
+        allidx = np.sort(np.concatenate(shards))
+        np.testing.assert_array_equal(allidx, np.arange(len(pr.body)))
+        # spatial compactness: the mean bounding-box volume of a Morton shard is far below that of an index-order shard
+        vol_m = np.mean([np.prod(np.ptp(pr.body[s], axis=0)) for s in shards])
+        vol_i = np.mean([np.prod(np.ptp(pr.body[slice(*fdist.shard_bounds(len(pr.body), r, w))], axis=0)) for r in range(w)])
+        assert vol_m < 0.7 * vol_i
+
+
+# ------------------------------------------------------------------------- map partitioned over the ranks (configs[4])
+def test_partition_slabs_hold_every_neighbour_that_can_matter():
+    """For a query owned by rank r, the 5-NN inside the gate (d2[4] <= 5, src/laserMapping.cpp:671) found in r's slab + halo
+    are the 5-NN of the full map; a query the full map rejects is rejected on the slab too."""
+    pr = synth.make_problem(120000, 8000, "avia", cfg=104)
+    full = po.Map(pr.map_xyz)
+    sc = po.Scan(pr.body, nthreads=2)
+    sc.h_share_model(full, pr.x_true, True, False)
+    world = sc.world.copy()
+    for ranks in (2, 5):
+        axis, edges = fdist.partition_bounds(pr.map_xyz, ranks)
+        assert edges[0] == -np.inf and edges[-1] == np.inf and np.all(np.diff(edges[1:-1]) > 0)
+        owner = np.searchsorted(edges[1:-1], world[:, axis], side="right")   # [e_r, e_r+1)
+        assert owner.min() >= 0 and owner.max() <= ranks - 1
+        seen = np.zeros(len(world), int)
+        for r in range(ranks):
+            keep = fdist.partition_slab(pr.map_xyz, axis, edges, r, fdist.HALO_DEFAULT)
+            sub = po.Map(pr.map_xyz[keep])
+            mine = np.nonzero(owner == r)[0]
+            seen[mine] += 1
+            idx, d2, cnt = sub.knn5_batch(world[mine], 2)
+            f_idx, f_d2, f_cnt = sc.nn_idx[mine], sc.nn_d2[mine], sc.nn_cnt[mine]
+            gate = (f_cnt == 5) & (f_d2[:, 4] <= 5.0)
+            np.testing.assert_array_equal(keep[idx[gate]], f_idx[gate])          # same points, same (d2, index) order
+            np.testing.assert_array_equal(d2[gate].view(np.uint32), f_d2[gate].view(np.uint32))
+            assert np.all((cnt[~gate] < 5) | (d2[~gate][:, 4] > 5.0))
+        assert np.all(seen == 1)
+
+
+def _worker_partitioned(rank, world, port, n_scan, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pr = synth.make_problem(80000, n_scan, "avia", cfg=105)
+        xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
+        axis, edges = fdist.partition_bounds(pr.map_xyz, world)
+        keep = fdist.partition_slab(pr.map_xyz, axis, edges, rank, fdist.HALO_DEFAULT)
+        m = po.Map(pr.map_xyz[keep])                 # this rank's slab + halo
+        sc = po.Scan(pr.body, nthreads=1)            # the whole scan on every rank
+        buf = torch.zeros(256, dtype=torch.float64)
+        state = {"own": None}
+
+        def eval_partial(x, converge):
+            valid = sc.h_share_model(m, x, converge, False)
+            if converge:  # ownership is decided by the world position at the state of the search
+                c = sc.world[:, axis]
+                state["own"] = (c >= edges[rank]) & (c < edges[rank + 1])
+            g = np.zeros(256)
+            if valid:
+                sel_idx = np.nonzero(sc.selected)[0]
+                mine = state["own"][sel_idx]
+                hx, hv = sc.h_x[mine], sc.h[mine]
+                res = np.abs(sc.normvec[sel_idx[mine], 3].astype(np.float64))
+                g = fdist.pack_gram(hx.T @ hx, hx.T @ hv, int(mine.sum()), float(res.sum()))
+            buf.copy_(torch.from_numpy(g))
+            return buf
+
+        kf = capi.Esekf(None, max_iter=3, extrinsic_est_en=False)
+        kf.set_meas_model(fdist.make_sharded_model(eval_partial, lambda t: fdist.torch_allreduce(dist, t), None))
+        kf.change_x(xp)
+        kf.change_P(P)
+        st = kf.update(0.001)
+        flags = torch.from_numpy((sc.selected.astype(bool) & state["own"]).astype(np.int32))
+        dist.all_reduce(flags)
+        if rank == 0:
+            np.savez(out_path, x=kf.get_x(), P=kf.get_P(), passes=st.passes, n_eff=np.array(list(st.n_eff)), flags=flags.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_partitioned_map_update_matches_single_process(tmp_path):
+    world, n_scan = 2, 4000
+    out = str(tmp_path / "p0.npz")
+    mp.spawn(_worker_partitioned, args=(world, _free_port(), n_scan, out), nprocs=world, join=True)
+    got = np.load(out)
+    pr = synth.make_problem(80000, n_scan, "avia", cfg=105)
+    m = po.Map(pr.map_xyz)
+    xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
+    sc = po.Scan(pr.body, nthreads=2)
+    x_ref, P_ref, st_ref = sc.update_iterated(m, xp, P)
+    assert int(got["passes"]) == st_ref.passes
+    assert list(got["n_eff"])[: st_ref.passes] == list(st_ref.n_eff)[: st_ref.passes]
+    np.testing.assert_array_equal(got["flags"], sc.selected.astype(np.int32))   # every point owned once, same verdicts
+    np.testing.assert_allclose(got["x"], x_ref, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(got["P"], P_ref, rtol=0, atol=1e-6 * np.abs(P_ref).max())

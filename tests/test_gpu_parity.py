@@ -382,3 +382,96 @@ def test_frame_world_and_points_body_to_world(prob):
         h.frame_world(x, slot=3, dense=True)
     assert h.points_body_to_world(x, cloud[:0]).shape == (0, 3)
     h.close()
+
+
+def test_rccl_allreduce_path_single_rank(prob):
+    """The native multi-GPU path (flh_rccl_*): with a communicator attached, flh_eval leaves its Gram block on the device,
+    RCCL sums it over the ranks and a publish kernel hands it to the host.  One rank here (the box has one GPU): the result
+    must be the plain path's, bit for bit, through eval, the full update and flh_eval_group."""
+    pr, m, xp, P, _ = prob
+    body = pr.body[:6000]
+    ref_h = capi.Handle()
+    ref_h.map_build(pr.map_xyz)
+    ref_h.scan_upload(body)
+    ref = ref_h.eval(xp, True, False)
+    kf0 = capi.Esekf(ref_h, max_iter=3)
+    kf0.change_x(xp); kf0.change_P(P)
+    st0 = kf0.update(0.001)
+    h = capi.Handle()
+    h.rccl_init_rank(1, capi.rccl_unique_id(), 0)
+    assert h.rccl_size() == 1
+    h.map_build(pr.map_xyz)
+    h.scan_upload(body)
+    got = h.eval(xp, True, False)
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+    got2 = h.eval(xp, False, False)
+    np.testing.assert_array_equal(got2[0], ref[0])
+    kf = capi.Esekf(h, max_iter=3)
+    kf.change_x(xp); kf.change_P(P)
+    st = kf.update(0.001)
+    assert st.passes == st0.passes and list(st.n_eff) == list(st0.n_eff)
+    np.testing.assert_array_equal(kf.get_x(), kf0.get_x())
+    np.testing.assert_array_equal(kf.get_P(), kf0.get_P())
+    h.close()
+    # one process, one handle per device
+    g = capi.Handle()
+    capi.rccl_init_all([g])
+    g.map_build(pr.map_xyz)
+    g.scan_upload(body)
+    grp = capi.eval_group([g], xp, True, False)
+    for a, b in zip(grp, ref):
+        np.testing.assert_array_equal(a, b)
+    g.close()
+    ref_h.close()
+
+
+def test_map_partitioned_over_two_handles_equals_the_whole_map(prob):
+    """BASELINE configs[4] in miniature: the map cut into two slabs (+ halo), each on its own handle with the WHOLE scan and
+    an owned interval; the sum of the two Gram blocks drives the same host filter.  Flags, n_eff per pass: identical to the
+    single-handle update; posterior: equal up to the order of the fp64 sums."""
+    from fast_lio_amd import dist as fdist
+
+    pr, m, xp, P, _ = prob
+    body = pr.body
+    one = capi.Handle()
+    one.map_build(pr.map_xyz)
+    one.scan_upload(body)
+    kf1 = capi.Esekf(one, max_iter=3)
+    kf1.change_x(xp); kf1.change_P(P)
+    st1 = kf1.update(0.001)
+    sel1 = one.fetch_selected()
+    axis, edges = fdist.partition_bounds(pr.map_xyz, 2)
+    parts = []
+    for r in range(2):
+        keep = fdist.partition_slab(pr.map_xyz, axis, edges, r, fdist.HALO_DEFAULT)
+        hh = capi.Handle()
+        hh.map_build(pr.map_xyz[keep])
+        hh.set_owned_interval(axis, edges[r], edges[r + 1])
+        hh.scan_upload(body)
+        parts.append(hh)
+        assert hh.M < 0.75 * one.M
+
+    def model(x, converge):
+        tot = None
+        for hh in parts:
+            HTH, HTh, n_eff, tres = hh.eval(x, converge, False)
+            cur = [HTH.copy(), HTh.copy(), n_eff, tres]
+            tot = cur if tot is None else [tot[0] + cur[0], tot[1] + cur[1], tot[2] + cur[2], tot[3] + cur[3]]
+        if tot[2] < 1:
+            return {"valid": False, "n_eff": 0}
+        return {"valid": True, "n_eff": tot[2], "HTH": tot[0], "HTh": tot[1], "total_residual": tot[3]}
+
+    kf = capi.Esekf(None, max_iter=3)
+    kf.set_meas_model(model)
+    kf.change_x(xp); kf.change_P(P)
+    st = kf.update(0.001)
+    assert st.passes == st1.passes and list(st.n_eff)[: st.passes] == list(st1.n_eff)[: st1.passes]
+    sels = [hh.fetch_selected() for hh in parts]
+    assert not np.any(sels[0] & sels[1])                       # every point has one owner
+    np.testing.assert_array_equal(sels[0] | sels[1], sel1)     # and the same verdict as on the whole map
+    np.testing.assert_allclose(kf.get_x(), kf1.get_x(), rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(kf.get_P(), kf1.get_P(), rtol=0, atol=1e-9 * np.abs(kf1.get_P()).max())
+    for hh in parts:
+        hh.close()
+    one.close()
