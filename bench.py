@@ -89,11 +89,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--scans", type=int, default=128, help="distinct seeded scans cycled through (>= 100 by default)")
-    ap.add_argument("--mode", default="auto", choices=["auto", "streams", "shard"],
+    ap.add_argument("--mode", default="auto", choices=["auto", "streams", "shard", "partition"],
                     help="multi-GPU: streams = one independent scan stream per rank, replicated map, no collective "
                          "(weak scaling; the headline value); shard = ONE scan's points split over the ranks + RCCL "
-                         "all-reduce of the 16x16 normal-equation block per pass (strong scaling).  auto = streams, "
-                         "plus a short shard-mode leg reported under \"shard_mode\"")
+                         "all-reduce of the 16x16 normal-equation block per pass (strong scaling); partition = the map cut "
+                         "into one slab per rank, whole scan on every rank (BASELINE configs[4]).  auto = streams, plus a short "
+                         "shard-mode (config 5: partition-mode) leg reported under \"shard_mode\"")
     ap.add_argument("--lpq", type=int, default=4)
     ap.add_argument("--cell", type=float, default=1.5)
     ap.add_argument("--first-stage", type=int, default=0)
@@ -106,6 +107,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=3, help="OpenMP threads (reference MP_PROC_NUM = 3)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo for debugging")
     ap.add_argument("--single-device", type=int, default=0, help="debug: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--force-shard-leg", action="store_true",
+                    help="debug: run the shard / partition leg on ONE rank too (a one-rank RCCL communicator), to exercise its code")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,7 +134,7 @@ def main():
     mode = args.mode
     if mode == "auto":
         mode = "streams"
-    run_shard_leg = G > 1 and args.mode in ("auto", "shard")
+    run_shard_leg = (G > 1 or args.force_shard_leg) and args.mode in ("auto", "shard", "partition")
 
     from fast_lio_amd import dist as fdist
 
@@ -150,7 +153,7 @@ def main():
     # streams: every rank follows its own scan stream; the shard leg uses scans common to all ranks
     probs, priors = gen(1000 * rank if G > 1 else 0, S)
     S_sh = min(S, 8)
-    sh_probs, sh_priors = (gen(0, S_sh) if rank != 0 else (probs[:S_sh], priors[:S_sh])) if run_shard_leg else (None, None)
+    sh_probs, sh_priors = (gen(0, S_sh) if (rank != 0 and G > 1) else (probs[:S_sh], priors[:S_sh])) if run_shard_leg else (None, None)
     # the scans as the node would hold them: host buffers (page-locked so that the DMA engine reads them where they lie)
     bodies = []
     for p in probs:
@@ -161,15 +164,8 @@ def main():
         log(f"[bench] config {args.config}: M={M} N={N} sensor={sensor} scans={S} ranks={G} mode={args.mode} "
             f"gen {time.time() - t0:.1f}s")
 
-    # with more than one rank the handle runs on torch's current stream so torch.distributed (RCCL) orders
-    # after our kernels
-    stream_ptr = None
-    if G > 1:
-        ts = torch.cuda.Stream()  # a non-default stream: its handle is a real hipStream_t (the default one is 0)
-        torch.cuda.set_stream(ts)
-        stream_ptr = ts.cuda_stream
-    h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, stream=stream_ptr,
-                    sort_queries=args.sort, first_stage=args.first_stage)
+    h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
+                    first_stage=args.first_stage)
     t0 = time.time()
     h.map_build(scene.map_xyz)
     t_build = time.time() - t0
@@ -251,52 +247,66 @@ def main():
         return st
 
     shard_out = None
-    if mode == "shard":
-        run_shard_leg = True
-    if mode == "streams" or G == 1:
+    if mode in ("shard", "partition") and G == 1 and not args.force_shard_leg:
+        mode = "streams"  # one rank: nothing to shard
+    if mode == "streams":
         dt, acc, ctr = run(step_pipelined, args.warmup, args.steps, prologue=stage)
         units = args.steps * G
         n_pts = N
-    # ---------------- sharded leg: ONE scan's points over all ranks + all-reduce of the Gram block (C1)
+    # ---------------- sharded leg (north_star C1): ONE scan's points split over the ranks Morton-first, map replicated (or,
+    # --mode partition / config 5, the map cut into slabs with a halo and every rank holding the whole scan); per pass each
+    # rank reduces its part to the 16x16 Gram block in device memory and RCCL sums the blocks INSIDE flh_eval (native
+    # call site, no Python and no D2H in the pass); every rank then runs the identical 23x23 solve.
     if run_shard_leg:
-        for s, p in enumerate(sh_probs):
-            h.scan_stage(8 + s, p.body[lo:hi])
-        gram = torch.zeros(256, dtype=torch.float64, device="cuda")
-
-        def eval_partial(x, converge):
-            h.eval_device(x, converge, ext, gram.data_ptr())
-            return gram
-
-        def gather_rows(x):
-            rows = [None] * G
-            hx, hv = h.fetch_rows()
-            dist.all_gather_object(rows, (hx, hv))
-            return np.concatenate([r[0] for r in rows], axis=0), np.concatenate([r[1] for r in rows])
-
-        kf.set_meas_model(fdist.make_sharded_model(eval_partial, lambda t: fdist.torch_allreduce(dist, t), gather_rows))
+        partition = args.mode == "partition" or (args.mode == "auto" and args.config == 5)
+        uid = [capi.rccl_unique_id() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(uid, src=0)
+        hs = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
+                         first_stage=args.first_stage)
+        hs.rccl_init_rank(G, uid[0], rank)
+        if partition:
+            axis, edges = fdist.partition_bounds(scene.map_xyz, G)
+            keep = fdist.partition_slab(scene.map_xyz, axis, edges, rank, fdist.HALO_DEFAULT)
+            hs.map_build(scene.map_xyz[keep])
+            hs.set_owned_interval(axis, edges[rank], edges[rank + 1])
+            for s, p in enumerate(sh_probs):
+                hs.scan_stage(s, p.body)
+            pts_here = N
+        else:
+            hs.map_build(scene.map_xyz)
+            for s, p in enumerate(sh_probs):
+                hs.scan_stage(s, np.ascontiguousarray(p.body[fdist.morton_shard(p.body, rank, G)]))
+            pts_here = hi - lo
+        kfs = capi.Esekf(hs, max_iter=3, extrinsic_est_en=ext)
+        hsave, h = h, hs  # run() reads its counters from `h`
 
         def step_shard(i, n_total):
             s = i % S_sh
-            h.scan_activate(8 + s)
-            kf.change_x(sh_priors[s][0])
-            kf.change_P(sh_priors[s][1])
-            return kf.update(0.001)
+            return kfs.update_scan(s, sh_priors[s][0], sh_priors[s][1], 0.001)
 
-        k2 = args.steps if mode == "shard" else max(10, min(60, args.steps // 4))
-        dt2, acc2, _ = run(step_shard, max(3, args.warmup // 4), k2)
+        k2 = args.steps if mode in ("shard", "partition") else max(10, min(60, args.steps // 4))
+        dt2, acc2, ctr2 = run(step_shard, max(3, args.warmup // 4), k2)
+        h = hsave
         # every rank must have produced the same posterior
-        xs = [None] * G
-        dist.all_gather_object(xs, kf.get_x())
+        xs = [kfs.get_x()] * G
+        if dist is not None:
+            dist.all_gather_object(xs, kfs.get_x())
         agree = float(max(np.abs(np.asarray(x_) - np.asarray(xs[0])).max() for x_ in xs))
         shard_out = {"value": round(k2 / dt2, 3), "unit": "scans/s", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 4),
-                     "ms_per_iekf_pass": round(dt2 / max(acc2.passes, 1) * 1e3, 4), "points_per_rank": hi - lo,
-                     "collective": f"all_reduce(sum) of 256 f64 per pass over {args.backend}",
+                     "ms_per_iekf_pass": round(dt2 / max(acc2.passes, 1) * 1e3, 4),
+                     "layout": ("map partitioned into slabs (+%.2f m halo), whole scan on every rank, queries owned by position" % fdist.HALO_DEFAULT
+                                if partition else "scan sharded Morton-first, map replicated"),
+                     "points_per_rank": pts_here, "map_points_this_rank": hs.M,
+                     "collective": "ncclAllReduce(sum) of 256 f64 per pass, issued by flh_eval on the handle's stream (RCCL over xGMI)",
+                     "ranks_in_communicator": hs.rccl_size(),
                      "max_abs_state_disagreement_across_ranks": agree, "scaling": "strong"}
-        kf.set_meas_model(None)
-        if mode == "shard":
-            dt, acc, ctr = dt2, acc2, h.counters()
+        if mode in ("shard", "partition"):
+            dt, acc, ctr = dt2, acc2, ctr2
             units = args.steps
-            n_pts = hi - lo
+            n_pts = pts_here
+        kfs.close()
+        hs.close()
     value = units / dt
     ms_per_step = dt / args.steps * 1e3
 
@@ -325,7 +335,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "strong" if mode == "shard" else "weak",
+        "scaling": "strong" if mode in ("shard", "partition") else "weak",
         "vs_baseline": None,
         "dtype": "f32 (kNN, plane fit) + f64 (transform, Jacobian, normal equations)",
         "data": "synthetic",
@@ -334,10 +344,10 @@ def main():
                                + (", map_incremental after every update" if with_map_inserts else ""),
                    "timed_region": ("scan handed over as a page-locked host buffer, staged (H2D + re-stride + Morton sort) on the "
                                     "copy stream while the previous scan updates, then the full iterated update"
-                                    if mode != "shard" else "scan shards resident in HBM, full iterated update"),
+                                    if mode not in ("shard", "partition") else "scan shards resident in HBM, full iterated update"),
                    "parallelism": ("1 GPU" if G == 1 else
                                    (f"scan points sharded over {G} ranks + all-reduce of the 16x16 normal-equation block "
-                                    f"per pass" if mode == "shard" else
+                                    f"per pass" if mode in ("shard", "partition") else
                                     f"{G} independent scan streams (one per rank), replicated map, no collective in the data path")),
                    "distinct_scans": S, "cell_size_m": args.cell, "lanes_per_query": args.lpq, "first_stage": args.first_stage},
         "ms_per_iekf_pass": round(dt / max(acc.passes, 1) * 1e3, 4),
@@ -349,11 +359,12 @@ def main():
     }
     if G > 1 and dist is not None:
         out["ranks_seen_by_collective"] = int(dist.get_world_size())
+        out["ranks_in_rccl_communicator"] = shard_out["ranks_in_communicator"] if shard_out else None
 
     # ---- the same update with the scans already resident in HBM (staged before the timed loop): what round 1 reported
     # as `value`.  Not PCIe-inclusive, hence a sub-field.
-    extra = rank == 0 and G == 1 and mode != "shard" and not args.no_extra_legs
-    if rank == 0 and G == 1 and mode != "shard":
+    extra = rank == 0 and G == 1 and mode == "streams" and not args.no_extra_legs
+    if rank == 0 and G == 1 and mode == "streams":
         Sd = min(S, 32)
         for s in range(Sd):
             h.scan_stage(16 + s, bodies[s])
@@ -385,7 +396,7 @@ def main():
         roof["candidates_per_query"] = round(cand_per_query, 2)
         roof["candidate_traffic_GBs"] = round(cand_per_query * 16 * n_pts / (roof["avg_kernel_us"] * 1e-6) / 1e9, 2)
         out["roofline"] = roof
-    if shard_out is not None and mode != "shard":
+    if shard_out is not None and mode not in ("shard", "partition"):
         out["shard_mode"] = shard_out
 
     # ---- two independent scan streams in flight on this GPU (two handles, two host threads): while one stream's host

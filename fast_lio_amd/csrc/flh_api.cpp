@@ -120,7 +120,7 @@ struct flh_handle {
     DevBuf<float4> world, nn_pts, normvec;
     DevBuf<float> nn_d2;
     DevBuf<uint8_t> nn_cnt, selected;
-    DevBuf<double> partials, part2, gram;
+    DevBuf<double> partials, part2, gram, gather_buf;
     DevBuf<u64> counter;
     DevBuf<uint32_t> slow_list, slow_list2, slow_count;  // work lists between the search stages (striped) and their counters
     DevBuf<float> slow_ub;                   // per-query bound on the 5th squared distance handed from A1 to A2
@@ -292,7 +292,7 @@ void flh_destroy(flh_handle* h) {
     h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_list2.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
     h->world.release(); h->nn_pts.release(); h->normvec.release();
     h->nn_d2.release(); h->nn_cnt.release(); h->selected.release();
-    h->partials.release(); h->part2.release(); h->gram.release(); h->counter.release();
+    h->partials.release(); h->part2.release(); h->gram.release(); h->gather_buf.release(); h->counter.release();
     for (auto& sl : h->slots) {
         sl.body.release();
         sl.dense.release();
@@ -1567,9 +1567,15 @@ static void host_quat_rot(const double q[4], const double v[3], double o[3]) {
 // ekfom_data.h_x / ekfom_data.h in original order (src/laserMapping.cpp:720-752), rebuilt on the host from
 // the device-resident planes.  Only the n_eff < 23 gain-form branch (esekfom.hpp:1715) and debugging use
 // this; the hot path never materialises rows.
+static int fetch_rows_local(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* n_rows);
+static int fetch_rows_gathered(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* n_rows);
 int flh_fetch_rows(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* n_rows) {
     if (!h || !n_rows) return fail("flh_fetch_rows: null argument");
     if (!h->have_eval) return fail("flh_fetch_rows: no evaluation yet");
+    if (h->comm && h->comm_size > 1) return fetch_rows_gathered(h, hx, hv, cap, n_rows);
+    return fetch_rows_local(h, hx, hv, cap, n_rows);
+}
+static int fetch_rows_local(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* n_rows) {
     const size_t N = h->N;
     std::vector<uint8_t> sel(N ? N : 1);
     std::vector<float4> nv(N ? N : 1);
@@ -1767,6 +1773,47 @@ int flh_eval_group(flh_handle* const* handles, int n, const double state[FLH_NST
     std::atomic_thread_fence(std::memory_order_acquire);
     h0->h_gram[255] = 0.0;
     flh_unpack_gram(h0->h_gram, HTH, HTh, n_eff, total_residual);
+    return 0;
+}
+
+// flh_fetch_rows with a communicator: the rows of ALL ranks in rank order (the gain-form branch, esekfom.hpp:1715-1744, runs
+// when the GLOBAL n_eff is below 23, so every rank holds at most 22 of them): one all-gather of a fixed-size record.
+static int fetch_rows_gathered(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* n_rows) {
+    constexpr int kMaxLocal = 64, kRec = 1 + kMaxLocal * 13;
+    int64_t n_local = 0;
+    if (fetch_rows_local(h, nullptr, nullptr, 0, &n_local) != 0) return -1;
+    if (n_local > kMaxLocal) return fail("flh_fetch_rows: more rows on this rank than the gathered fetch carries (the information form needs none)");
+    std::vector<double> lhx((size_t)std::max<int64_t>(n_local, 1) * 12), lhv((size_t)std::max<int64_t>(n_local, 1));
+    if (n_local > 0 && fetch_rows_local(h, lhx.data(), lhv.data(), n_local, &n_local) != 0) return -1;
+    const int G = h->comm_size;
+    std::vector<double> rec((size_t)kRec, 0.0), all((size_t)kRec * G, 0.0);
+    rec[0] = (double)n_local;
+    for (int64_t k = 0; k < n_local; ++k) {
+        for (int c = 0; c < 12; ++c) rec[1 + (size_t)k * 13 + c] = lhx[(size_t)c * n_local + k];
+        rec[1 + (size_t)k * 13 + 12] = lhv[k];
+    }
+    HIPC(hipSetDevice(h->device));
+    HIPC(h->gather_buf.reserve((size_t)kRec * (G + 1)));
+    double* d_send = h->gather_buf.p;
+    double* d_recv = h->gather_buf.p + kRec;
+    HIPC(hipMemcpyAsync(d_send, rec.data(), sizeof(double) * kRec, hipMemcpyHostToDevice, h->stream));
+    NCCLC(g_rccl.AllGather(d_send, d_recv, kRec, ncclDouble, h->comm, h->stream));
+    HIPC(hipMemcpyAsync(all.data(), d_recv, sizeof(double) * kRec * G, hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    int64_t n = 0;
+    for (int r = 0; r < G; ++r) n += (int64_t)all[(size_t)r * kRec];
+    *n_rows = n;
+    if (!hx || !hv) return 0;
+    if (cap < n) return fail("flh_fetch_rows: buffers too small");
+    int64_t k = 0;
+    for (int r = 0; r < G; ++r) {
+        const double* a = all.data() + (size_t)r * kRec;
+        const int64_t nr = (int64_t)a[0];
+        for (int64_t j = 0; j < nr; ++j, ++k) {
+            for (int c = 0; c < 12; ++c) hx[(size_t)c * n + k] = a[1 + (size_t)j * 13 + c];
+            hv[k] = a[1 + (size_t)j * 13 + 12];
+        }
+    }
     return 0;
 }
 
