@@ -1222,7 +1222,7 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
         h->search_state = s;
     }
     if (timed) HIPC(hipEventRecord(h->ev[1], st));
-    HIPC(flh::launch_fit(h->cfg.eigen_order, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
+    HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
                          h->world.p, h->partials.p, h->part2.p, d_out, seq, h->tickets.p, h->slow_count.p, st));
     if (timed) HIPC(hipEventRecord(h->ev[2], st));
     h->last_state = s;
@@ -1450,7 +1450,7 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
             h->searched_once = true;
             h->search_state = s;
         } else {
-            HIPC(flh::launch_fit(h->cfg.eigen_order, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p,
+            HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p,
                                  h->normvec.p, h->world.p, h->partials.p, h->part2.p, h->gram.p, 0.0, h->tickets.p, h->slow_count.p, st));
         }
     }

@@ -86,81 +86,101 @@ __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, f
 //   2 PAIRWISE  the same with (a0 + a1) + (a2 + a3)  (NEON / hadd)
 //   3 NOVEC     EIGEN_DONT_VECTORIZE: fixed 5 = (e0 + e1) + (e2 + (e3 + e4)), fixed 3 = e0 + (e1 + e2), dynamic ascending
 // ---------------------------------------------------------------------------------------------
-template <int ORD>
-__device__ __forceinline__ float ord_sum4(float a0, float a1, float a2, float a3) {
+// The factorisation is written once over the scalar type T: float for the reference-exact path, _Float16 for the fp16
+// ablation of BASELINE configs[4] (flh_config.plane_fit_dtype = 1, never the default).
+template <class T> struct fit_traits;
+template <> struct fit_traits<float> {
+    static constexpr float eps = 1.1920929e-07f;      // NumTraits<float>::epsilon()
+    static constexpr float tiny = 1.17549435e-38f;    // numeric_limits<float>::min()
+};
+template <> struct fit_traits<_Float16> {
+    static constexpr float eps = 9.765625e-04f;       // 2^-10
+    static constexpr float tiny = 6.103515625e-05f;   // smallest normal half
+};
+// correctly rounded sqrt / divide in T (for half: through float, whose 24 bits make the double rounding innocuous)
+__device__ __forceinline__ float t_sqrt(float x) { return sqrt_rn(x); }
+__device__ __forceinline__ float t_div(float a, float b) { return div_rn(a, b); }
+__device__ __forceinline__ _Float16 t_sqrt(_Float16 x) { return (_Float16)__builtin_sqrtf((float)x); }
+__device__ __forceinline__ _Float16 t_div(_Float16 a, _Float16 b) { return (_Float16)((float)a / (float)b); }
+__device__ __forceinline__ float t_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ _Float16 t_abs(_Float16 x) { return x < (_Float16)0 ? -x : x; }
+
+template <int ORD, class T>
+__device__ __forceinline__ T ord_sum4(T a0, T a1, T a2, T a3) {
     if (ORD == 1) return (a0 + a2) + (a1 + a3);
     if (ORD == 2) return (a0 + a1) + (a2 + a3);
     return ((a0 + a1) + a2) + a3;
 }
 // dynamic-size reduction of the n = 4 - K addends a[0..n) (K = the Householder step: sizes 4, 3, 2)
-template <int ORD, int K>
-__device__ __forceinline__ float ord_sum_dyn(const float a[4]) {
-    if (K == 0) return (ORD == 1 || ORD == 2) ? ord_sum4<ORD>(a[0], a[1], a[2], a[3]) : ((a[0] + a[1]) + a[2]) + a[3];
+template <int ORD, int K, class T>
+__device__ __forceinline__ T ord_sum_dyn(const T a[4]) {
+    if (K == 0) return (ORD == 1 || ORD == 2) ? ord_sum4<ORD, T>(a[0], a[1], a[2], a[3]) : ((a[0] + a[1]) + a[2]) + a[3];
     if (K == 1) return (a[0] + a[1]) + a[2];
     return a[0] + a[1];
 }
-template <int ORD>
-__device__ __forceinline__ float ord_sum_fixed5(float a0, float a1, float a2, float a3, float a4) {
-    if (ORD == 1 || ORD == 2) return ord_sum4<ORD>(a0, a1, a2, a3) + a4;
+template <int ORD, class T>
+__device__ __forceinline__ T ord_sum_fixed5(T a0, T a1, T a2, T a3, T a4) {
+    if (ORD == 1 || ORD == 2) return ord_sum4<ORD, T>(a0, a1, a2, a3) + a4;
     if (ORD == 3) return (a0 + a1) + (a2 + (a3 + a4));
     return (((a0 + a1) + a2) + a3) + a4;
 }
-template <int ORD>
-__device__ __forceinline__ float ord_sum_fixed3(float a0, float a1, float a2) {
+template <int ORD, class T>
+__device__ __forceinline__ T ord_sum_fixed3(T a0, T a1, T a2) {
     if (ORD == 0) return (a0 + a1) + a2;
     return a0 + (a1 + a2);
 }
 
 // One Householder step K of the factorisation (column pivot, reflector, trailing update, norm down-date).
-template <int ORD, int K>
-__device__ __forceinline__ void qr_step(float (&qr)[5][3], float (&hC)[3], int (&tr)[3], float (&nU)[3], float (&nD)[3],
-                                        int& nz, float threshold_helper, float downdate_thr) {
-    constexpr float kMin = 1.17549435e-38f;  // numeric_limits<float>::min()
+template <int ORD, int K, class T>
+__device__ __forceinline__ void qr_step(T (&qr)[5][3], T (&hC)[3], int (&tr)[3], T (&nU)[3], T (&nD)[3], int& nz,
+                                        T threshold_helper, T downdate_thr) {
+    const T kMin = (T)fit_traits<T>::tiny;
+    const T zero = (T)0, one = (T)1;
     constexpr int k = K;
     int big = k;
-    float bigv = nU[k];
+    T bigv = nU[k];
 #pragma unroll
     for (int j = k + 1; j < 3; ++j)
         if (nU[j] > bigv) { bigv = nU[j]; big = j; }
-    const float bsq = bigv * bigv;
-    if (nz == 3 && bsq < threshold_helper * (float)(5 - k)) nz = k;
+    const T bsq = bigv * bigv;
+    if (nz == 3 && bsq < threshold_helper * (T)(float)(5 - k)) nz = k;
     tr[k] = big;
 #pragma unroll
     for (int j = k + 1; j < 3; ++j)
         if (big == j) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) { float t = qr[i][k]; qr[i][k] = qr[i][j]; qr[i][j] = t; }
-            float t = nU[k]; nU[k] = nU[j]; nU[j] = t;
+            for (int i = 0; i < 5; ++i) { T t = qr[i][k]; qr[i][k] = qr[i][j]; qr[i][j] = t; }
+            T t = nU[k]; nU[k] = nU[j]; nU[j] = t;
             t = nD[k]; nD[k] = nD[j]; nD[j] = t;
         }
-    float sq[4] = {0.f, 0.f, 0.f, 0.f};
+    T sq[4] = {zero, zero, zero, zero};
 #pragma unroll
     for (int i = k + 1; i < 5; ++i) sq[i - k - 1] = qr[i][k] * qr[i][k];
-    const float tail = ord_sum_dyn<ORD, K>(sq);  // tail.squaredNorm()
-    const float c0 = qr[k][k];
-    float tau, beta;
+    const T tail = ord_sum_dyn<ORD, K, T>(sq);  // tail.squaredNorm()
+    const T c0 = qr[k][k];
+    T tau, beta;
     if (tail <= kMin) {
-        tau = 0.f;
+        tau = zero;
         beta = c0;
 #pragma unroll
-        for (int i = k + 1; i < 5; ++i) qr[i][k] = 0.f;
+        for (int i = k + 1; i < 5; ++i) qr[i][k] = zero;
     } else {
-        beta = sqrt_rn(c0 * c0 + tail);
-        if (c0 >= 0.f) beta = -beta;
-        const float den = c0 - beta;
+        beta = t_sqrt(c0 * c0 + tail);
+        if (c0 >= zero) beta = -beta;
+        const T den = c0 - beta;
 #pragma unroll
-        for (int i = k + 1; i < 5; ++i) qr[i][k] = div_rn(qr[i][k], den);
-        tau = div_rn(beta - c0, beta);
+        for (int i = k + 1; i < 5; ++i) qr[i][k] = t_div(qr[i][k], den);
+        tau = t_div(beta - c0, beta);
     }
     hC[k] = tau;
     qr[k][k] = beta;
-    if (tau != 0.f) {
+    if (tau != zero) {
 #pragma unroll
         for (int j = k + 1; j < 3; ++j) {
-            float pr[4] = {0.f, 0.f, 0.f, 0.f};
+            T pr[4] = {zero, zero, zero, zero};
 #pragma unroll
             for (int i = k + 1; i < 5; ++i) pr[i - k - 1] = qr[i][k] * qr[i][j];
-            float tmp = ord_sum_dyn<ORD, K>(pr);  // essential^T * bottom.col(j)
+            T tmp = ord_sum_dyn<ORD, K, T>(pr);  // essential^T * bottom.col(j)
             tmp = tmp + qr[k][j];
             qr[k][j] = qr[k][j] - tau * tmp;
 #pragma unroll
@@ -169,35 +189,35 @@ __device__ __forceinline__ void qr_step(float (&qr)[5][3], float (&hC)[3], int (
     }
 #pragma unroll
     for (int j = k + 1; j < 3; ++j) {
-        if (nU[j] != 0.f) {
-            float temp = div_rn(fabsf(qr[k][j]), nU[j]);
-            temp = (1.f + temp) * (1.f - temp);
-            temp = temp < 0.f ? 0.f : temp;
-            const float r = div_rn(nU[j], nD[j]);
-            const float temp2 = temp * (r * r);
+        if (nU[j] != zero) {
+            T temp = t_div(t_abs(qr[k][j]), nU[j]);
+            temp = (one + temp) * (one - temp);
+            temp = temp < zero ? zero : temp;
+            const T r = t_div(nU[j], nD[j]);
+            const T temp2 = temp * (r * r);
             if (temp2 <= downdate_thr) {
-                float s2[4] = {0.f, 0.f, 0.f, 0.f};
+                T s2[4] = {zero, zero, zero, zero};
 #pragma unroll
                 for (int i = k + 1; i < 5; ++i) s2[i - k - 1] = qr[i][j] * qr[i][j];
-                nD[j] = sqrt_rn(ord_sum_dyn<ORD, K>(s2));  // col(j).tail(rows - k - 1).norm()
+                nD[j] = t_sqrt(ord_sum_dyn<ORD, K, T>(s2));  // col(j).tail(rows - k - 1).norm()
                 nU[j] = nD[j];
             } else {
-                nU[j] = nU[j] * sqrt_rn(temp);
+                nU[j] = nU[j] * t_sqrt(temp);
             }
         }
     }
 }
 // Q^T c, reflector K (HouseholderSequence::applyThisOnTheLeft, one inner product per reflector)
-template <int ORD, int K>
-__device__ __forceinline__ void qt_step(const float (&qr)[5][3], const float (&hC)[3], int nz, float (&c)[5]) {
+template <int ORD, int K, class T>
+__device__ __forceinline__ void qt_step(const T (&qr)[5][3], const T (&hC)[3], int nz, T (&c)[5]) {
     constexpr int k = K;
     if (k < nz) {
-        const float tau = hC[k];
-        if (tau != 0.f) {
-            float pr[4] = {0.f, 0.f, 0.f, 0.f};
+        const T tau = hC[k];
+        if (tau != (T)0) {
+            T pr[4] = {(T)0, (T)0, (T)0, (T)0};
 #pragma unroll
             for (int i = k + 1; i < 5; ++i) pr[i - k - 1] = qr[i][k] * c[i];
-            float tmp = ord_sum_dyn<ORD, K>(pr);
+            T tmp = ord_sum_dyn<ORD, K, T>(pr);
             tmp = tmp + c[k];
             c[k] = c[k] - tau * tmp;
 #pragma unroll
@@ -206,33 +226,29 @@ __device__ __forceinline__ void qt_step(const float (&qr)[5][3], const float (&h
     }
 }
 
-template <int ORD>
-__device__ __forceinline__ bool esti_plane(const float P[5][3], float threshold, float pabcd[4]) {
-    constexpr float kEps = 1.1920929e-07f;       // NumTraits<float>::epsilon()
-    float qr[5][3];
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) qr[i][j] = P[i][j];
-    float hC[3];
+// A.colPivHouseholderQr().solve(b), A = qr (5x3, destroyed), b = -1 (common_lib.h:229-241)
+template <int ORD, class T>
+__device__ __forceinline__ void qr_solve_5x3(T (&qr)[5][3], T (&nv)[3]) {
+    const T kEps = (T)fit_traits<T>::eps;
+    T hC[3];
     int tr[3];
-    float nU[3], nD[3];
+    T nU[3], nD[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {  // m_qr.col(k).norm(): fixed size 5
-        nD[k] = sqrt_rn(ord_sum_fixed5<ORD>(qr[0][k] * qr[0][k], qr[1][k] * qr[1][k], qr[2][k] * qr[2][k], qr[3][k] * qr[3][k],
-                                            qr[4][k] * qr[4][k]));
+        nD[k] = t_sqrt(ord_sum_fixed5<ORD, T>(qr[0][k] * qr[0][k], qr[1][k] * qr[1][k], qr[2][k] * qr[2][k], qr[3][k] * qr[3][k],
+                                              qr[4][k] * qr[4][k]));
         nU[k] = nD[k];
     }
-    float maxn = nU[0];
+    T maxn = nU[0];
     if (nU[1] > maxn) maxn = nU[1];
     if (nU[2] > maxn) maxn = nU[2];
-    const float th = maxn * kEps;
-    const float threshold_helper = (th * th) / 5.0f;
-    const float downdate_thr = sqrt_rn(kEps);
+    const T th = maxn * kEps;
+    const T threshold_helper = t_div(th * th, (T)5.0f);
+    const T downdate_thr = t_sqrt(kEps);
     int nz = 3;
-    qr_step<ORD, 0>(qr, hC, tr, nU, nD, nz, threshold_helper, downdate_thr);
-    qr_step<ORD, 1>(qr, hC, tr, nU, nD, nz, threshold_helper, downdate_thr);
-    qr_step<ORD, 2>(qr, hC, tr, nU, nD, nz, threshold_helper, downdate_thr);
+    qr_step<ORD, 0, T>(qr, hC, tr, nU, nD, nz, threshold_helper, downdate_thr);
+    qr_step<ORD, 1, T>(qr, hC, tr, nU, nD, nz, threshold_helper, downdate_thr);
+    qr_step<ORD, 2, T>(qr, hC, tr, nU, nD, nz, threshold_helper, downdate_thr);
     // column permutation from the transpositions
     int perm[3] = {0, 1, 2};
 #pragma unroll
@@ -241,29 +257,40 @@ __device__ __forceinline__ bool esti_plane(const float P[5][3], float threshold,
         for (int j = k + 1; j < 3; ++j)
             if (tr[k] == j) { int t = perm[k]; perm[k] = perm[j]; perm[j] = t; }
     }
-    float nv[3] = {0.f, 0.f, 0.f};
+    nv[0] = nv[1] = nv[2] = (T)0;
     if (nz != 0) {
-        float c[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};
-        qt_step<ORD, 0>(qr, hC, nz, c);
-        qt_step<ORD, 1>(qr, hC, nz, c);
-        qt_step<ORD, 2>(qr, hC, nz, c);
+        T c[5] = {(T)-1.f, (T)-1.f, (T)-1.f, (T)-1.f, (T)-1.f};
+        qt_step<ORD, 0, T>(qr, hC, nz, c);
+        qt_step<ORD, 1, T>(qr, hC, nz, c);
+        qt_step<ORD, 2, T>(qr, hC, nz, c);
 #pragma unroll
         for (int i = 2; i >= 0; --i) {
             if (i < nz) {
-                c[i] = div_rn(c[i], qr[i][i]);
+                c[i] = t_div(c[i], qr[i][i]);
 #pragma unroll
                 for (int r = 0; r < i; ++r) c[r] = c[r] - c[i] * qr[r][i];
             }
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float v = (i < nz) ? c[i] : 0.f;
+            const T v = (i < nz) ? c[i] : (T)0;
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 if (perm[i] == t) nv[t] = v;
         }
     }
-    const float n = sqrt_rn(ord_sum_fixed3<ORD>(nv[0] * nv[0], nv[1] * nv[1], nv[2] * nv[2]));  // normvec.norm()
+}
+
+template <int ORD>
+__device__ __forceinline__ bool esti_plane(const float P[5][3], float threshold, float pabcd[4]) {
+    float qr[5][3];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) qr[i][j] = P[i][j];
+    float nv[3];
+    qr_solve_5x3<ORD, float>(qr, nv);
+    const float n = sqrt_rn(ord_sum_fixed3<ORD, float>(nv[0] * nv[0], nv[1] * nv[1], nv[2] * nv[2]));  // normvec.norm()
     pabcd[0] = div_rn(nv[0], n);
     pabcd[1] = div_rn(nv[1], n);
     pabcd[2] = div_rn(nv[2], n);
@@ -273,6 +300,54 @@ __device__ __forceinline__ bool esti_plane(const float P[5][3], float threshold,
     for (int j = 0; j < 5; ++j) {
         const float v = ((pabcd[0] * P[j][0] + pabcd[1] * P[j][1]) + pabcd[2] * P[j][2]) + pabcd[3];
         if (fabsf(v) > threshold) ok = false;
+    }
+    return ok;
+}
+
+// ABLATION (BASELINE configs[4], flh_config.plane_fit_dtype = 1): the same fit with the 5x3 system in fp16.  Half's 11 bits
+// cannot hold absolute map coordinates, so the five points are first moved (in fp32) to an origin about one metre off their
+// plane -- their centroid pushed along a rough normal (cross product of two edges) -- where the A n = -1 formulation is
+// well conditioned; the factorisation and the solve then run in _Float16, and the plane is carried back to absolute
+// coordinates in fp32.  NOT bit-exact with the reference and never the default; tests report its flag-mismatch rate.
+template <int ORD>
+__device__ __forceinline__ bool esti_plane_half(const float P[5][3], float threshold, float pabcd[4]) {
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { cx += P[j][0]; cy += P[j][1]; cz += P[j][2]; }
+    cx *= 0.2f; cy *= 0.2f; cz *= 0.2f;
+    // rough normal: the largest of the cross products of edges from point 0
+    float bx = 0.f, by = 0.f, bz = 0.f, bn = -1.f;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        const float ux = P[j][0] - P[0][0], uy = P[j][1] - P[0][1], uz = P[j][2] - P[0][2];
+        const float vx = P[j + 1][0] - P[0][0], vy = P[j + 1][1] - P[0][1], vz = P[j + 1][2] - P[0][2];
+        const float wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx;
+        const float wn = wx * wx + wy * wy + wz * wz;
+        if (wn > bn) { bn = wn; bx = wx; by = wy; bz = wz; }
+    }
+    const float inv = bn > 1e-12f ? 1.0f / sqrtf(bn) : 0.f;
+    const float ox = cx - bx * inv, oy = cy - by * inv, oz = cz - bz * inv;  // origin: 1 m off the points along the rough normal
+    _Float16 qr[5][3];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        qr[i][0] = (_Float16)(P[i][0] - ox);
+        qr[i][1] = (_Float16)(P[i][1] - oy);
+        qr[i][2] = (_Float16)(P[i][2] - oz);
+    }
+    _Float16 nvh[3];
+    qr_solve_5x3<ORD, _Float16>(qr, nvh);
+    const float nx = (float)nvh[0], ny = (float)nvh[1], nz_ = (float)nvh[2];
+    const float n = sqrtf((nx * nx + ny * ny) + nz_ * nz_);
+    pabcd[0] = nx / n;
+    pabcd[1] = ny / n;
+    pabcd[2] = nz_ / n;
+    const float dl = 1.0f / n;  // offset in the shifted frame: a (p - o) + dl = 0
+    pabcd[3] = dl - ((pabcd[0] * ox + pabcd[1] * oy) + pabcd[2] * oz);
+    bool ok = n > 0.f && n < 3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const float v = ((pabcd[0] * (P[j][0] - ox) + pabcd[1] * (P[j][1] - oy)) + pabcd[2] * (P[j][2] - oz)) + dl;
+        if (!(fabsf(v) <= threshold)) ok = false;
     }
     return ok;
 }

@@ -823,7 +823,7 @@ constexpr int kRed1 = 16;   // blocks per first-level reduction group
 constexpr int kRed2 = 32;   // group sums added per unrolled batch at the top level
 constexpr int kTileStride = 17;  // doubles per row: 16 + 1 pad (conflict-free ds_write_b64 / ds_read_b64)
 
-template <int ORD>
+template <int ORD, bool HALF>
 __global__ void __launch_bounds__(256)
 k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn_pts, int N, int ext, float thr,
       uint8_t* __restrict__ selected, float4* __restrict__ normvec, float4* __restrict__ world,
@@ -864,7 +864,7 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
         for (int j = 0; j < 5; ++j) { P[j][0] = nn[j].x; P[j][1] = nn[j].y; P[j][2] = nn[j].z; }
         float pabcd[4];
         FPH(2);  // neighbours loaded
-        const bool ok = esti_plane<ORD>(P, thr, pabcd);  // :678
+        const bool ok = HALF ? esti_plane_half<ORD>(P, thr, pabcd) : esti_plane<ORD>(P, thr, pabcd);  // :678
         FPH(3);  // plane fit
         bool sel = false;
         float pd2 = 0.f;
@@ -1225,13 +1225,18 @@ int reduce1_blocks(int nblk, int* per_out) {
     return cdiv(nblk, kRed1);
 }
 
-hipError_t launch_fit(int order, const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
+hipError_t launch_fit(int order, int half_fit, const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
                       uint8_t* selected, float4* normvec, float4* world, double* partials, double* part2,
                       double* out256, double seq, uint32_t* tickets, uint32_t* slow_count, hipStream_t st) {
     const int nblk = fit_blocks(N);
 #define FLH_FIT(O)                                                                                                      \
-    hipLaunchKernelGGL(k_fit<O>, dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world, \
+    hipLaunchKernelGGL((k_fit<O, false>), dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world, \
                        partials, part2, out256, seq, tickets, slow_count)
+    if (half_fit) {  // the fp16 ablation exists for the default summation order only
+        hipLaunchKernelGGL((k_fit<1, true>), dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world,
+                           partials, part2, out256, seq, tickets, slow_count);
+        return hipGetLastError();
+    }
     switch (order) {
         case 0: FLH_FIT(0); break;
         case 2: FLH_FIT(2); break;

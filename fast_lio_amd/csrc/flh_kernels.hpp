@@ -44,7 +44,7 @@ void dump_fit_phases();
 #endif
 int fit_blocks(int N);
 int reduce1_blocks(int nblk, int* per_out);
-hipError_t launch_fit(int order, const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
+hipError_t launch_fit(int order, int half_fit, const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
                       uint8_t* selected, float4* normvec, float4* world, double* partials, double* part2,
                       double* out256, double seq, uint32_t* tickets, uint32_t* slow_count, hipStream_t st);
 
