@@ -3,6 +3,7 @@
 // flh_kernels.hip.  There is NO CPU fallback: without a HIP device every entry point fails loudly.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <emmintrin.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -33,6 +34,8 @@ typedef unsigned long long u64;
 #define FLH_COUNTER_WORDS 1
 #endif
 
+constexpr int kGranGroups = 64;   // at most this many first-level groups go the granule way (else the in-kernel two-level sum)
+constexpr int kGranSlots = 92;    // gram_nslots(12)
 static thread_local std::string g_err;
 static int fail(const std::string& m) {
     g_err = m;
@@ -131,6 +134,7 @@ struct flh_handle {
     // map partitioned over the ranks: only queries whose world coordinate own_axis lies in [own_lo, own_hi) are searched here
     int own_axis = -1;
     float own_lo = -INFINITY, own_hi = INFINITY;
+    double* h_gran = nullptr;  // pinned: [kGranGroups][92] x {value, sequence} granules written by k_fit's group reducers
     double* h_gram = nullptr;  // pinned 256 doubles
     u64* h_counter = nullptr;  // pinned
     // last evaluation
@@ -259,11 +263,13 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (hipHostMalloc((void**)&h->h_gram, 256 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_counter, sizeof(u64), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_ctr, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_small, 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void**)&h->h_small, 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_gran, (size_t)kGranGroups * kGranSlots * 16, hipHostMallocDefault) != hipSuccess) {
         flh_destroy(h);
         return fail("hipHostMalloc failed");
     }
     std::memset(h->h_gram, 0, 256 * sizeof(double));
+    std::memset(h->h_gran, 0, (size_t)kGranGroups * kGranSlots * 16);
     if (h->gram.reserve(256) != hipSuccess || h->counter.reserve(FLH_COUNTER_WORDS) != hipSuccess || h->slow_count.reserve(2 * flh::list_stripes()) != hipSuccess ||
         hipMemset(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t)) != hipSuccess) {
         flh_destroy(h);
@@ -308,6 +314,7 @@ void flh_destroy(flh_handle* h) {
     h->st_raw.release(); h->st_k0.release(); h->st_k1.release(); h->st_v0.release(); h->st_v1.release(); h->st_tmp.release();
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->h_gram) (void)hipHostFree(h->h_gram);
+    if (h->h_gran) (void)hipHostFree(h->h_gran);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -1205,7 +1212,17 @@ static StateDev make_state(const double rot[4], const double pos[3], const doubl
     return s;
 }
 
-static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext, double* d_out, double seq, bool timed) {
+// Group size of k_fit's first-level reduction when the group sums go to the host as granules: 16 blocks, more when that
+// would make more than kGranGroups groups; 0 = too many points for the granule path.
+static int gran_group_size(size_t N) {
+    const int nblk = flh::fit_blocks((int)N);
+    int red = 16;
+    while ((nblk + red - 1) / red > kGranGroups) red *= 2;
+    return red <= 128 ? red : 0;
+}
+
+static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext, double* d_out, double seq, bool timed,
+                        bool host_granules = false) {
     hipStream_t st = h->stream;
     if (!h->cur_body || !h->selected.p) return fail("flh_eval: no active scan (flh_scan_upload / flh_scan_activate first)");
     if (!h->grid.hash && h->N > 0) return fail("flh_eval: no map (flh_map_build / flh_map_add first)");
@@ -1223,7 +1240,8 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
     }
     if (timed) HIPC(hipEventRecord(h->ev[1], st));
     HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
-                         h->world.p, h->partials.p, h->part2.p, d_out, seq, h->tickets.p, h->slow_count.p, st));
+                         h->world.p, h->partials.p, h->part2.p, d_out, seq, h->tickets.p, h->slow_count.p,
+                         host_granules ? h->h_gran : nullptr, host_granules ? gran_group_size(h->N) : 0, st));
     if (timed) HIPC(hipEventRecord(h->ev[2], st));
     h->last_state = s;
     h->last_ext = ext;
@@ -1251,16 +1269,56 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     const bool timed = h->timing_stride > 0 && (h->eval_no++ % (uint64_t)h->timing_stride) == 0;
     const double seq = (double)(++h->seq);
     hipStream_t st = h->stream;
+    const int gran_red = (!h->comm && !h->stats && h->N > 0) ? gran_group_size(h->N) : 0;
     if (h->comm) {
         // this rank's partial block stays in device memory, RCCL sums the ranks' blocks in place (256 doubles: latency-bound,
         // xGMI bandwidth is irrelevant), then one small kernel publishes the sum + sequence word to pinned host memory
         if (enqueue_eval(h, s, do_search, ext, h->gram.p, 0.0, timed) != 0) return -1;
         if (rccl_allreduce_publish(h, seq) != 0) return -1;
-    } else if (enqueue_eval(h, s, do_search, ext, h->h_gram, seq, timed) != 0) {
+    } else if (enqueue_eval(h, s, do_search, ext, h->h_gram, seq, timed, gran_red > 0) != 0) {
         return -1;
     }
     if (h->stats && do_search) HIPC(hipMemcpyAsync(h->h_counter, h->counter.p, sizeof(u64), hipMemcpyDeviceToHost, st));
-    if (h->stats) {
+    if (gran_red > 0) {
+        // k_fit's group reducers write {value, sequence} granules straight into pinned memory: wait until every granule of
+        // every group carries this evaluation's sequence number, then add the groups up in group order (fixed order ->
+        // run-to-run identical bits).  No device-side final sum, no drain, no flag.
+        const int ncol = ext ? 12 : 6;
+        const int nslots = flh::gram_slots_host(ncol);
+        const int nblk = flh::fit_blocks((int)h->N);
+        const int ngroups = (nblk + gran_red - 1) / gran_red;
+        const int total = ngroups * nslots;
+        const double* g = h->h_gran;
+        int next = 0;
+        uint64_t spins = 0;
+        while (next < total) {
+            const __m128d x = _mm_load_pd(g + 2 * (size_t)next);  // one 16-byte read: {value, sequence}
+            if (_mm_cvtsd_f64(_mm_unpackhi_pd(x, x)) == seq) { ++next; continue; }
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFFu) == 0 && hipStreamQuery(st) != hipErrorNotReady) {  // finished or failed without publishing
+                HIPC(hipStreamSynchronize(st));
+                const __m128d y = _mm_load_pd(g + 2 * (size_t)next);
+                if (_mm_cvtsd_f64(_mm_unpackhi_pd(y, y)) != seq) return fail("flh_eval: kernel retired without publishing its result");
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        double sum[kGranSlots];
+        for (int k = 0; k < nslots; ++k) sum[k] = 0.0;
+        for (int gi = 0; gi < ngroups; ++gi) {
+            const double* gg = g + 2 * (size_t)gi * nslots;
+            for (int k = 0; k < nslots; ++k) sum[k] += gg[2 * k];
+        }
+        double* G = h->h_gram;
+        std::memset(G, 0, 256 * sizeof(double));
+        for (int r = 0; r < 16; ++r)
+            for (int c = 0; c < 16; ++c) {
+                const int sl = flh::gram_slot_host(r, c, ncol);
+                if (sl < 0) continue;
+                G[r * 16 + c] = sum[sl];
+                if (c < 12 && r < c) G[c * 16 + r] = sum[sl];  // the block is symmetric bit for bit (same products, same order)
+            }
+        G[255] = seq;
+    } else if (h->stats) {
         HIPC(hipStreamSynchronize(st));
     } else {
         // k_fit publishes the block with system-scope stores and then the sequence word in G[15][15]: poll it instead of
@@ -1451,7 +1509,8 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
             h->search_state = s;
         } else {
             HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p,
-                                 h->normvec.p, h->world.p, h->partials.p, h->part2.p, h->gram.p, 0.0, h->tickets.p, h->slow_count.p, st));
+                                 h->normvec.p, h->world.p, h->partials.p, h->part2.p, h->gram.p, 0.0, h->tickets.p, h->slow_count.p,
+                                 nullptr, 0, st));
         }
     }
     HIPC(hipEventRecord(h->ev[3], st));

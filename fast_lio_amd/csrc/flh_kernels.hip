@@ -819,6 +819,20 @@ __device__ u64 g_fit_ph[4096 * 4 * 12];
 #define FPH_DUMP()
 #endif
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+// Compact layout of the entries of the 16x16 Gram block the filter reads: the upper triangle of the leading ncol x ncol block
+// (ncol = 12 with extrinsic estimation, else 6: the last six columns are structurally zero, laserMapping.cpp:745), then the
+// ncol entries of column 12 (H^T h), then n_eff (G[13][13]) and total_residual (G[14][13]).  -1 = not transmitted.
+__host__ __device__ inline int gram_nslots(int ncol) { return ncol * (ncol + 1) / 2 + ncol + 2; }
+__host__ __device__ inline int gram_slot(int r, int c, int ncol) {
+    const int tri = ncol * (ncol + 1) / 2;
+    if (c < ncol && r <= c) return r * ncol - r * (r - 1) / 2 + (c - r);
+    if (c == 12 && r < ncol) return tri + r;
+    if (r == 13 && c == 13) return tri + ncol;
+    if (r == 14 && c == 13) return tri + ncol + 1;
+    return -1;
+}
+int gram_slots_host(int ncol) { return gram_nslots(ncol); }
+int gram_slot_host(int r, int c, int ncol) { return gram_slot(r, c, ncol); }
 constexpr int kRed1 = 16;   // blocks per first-level reduction group
 constexpr int kRed2 = 32;   // group sums added per unrolled batch at the top level
 constexpr int kTileStride = 17;  // doubles per row: 16 + 1 pad (conflict-free ds_write_b64 / ds_read_b64)
@@ -828,7 +842,7 @@ __global__ void __launch_bounds__(256)
 k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn_pts, int N, int ext, float thr,
       uint8_t* __restrict__ selected, float4* __restrict__ normvec, float4* __restrict__ world,
       double* __restrict__ partials, double* __restrict__ part2, double* __restrict__ out256, double seq,
-      uint32_t* __restrict__ tickets, uint32_t* __restrict__ slow_count) {
+      uint32_t* __restrict__ tickets, uint32_t* __restrict__ slow_count, double* __restrict__ gran, int red1, int ncol) {
     __shared__ double lds[4 * 64 * kTileStride];
     __shared__ uint32_t s_ticket;
 #ifdef FLH_PHASES
@@ -939,15 +953,46 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
     __hip_atomic_store(gpart + (size_t)blockIdx.x * 256 + t, (Rb[t] + Rb[256 + t]) + (Rb[512 + t] + Rb[768 + t]),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int nblk = gridDim.x;
-    const int group = blockIdx.x / kRed1;
+    const int red = gran ? red1 : kRed1;
+    const int group = blockIdx.x / red;
     const int ngroups = (nblk + kRed1 - 1) / kRed1;
-    const int gsize = min(kRed1, nblk - group * kRed1);
+    const int gsize = min(red, nblk - group * red);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) s_ticket = __hip_atomic_fetch_add(&tickets[1 + group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     FPH(6);  // partial stored, ticket taken
     if (s_ticket != (uint32_t)(gsize - 1)) { FPH_DUMP(); return; }  // block-uniform
+    if (gran) {
+        // ---- flh_eval's path: ONE level on the device.  The last block of a group sums the group's partials in block
+        // order and hands the entries the host needs (upper triangle of the leading ncol x ncol block, the Hth column,
+        // n_eff, total_residual -- 29 values without extrinsic estimation, 92 with) straight to pinned host memory as
+        // 16-byte {value, sequence} granules: no drain, no flag, no second ticket, no final block.  The host checks every
+        // granule's tag and adds the groups up in group order (gram_slot() below is shared with it).
+        const int b0 = group * red;
+        double s0 = 0.0;
+        for (int j0 = 0; j0 < gsize; j0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                v[j] = (j0 + j < gsize) ? __hip_atomic_load(gpart + (size_t)(b0 + j0 + j) * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                        : 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s0 += v[j];
+        }
+        const int slot = gram_slot(t >> 4, t & 15, ncol);
+        if (slot >= 0) {
+            typedef double v2f64 __attribute__((ext_vector_type(2)));
+            const v2f64 g2 = {s0, seq};
+            double* dst = gran + ((size_t)group * gram_nslots(ncol) + slot) * 2;
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(g2) : "memory");  // one 16-byte system-scope store
+        }
+        if (t == 0) tickets[1 + group] = 0;                         // re-arm this group's ticket for the next launch
+        if (group == 0 && t < 2 * kStripes) slow_count[t] = 0;      // and the A1 -> A2 work-list counters (A2 has retired)
+        FPH(7);
+        FPH_DUMP();
+        return;
+    }
     {
         const int b0 = group * kRed1;
         double v[kRed1];
@@ -1227,14 +1272,15 @@ int reduce1_blocks(int nblk, int* per_out) {
 
 hipError_t launch_fit(int order, int half_fit, const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
                       uint8_t* selected, float4* normvec, float4* world, double* partials, double* part2,
-                      double* out256, double seq, uint32_t* tickets, uint32_t* slow_count, hipStream_t st) {
+                      double* out256, double seq, uint32_t* tickets, uint32_t* slow_count, double* gran, int red1, hipStream_t st) {
     const int nblk = fit_blocks(N);
+    const int ncol = ext ? 12 : 6;
 #define FLH_FIT(O)                                                                                                      \
     hipLaunchKernelGGL((k_fit<O, false>), dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world, \
-                       partials, part2, out256, seq, tickets, slow_count)
+                       partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol)
     if (half_fit) {  // the fp16 ablation exists for the default summation order only
         hipLaunchKernelGGL((k_fit<1, true>), dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world,
-                           partials, part2, out256, seq, tickets, slow_count);
+                           partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol);
         return hipGetLastError();
     }
     switch (order) {
