@@ -179,78 +179,50 @@ def main():
             torch.cuda.synchronize()
 
     class Acc:
-        def __init__(self):
+        def __init__(self, rs=None):
             self.passes = self.searches = 0
-            self.ms_s = self.ms_n = 0.0
+            self.ms_s = self.ms_n = self.ms_mi = 0.0
             self.n_s = self.n_n = 0
+            if rs is not None:
+                self.passes, self.searches = int(rs.passes), int(rs.searches)
+                self.ms_s, self.n_s = float(rs.ms_search_passes), int(rs.n_search_passes)
+                self.ms_n, self.n_n = float(rs.ms_nosearch_passes), int(rs.n_nosearch_passes)
+                self.ms_mi = float(rs.ms_map_incremental)
 
-        def add(self, st):
-            self.passes += st.passes
-            self.searches += st.searches
-            for k in range(min(st.passes, 8)):
-                if st.pass_search[k]:
-                    self.ms_s += st.pass_ms[k]
-                    self.n_s += 1
-                else:
-                    self.ms_n += st.pass_ms[k]
-                    self.n_n += 1
-
-    def run(step_fn, n_warm, n_steps, prologue=None):
-        if prologue:
-            prologue(0)
-        for i in range(n_warm):
-            step_fn(i, n_warm + n_steps)
-        # A generation-2 pass of Python's cyclic GC over the synthetic-scene objects costs ~40 ms of pure host time and
-        # landed deterministically inside the timed loop (found with FLH_BENCH_TRACE); collect now, then keep the
-        # collector out of the timed region, as timeit does.
+    def run(kfx, hx, jobs, n_warm, n_steps):
+        """W untimed warm-up scans, then EXACTLY n_steps scans inside one native call (flh_esekf_run_scans: the node's main
+        loop, scan i+1 staged while scan i updates) bracketed by barrier + device synchronisation; max over ranks."""
+        # the stream does not stop at the boundary of the timed region: the first timed scan is staged while the last
+        # warm-up scan updates, exactly as every later scan is staged while its predecessor updates
+        kfx.run_scans(jobs, 0, n_warm, ring=RING, map_incremental=with_map_inserts, stage_next=True)
+        # keep Python's cyclic GC out of the timed region, as timeit does
         gc.collect()
         gc.disable()
         sync()
-        h.set_timing_stride(max(1, (n_steps * 4) // max(args.timing_samples, 16)))
-        h.counters(reset=True)
-        acc = Acc()
+        hx.set_timing_stride(max(1, (n_steps * 4) // max(args.timing_samples, 16)))
+        hx.counters(reset=True)
         t1 = time.perf_counter()
-        trace = [] if os.environ.get("FLH_BENCH_TRACE") else None
-        for i in range(n_warm, n_warm + n_steps):
-            ta = time.perf_counter()
-            st = step_fn(i, n_warm + n_steps)
-            if trace is not None:
-                trace.append(time.perf_counter() - ta)
-            acc.add(st)
+        rs = kfx.run_scans(jobs, n_warm, n_steps, ring=RING, map_incremental=with_map_inserts, first_staged=n_warm > 0)
         sync()
         dt_ = time.perf_counter() - t1
         gc.enable()
-        h.set_timing_stride(0)
-        if trace:
-            order = sorted(range(len(trace)), key=lambda j: -trace[j])[:6]
-            print("[trace] slowest steps:", [(j, round(trace[j] * 1e3, 3)) for j in order], "median ms",
-                  round(sorted(trace)[len(trace) // 2] * 1e3, 4), file=sys.stderr)
+        hx.set_timing_stride(0)
         if dist is not None:
             tt = torch.tensor([dt_], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_ = float(tt.item())
-        return dt_, acc, h.counters()
+        return dt_, Acc(rs), hx.counters()
 
     # ---------------- headline leg: the pipelined loop.  Scan i+1 is handed to the staging thread (host buffer -> H2D ->
-    # re-stride + Morton sort on the copy stream) before the update of scan i starts; update_scan(i) waits for ITS
-    # staging only.  Every scan of the timed region crosses PCIe inside the timed region.
-    def stage(i):
-        h.scan_stage_async(i % RING, bodies[i % S])
-
-    def step_pipelined(i, n_total):
-        if i + 1 < n_total:
-            stage(i + 1)
-        s = i % S
-        st = kf.update_scan(i % RING, priors[s][0], priors[s][1], 0.001)  # activate staged scan + (x, P) + update
-        if with_map_inserts:
-            h.map_incremental(kf.get_x(), 0.5, True, apply=True)
-        return st
+    # re-stride + Morton sort on the copy stream) before the update of scan i starts; the update waits for ITS staging
+    # only.  Every scan of the timed region crosses PCIe inside the timed region.
+    jobs_pipe = capi.Esekf.make_jobs(bodies, priors)
 
     shard_out = None
     if mode in ("shard", "partition") and G == 1 and not args.force_shard_leg:
         mode = "streams"  # one rank: nothing to shard
     if mode == "streams":
-        dt, acc, ctr = run(step_pipelined, args.warmup, args.steps, prologue=stage)
+        dt, acc, ctr = run(kf, h, jobs_pipe, args.warmup, args.steps)
         units = args.steps * G
         n_pts = N
     # ---------------- sharded leg (north_star C1): ONE scan's points split over the ranks Morton-first, map replicated (or,
@@ -279,15 +251,9 @@ def main():
                 hs.scan_stage(s, np.ascontiguousarray(p.body[fdist.morton_shard(p.body, rank, G)]))
             pts_here = hi - lo
         kfs = capi.Esekf(hs, max_iter=3, extrinsic_est_en=ext)
-        hsave, h = h, hs  # run() reads its counters from `h`
-
-        def step_shard(i, n_total):
-            s = i % S_sh
-            return kfs.update_scan(s, sh_priors[s][0], sh_priors[s][1], 0.001)
-
+        jobs_sh = capi.Esekf.make_jobs([np.zeros((1, 3), np.float32)] * S_sh, sh_priors, slots=list(range(S_sh)))
         k2 = args.steps if mode in ("shard", "partition") else max(10, min(60, args.steps // 4))
-        dt2, acc2, ctr2 = run(step_shard, max(3, args.warmup // 4), k2)
-        h = hsave
+        dt2, acc2, ctr2 = run(kfs, hs, jobs_sh, max(3, args.warmup // 4), k2)
         # every rank must have produced the same posterior
         xs = [kfs.get_x()] * G
         if dist is not None:
@@ -326,6 +292,8 @@ def main():
                 "fit_achieved_GBs": round(ALG_BYTES_NOSEARCH * n_pts / fit_s / 1e9, 2),
                 "fit_frac": round(ALG_BYTES_NOSEARCH * n_pts / fit_s / 1e9 / HBM_PEAK_GBS, 5)}
 
+    if with_map_inserts:
+        acc_mi = acc.ms_mi / max(args.steps, 1)
     out = {
         "metric": "scans/sec + ms/IEKF-iter, 100k-pt scan vs 5M-pt map, 1/2/4/8 MI355X",
         "value": round(value, 3),
@@ -350,13 +318,15 @@ def main():
                                     f"per pass" if mode in ("shard", "partition") else
                                     f"{G} independent scan streams (one per rank), replicated map, no collective in the data path")),
                    "distinct_scans": S, "cell_size_m": args.cell, "lanes_per_query": args.lpq, "first_stage": args.first_stage},
-        "ms_per_iekf_pass": round(dt / max(acc.passes, 1) * 1e3, 4),
+        "ms_per_iekf_pass": round((acc.ms_s + acc.ms_n) / max(acc.passes, 1), 4),
         "ms_search_pass": round(acc.ms_s / max(acc.n_s, 1), 4),
         "ms_nosearch_pass": round(acc.ms_n / max(acc.n_n, 1), 4),
         "passes_per_scan": round(acc.passes / args.steps, 3),
         "searches_per_scan": round(acc.searches / args.steps, 3),
         "map_build_s": round(t_build, 3),
     }
+    if with_map_inserts:
+        out["ms_map_incremental_per_scan"] = round(acc_mi, 4)
     if G > 1 and dist is not None:
         out["ranks_seen_by_collective"] = int(dist.get_world_size())
         out["ranks_in_rccl_communicator"] = shard_out["ranks_in_communicator"] if shard_out else None
@@ -368,15 +338,8 @@ def main():
         Sd = min(S, 32)
         for s in range(Sd):
             h.scan_stage(16 + s, bodies[s])
-
-        def step_resident(i, n_total):
-            s = i % Sd
-            st = kf.update_scan(16 + s, priors[s][0], priors[s][1], 0.001)
-            if with_map_inserts:
-                h.map_incremental(kf.get_x(), 0.5, True, apply=True)
-            return st
-
-        dtr, accr, _ = run(step_resident, max(4, args.warmup // 2), args.steps)
+        jobs_res = capi.Esekf.make_jobs(bodies[:Sd], priors[:Sd], slots=[16 + s for s in range(Sd)])
+        dtr, accr, _ = run(kf, h, jobs_res, max(4, args.warmup // 2), args.steps)
         out["device_resident_scans_per_s"] = round(args.steps / dtr, 3)
         out["device_resident_ms_per_step"] = round(dtr / args.steps * 1e3, 4)
 
@@ -415,10 +378,10 @@ def main():
         h2.set_timing_stride(0)
         per = max(args.steps // 2, 8)
 
+        jobs2 = capi.Esekf.make_jobs(bodies[:Sd], priors[:Sd], slots=[16 + s for s in range(Sd)])
+
         def worker(kfx, off):
-            for i in range(per):
-                s = (i + off) % Sd
-                kfx.update_scan(16 + s, priors[s][0], priors[s][1], 0.001)
+            kfx.run_scans(jobs2, off, per, ring=RING)
 
         for kfx in (kf, kf2):  # warm-up
             worker(kfx, 0)

@@ -64,6 +64,17 @@ class FlhUpdateStats(C.Structure):
     ]
 
 
+class FlhScanJob(C.Structure):
+    _fields_ = [("pts", C.c_void_p), ("stride_bytes", C.c_size_t), ("N", C.c_size_t), ("x", C.c_void_p), ("P", C.c_void_p),
+                ("slot", C.c_int)]
+
+
+class FlhRunStats(C.Structure):
+    _fields_ = [("scans", C.c_int64), ("passes", C.c_int64), ("searches", C.c_int64), ("n_search_passes", C.c_int64),
+                ("n_nosearch_passes", C.c_int64), ("ms_search_passes", C.c_double), ("ms_nosearch_passes", C.c_double),
+                ("ms_map_incremental", C.c_double)]
+
+
 MEAS_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(FlhMeas))
 
 # every symbol include/fastlio_hip.h declares (checked by tests/test_abi.py)
@@ -80,7 +91,7 @@ EXPORTS = [
     "flh_scan_stage_undistorted", "flh_esekf_update_scan", "flh_map_stats",
     "flh_scan_stage_async", "flh_scan_wait", "flh_host_alloc", "flh_host_free", "flh_frame_world", "flh_points_body_to_world",
     "flh_esekf_last_error", "flh_rccl_unique_id", "flh_rccl_init_rank", "flh_rccl_init_all", "flh_rccl_destroy", "flh_rccl_size",
-    "flh_rccl_rank", "flh_eval_group", "flh_set_owned_interval",
+    "flh_rccl_rank", "flh_eval_group", "flh_set_owned_interval", "flh_esekf_run_scans",
 ]
 
 _lib = None
@@ -182,6 +193,8 @@ def lib():
     L.flh_eval_group.argtypes = [C.POINTER(C.c_void_p), C.c_int, _f64p, C.c_int, C.c_int, _f64p, _f64p, C.POINTER(C.c_int64),
                                  C.POINTER(C.c_double)]
     L.flh_set_owned_interval.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float]
+    L.flh_esekf_run_scans.argtypes = [C.c_void_p, C.POINTER(FlhScanJob), C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_int,
+                                      C.c_double, C.c_int, C.POINTER(FlhRunStats), C.c_void_p, C.c_void_p]
     L.flh_esekf_last_error.restype = C.c_char_p
     L.flh_esekf_last_error.argtypes = [C.c_void_p]
     L.flh_scan_stage_downsampled.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float,
@@ -560,6 +573,34 @@ class Esekf:
         if rc != 0:
             raise FlhError("flh_esekf_update_scan failed: " + lib().flh_esekf_last_error(self._e).decode())
         return st
+
+    @staticmethod
+    def make_jobs(bodies, priors, slots=None):
+        """ctypes array of flh_scan_job for run_scans: bodies = list of float32 C-contiguous N x 3/4 arrays (kept alive by the
+        caller), priors = list of (x, P) float64 C-contiguous arrays, slots = None (stage from the buffers) or a list of slots."""
+        arr = (FlhScanJob * len(bodies))()
+        for i, (b, (x, P)) in enumerate(zip(bodies, priors)):
+            assert b.dtype == np.float32 and b.flags["C_CONTIGUOUS"] and x.dtype == np.float64 and P.dtype == np.float64
+            arr[i].pts = b.ctypes.data
+            arr[i].stride_bytes = b.shape[1] * 4
+            arr[i].N = b.shape[0]
+            arr[i].x = x.ctypes.data
+            arr[i].P = P.ctypes.data
+            arr[i].slot = -1 if slots is None else int(slots[i])
+        return arr
+
+    def run_scans(self, jobs, first: int, count: int, ring: int = 4, R: float = 0.001, map_incremental: bool = False,
+                  filter_size_map: float = 0.5, first_staged: bool = False, stage_next: bool = False) -> FlhRunStats:
+        """The node's main loop over `count` scans, natively (flh_esekf_run_scans): no Python between the scans.
+        stage_next / first_staged chain two calls into one continuous stream (the scan after this call's last is staged while
+        the last one updates)."""
+        rs = FlhRunStats()
+        rc = lib().flh_esekf_run_scans(self._e, jobs, len(jobs), int(first), int(count), int(ring), float(R), int(map_incremental),
+                                       float(filter_size_map), (1 if first_staged else 0) | (2 if stage_next else 0),
+                                       C.byref(rs), None, None)
+        if rc != 0:
+            raise FlhError("flh_esekf_run_scans failed: " + lib().flh_esekf_last_error(self._e).decode())
+        return rs
 
     def update(self, R: float = 0.001):
         st = FlhUpdateStats()

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -1056,6 +1057,11 @@ int flh_scan_stage(flh_handle* h, int slot, const void* pts, size_t stride_bytes
     if (!h) return fail("flh_scan_stage: null handle");
     if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_stage: bad slot");
     if (wait_slot(h, h->slots[slot]) != 0) return -1;
+    if (h->cur == &h->slots[slot]) {  // re-staging the active scan's slot ends that scan
+        h->cur = nullptr;
+        h->cur_body = nullptr;
+        h->have_eval = false;
+    }
     return stage_into(h, h->slots[slot], pts, stride_bytes, N, true);
 }
 
@@ -1063,7 +1069,11 @@ int flh_scan_stage_async(flh_handle* h, int slot, const void* pts, size_t stride
     if (!h) return fail("flh_scan_stage_async: null handle");
     if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_stage_async: bad slot");
     if (N > 0 && !pts) return fail("flh_scan_stage_async: null points");
-    if (h->cur == &h->slots[slot]) return fail("flh_scan_stage_async: the slot holds the active scan");
+    if (h->cur == &h->slots[slot]) {  // the active scan's slot is being re-used: that scan is over (no evaluation is in flight)
+        h->cur = nullptr;
+        h->cur_body = nullptr;
+        h->have_eval = false;
+    }
     std::lock_guard<std::mutex> lk(h->st_mu);
     if (h->slots[slot].pending) return fail("flh_scan_stage_async: the slot is still being staged");
     if (!h->stager.joinable()) h->stager = std::thread(stager_main, h);
@@ -1234,7 +1244,8 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
         HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
                                 h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
                                 h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr,
-                                h->own_axis, h->own_lo, h->own_hi, st));
+                                h->own_axis, h->own_lo, h->own_hi,
+                                (h->searched_once && h->own_axis < 0 && !std::getenv("FLH_NO_CACHE_BOUND")) ? 1 : 0, st));
         h->searched_once = true;
         h->search_state = s;
     }
@@ -1269,6 +1280,8 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     const bool timed = h->timing_stride > 0 && (h->eval_no++ % (uint64_t)h->timing_stride) == 0;
     const double seq = (double)(++h->seq);
     hipStream_t st = h->stream;
+    static const bool host_prof = std::getenv("FLH_HOST_PROFILE") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
     const int gran_red = (!h->comm && !h->stats && h->N > 0) ? gran_group_size(h->N) : 0;
     if (h->comm) {
         // this rank's partial block stays in device memory, RCCL sums the ranks' blocks in place (256 doubles: latency-bound,
@@ -1279,6 +1292,7 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
         return -1;
     }
     if (h->stats && do_search) HIPC(hipMemcpyAsync(h->h_counter, h->counter.p, sizeof(u64), hipMemcpyDeviceToHost, st));
+    const auto tp1 = std::chrono::steady_clock::now();
     if (gran_red > 0) {
         // k_fit's group reducers write {value, sequence} granules straight into pinned memory: wait until every granule of
         // every group carries this evaluation's sequence number, then add the groups up in group order (fixed order ->
@@ -1340,6 +1354,21 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     if (h->h_gram[255] != seq) return fail("flh_eval: result sequence mismatch");
     h->h_gram[255] = 0.0;  // G[15][15] is structurally zero
     flh_unpack_gram(h->h_gram, HTH, HTh, n_eff, total_residual);
+    if (host_prof) {  // developer aid: where the host's share of a pass goes (enqueue / wait for the device / unpack)
+        const auto tp2 = std::chrono::steady_clock::now();
+        static thread_local double acc_[2][3] = {{0, 0, 0}, {0, 0, 0}};
+        static thread_local uint64_t n_[2] = {0, 0};
+        static thread_local std::chrono::steady_clock::time_point last_end_;
+        static thread_local double gap_[2] = {0, 0};
+        const int k = do_search ? 1 : 0;
+        acc_[k][0] += std::chrono::duration<double, std::micro>(tp1 - tp0).count();
+        acc_[k][1] += std::chrono::duration<double, std::micro>(tp2 - tp1).count();
+        if (n_[0] + n_[1] > 0) gap_[k] += std::chrono::duration<double, std::micro>(tp0 - last_end_).count();
+        last_end_ = tp2;
+        if (++n_[k] % 2000 == 0)
+            std::fprintf(stderr, "[host] %s pass: enqueue %.2f us, wait+sum %.2f us, host time before it (algebra, caller) %.2f us (n=%llu)\n",
+                         k ? "search" : "no-search", acc_[k][0] / n_[k], acc_[k][1] / n_[k], gap_[k] / n_[k], (unsigned long long)n_[k]);
+    }
     float a = 0, b = 0, c = 0;
     if (timed) {
         (void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
@@ -1503,7 +1532,7 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
         if (which == 0) {
             HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
                                     h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
-                                    h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, nullptr, h->own_axis, h->own_lo, h->own_hi, st));
+                                    h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, nullptr, h->own_axis, h->own_lo, h->own_hi, 0, st));
             HIPC(hipMemsetAsync(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t), st));
             h->searched_once = true;
             h->search_state = s;

@@ -1,6 +1,9 @@
 // flh_esekf.cpp -- layer 2 of the C ABI: a C binding of the C++ host filter in
 // include/fastlio_amd/esekfom.hpp (the mirror of esekfom::esekf<state_ikfom,12,input_ikfom>), so that
 // ctypes / C callers run exactly the code a C++ node would.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <string>
@@ -132,6 +135,67 @@ int flh_esekf_update_scan(flh_esekf* e, int slot, const double x[FLH_NSTATE], co
     if (x) flh_esekf_change_x(e, x);
     if (P) flh_esekf_change_P(e, P);
     return flh_esekf_update(e, R, st);
+}
+
+
+int flh_esekf_run_scans(flh_esekf* e, const flh_scan_job* jobs, int n_jobs, int64_t first, int64_t count, int ring, double R,
+                        int with_map_incremental, double filter_size_map, int flags, flh_run_stats* out, double x_last[FLH_NSTATE],
+                        double P_last[FLH_NDOF * FLH_NDOF]) {
+    if (!e) return -1;
+    e->err.clear();
+    flh_handle* h = e->gpu_ctx.handle;
+    if (!h) { e->err = "flh_esekf_run_scans: filter has no device handle"; return -1; }
+    if (!jobs || n_jobs < 1 || count < 0 || first < 0) { e->err = "flh_esekf_run_scans: bad arguments"; return -1; }
+    if (ring < 2) ring = 2;
+    if (ring > FLH_MAX_SLOTS) ring = FLH_MAX_SLOTS;
+    flh_run_stats rs;
+    std::memset(&rs, 0, sizeof(rs));
+    typedef std::chrono::steady_clock clk;
+    auto stage = [&](int64_t i) -> int {
+        const flh_scan_job& j = jobs[i % n_jobs];
+        if (j.slot >= 0) return 0;
+        if (flh_scan_stage_async(h, (int)(i % ring), j.pts, j.stride_bytes, j.N) != 0) {
+            e->err = std::string("flh_scan_stage_async: ") + flh_last_error();
+            return -1;
+        }
+        return 0;
+    };
+    if (count > 0 && !(flags & FLH_RUN_FIRST_STAGED) && stage(first) != 0) return -1;
+    static const bool trace = std::getenv("FLH_RUN_TRACE") != nullptr;  // developer aid: per-scan wall times on stderr
+    auto t_prev = clk::now();
+    for (int64_t i = first; i < first + count; ++i) {
+        const flh_scan_job& j = jobs[i % n_jobs];
+        if (trace) {
+            const auto t_now = clk::now();
+            if (i > first && i - first <= 40) std::fprintf(stderr, "%s%.0f", (i - first == 1) ? "[run_scans] us/scan:" : " ", std::chrono::duration<double, std::micro>(t_now - t_prev).count());
+            if (i - first == 40 || i + 1 == first + count) std::fprintf(stderr, "\n");
+            t_prev = t_now;
+        }
+        if ((i + 1 < first + count || (flags & FLH_RUN_STAGE_NEXT)) && stage(i + 1) != 0) return -1;  // scan i+1 crosses PCIe while scan i updates
+        flh_update_stats st;
+        if (flh_esekf_update_scan(e, j.slot >= 0 ? j.slot : (int)(i % ring), j.x, j.P, R, &st) != 0) return -1;
+        rs.scans++;
+        rs.passes += st.passes;
+        rs.searches += st.searches;
+        for (int k = 0; k < st.passes && k < 8; ++k) {
+            if (st.pass_search[k]) { rs.ms_search_passes += st.pass_ms[k]; rs.n_search_passes++; }
+            else { rs.ms_nosearch_passes += st.pass_ms[k]; rs.n_nosearch_passes++; }
+        }
+        if (with_map_incremental) {
+            const auto t0 = clk::now();
+            double x26[FLH_NSTATE];
+            e->kf.get_x().to_flat(x26);
+            if (flh_map_incremental(h, x26, filter_size_map, 1, 1, nullptr, nullptr) != 0) {
+                e->err = std::string("flh_map_incremental: ") + flh_last_error();
+                return -1;
+            }
+            rs.ms_map_incremental += std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+        }
+    }
+    if (out) *out = rs;
+    if (x_last) flh_esekf_get_x(e, x_last);
+    if (P_last) flh_esekf_get_P(e, P_last);
+    return 0;
 }
 
 }  // extern "C"

@@ -311,7 +311,7 @@ __device__ __forceinline__ void top5_finish(Top5& L, const GridParams& g, int q,
                                             float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
                                             uint8_t* __restrict__ selected);
 
-template <int LPQ, int RING, bool BOUNDED, int PB, bool FINAL, bool OCT = false>
+template <int LPQ, int RING, bool BOUNDED, int PB, bool FINAL, bool OCT = false, bool CACHED = false>
 __global__ void __launch_bounds__(256)
 k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist,
               float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
@@ -323,6 +323,10 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
     // [own_lo, own_hi) belongs to another rank: its flag is cleared and it is not searched here.
     // FINAL: a query this stage cannot settle is finished on the spot by its group with the general exact search
     // (exact_query) instead of being listed for one more kernel -- each extra kernel costs ~6 us of fixed latency per pass.
+    // CACHED (first stage, later searches of a scan): the five neighbours the PREVIOUS search of this scan left in the cache
+    // are map points, so the largest of their distances to the query's new position bounds its true 5th distance from above:
+    // rows and row ends outside that ball are not visited (the state moves by centimetres between searches, so the ball is
+    // a fraction of the 3x3x3 block: ~25 candidates instead of ~80, and most segment look-ups masked off).
     // BOUNDED: the query comes with an upper bound ub of its true 5th squared distance (found by a smaller
     // ring); rows and row ends that lie entirely outside that ball are not visited.
     // Work lists are striped kStripes ways (stripe = blockIdx & (kStripes-1)) and appended to with one global
@@ -378,8 +382,26 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
         PH_MARK(1);  // 1: query loaded + transformed
 
         // ---- phase 1: directory probes of this lane's segments
-        float ubq = INFINITY;
+        float ubq = INFINITY, ub_raw = INFINITY;
         if (BOUNDED) ubq = fminf(ub_in[q], max_sqdist) * 1.0001f + 1e-6f;
+        if (CACHED) {
+            // lane l holds cached ranks l, l + LPQ, ...; the group's maximum is the bound (only when all five were found)
+            float dm = 0.f;
+#pragma unroll
+            for (int r = 0; r < (5 + LPQ - 1) / LPQ; ++r) {
+                const int j = lane + r * LPQ;
+                if (j < 5) {
+                    const float4 c = nn_pts[(size_t)j * N + q];
+                    dm = fmaxf(dm, dist2(qx, qy, qz, c.x, c.y, c.z));
+                }
+            }
+            if (LPQ >= 2) dm = fmaxf(dm, __uint_as_float(dpp_u32<0xB1>(__float_as_uint(dm))));
+            if (LPQ >= 4) dm = fmaxf(dm, __uint_as_float(dpp_u32<0x4E>(__float_as_uint(dm))));
+            if (LPQ >= 8) dm = fmaxf(dm, __uint_as_float(dpp_u32<0x141>(__float_as_uint(dm))));
+            if (LPQ >= 16) dm = fmaxf(dm, __uint_as_float(dpp_u32<0x140>(__float_as_uint(dm))));
+            ub_raw = (nn_cnt[q] == 5) ? dm : INFINITY;
+            ubq = fminf(ub_raw, max_sqdist * 4.f) * 1.0001f + 1e-6f;  // beyond twice the gate radius the whole block is inside anyway
+        }
         const float inv_c2 = g.inv_c * g.inv_c;
         uint32_t key[SPL], i0[SPL], i1[SPL];
         u64 he[SPL];
@@ -392,7 +414,7 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             const int y = cy + dy, z = cz + dz;
             int xlo = OCT ? cx - (fx < 0.5f ? 1 : 0) : cx - RING, xhi = OCT ? xlo + 1 : cx + RING;
             bool inball = true;
-            if (BOUNDED) {
+            if (BOUNDED || CACHED) {
                 // distance (in cells) from the query to the row's (y,z) slab; what is left of the ball bounds x
                 const float gy = dy > 0 ? (float)dy - fy : (dy < 0 ? fy - (float)(dy + 1) : 0.f);
                 const float gz = dz > 0 ? (float)dz - fz : (dz < 0 ? fz - (float)(dz + 1) : 0.f);
@@ -657,12 +679,12 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
             wbase = __shfl(wbase, leader, 64);
             if (append) {
                 out_list[wbase + (uint32_t)__popcll(bal & ((1ull << wlane) - 1ull))] = (uint32_t)q;
-                ub_out[q] = BOUNDED ? fminf(d5hi, ub_in[q]) : d5hi;  // the true 5th distance is <= the one found so far
+                ub_out[q] = BOUNDED ? fminf(d5hi, ub_in[q]) : (CACHED ? fminf(d5hi, ub_raw) : d5hi);  // the true 5th distance is <= either bound
             }
         }
         PH_MARK(8);  // 8: appended
         PH_NEXT_TRIP();
-        if (!BOUNDED) break;  // single trip (see above)
+        if (!BOUNDED) break;  // no input list: single trip (see above)
         wave_sync();  // seg[] is rewritten by the next trip
     }
     PH_DUMP(RING == 1 ? 0 : 8);
@@ -1180,7 +1202,7 @@ uint32_t list_stripe_cap(int N) { return (uint32_t)(cdiv(cdiv(N > 0 ? N : 1, 16)
 hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points,
                          float max_sqdist, int rmax, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
                          uint32_t* list1, uint32_t* list2, float* ub, uint32_t* counts /* [2 * kStripes] */,
-                         u64* cand_counter, int own_axis, float own_lo, float own_hi, hipStream_t st) {
+                         u64* cand_counter, int own_axis, float own_lo, float own_hi, int cache_bound, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     const dim3 blk(256);
     const uint32_t cap = list_stripe_cap(N);
@@ -1191,6 +1213,12 @@ hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const St
     }
     // A1: ring 1, every query
 #define FLH_A1(L, O)                                                                                                     \
+    if (cache_bound && L == 4 && !O)                                                                                     \
+        hipLaunchKernelGGL((k_search_ring<4, 1, false, 8, false, false, true>), dim3(cdiv(N, 64)), blk, 0, st, g, s, body, N, \
+                           map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,            \
+                           (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter,  \
+                           own_axis, own_lo, own_hi);                                                                    \
+    else                                                                                                                 \
     hipLaunchKernelGGL((k_search_ring<L, 1, false, 8, false, O>), dim3(cdiv(N, 256 / L)), blk, 0, st, g, s, body, N, \
                        map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,                \
                        (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter, own_axis,     \

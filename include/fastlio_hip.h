@@ -312,6 +312,29 @@ int flh_esekf_update(flh_esekf* kf, double R, flh_update_stats* stats);
  * state / covariance handed over by the IMU front end (either may be NULL = keep), run the update (:960). */
 int flh_esekf_update_scan(flh_esekf* e, int slot, const double x[FLH_NSTATE], const double P[FLH_NDOF * FLH_NDOF], double R,
                           flh_update_stats* st);
+/* The node's main loop (src/laserMapping.cpp:865-969) over a sequence of scans, run natively: for each scan, hand the NEXT
+ * one to the staging thread (flh_scan_stage_async, slots 0..ring-1 in turn), make this one the active scan, set the
+ * propagated (x, P) the IMU front end produced, update (:960), optionally map_incremental (:923) with the posterior.
+ * jobs are cycled: scan i uses jobs[i % n_jobs].  slot >= 0 in a job means that scan is already staged there (nothing crosses
+ * PCIe); pts must stay valid during the call.  Statistics are summed over the scans run. */
+typedef struct flh_scan_job {
+    const void* pts;          /* feats_down_body as a host buffer (page-locked if from flh_host_alloc) */
+    size_t stride_bytes, N;
+    const double* x;          /* FLH_NSTATE: the propagated state for this scan */
+    const double* P;          /* FLH_NDOF x FLH_NDOF */
+    int slot;                 /* < 0: stage from pts; >= 0: already staged in this slot */
+} flh_scan_job;
+typedef struct flh_run_stats {
+    int64_t scans, passes, searches;
+    int64_t n_search_passes, n_nosearch_passes;
+    double ms_search_passes, ms_nosearch_passes; /* sums of flh_update_stats.pass_ms by kind */
+    double ms_map_incremental;
+} flh_run_stats;
+#define FLH_RUN_FIRST_STAGED 1 /* scan `first` was staged by the previous call (which had FLH_RUN_STAGE_NEXT) */
+#define FLH_RUN_STAGE_NEXT 2   /* while the last scan updates, stage scan first + count for the next call: a continuous stream */
+int flh_esekf_run_scans(flh_esekf* kf, const flh_scan_job* jobs, int n_jobs, int64_t first, int64_t count, int ring, double R,
+                        int with_map_incremental, double filter_size_map, int flags, flh_run_stats* stats,
+                        double x_last[FLH_NSTATE], double P_last[FLH_NDOF * FLH_NDOF]);
 /* Text of the last error a flh_esekf_* call on this filter returned (failures inside the measurement model included). */
 const char* flh_esekf_last_error(const flh_esekf* kf);
 
