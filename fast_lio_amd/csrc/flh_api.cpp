@@ -133,6 +133,10 @@ struct flh_handle {
     ncclComm_t comm = nullptr;
     int comm_size = 1, comm_rank = 0;
     // map partitioned over the ranks: only queries whose world coordinate own_axis lies in [own_lo, own_hi) are searched here
+    // launch plan of the search: number of queries the first stage left unsettled in the most recent LATER search of a scan
+    // (-1 = unknown): when it was tiny, the next later search lets the first stage finish them itself and skips the second
+    int64_t later_unsettled = -1;
+    bool last_search_was_later = false;
     int own_axis = -1;
     float own_lo = -INFINITY, own_hi = INFINITY;
     double* h_gran = nullptr;  // pinned: [kGranGroups][92] x {value, sequence} granules written by k_fit's group reducers
@@ -265,12 +269,12 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
         hipHostMalloc((void**)&h->h_counter, sizeof(u64), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_ctr, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_small, 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_gran, (size_t)kGranGroups * kGranSlots * 16, hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void**)&h->h_gran, ((size_t)kGranGroups * kGranSlots + 1) * 16, hipHostMallocDefault) != hipSuccess) {
         flh_destroy(h);
         return fail("hipHostMalloc failed");
     }
     std::memset(h->h_gram, 0, 256 * sizeof(double));
-    std::memset(h->h_gran, 0, (size_t)kGranGroups * kGranSlots * 16);
+    std::memset(h->h_gran, 0, ((size_t)kGranGroups * kGranSlots + 1) * 16);
     if (h->gram.reserve(256) != hipSuccess || h->counter.reserve(FLH_COUNTER_WORDS) != hipSuccess || h->slow_count.reserve(2 * flh::list_stripes()) != hipSuccess ||
         hipMemset(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t)) != hipSuccess) {
         flh_destroy(h);
@@ -1222,6 +1226,17 @@ static StateDev make_state(const double rot[4], const double pos[3], const doubl
     return s;
 }
 
+// 0: first stage + second stage; 1: the same with the first stage bounded by the cached neighbours (a later search of the scan);
+// 2 (experiment, FLH_SOLO=1 only): bounded first stage that finishes its few leftovers itself, no second-stage launch, when
+// the last later search left at most N/512 queries unsettled.  Measured on BASELINE configs[1]: the leftovers lengthen the
+// first stage's slowest waves by more than the second stage's launch costs (search pass 63.5 vs 61.7 us) -- hence off.
+static int search_plan(const flh_handle* h, bool host_granules) {
+    static const bool no_bound = std::getenv("FLH_NO_CACHE_BOUND") != nullptr, solo = std::getenv("FLH_SOLO") != nullptr;
+    if (!h->searched_once || h->own_axis >= 0 || no_bound) return 0;
+    if (host_granules && solo && h->later_unsettled >= 0 && h->later_unsettled * 512 <= (int64_t)h->N) return 2;
+    return 1;
+}
+
 // Group size of k_fit's first-level reduction when the group sums go to the host as granules: 16 blocks, more when that
 // would make more than kGranGroups groups; 0 = too many points for the granule path.
 static int gran_group_size(size_t N) {
@@ -1244,8 +1259,8 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
         HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
                                 h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
                                 h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr,
-                                h->own_axis, h->own_lo, h->own_hi,
-                                (h->searched_once && h->own_axis < 0 && !std::getenv("FLH_NO_CACHE_BOUND")) ? 1 : 0, st));
+                                h->own_axis, h->own_lo, h->own_hi, search_plan(h, host_granules), st));
+        h->last_search_was_later = h->searched_once;
         h->searched_once = true;
         h->search_state = s;
     }
@@ -1301,7 +1316,7 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
         const int nslots = flh::gram_slots_host(ncol);
         const int nblk = flh::fit_blocks((int)h->N);
         const int ngroups = (nblk + gran_red - 1) / gran_red;
-        const int total = ngroups * nslots;
+        const int total = ngroups * nslots + 1;  // + the count of first-stage-unsettled queries behind the last group
         const double* g = h->h_gran;
         int next = 0;
         uint64_t spins = 0;
@@ -1322,6 +1337,7 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
             const double* gg = g + 2 * (size_t)gi * nslots;
             for (int k = 0; k < nslots; ++k) sum[k] += gg[2 * k];
         }
+        if (do_search && h->last_search_was_later) h->later_unsettled = (int64_t)g[2 * (size_t)ngroups * nslots];
         double* G = h->h_gram;
         std::memset(G, 0, 256 * sizeof(double));
         for (int r = 0; r < 16; ++r)

@@ -1,12 +1,16 @@
 // flh_kernels.hip -- the HIP kernels of the hot path, written for gfx950 (CDNA4, wave64) only.
 //
-//   K0  map index build   keys -> (radix sort) -> gather -> brick/cell tables        [setup]
-//   A   k_search<LPQ>     body->world transform + exact 5-NN over the cell grid       [search passes]
-//   B   k_fit             plane fit + residual gate + 12-col Jacobian row + 16x16 Gram
-//                         contraction on v_mfma_f64_16x16x4_f64                       [every pass]
-//   R   k_reduce1/2       deterministic cross-block sum of the Gram partials          [every pass]
+//   K0  map index build     keys -> (radix sort) -> bricks, per-brick cell tables, directory            [setup]
+//   A1  k_search_ring<4,1>  body->world transform + 5-NN over the 3x3x3 cell block, 4 lanes per query    [search passes]
+//                           (later searches of a scan: the ball of the cached neighbours bounds the rows it visits)
+//   A2  k_search_ring<16,2> the queries A1 could not settle: 5x5x5 block inside A1's bound, 16 lanes per
+//                           query, finishing leftovers itself with the general exact search (exact_query)
+//   A3  k_search_exact      the general exact search as a kernel (lanes_per_query = 0, grids without ring 2)
+//   B   k_fit<ORD,HALF>     plane fit + residual gate + 12-col Jacobian row + 16x16 Gram contraction on
+//                           v_mfma_f64_16x16x4_f64 + deterministic cross-block sum                       [every pass]
+//   S   k_scan_restride / k_scan_keys / k_scan_gather   scan staging (records -> float4 + Morton key -> order)
 //
-// Reference lines replaced: src/laserMapping.cpp:650-693 (A,B), :695-752 + esekfom.hpp:1784,1804 (B,R).
+// Reference lines replaced: src/laserMapping.cpp:650-693 (A1-A3, B), :695-752 + esekfom.hpp:1784,1804 (B).
 // Built with -ffp-contract=off (see flh_device.hpp).
 #include "flh_kernels.hpp"
 
@@ -662,11 +666,16 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
         }
         if (FINAL) {
             if (live && !done2) {
-                const float ubx = fminf(BOUNDED ? fminf(d5hi, ub_in[q]) : d5hi, max_sqdist);
+                const float ubx = fminf(BOUNDED ? fminf(d5hi, ub_in[q]) : (CACHED ? fminf(d5hi, ub_raw) : d5hi), max_sqdist);
                 const uint32_t nc = exact_query<LPQ>(g, q, N, qx, qy, qz, cx, cy, cz, fx, fy, fz, ubx, rmax, max_sqdist, lane, nn_pts,
                                                      nn_d2, nn_cnt, selected);
                 if (cand_counter && lane == 0) atomicAdd(cand_counter, (u64)nc);
             }
+        }
+        if (FINAL && !in_list) {  // first stage finishing alone: only count the queries that took the slow path (for the host's
+                                  // choice of the launch plan of the next search pass), one atomic per wave
+            const u64 bslow = __ballot(live && !done && lane == 0);
+            if (bslow && (threadIdx.x & 63) == (__ffsll((long long)bslow) - 1)) atomicAdd(out_count + stripe, (uint32_t)__popcll(bslow));
         }
         // ---- unsettled queries go to the next stage's list: one global atomic per wave, 64 striped counters
         const bool append = !FINAL && live && !done2 && lane == 0;
@@ -976,6 +985,7 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int nblk = gridDim.x;
     const int red = gran ? red1 : kRed1;
+    const int ngroups_gran = gran ? (nblk + red1 - 1) / red1 : 0;
     const int group = blockIdx.x / red;
     const int ngroups = (nblk + kRed1 - 1) / kRed1;
     const int gsize = min(red, nblk - group * red);
@@ -1010,7 +1020,24 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
             asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(g2) : "memory");  // one 16-byte system-scope store
         }
         if (t == 0) tickets[1 + group] = 0;                         // re-arm this group's ticket for the next launch
-        if (group == 0 && t < 2 * kStripes) slow_count[t] = 0;      // and the A1 -> A2 work-list counters (A2 has retired)
+        if (group == 0) {
+            // the number of queries the first search stage could not settle in this pass (its work-list counters): handed to the
+            // host as one more granule behind the last group's -- it picks the launch plan of the next search pass from it --
+            // then the counters are re-armed (the second stage has retired)
+            if (t >= 192) {
+                uint32_t c = slow_count[t - 192];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+                if (t == 255) {
+                    typedef double v2f64 __attribute__((ext_vector_type(2)));
+                    const v2f64 g2 = {(double)c, seq};
+                    double* dst = gran + (size_t)ngroups_gran * gram_nslots(ncol) * 2;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(g2) : "memory");
+                }
+            }
+            __syncthreads();
+            if (t < 2 * kStripes) slow_count[t] = 0;
+        }
         FPH(7);
         FPH_DUMP();
         return;
@@ -1213,7 +1240,12 @@ hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const St
     }
     // A1: ring 1, every query
 #define FLH_A1(L, O)                                                                                                     \
-    if (cache_bound && L == 4 && !O)                                                                                     \
+    if (cache_bound == 2 && L == 4 && !O)                                                                                \
+        hipLaunchKernelGGL((k_search_ring<4, 1, false, 8, true, false, true>), dim3(cdiv(N, 64)), blk, 0, st, g, s, body, N, \
+                           map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,            \
+                           (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter,  \
+                           own_axis, own_lo, own_hi);                                                                    \
+    else if (cache_bound && L == 4 && !O)                                                                                \
         hipLaunchKernelGGL((k_search_ring<4, 1, false, 8, false, false, true>), dim3(cdiv(N, 64)), blk, 0, st, g, s, body, N, \
                            map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,            \
                            (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter,  \
@@ -1239,6 +1271,7 @@ hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const St
         }
     }
 #undef FLH_A1
+    if (cache_bound == 2 && lpq == 4 && !(first_stage == 2 && rmax >= 2)) return hipGetLastError();  // the first stage finished everything
     if (rmax >= 2) {
         // A2: ring 2 over list 1, inside the ball A1's 5th distance defines; whatever it cannot settle (distance ties, a
         // 5th neighbour beyond the 5x5x5 block) it finishes itself with the general exact search

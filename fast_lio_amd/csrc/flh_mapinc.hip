@@ -7,8 +7,10 @@
 //                     (oracle_path.c: orc_map_add) states them]
 //   k_delete_boxes    ikdtree.Delete_Point_Boxes (:275)
 //
-// The map index is rebuilt from the compacted point array after every change (O(M) per scan; an in-place merge
-// of the sorted arrays is the obvious next step).  Built with -ffp-contract=off like the rest.
+//   k_ins_prepare / k_brick_rewrite   the surviving new points enter the brick storage: only the bricks that receive points
+//                     are rewritten (LDS counting sort, in place while they fit their slack, else relocated); the whole
+//                     index is rebuilt only when something no longer fits (flh_api.cpp: apply_map_changes)
+// Built with -ffp-contract=off like the rest.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
