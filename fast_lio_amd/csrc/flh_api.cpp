@@ -149,6 +149,8 @@ struct flh_handle {
     bool stats = false;
     flh_timing timing{};
     bool searched_once = false;
+    bool d2_valid = false;    // nn_d2 holds the distances of the current neighbour cache (filled on demand, ensure_d2)
+    bool aux_valid = false;   // world / normvec hold the last evaluation's (filled on demand, ensure_aux)
     int timing_stride = 1;   // record HIP events on every n-th evaluation (0 = never)
     uint64_t eval_no = 0;
     uint64_t seq = 0;        // sequence number of the last flh_eval (published by k_fit next to the result)
@@ -744,6 +746,8 @@ static int prepare_scan_buffers(flh_handle* h, size_t N, bool full_clear) {
     h->N = N;
     h->have_eval = false;
     h->searched_once = false;
+    h->d2_valid = false;
+    h->aux_valid = false;
     h->mi_valid_N = (size_t)-1;
     return 0;
 }
@@ -1262,16 +1266,38 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
                                 h->own_axis, h->own_lo, h->own_hi, search_plan(h, host_granules), st));
         h->last_search_was_later = h->searched_once;
         h->searched_once = true;
+        h->d2_valid = false;
         h->search_state = s;
     }
     if (timed) HIPC(hipEventRecord(h->ev[1], st));
     HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
                          h->world.p, h->partials.p, h->part2.p, d_out, seq, h->tickets.p, h->slow_count.p,
-                         host_granules ? h->h_gran : nullptr, host_granules ? gran_group_size(h->N) : 0, st));
+                         host_granules ? h->h_gran : nullptr, host_granules ? gran_group_size(h->N) : 0, 0, st));
+    h->aux_valid = false;
     if (timed) HIPC(hipEventRecord(h->ev[2], st));
     h->last_state = s;
     h->last_ext = ext;
     h->have_eval = true;
+    return 0;
+}
+
+// feats_down_world / normvec of the LAST evaluation, and pointSearchSqDis of the current neighbour cache, are produced on
+// demand: the hot path neither writes nor reads them.
+static int ensure_aux(flh_handle* h) {
+    if (h->aux_valid || !h->have_eval || h->N == 0) return 0;
+    HIPC(hipSetDevice(h->device));
+    HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, h->last_state, h->cur_body, h->nn_pts.p, (int)h->N, h->last_ext,
+                         h->cfg.plane_threshold, h->selected.p, h->normvec.p, h->world.p, h->partials.p, h->part2.p, h->gram.p, 0.0,
+                         h->tickets.p, h->slow_count.p, nullptr, 0, 1, h->stream));
+    h->aux_valid = true;
+    return 0;
+}
+static int ensure_d2(flh_handle* h) {
+    if (h->d2_valid || h->N == 0) return 0;
+    if (!h->searched_once) return fail("no search on this scan yet");
+    HIPC(hipSetDevice(h->device));
+    HIPC(flh::launch_fill_d2(h->search_state, h->cur_body, h->nn_pts.p, (int)h->N, h->nn_d2.p, h->stream));
+    h->d2_valid = true;
     return 0;
 }
 
@@ -1467,6 +1493,7 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
     hipStream_t st = h->stream;
     const size_t N = h->N;
     const StateDev s_post = make_state(x + 3, x + 0, x + 7, x + 11);
+    if (ensure_d2(h) != 0) return -1;
     HIPC(h->mi_world.reserve(N ? N : 1)); HIPC(h->mi_cls.reserve(N ? N : 1));
     HIPC(flh::launch_mi_classify(h->grid, h->grid.hash_mask + 1, (uint32_t)h->M, h->search_state, s_post, h->cur_body,
                                  h->nn_pts.p, h->nn_cnt.p, h->nn_d2.p, h->cfg.max_sqdist, (int)N, filter_size_map, flg_EKF_inited,
@@ -1555,7 +1582,7 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
         } else {
             HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p,
                                  h->normvec.p, h->world.p, h->partials.p, h->part2.p, h->gram.p, 0.0, h->tickets.p, h->slow_count.p,
-                                 nullptr, 0, st));
+                                 nullptr, 0, 0, st));
         }
     }
     HIPC(hipEventRecord(h->ev[3], st));
@@ -1593,6 +1620,7 @@ int flh_fetch_neighbors(flh_handle* h, int32_t* idx, float* d2, uint8_t* cnt) {
     const size_t N = h->N;
     if (N == 0) return 0;
     HIPC(hipSetDevice(h->device));
+    if (ensure_d2(h) != 0) return -1;
     std::vector<float4> pts(5 * N);
     std::vector<float> dd(5 * N);
     std::vector<uint8_t> cc(N);
@@ -1632,6 +1660,7 @@ int flh_fetch_world(flh_handle* h, float* xyz) {
     const size_t N = h->N;
     if (N == 0) return 0;
     HIPC(hipSetDevice(h->device));
+    if (ensure_aux(h) != 0) return -1;
     std::vector<float4> w(N);
     HIPC(hipMemcpyAsync(w.data(), h->world.p, N * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
@@ -1650,6 +1679,7 @@ int flh_fetch_normvec(flh_handle* h, float* out) {
     const size_t N = h->N;
     if (N == 0) return 0;
     HIPC(hipSetDevice(h->device));
+    if (ensure_aux(h) != 0) return -1;
     std::vector<float4> nv(N);
     HIPC(hipMemcpyAsync(nv.data(), h->normvec.p, N * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
@@ -1685,6 +1715,7 @@ static int fetch_rows_local(flh_handle* h, double* hx, double* hv, int64_t cap, 
     std::vector<float4> nv(N ? N : 1);
     if (N) {
         HIPC(hipSetDevice(h->device));
+        if (ensure_aux(h) != 0) return -1;
         HIPC(hipMemcpyAsync(sel.data(), h->selected.p, N, hipMemcpyDeviceToHost, h->stream));
         HIPC(hipMemcpyAsync(nv.data(), h->normvec.p, N * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
         HIPC(hipStreamSynchronize(h->stream));

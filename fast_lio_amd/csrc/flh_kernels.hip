@@ -624,8 +624,7 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
                             e += (i < m && (da[i] < dv[r] || (da[i] == dv[r] && ia[i] < myid))) ? 1 : 0;
                     }
                     if (e < 5) {
-                        nn_pts[(size_t)e * N + q] = pv[r];
-                        nn_d2[(size_t)e * N + q] = dv[r];
+                        nn_pts[(size_t)e * N + q] = pv[r];  // the squared distances are not stored: k_fill_d2 recomputes them on demand
                         if (e == 4) selected[q] = (j < m && !(dv[r] > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
                     }
                 }
@@ -745,7 +744,7 @@ __device__ __forceinline__ void top5_finish(Top5& L, const GridParams& g, int q,
             float4 v = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
             if (has) v = g.pts[pp];
             nn_pts[(size_t)jr * N + q] = v;
-            nn_d2[(size_t)jr * N + q] = has ? __uint_as_float((uint32_t)(kk >> 32)) : INFINITY;
+            (void)kk;
         }
     }
     if (lane == 0) {
@@ -873,7 +872,11 @@ __global__ void __launch_bounds__(256)
 k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn_pts, int N, int ext, float thr,
       uint8_t* __restrict__ selected, float4* __restrict__ normvec, float4* __restrict__ world,
       double* __restrict__ partials, double* __restrict__ part2, double* __restrict__ out256, double seq,
-      uint32_t* __restrict__ tickets, uint32_t* __restrict__ slow_count, double* __restrict__ gran, int red1, int ncol) {
+      uint32_t* __restrict__ tickets, uint32_t* __restrict__ slow_count, double* __restrict__ gran, int red1, int ncol,
+      int store_aux) {
+    // store_aux: also write feats_down_world and normvec (16 B per point each).  The filter never reads them, so the passes of an
+    // update leave them out; a fetch (flh_fetch_world / _normvec / _rows) re-runs this kernel once with the flag set -- the
+    // arithmetic is deterministic, so that run reproduces the pass bit for bit.
     __shared__ double lds[4 * 64 * kTileStride];
     __shared__ uint32_t s_ticket;
 #ifdef FLH_PHASES
@@ -900,7 +903,7 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
     for (int j = 0; j < 5; ++j) nn[j] = nn_pts[(size_t)j * N + ic];
     if (i < N) {  // feats_down_world is rewritten for every point on every pass (laserMapping.cpp:656-661)
         body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
-        world[i] = make_float4(wx, wy, wz, 0.f);
+        if (store_aux) world[i] = make_float4(wx, wy, wz, 0.f);
     }
     FPH(1);  // point loaded + transformed
     if (i < N && sel_in) {  // laserMapping.cpp:674
@@ -922,7 +925,7 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
         }
         selected[i] = sel ? 1 : 0;
         if (sel) {
-            normvec[i] = make_float4(pabcd[0], pabcd[1], pabcd[2], pd2);  // :686-689
+            if (store_aux) normvec[i] = make_float4(pabcd[0], pabcd[1], pabcd[2], pd2);  // :686-689
             // Jacobian row, fp64 (:723-752)
             const double bx = (double)b.x, by = (double)b.y, bz = (double)b.z;
             double px, py, pz;
@@ -1325,6 +1328,27 @@ hipError_t launch_publish256(const double* src, double* out256, double seq, hipS
     return hipGetLastError();
 }
 
+// pointSearchSqDis on demand: the squared distances of the cached neighbours to the query's world position at the state of
+// the search that found them -- the very expression (and bits) the search compared; rows without a neighbour get +inf.
+__global__ void __launch_bounds__(256) k_fill_d2(StateDev s_search, const float4* __restrict__ body, const float4* __restrict__ nn_pts,
+                                                 int N, float* __restrict__ nn_d2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float4 b = body[i];
+    float wx, wy, wz;
+    body_to_world(s_search, b.x, b.y, b.z, wx, wy, wz);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const float4 p = nn_pts[(size_t)j * N + i];
+        nn_d2[(size_t)j * N + i] = (__float_as_uint(p.w) == 0xFFFFFFFFu) ? INFINITY : dist2(wx, wy, wz, p.x, p.y, p.z);
+    }
+}
+hipError_t launch_fill_d2(const StateDev& s_search, const float4* body, const float4* nn_pts, int N, float* nn_d2, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_d2, dim3(cdiv(N, 256)), dim3(256), 0, st, s_search, body, nn_pts, N, nn_d2);
+    return hipGetLastError();
+}
+
 int fit_blocks(int N) { return cdiv(N > 0 ? N : 1, 256); }
 int reduce1_blocks(int nblk, int* per_out) {
     if (per_out) *per_out = kRed1;
@@ -1333,15 +1357,16 @@ int reduce1_blocks(int nblk, int* per_out) {
 
 hipError_t launch_fit(int order, int half_fit, const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
                       uint8_t* selected, float4* normvec, float4* world, double* partials, double* part2,
-                      double* out256, double seq, uint32_t* tickets, uint32_t* slow_count, double* gran, int red1, hipStream_t st) {
+                      double* out256, double seq, uint32_t* tickets, uint32_t* slow_count, double* gran, int red1, int store_aux,
+                      hipStream_t st) {
     const int nblk = fit_blocks(N);
     const int ncol = ext ? 12 : 6;
 #define FLH_FIT(O)                                                                                                      \
     hipLaunchKernelGGL((k_fit<O, false>), dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world, \
-                       partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol)
+                       partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux)
     if (half_fit) {  // the fp16 ablation exists for the default summation order only
         hipLaunchKernelGGL((k_fit<1, true>), dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world,
-                           partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol);
+                           partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux);
         return hipGetLastError();
     }
     switch (order) {
