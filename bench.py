@@ -100,16 +100,20 @@ def main():
     ap.add_argument("--first-stage", type=int, default=0)
     ap.add_argument("--sort", type=int, default=1, help="Morton-order the scan at staging (0 = keep input order)")
     ap.add_argument("--extrinsic-est", type=int, default=0)
-    ap.add_argument("--timing-samples", type=int, default=24,
+    ap.add_argument("--timing-samples", type=int, default=16,
                     help="evaluations of the timed region whose kernels are bracketed by HIP events (>= 16)")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the headline + roofline (profiling runs)")
     ap.add_argument("--cpu-scans", type=int, default=3, help="scans timed on the CPU oracle per thread count (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=3, help="OpenMP threads (reference MP_PROC_NUM = 3)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo for debugging")
     ap.add_argument("--single-device", type=int, default=0, help="debug: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--leg", default="", help="internal: run only the named group of side legs (used by the child process)")
+    ap.add_argument("--two-streams", action="store_true", help="side legs: also time two scan streams on one GPU")
     ap.add_argument("--force-shard-leg", action="store_true",
                     help="debug: run the shard / partition leg on ONE rank too (a one-rank RCCL communicator), to exercise its code")
     args = ap.parse_args()
+    if args.leg == "extras":
+        return extra_legs(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,10 +198,11 @@ def main():
         loop, scan i+1 staged while scan i updates) bracketed by barrier + device synchronisation; max over ranks."""
         # the stream does not stop at the boundary of the timed region: the first timed scan is staged while the last
         # warm-up scan updates, exactly as every later scan is staged while its predecessor updates
-        kfx.run_scans(jobs, 0, n_warm, ring=RING, map_incremental=with_map_inserts, stage_next=True)
-        # keep Python's cyclic GC out of the timed region, as timeit does
+        # keep Python's cyclic GC out of the timed region, as timeit does (collected before the warm-up so that the device does
+        # not sit idle between the warm-up scans and the timed ones any longer than the synchronisation takes)
         gc.collect()
         gc.disable()
+        kfx.run_scans(jobs, 0, n_warm, ring=RING, map_incremental=with_map_inserts, stage_next=True)
         sync()
         hx.set_timing_stride(max(1, (n_steps * 4) // max(args.timing_samples, 16)))
         hx.counters(reset=True)
@@ -230,49 +235,54 @@ def main():
     # rank reduces its part to the 16x16 Gram block in device memory and RCCL sums the blocks INSIDE flh_eval (native
     # call site, no Python and no D2H in the pass); every rank then runs the identical 23x23 solve.
     if run_shard_leg:
-        partition = args.mode == "partition" or (args.mode == "auto" and args.config == 5)
-        uid = [capi.rccl_unique_id() if rank == 0 else None]
-        if dist is not None:
-            dist.broadcast_object_list(uid, src=0)
-        hs = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
-                         first_stage=args.first_stage)
-        hs.rccl_init_rank(G, uid[0], rank)
-        if partition:
-            axis, edges = fdist.partition_bounds(scene.map_xyz, G)
-            keep = fdist.partition_slab(scene.map_xyz, axis, edges, rank, fdist.HALO_DEFAULT)
-            hs.map_build(scene.map_xyz[keep])
-            hs.set_owned_interval(axis, edges[rank], edges[rank + 1])
-            for s, p in enumerate(sh_probs):
-                hs.scan_stage(s, p.body)
-            pts_here = N
-        else:
-            hs.map_build(scene.map_xyz)
-            for s, p in enumerate(sh_probs):
-                hs.scan_stage(s, np.ascontiguousarray(p.body[fdist.morton_shard(p.body, rank, G)]))
-            pts_here = hi - lo
-        kfs = capi.Esekf(hs, max_iter=3, extrinsic_est_en=ext)
-        jobs_sh = capi.Esekf.make_jobs([np.zeros((1, 3), np.float32)] * S_sh, sh_priors, slots=list(range(S_sh)))
-        k2 = args.steps if mode in ("shard", "partition") else max(10, min(60, args.steps // 4))
-        dt2, acc2, ctr2 = run(kfs, hs, jobs_sh, max(3, args.warmup // 4), k2)
-        # every rank must have produced the same posterior
-        xs = [kfs.get_x()] * G
-        if dist is not None:
-            dist.all_gather_object(xs, kfs.get_x())
-        agree = float(max(np.abs(np.asarray(x_) - np.asarray(xs[0])).max() for x_ in xs))
-        shard_out = {"value": round(k2 / dt2, 3), "unit": "scans/s", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 4),
-                     "ms_per_iekf_pass": round(dt2 / max(acc2.passes, 1) * 1e3, 4),
-                     "layout": ("map partitioned into slabs (+%.2f m halo), whole scan on every rank, queries owned by position" % fdist.HALO_DEFAULT
-                                if partition else "scan sharded Morton-first, map replicated"),
-                     "points_per_rank": pts_here, "map_points_this_rank": hs.M,
-                     "collective": "ncclAllReduce(sum) of 256 f64 per pass, issued by flh_eval on the handle's stream (RCCL over xGMI)",
-                     "ranks_in_communicator": hs.rccl_size(),
-                     "max_abs_state_disagreement_across_ranks": agree, "scaling": "strong"}
-        if mode in ("shard", "partition"):
-            dt, acc, ctr = dt2, acc2, ctr2
-            units = args.steps
-            n_pts = pts_here
-        kfs.close()
-        hs.close()
+        try:
+            partition = args.mode == "partition" or (args.mode == "auto" and args.config == 5)
+            uid = [capi.rccl_unique_id() if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(uid, src=0)
+            hs = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
+                             first_stage=args.first_stage)
+            hs.rccl_init_rank(G, uid[0], rank)
+            if partition:
+                axis, edges = fdist.partition_bounds(scene.map_xyz, G)
+                keep = fdist.partition_slab(scene.map_xyz, axis, edges, rank, fdist.HALO_DEFAULT)
+                hs.map_build(scene.map_xyz[keep])
+                hs.set_owned_interval(axis, edges[rank], edges[rank + 1])
+                for s, p in enumerate(sh_probs):
+                    hs.scan_stage(s, p.body)
+                pts_here = N
+            else:
+                hs.map_build(scene.map_xyz)
+                for s, p in enumerate(sh_probs):
+                    hs.scan_stage(s, np.ascontiguousarray(p.body[fdist.morton_shard(p.body, rank, G)]))
+                pts_here = hi - lo
+            kfs = capi.Esekf(hs, max_iter=3, extrinsic_est_en=ext)
+            jobs_sh = capi.Esekf.make_jobs([np.zeros((1, 3), np.float32)] * S_sh, sh_priors, slots=list(range(S_sh)))
+            k2 = args.steps if mode in ("shard", "partition") else max(10, min(60, args.steps // 4))
+            dt2, acc2, ctr2 = run(kfs, hs, jobs_sh, max(3, args.warmup // 4), k2)
+            # every rank must have produced the same posterior
+            xs = [kfs.get_x()] * G
+            if dist is not None:
+                dist.all_gather_object(xs, kfs.get_x())
+            agree = float(max(np.abs(np.asarray(x_) - np.asarray(xs[0])).max() for x_ in xs))
+            shard_out = {"value": round(k2 / dt2, 3), "unit": "scans/s", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 4),
+                         "ms_per_iekf_pass": round(dt2 / max(acc2.passes, 1) * 1e3, 4),
+                         "layout": ("map partitioned into slabs (+%.2f m halo), whole scan on every rank, queries owned by position" % fdist.HALO_DEFAULT
+                                    if partition else "scan sharded Morton-first, map replicated"),
+                         "points_per_rank": pts_here, "map_points_this_rank": hs.M,
+                         "collective": "ncclAllReduce(sum) of 256 f64 per pass, issued by flh_eval on the handle's stream (RCCL over xGMI)",
+                         "ranks_in_communicator": hs.rccl_size(),
+                         "max_abs_state_disagreement_across_ranks": agree, "scaling": "strong"}
+            if mode in ("shard", "partition"):
+                dt, acc, ctr = dt2, acc2, ctr2
+                units = args.steps
+                n_pts = pts_here
+            kfs.close()
+            hs.close()
+        except Exception as e:  # the side leg must not cost the headline line (streams mode); in shard / partition mode it IS the headline
+            if mode in ("shard", "partition"):
+                raise
+            shard_out = {"error": repr(e)[:400]}
     value = units / dt
     ms_per_step = dt / args.steps * 1e3
 
@@ -329,7 +339,7 @@ def main():
         out["ms_map_incremental_per_scan"] = round(acc_mi, 4)
     if G > 1 and dist is not None:
         out["ranks_seen_by_collective"] = int(dist.get_world_size())
-        out["ranks_in_rccl_communicator"] = shard_out["ranks_in_communicator"] if shard_out else None
+        out["ranks_in_rccl_communicator"] = shard_out.get("ranks_in_communicator") if shard_out else None
 
     # ---- the same update with the scans already resident in HBM (staged before the timed loop): what round 1 reported
     # as `value`.  Not PCIe-inclusive, hence a sub-field.
@@ -362,46 +372,6 @@ def main():
     if shard_out is not None and mode not in ("shard", "partition"):
         out["shard_mode"] = shard_out
 
-    # ---- two independent scan streams in flight on this GPU (two handles, two host threads): while one stream's host
-    # solves its 23x23 system the other's kernels run.  Same work per scan, so this is the GPU's throughput with the host
-    # turn-around hidden; the headline `value` stays one stream per GPU (the latency a single LiDAR stream sees).
-    if extra and not with_map_inserts:
-        import threading
-
-        h2 = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
-                         first_stage=args.first_stage)
-        h2.map_build(scene.map_xyz)
-        Sd = min(S, 32)
-        for s in range(Sd):
-            h2.scan_stage(16 + s, bodies[s])
-        kf2 = capi.Esekf(h2, max_iter=3, extrinsic_est_en=ext)
-        h2.set_timing_stride(0)
-        per = max(args.steps // 2, 8)
-
-        jobs2 = capi.Esekf.make_jobs(bodies[:Sd], priors[:Sd], slots=[16 + s for s in range(Sd)])
-
-        def worker(kfx, off):
-            kfx.run_scans(jobs2, off, per, ring=RING)
-
-        for kfx in (kf, kf2):  # warm-up
-            worker(kfx, 0)
-        torch.cuda.synchronize()
-        gc.collect()
-        gc.disable()
-        th = [threading.Thread(target=worker, args=(kf, 0)), threading.Thread(target=worker, args=(kf2, Sd // 2))]
-        t1 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t1
-        gc.enable()
-        out["two_streams_per_gpu"] = {"scans_per_s": round(2 * per / dt2, 3), "scans": 2 * per,
-                                      "note": "two independent scan streams (device-resident scans), one handle + one host thread each, same GPU"}
-        kf2.close()
-        h2.close()
-
     # ---- CPU baseline: the oracle's restated reference path on this box's host cores (rank 0, N=1 only), at the
     # reference's own thread count (MP_PROC_NUM = 3, CMakeLists.txt:21-24) and at all host cores
     if rank == 0 and G == 1 and args.cpu_scans > 0:
@@ -430,73 +400,159 @@ def main():
                                "speedup_vs_cpu": round(value / r3, 1),
                                "all_cores": {"value": round(rall, 4), "cores": ncores, "speedup_vs_cpu": round(value / rall, 1)}}
 
-    # ---- map_incremental (classification + Add_Points into the device map) after an update.
-    # Outside the timed region and last, because it grows the map.  t_map = classify + insert + re-index, the
-    # reference's "Incremental Mapping" timer (src/laserMapping.cpp:921-924).
+    # ---- the legs beside the headline (map_incremental, the raw-scan front end incl. frame_world, optionally two scan
+    # streams on one GPU) run in a CHILD process after this one has finished its own GPU work: they are reported beside
+    # the contract fields, never part of them, and a failure there must not cost the line
     if extra:
-        t_cls = t_all = 0.0
-        added = 0
-        reps = min(3, S)
-        for s in range(reps):
-            kf.update_scan(16 + s, priors[s][0], priors[s][1], 0.001)
-            xpost = kf.get_x()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            h.map_incremental(xpost, 0.5, True, apply=False)
-            t2 = time.perf_counter()
-            m0 = h.M
-            n1, n2 = h.map_incremental(xpost, 0.5, True, apply=True)
-            t3 = time.perf_counter()
-            t_cls += t2 - t1
-            t_all += t3 - t2
-            added += h.M - m0
-        out["map_incremental"] = {"ms_per_scan": round(t_all / reps * 1e3, 3), "classify_only_ms": round(t_cls / reps * 1e3, 3),
-                                  "net_points_added_per_scan": round(added / reps, 1), "scans": reps,
-                                  "note": "filter_size_map 0.5; only the touched bricks are rewritten (slack-carrying brick storage)"}
-
-    # ---- the raw-scan front end (undistortion + VoxelGrid + staging) for one raw scan handed over
-    # as a host buffer, and publish_frame_world's dense cloud: PCIe-inclusive by nature, reported beside the headline.
-    if extra:
-        rng = np.random.default_rng(11)
-        body = probs[0].body
-        raw = np.repeat(body, 3, axis=0) + rng.normal(0, 0.03, (3 * len(body), 3)).astype(np.float32)
-        tms = np.repeat(rng.uniform(0.0, 100.0, len(body)), 3).astype(np.float32)  # neighbours in space are neighbours in time
-        pts = capi.pinned_empty((len(raw), 4), np.float32)
-        pts[:, :3] = raw
-        pts[:, 3] = tms
-        poses, x_end = synth.imu_poses(priors[0][0], capi.predict_fn)
-        h.scan_stage_undistorted(0, pts, poses, x_end, 0.5, want_undistorted=False)  # warm-up (allocations)
-        torch.cuda.synchronize()
-        reps = 5
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            n_down, _u = h.scan_stage_undistorted(0, pts, poses, x_end, 0.5, want_undistorted=False)
-        h.scan_wait(0)
-        torch.cuda.synchronize()
-        t_fe = (time.perf_counter() - t1) / reps
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            h.scan_stage_undistorted(0, pts, poses, x_end, 0.5, want_undistorted=True)
-        t_fe_back = (time.perf_counter() - t1) / reps
-        h.frame_world(x_end, slot=0, dense=True)
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            h.frame_world(x_end, slot=0, dense=True)
-        t_fw = (time.perf_counter() - t1) / reps
-        out["scan_front_end"] = {"raw_points": int(len(pts)), "feats_down_size": int(n_down),
-                                 "undistort_voxelgrid_stage_ms": round(t_fe * 1e3, 3),
-                                 "same_with_feats_undistort_copied_back_ms": round(t_fe_back * 1e3, 3),
-                                 "frame_world_dense_ms": round(t_fw * 1e3, 3),
-                                 "note": "page-locked host buffer in; filter_size_surf 0.5; frame_world = RGBpointBodyToWorld over "
-                                         "the device-resident feats_undistort + D2H (publish_frame_world, dense_pub_en)"}
+        kf.close()
+        h.close()
+        kf = h = None
+        out.update(run_extra_legs_in_child(args))
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    kf.close()
-    h.close()
+    if kf is not None:
+        kf.close()
+        h.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_extra_legs_in_child(args):
+    """python bench.py --leg extras ... in a child process; returns its dict (or an error note)."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", "extras", "--config", str(args.config), "--lpq", str(args.lpq),
+           "--cell", str(args.cell), "--first-stage", str(args.first_stage), "--sort", str(args.sort),
+           "--extrinsic-est", str(args.extrinsic_est), "--steps", str(args.steps)]
+    if args.two_streams:
+        cmd.append("--two-streams")
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+        lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"extra_legs_error": f"child exited with {r.returncode}: {r.stderr.decode()[-300:]}"}
+    except Exception as e:  # timeout, spawn failure
+        return {"extra_legs_error": repr(e)[:300]}
+
+
+def extra_legs(args):
+    """The child: SURVEY 8(f) timings beside the headline.  Prints one JSON dict."""
+    import torch
+
+    M, N, sensor = CONFIGS[args.config]
+    ext = bool(args.extrinsic_est)
+    scene = synth.make_scene(M, synth.CONFIG_SEED_BASE + args.config)
+    S = 3
+    probs = [synth.make_problem(M, N, sensor, cfg=args.config, scan_seed=s, scene=scene) for s in range(S)]
+    priors = [synth.propagate_prior_cov(capi.predict_fn, p.x_prior) for p in probs]
+    priors = [(np.ascontiguousarray(x, np.float64), np.ascontiguousarray(P, np.float64)) for x, P in priors]
+    bodies = []
+    for p in probs:
+        a = capi.pinned_empty((N, 3), np.float32)
+        a[:] = p.body
+        bodies.append(a)
+    h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, sort_queries=args.sort, first_stage=args.first_stage)
+    h.map_build(scene.map_xyz)
+    h.set_timing_stride(0)
+    for s in range(S):
+        h.scan_stage(16 + s, bodies[s])
+    kf = capi.Esekf(h, max_iter=3, extrinsic_est_en=ext)
+    out = {}
+
+    if args.two_streams:
+        # two independent scan streams in flight on this GPU (two handles, two host threads): while one stream's host solves
+        # its 23x23 system the other's kernels run
+        import threading
+
+        h2 = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, sort_queries=args.sort, first_stage=args.first_stage)
+        h2.map_build(scene.map_xyz)
+        h2.set_timing_stride(0)
+        for s in range(S):
+            h2.scan_stage(16 + s, bodies[s])
+        kf2 = capi.Esekf(h2, max_iter=3, extrinsic_est_en=ext)
+        per = max(args.steps // 2, 8)
+        jobs2 = capi.Esekf.make_jobs(bodies, priors, slots=[16 + s for s in range(S)])
+
+        def worker(kfx, off):
+            kfx.run_scans(jobs2, off, per, ring=RING)
+
+        for kfx in (kf, kf2):
+            worker(kfx, 0)
+        torch.cuda.synchronize()
+        th = [threading.Thread(target=worker, args=(kf, 0)), threading.Thread(target=worker, args=(kf2, 1))]
+        t1 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        out["two_streams_per_gpu"] = {"scans_per_s": round(2 * per / dt2, 3), "scans": 2 * per,
+                                      "note": "two independent scan streams (device-resident scans), one handle + one host thread each, same GPU"}
+        kf2.close()
+        h2.close()
+
+    # ---- SURVEY 8(f) row 1: map_incremental (classification + Add_Points into the device map) after an update.
+    # t_map = classify + insert + re-index, the reference's "Incremental Mapping" timer (src/laserMapping.cpp:921-924).
+    t_cls = t_all = 0.0
+    added = 0
+    for s in range(S):
+        kf.update_scan(16 + s, priors[s][0], priors[s][1], 0.001)
+        xpost = kf.get_x()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        h.map_incremental(xpost, 0.5, True, apply=False)
+        t2 = time.perf_counter()
+        m0 = h.M
+        h.map_incremental(xpost, 0.5, True, apply=True)
+        t3 = time.perf_counter()
+        t_cls += t2 - t1
+        t_all += t3 - t2
+        added += h.M - m0
+    out["map_incremental"] = {"ms_per_scan": round(t_all / S * 1e3, 3), "classify_only_ms": round(t_cls / S * 1e3, 3),
+                              "net_points_added_per_scan": round(added / S, 1), "scans": S,
+                              "note": "filter_size_map 0.5; only the touched bricks are rewritten (slack-carrying brick storage)"}
+
+    # ---- SURVEY 8(f) rows 2-4: the raw-scan front end (undistortion + VoxelGrid + staging) for one raw scan handed over
+    # as a host buffer, and publish_frame_world's dense cloud: PCIe-inclusive by nature.
+    rng = np.random.default_rng(11)
+    body = probs[0].body
+    raw = np.repeat(body, 3, axis=0) + rng.normal(0, 0.03, (3 * len(body), 3)).astype(np.float32)
+    tms = np.repeat(rng.uniform(0.0, 100.0, len(body)), 3).astype(np.float32)  # neighbours in space are neighbours in time
+    pts = capi.pinned_empty((len(raw), 4), np.float32)
+    pts[:, :3] = raw
+    pts[:, 3] = tms
+    poses, x_end = synth.imu_poses(priors[0][0], capi.predict_fn)
+    h.scan_stage_undistorted(0, pts, poses, x_end, 0.5, want_undistorted=False)  # warm-up (allocations)
+    torch.cuda.synchronize()
+    reps = 5
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        n_down, _u = h.scan_stage_undistorted(0, pts, poses, x_end, 0.5, want_undistorted=False)
+    h.scan_wait(0)
+    torch.cuda.synchronize()
+    t_fe = (time.perf_counter() - t1) / reps
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        h.scan_stage_undistorted(0, pts, poses, x_end, 0.5, want_undistorted=True)
+    t_fe_back = (time.perf_counter() - t1) / reps
+    h.frame_world(x_end, slot=0, dense=True)
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        h.frame_world(x_end, slot=0, dense=True)
+    t_fw = (time.perf_counter() - t1) / reps
+    out["scan_front_end"] = {"raw_points": int(len(pts)), "feats_down_size": int(n_down),
+                             "undistort_voxelgrid_stage_ms": round(t_fe * 1e3, 3),
+                             "same_with_feats_undistort_copied_back_ms": round(t_fe_back * 1e3, 3),
+                             "frame_world_dense_ms": round(t_fw * 1e3, 3),
+                             "note": "page-locked host buffer in; filter_size_surf 0.5; frame_world = RGBpointBodyToWorld over "
+                                     "the device-resident feats_undistort + D2H (publish_frame_world, dense_pub_en)"}
+    print(json.dumps(out), flush=True)
+    kf.close()
+    h.close()
 
 
 if __name__ == "__main__":

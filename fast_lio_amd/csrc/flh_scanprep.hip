@@ -56,7 +56,9 @@ __global__ void __launch_bounds__(256) k_vg_reduce(const float4* __restrict__ ra
 // carried from its own sampling time to the scan-end frame.  raw.w = the point's time offset in ms (PointType::curvature).
 // pose rows: 22 doubles each = {offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]} (msg/Pose6D.msg).
 // Segment of a point = the last k <= n_pose-2 with offset_time[k] < t (what the reference's back-to-front sweep over the
-// time-sorted cloud amounts to; no ordering of the offset_times is assumed); a point no segment claims stays as it is.  Exp() = so3_math.h:36-58.
+// time-sorted cloud amounts to; no ordering of the offset_times is assumed); a point no segment claims stays as it is.
+// Not reproduced: the reference's loop re-compensates the earliest point once per earlier segment when that point is younger
+// than IMUpose[1] (`if (it_pcl == begin) break` leaves without stepping past it, :345) -- see oracle_path.c.  Exp() = so3_math.h:36-58.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_undistort(StateDev s_end, const double* __restrict__ poses, int n_pose,
                                                    const float4* __restrict__ raw, uint32_t n, float4* __restrict__ out) {

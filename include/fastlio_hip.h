@@ -160,7 +160,10 @@ int flh_scan_stage_downsampled(flh_handle* h, int slot, const void* pts, size_t 
  * flh_eval_device), time_offset_bytes = where the float time offset in ms (PointType::curvature) sits in a point record.
  * A point at time t is carried to the scan-end frame with the LAST segment k <= n_pose-2 whose offset_time is < t
  * (what the reference's back-to-front sweep over the time-sorted cloud amounts to, also when the first IMU sample
- * precedes the first point and offset_time[1] < offset_time[0] = 0); a point no segment claims is left as it is.  The cloud is NOT re-ordered by time (the reference's sort only serves its sweep).
+ * precedes the first point and offset_time[1] < offset_time[0] = 0); a point no segment claims is left as it is.  The cloud
+ * is NOT re-ordered by time (the reference's sort only serves its sweep).  One deliberate deviation: the reference's loop
+ * (:326-346) compensates the EARLIEST point of the cloud once more per earlier segment when that point is younger than
+ * IMUpose[1] (it breaks at begin() without stepping past it); here that point is carried once, like every other.
  * leaf_size <= 0 skips the down-sampling; undistorted_xyz (optional, 3*n floats) receives feats_undistort. */
 typedef struct flh_pose6d {
     double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9];

@@ -1055,7 +1055,13 @@ size_t orc_voxel_grid(const float* in, size_t stride, size_t n, float leaf, floa
    The reference first sorts the cloud by curvature (= time offset in ms, :234) and sweeps segments from the back;
    since every point is handled independently the sweep reduces to: segment k = the LAST k <= n_pose-2 with
    poses[k].offset_time < t (a segment skipped for a later point has offset_time >= that point's time, hence >= every
-   earlier point's too); a point no segment claims is left untouched, as the sweep never reaches it.  No ordering of the
+   earlier point's too); a point no segment claims is left untouched, as the sweep never reaches it.
+   ONE DELIBERATE DEVIATION (ADVICE r1): the reference's inner loop leaves through `if (it_pcl == begin) break` WITHOUT
+   stepping past the first point (:345), so the earliest point of the cloud -- and only that one -- is compensated AGAIN by
+   every earlier segment whose head is older than it, each time on its already-moved coordinates.  That happens only when the
+   earliest point is younger than IMUpose[1] (> ~5 ms into the scan at 200 Hz); it is an artefact of the loop, not a model
+   of anything, concerns one point per scan, and is NOT reproduced here nor in the product (fast_lio_amd/csrc/flh_scanprep.hip:
+   k_undistort): that point is carried once, with its own segment, like every other point.  No ordering of the
    offset_times is assumed: IMUpose[1] precedes IMUpose[0] = 0 whenever the first IMU sample is older than the first point.  The order of the output is the order of the input: the
    reference's (unstable) sort order is not reproduced.
    Exp() is so3_math.h:36-58.  Double arithmetic in source order; Eigen's internal evaluation order of the 3x3
