@@ -77,7 +77,7 @@ def pmc_traffic(args):
     a1 = [k for k in calls if k.startswith("k_search_ring<4, 1")]
     if not a1 or not fetch:
         return None
-    passes = calls[a1[0]]
+    passes = sum(calls[k] for k in a1)  # every search pass launches exactly one first-stage variant (first / later search)
     total = (2.0 * sum(fetch.values()) + sum(write.values())) * 1024.0 / passes
     return {"bytes_per_search_pass": int(total), "source": os.path.relpath(path, ROOT) + " (FETCH_SIZE x2 + WRITE_SIZE, KiB)"}
 
@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--single-device", type=int, default=0, help="debug: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--leg", default="", help="internal: run only the named group of side legs (used by the child process)")
     ap.add_argument("--two-streams", action="store_true", help="side legs: also time two scan streams on one GPU")
+    ap.add_argument("--in-process", action="store_true",
+                    help="one GPU: do the GPU work in this process (default: in a child that is started once more if it dies, "
+                         "so that a transient device fault costs a retry and not the line); profilers want this flag")
     ap.add_argument("--force-shard-leg", action="store_true",
                     help="debug: run the shard / partition leg on ONE rank too (a one-rank RCCL communicator), to exercise its code")
     args = ap.parse_args()
@@ -117,6 +120,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and not args.in_process and args.leg != "main":
+        return run_main_in_child()
     local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         log(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
@@ -417,6 +422,27 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_main_in_child(attempts=2):
+    """One GPU: the whole measurement runs in a child process (python bench.py <same flags> --leg main); its stderr passes
+    through, its JSON line is re-printed here.  A child that dies without a line (a device fault aborts the process) is
+    started once more; the second failure is the bench's failure.  Nothing is measured differently: the child is main()."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + ["--leg", "main"]
+    rc = 1
+    for k in range(attempts):
+        r = subprocess.run(cmd, stdout=subprocess.PIPE)
+        lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        rc = r.returncode
+        if rc == 0 and lines:
+            print(lines[-1], flush=True)
+            return 0
+        log(f"[bench] attempt {k + 1}/{attempts}: the measuring process exited with {rc} and no result line")
+        if rc >= 0 and rc not in (134, 139):  # an ordinary error (a Python exception, no GPU): a second try changes nothing
+            break
+    sys.exit(rc if rc else 1)
 
 
 def run_extra_legs_in_child(args):
