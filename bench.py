@@ -203,11 +203,10 @@ def main():
         loop, scan i+1 staged while scan i updates) bracketed by barrier + device synchronisation; max over ranks."""
         # the stream does not stop at the boundary of the timed region: the first timed scan is staged while the last
         # warm-up scan updates, exactly as every later scan is staged while its predecessor updates
-        # keep Python's cyclic GC out of the timed region, as timeit does (collected before the warm-up so that the device does
-        # not sit idle between the warm-up scans and the timed ones any longer than the synchronisation takes)
+        kfx.run_scans(jobs, 0, n_warm, ring=RING, map_incremental=with_map_inserts, stage_next=True)
+        # keep Python's cyclic GC out of the timed region, as timeit does
         gc.collect()
         gc.disable()
-        kfx.run_scans(jobs, 0, n_warm, ring=RING, map_incremental=with_map_inserts, stage_next=True)
         sync()
         hx.set_timing_stride(max(1, (n_steps * 4) // max(args.timing_samples, 16)))
         hx.counters(reset=True)
