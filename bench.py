@@ -130,7 +130,8 @@ def main():
     import torch
 
     if not torch.cuda.is_available() or not capi.device_available():
-        raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+        log("bench.py needs a GPU (the product has no CPU fallback)")
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
     dist = None
     if G > 1:
@@ -331,7 +332,8 @@ def main():
                                    (f"scan points sharded over {G} ranks + all-reduce of the 16x16 normal-equation block "
                                     f"per pass" if mode in ("shard", "partition") else
                                     f"{G} independent scan streams (one per rank), replicated map, no collective in the data path")),
-                   "distinct_scans": S, "cell_size_m": args.cell, "lanes_per_query": args.lpq, "first_stage": args.first_stage},
+                   "distinct_scans": S, "cell_size_m": args.cell, "lanes_per_query": args.lpq, "first_stage": args.first_stage,
+                   "event_reading": "synchronous" if os.environ.get("FLH_SYNC_EVENTS") else "deferred"},
         "ms_per_iekf_pass": round((acc.ms_s + acc.ms_n) / max(acc.passes, 1), 4),
         "ms_search_pass": round(acc.ms_s / max(acc.n_s, 1), 4),
         "ms_nosearch_pass": round(acc.ms_n / max(acc.n_n, 1), 4),
@@ -432,16 +434,24 @@ def run_main_in_child(attempts=2):
     cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + ["--leg", "main"]
     rc = 1
     for k in range(attempts):
-        r = subprocess.run(cmd, stdout=subprocess.PIPE)
-        lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
-        rc = r.returncode
+        env = dict(os.environ)
+        if k > 0:
+            # the second attempt reads its roofline events synchronously (the library's older, longer-proven way); it costs
+            # throughput in short runs -- the line says so in config.event_reading
+            env["FLH_SYNC_EVENTS"] = "1"
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, timeout=1500)
+            rc, out = r.returncode, r.stdout
+        except subprocess.TimeoutExpired as e:
+            rc, out = -9, (e.stdout or b"")
+        lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{")]
         if rc == 0 and lines:
             print(lines[-1], flush=True)
             return 0
         log(f"[bench] attempt {k + 1}/{attempts}: the measuring process exited with {rc} and no result line")
-        if rc >= 0 and rc not in (134, 139):  # an ordinary error (a Python exception, no GPU): a second try changes nothing
+        if rc == 3:  # no GPU: a second try changes nothing
             break
-    sys.exit(rc if rc else 1)
+    sys.exit(rc if rc > 0 else 1)
 
 
 def run_extra_legs_in_child(args):

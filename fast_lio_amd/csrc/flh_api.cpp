@@ -153,6 +153,14 @@ struct flh_handle {
     bool aux_valid = false;   // world / normvec hold the last evaluation's (filled on demand, ensure_aux)
     int timing_stride = 1;   // record HIP events on every n-th evaluation (0 = never)
     uint64_t eval_no = 0;
+    // timing_stride >= 2 (sampling inside a running stream, bench.py): a timed evaluation records into the next free event
+    // triple and does NOT wait for it -- waiting on an event costs the host tens of microseconds, more than a whole pass; the
+    // elapsed times are read when somebody asks for them (drain_events).  timing_stride == 1 keeps the synchronous reading.
+    static constexpr int kEvPool = 64;
+    hipEvent_t evp[kEvPool][3]{};
+    uint8_t evp_search[kEvPool]{};
+    int evp_n = 0;            // triples recorded and not yet read
+    bool evp_ready = false;   // the pool's events exist
     uint64_t seq = 0;        // sequence number of the last flh_eval (published by k_fit next to the result)
     double acc[6] = {0, 0, 0, 0, 0, 0};
     // staging ring
@@ -325,6 +333,9 @@ void flh_destroy(flh_handle* h) {
     if (h->h_counter) (void)hipHostFree(h->h_counter);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& t3 : h->evp)
+        for (auto& e : t3)
+            if (e) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1250,14 +1261,51 @@ static int gran_group_size(size_t N) {
     return red <= 128 ? red : 0;
 }
 
-static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext, double* d_out, double seq, bool timed,
+// Deferred event timing (see flh_handle::evp).
+static bool ensure_event_pool(flh_handle* h) {
+    if (h->evp_ready) return true;
+    for (int k = 0; k < flh_handle::kEvPool; ++k)
+        for (int j = 0; j < 3; ++j)
+            if (hipEventCreate(&h->evp[k][j]) != hipSuccess) {
+                (void)hipGetLastError();
+                for (int k2 = 0; k2 <= k; ++k2)
+                    for (int j2 = 0; j2 < 3; ++j2)
+                        if (h->evp[k2][j2]) { (void)hipEventDestroy(h->evp[k2][j2]); h->evp[k2][j2] = nullptr; }
+                return false;  // the caller falls back to the synchronous reading
+            }
+    h->evp_ready = true;
+    return true;
+}
+static void drain_events(flh_handle* h) {
+    if (h->evp_n == 0) return;
+    (void)hipSetDevice(h->device);
+    for (int k = 0; k < h->evp_n; ++k) {
+        float a = 0, b = 0, c = 0;
+        if (hipEventSynchronize(h->evp[k][2]) != hipSuccess || hipEventElapsedTime(&a, h->evp[k][0], h->evp[k][1]) != hipSuccess ||
+            hipEventElapsedTime(&b, h->evp[k][1], h->evp[k][2]) != hipSuccess || hipEventElapsedTime(&c, h->evp[k][0], h->evp[k][2]) != hipSuccess) {
+            (void)hipGetLastError();
+            continue;  // a sample that cannot be read is dropped, not guessed
+        }
+        const bool srch = h->evp_search[k] != 0;
+        if (srch) { h->acc[0] += a; h->acc[1] += 1; }
+        h->acc[2] += b; h->acc[3] += 1;
+        h->acc[4] += c; h->acc[5] += 1;
+        h->timing.search_ms = srch ? a : 0.f;
+        h->timing.fit_ms = b;
+        h->timing.total_ms = c;
+    }
+    h->evp_n = 0;
+}
+
+static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext, double* d_out, double seq, hipEvent_t* ev3,
                         bool host_granules = false) {
+    const bool timed = ev3 != nullptr;  // three records: before the first launch, after the search kernels, after the fit kernel
     hipStream_t st = h->stream;
     if (!h->cur_body || !h->selected.p) return fail("flh_eval: no active scan (flh_scan_upload / flh_scan_activate first)");
     if (!h->grid.hash && h->N > 0) return fail("flh_eval: no map (flh_map_build / flh_map_add first)");
     if (!do_search && !h->searched_once && h->N > 0)
         return fail("flh_eval: do_search == 0 before any search on this scan (the reference always searches on the first pass)");
-    if (timed) HIPC(hipEventRecord(h->ev[0], st));
+    if (timed) HIPC(hipEventRecord(ev3[0], st));
     if (do_search) {
         if (h->stats) HIPC(hipMemsetAsync(h->counter.p, 0, FLH_COUNTER_WORDS * sizeof(u64), st));
         HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
@@ -1269,12 +1317,12 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
         h->d2_valid = false;
         h->search_state = s;
     }
-    if (timed) HIPC(hipEventRecord(h->ev[1], st));
+    if (timed) HIPC(hipEventRecord(ev3[1], st));
     HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
                          h->world.p, h->partials.p, h->part2.p, d_out, seq, h->tickets.p, h->slow_count.p,
                          host_granules ? h->h_gran : nullptr, host_granules ? gran_group_size(h->N) : 0, 0, st));
     h->aux_valid = false;
-    if (timed) HIPC(hipEventRecord(h->ev[2], st));
+    if (timed) HIPC(hipEventRecord(ev3[2], st));
     h->last_state = s;
     h->last_ext = ext;
     h->have_eval = true;
@@ -1319,6 +1367,14 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     // the final reduce kernel writes the 16x16 block straight into pinned, device-mapped host memory:
     // no copy kernel, no extra boundary -- the stream sync below is the only wait
     const bool timed = h->timing_stride > 0 && (h->eval_no++ % (uint64_t)h->timing_stride) == 0;
+    bool deferred = false;
+    hipEvent_t* ev3 = nullptr;
+    if (timed) {
+        static const bool sync_events = std::getenv("FLH_SYNC_EVENTS") != nullptr;  // force the synchronous reading
+        deferred = h->timing_stride >= 2 && !sync_events && ensure_event_pool(h);
+        if (deferred && h->evp_n == flh_handle::kEvPool) drain_events(h);
+        ev3 = deferred ? h->evp[h->evp_n] : h->ev;
+    }
     const double seq = (double)(++h->seq);
     hipStream_t st = h->stream;
     static const bool host_prof = std::getenv("FLH_HOST_PROFILE") != nullptr;
@@ -1327,9 +1383,9 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     if (h->comm) {
         // this rank's partial block stays in device memory, RCCL sums the ranks' blocks in place (256 doubles: latency-bound,
         // xGMI bandwidth is irrelevant), then one small kernel publishes the sum + sequence word to pinned host memory
-        if (enqueue_eval(h, s, do_search, ext, h->gram.p, 0.0, timed) != 0) return -1;
+        if (enqueue_eval(h, s, do_search, ext, h->gram.p, 0.0, ev3) != 0) return -1;
         if (rccl_allreduce_publish(h, seq) != 0) return -1;
-    } else if (enqueue_eval(h, s, do_search, ext, h->h_gram, seq, timed, gran_red > 0) != 0) {
+    } else if (enqueue_eval(h, s, do_search, ext, h->h_gram, seq, ev3, gran_red > 0) != 0) {
         return -1;
     }
     if (h->stats && do_search) HIPC(hipMemcpyAsync(h->h_counter, h->counter.p, sizeof(u64), hipMemcpyDeviceToHost, st));
@@ -1392,7 +1448,12 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     }
     // timed evaluations: three event records on the stream (before the first launch, after the search kernels, after the
     // fit kernel); the last one completes when k_fit retires, a moment after the flag
-    if (timed) HIPC(hipEventSynchronize(h->ev[2]));
+    if (deferred) {  // recorded, not awaited: read by drain_events
+        h->evp_search[h->evp_n] = do_search ? 1 : 0;
+        h->evp_n++;
+    } else if (timed) {
+        HIPC(hipEventSynchronize(h->ev[2]));
+    }
     if (h->h_gram[255] != seq) return fail("flh_eval: result sequence mismatch");
     h->h_gram[255] = 0.0;  // G[15][15] is structurally zero
     flh_unpack_gram(h->h_gram, HTH, HTh, n_eff, total_residual);
@@ -1412,14 +1473,16 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
                          k ? "search" : "no-search", acc_[k][0] / n_[k], acc_[k][1] / n_[k], gap_[k] / n_[k], (unsigned long long)n_[k]);
     }
     float a = 0, b = 0, c = 0;
-    if (timed) {
+    if (timed && !deferred) {
         (void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
         (void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
         (void)hipEventElapsedTime(&c, h->ev[0], h->ev[2]);
     }
-    h->timing.search_ms = do_search ? a : 0.f;
-    h->timing.fit_ms = b;
-    h->timing.total_ms = c;
+    if (!deferred && h->evp_n == 0) {  // (with samples pending the last timing is whatever drain_events reads last)
+        h->timing.search_ms = do_search ? a : 0.f;
+        h->timing.fit_ms = b;
+        h->timing.total_ms = c;
+    }
     h->timing.candidates = (h->stats && do_search) ? (int64_t)*h->h_counter : 0;
 #ifdef FLH_PHASES
     if (h->stats) flh::dump_fit_phases();
@@ -1456,7 +1519,7 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
         }
     }
 #endif
-    if (timed) {
+    if (timed && !deferred) {
         if (do_search) { h->acc[0] += a; h->acc[1] += 1; }
         h->acc[2] += b; h->acc[3] += 1;
         h->acc[4] += c; h->acc[5] += 1;
@@ -1466,6 +1529,7 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
 
 int flh_get_counters(flh_handle* h, double out[6], int reset) {
     if (!h || !out) return fail("flh_get_counters: null argument");
+    drain_events(h);
     for (int i = 0; i < 6; ++i) out[i] = h->acc[i];
     if (reset)
         for (int i = 0; i < 6; ++i) h->acc[i] = 0;
@@ -1476,7 +1540,7 @@ int flh_eval_device(flh_handle* h, const double x[FLH_NSTATE], int do_search, in
     if (!h || !x || !d_gram256) return fail("flh_eval_device: null argument");
     HIPC(hipSetDevice(h->device));
     const StateDev s = make_state(x + 3, x + 0, x + 7, x + 11);
-    return enqueue_eval(h, s, do_search, ext, d_gram256, 0.0, false);
+    return enqueue_eval(h, s, do_search, ext, d_gram256, 0.0, nullptr);
 }
 
 // map_incremental() -- src/laserMapping.cpp:427-474, on the neighbour cache the scan's last search left on the
@@ -1548,13 +1612,19 @@ int flh_fetch_map_incremental(flh_handle* h, uint8_t* cls, float* world_xyz) {
 
 int flh_last_timing(flh_handle* h, flh_timing* t) {
     if (!h || !t) return fail("flh_last_timing: null argument");
+    drain_events(h);
     *t = h->timing;
     return 0;
 }
 int flh_set_timing_stride(flh_handle* h, int every_n) {
     if (!h) return fail("flh_set_timing_stride: null handle");
+    drain_events(h);
     h->timing_stride = every_n < 0 ? 0 : every_n;
     h->eval_no = 0;
+    if (h->timing_stride >= 2) {  // create the event pool here, not inside the caller's timed region
+        (void)hipSetDevice(h->device);
+        (void)ensure_event_pool(h);
+    }
     return 0;
 }
 int flh_enable_stats(flh_handle* h, int on) {
@@ -1884,7 +1954,7 @@ int flh_eval_group(flh_handle* const* handles, int n, const double state[FLH_NST
     for (int i = 0; i < n; ++i) {
         flh_handle* h = handles[i];
         HIPC(hipSetDevice(h->device));
-        if (enqueue_eval(h, s, do_search, ext, h->gram.p, 0.0, false) != 0) return -1;
+        if (enqueue_eval(h, s, do_search, ext, h->gram.p, 0.0, nullptr) != 0) return -1;
     }
     flh_handle* h0 = handles[0];
     const double seq = (double)(++h0->seq);

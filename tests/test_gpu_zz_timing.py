@@ -1,0 +1,60 @@
+"""The roofline events of bench.py: with a timing stride >= 2 a timed evaluation records its three HIP events and does not wait
+for them; the elapsed times are read when the counters are asked for.  The sampling must not change any result, must count
+exactly the evaluations it was asked to, and must survive more pending samples than the event pool holds."""
+import numpy as np
+import pytest
+
+from fast_lio_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    pr = synth.make_problem(200000, 20000, "avia", cfg=1)
+    xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    h.scan_upload(pr.body)
+    return pr, xp, h
+
+
+def test_deferred_event_reading_counts_and_leaves_results_alone(setup):
+    pr, xp, h = setup
+    h.set_timing_stride(0)
+    ref_s = h.eval(xp, True, False)
+    ref_n = h.eval(xp, False, False)
+    h.set_timing_stride(2)
+    h.counters(reset=True)
+    outs = []
+    for k in range(12):  # evaluations 0, 2, 4, ... are sampled; even k search, odd k do not
+        outs.append(h.eval(xp, k % 2 == 0, False))
+    c = h.counters()
+    assert c["n_fit"] == 6 and c["n_search"] == 6   # every sampled evaluation was a searching one
+    assert 0.0 < c["fit_ms"] / c["n_fit"] < 5.0 and 0.0 < c["search_ms"] / c["n_search"] < 20.0
+    for k, o in enumerate(outs):
+        r = ref_s if k % 2 == 0 else ref_n
+        np.testing.assert_array_equal(o[0], r[0])
+        np.testing.assert_array_equal(o[1], r[1])
+        assert o[2] == r[2] and o[3] == r[3]
+    t = h.timing()
+    assert t["fit_ms"] > 0.0
+    h.set_timing_stride(1)
+
+
+def test_more_pending_samples_than_the_pool_holds(setup):
+    pr, xp, h = setup
+    h.set_timing_stride(2)
+    h.counters(reset=True)
+    n = 2 * 64 * 2 + 6  # 131 sampled evaluations: the pool of 64 triples is drained twice on the way
+    for k in range(n):
+        h.eval(xp, False, False)
+    c = h.counters()
+    assert c["n_fit"] == (n + 1) // 2 and c["n_search"] == 0
+    assert 0.0 < c["fit_ms"] / c["n_fit"] < 5.0
+    h.set_timing_stride(3)   # a change of the stride reads what is pending and restarts the count
+    for k in range(7):
+        h.eval(xp, k == 0, False)
+    c = h.counters(reset=True)
+    assert c["n_fit"] == (n + 1) // 2 + 3 and c["n_search"] == 1
+    h.set_timing_stride(1)
