@@ -253,8 +253,12 @@ int flh_last_timing(flh_handle* h, flh_timing* t);
  * out[0] = sum of search-kernel ms, out[1] = number of search launches, out[2] = sum of fit(+reduce) ms,
  * out[3] = number of fit launches, out[4] = sum of first-launch-to-host-visible ms, out[5] = evaluations. */
 int flh_get_counters(flh_handle* h, double out[6], int reset);
-/* The HIP events behind flh_last_timing / flh_get_counters cost ~15 us of host+queue time per evaluation:
- * record them only on every n-th flh_eval (1 = always, the default; 0 = never). */
+/* The HIP events behind flh_last_timing / flh_get_counters: recorded on every n-th flh_eval (1 = always, the default;
+ * 0 = never).  With every_n == 1 the evaluation waits for its last event and reads the three times at once (tens of
+ * microseconds of host time per evaluation).  With every_n >= 2 -- sampling inside a running stream -- a sampled evaluation
+ * only RECORDS its events; they are read when flh_get_counters / flh_last_timing / flh_set_timing_stride is called next
+ * (or when 64 samples are pending).  flh_last_timing then reports the most recent sample.  The environment variable
+ * FLH_SYNC_EVENTS=1 forces the waiting behaviour for every stride. */
 int flh_set_timing_stride(flh_handle* h, int every_n);
 int flh_enable_stats(flh_handle* h, int on); /* count candidate points examined (slower) */
 /* Run one kernel of the hot path `iters` times back-to-back on the handle's stream and return the
