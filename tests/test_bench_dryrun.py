@@ -1,0 +1,66 @@
+"""bench.py's own Python (legs, bookkeeping, torch.distributed calls, the JSON contract) run on the CPU with the device layer
+faked (tools/bench_dryrun.py): a typo in a leg must not wait for a GPU box to be found."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRY = os.path.join(ROOT, "tools", "bench_dryrun.py")
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline")
+
+
+def _line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_one_rank_all_legs_of_the_main_process():
+    r = subprocess.run([sys.executable, DRY, "--leg", "main", "--config", "1", "--steps", "6", "--warmup", "2", "--scans", "3",
+                        "--cpu-scans", "1", "--force-shard-leg"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    d = _line(r.stdout.decode())
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["config"]["workload"].startswith("BASELINE configs[0]")
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 3 and "all_cores" in d["cpu_baseline"]
+    assert d["shard_mode"]["ranks_in_communicator"] == 1 and "error" not in d["shard_mode"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"]
+
+
+def test_partition_mode_and_the_side_legs():
+    r = subprocess.run([sys.executable, DRY, "--leg", "main", "--config", "1", "--steps", "6", "--warmup", "2", "--scans", "3",
+                        "--cpu-scans", "0", "--force-shard-leg", "--mode", "partition"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    d = _line(r.stdout.decode())
+    assert d["scaling"] == "strong"
+    r = subprocess.run([sys.executable, DRY, "--leg", "extras", "--config", "1", "--steps", "8", "--two-streams"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    d = _line(r.stdout.decode())
+    assert set(d) >= {"two_streams_per_gpu", "map_incremental", "scan_front_end"}
+
+
+def test_two_ranks_over_gloo():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", DRY, "--gpus", "2", "--config", "1", "--steps", "6", "--warmup", "2", "--scans", "3",
+                        "--cpu-scans", "0", "--backend", "gloo", "--single-device", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900, env=env)
+    d = _line(r.stdout.decode())
+    assert d["n_gpus"] == 2 and d["ranks_seen_by_collective"] == 2 and d["scaling"] == "weak"
+    assert "shard_mode" in d and "error" not in d["shard_mode"], d.get("shard_mode")
+
+
+def test_without_a_device_the_real_bench_says_so_and_does_not_retry():
+    from fast_lio_amd import capi
+
+    if capi.device_available():
+        import pytest
+
+        pytest.skip("a device is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--scans", "2", "--config", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    err = r.stderr.decode()
+    assert r.returncode == 3 and "needs a GPU" in err and "attempt 2/2" not in err and r.stdout.decode().strip() == ""
