@@ -44,6 +44,8 @@ def test_deferred_event_reading_counts_and_leaves_results_alone(setup):
 
 def test_more_pending_samples_than_the_pool_holds(setup):
     pr, xp, h = setup
+    h.set_timing_stride(0)
+    h.eval(xp, True, False)  # the evaluations below reuse this search's neighbours
     h.set_timing_stride(2)
     h.counters(reset=True)
     n = 2 * 64 * 2 + 6  # 131 sampled evaluations: the pool of 64 triples is drained twice on the way
