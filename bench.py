@@ -60,9 +60,12 @@ def pmc_traffic(args):
     section).  Only valid for the workload the summary was taken on (default kernel settings)."""
     import csv
 
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_summary_config{args.config}.csv")
-    if not os.path.exists(path) or args.lpq != 4 or args.cell != 1.5 or args.first_stage != 0:
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_summary_config{args.config}.csv")))
+    if not found or args.lpq != 4 or args.cell != 1.5 or args.first_stage != 0:
         return None
+    path = found[-1]  # the latest round's
     fetch, write, calls = {}, {}, {}
     with open(path) as f:
         for r in csv.DictReader(f):
