@@ -103,8 +103,9 @@ def main():
     ap.add_argument("--first-stage", type=int, default=0)
     ap.add_argument("--sort", type=int, default=1, help="Morton-order the scan at staging (0 = keep input order)")
     ap.add_argument("--extrinsic-est", type=int, default=0)
-    ap.add_argument("--timing-samples", type=int, default=16,
-                    help="evaluations of the timed region whose kernels are bracketed by HIP events (>= 16)")
+    ap.add_argument("--timing-samples", type=int, default=32,
+                    help="evaluations of the timed region whose kernels are bracketed by HIP events (>= 16; half of them "
+                         "are searching evaluations, so the default gives >= 16 samples of the search kernels from 20 steps on)")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the headline + roofline (profiling runs)")
     ap.add_argument("--cpu-scans", type=int, default=3, help="scans timed on the CPU oracle per thread count (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=3, help="OpenMP threads (reference MP_PROC_NUM = 3)")
