@@ -444,7 +444,7 @@ def run_main_in_child(attempts=2):
             # throughput in short runs -- the line says so in config.event_reading
             env["FLH_SYNC_EVENTS"] = "1"
         try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, timeout=1500)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, timeout=800)  # a healthy run takes one to three minutes
             rc, out = r.returncode, r.stdout
         except subprocess.TimeoutExpired as e:
             rc, out = -9, (e.stdout or b"")
