@@ -436,6 +436,8 @@ def run_main_in_child(attempts=2):
     import subprocess
 
     cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + ["--leg", "main"]
+    big = any(a in ("4", "5") and i > 0 and sys.argv[i] == "--config" for i, a in enumerate(sys.argv[1:]))  # 20M / 50M maps: generation alone takes minutes
+    limit = 3000 if big else 800  # a healthy run of the default configuration takes one to three minutes
     rc = 1
     for k in range(attempts):
         env = dict(os.environ)
@@ -444,7 +446,7 @@ def run_main_in_child(attempts=2):
             # throughput in short runs -- the line says so in config.event_reading
             env["FLH_SYNC_EVENTS"] = "1"
         try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, timeout=800)  # a healthy run takes one to three minutes
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, timeout=limit)
             rc, out = r.returncode, r.stdout
         except subprocess.TimeoutExpired as e:
             rc, out = -9, (e.stdout or b"")
