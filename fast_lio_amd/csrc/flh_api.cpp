@@ -122,6 +122,8 @@ struct flh_handle {
     // scan
     size_t N = 0;
     DevBuf<float4> world, nn_pts, normvec;
+    DevBuf<float4> plane;     // experiment (FLH_PLANE_CACHE=1): (a, b, c, d) of the last searching pass's fits, reused by no-search passes
+    bool plane_cache = false;
     DevBuf<float> nn_d2;
     DevBuf<uint8_t> nn_cnt, selected;
     DevBuf<double> partials, part2, gram, gather_buf;
@@ -291,6 +293,7 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
         return fail("hipMalloc failed");
     }
     if (const char* e = std::getenv("FLH_TIMING_STRIDE")) h->timing_stride = std::max(0, std::atoi(e));
+    h->plane_cache = std::getenv("FLH_PLANE_CACHE") != nullptr;  // off by default: not yet validated on hardware
     h->rmax = (int)std::ceil((std::sqrt((double)cfg.max_sqdist) + 2e-3 * cfg.cell_size) / cfg.cell_size);
     if (h->rmax < 1) h->rmax = 1;
     *out = h;
@@ -311,7 +314,7 @@ void flh_destroy(flh_handle* h) {
     h->map_orig.release(); h->map_next.release(); h->mb_aabb.release(); h->mu_add.release(); h->mi_world.release();
     h->mu_alive.release(); h->mi_cls.release(); h->mu_flags.release(); h->mu_incl.release(); h->mu_boxes.release();
     h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_list2.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
-    h->world.release(); h->nn_pts.release(); h->normvec.release();
+    h->world.release(); h->nn_pts.release(); h->normvec.release(); h->plane.release();
     h->nn_d2.release(); h->nn_cnt.release(); h->selected.release();
     h->partials.release(); h->part2.release(); h->gram.release(); h->gather_buf.release(); h->counter.release();
     for (auto& sl : h->slots) {
@@ -726,6 +729,7 @@ static int prepare_scan_buffers(flh_handle* h, size_t N, bool full_clear) {
     hipStream_t st = h->stream;
     const size_t n1 = N ? N : 1;
     HIPC(h->world.reserve(n1)); HIPC(h->nn_pts.reserve(5 * n1)); HIPC(h->normvec.reserve(n1));
+    if (h->plane_cache) HIPC(h->plane.reserve(n1));
     HIPC(h->nn_d2.reserve(5 * n1)); HIPC(h->nn_cnt.reserve(n1)); HIPC(h->selected.reserve(n1));
     {
         const size_t ln = (size_t)flh::list_stripes() * flh::list_stripe_cap((int)N);
@@ -1320,7 +1324,8 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
     if (timed) HIPC(hipEventRecord(ev3[1], st));
     HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
                          h->world.p, h->partials.p, h->part2.p, d_out, seq, h->tickets.p, h->slow_count.p,
-                         host_granules ? h->h_gran : nullptr, host_granules ? gran_group_size(h->N) : 0, 0, st));
+                         host_granules ? h->h_gran : nullptr, host_granules ? gran_group_size(h->N) : 0, 0, st,
+                         h->plane_cache ? h->plane.p : nullptr, do_search ? 1 : 2));
     h->aux_valid = false;
     if (timed) HIPC(hipEventRecord(ev3[2], st));
     h->last_state = s;

@@ -867,13 +867,18 @@ constexpr int kRed1 = 16;   // blocks per first-level reduction group
 constexpr int kRed2 = 32;   // group sums added per unrolled batch at the top level
 constexpr int kTileStride = 17;  // doubles per row: 16 + 1 pad (conflict-free ds_write_b64 / ds_read_b64)
 
-template <int ORD, bool HALF>
+template <int ORD, bool HALF, int PM = 0>
 __global__ void __launch_bounds__(256)
 k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn_pts, int N, int ext, float thr,
       uint8_t* __restrict__ selected, float4* __restrict__ normvec, float4* __restrict__ world,
       double* __restrict__ partials, double* __restrict__ part2, double* __restrict__ out256, double seq,
       uint32_t* __restrict__ tickets, uint32_t* __restrict__ slow_count, double* __restrict__ gran, int red1, int ncol,
-      int store_aux) {
+      int store_aux, float4* __restrict__ plane_cache) {
+    // PM (experimental, FLH_PLANE_CACHE=1; 0 = off, the product's default -- its code is untouched by the other two): a plane depends on the five neighbours only, not on the state, and a
+    // point that enters a no-search pass with its flag set was fitted successfully on the pass before, from the very same
+    // neighbours.  1 (searching pass): fit as always and keep (a, b, c, d) per point; 2 (no-search pass): take the plane from there
+    // -- same bits -- instead of re-reading 80 B of neighbours and repeating the QR.  The gate and the Jacobian row are
+    // recomputed either way: they depend on the state.
     // store_aux: also write feats_down_world and normvec (16 B per point each).  The filter never reads them, so the passes of an
     // update leave them out; a fetch (flh_fetch_world / _normvec / _rows) re-runs this kernel once with the flag set -- the
     // arithmetic is deterministic, so that run reproduces the pass bit for bit.
@@ -899,8 +904,15 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
     const uint8_t sel_in = selected[ic];
     float4 nn[5];
     b = body[ic];
+    float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PM == 2) {
+        pc = plane_cache[ic];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) nn[j] = nn_pts[(size_t)j * N + ic];
+        for (int j = 0; j < 5; ++j) nn[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) nn[j] = nn_pts[(size_t)j * N + ic];
+    }
     if (i < N) {  // feats_down_world is rewritten for every point on every pass (laserMapping.cpp:656-661)
         body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
         if (store_aux) world[i] = make_float4(wx, wy, wz, 0.f);
@@ -912,7 +924,14 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
         for (int j = 0; j < 5; ++j) { P[j][0] = nn[j].x; P[j][1] = nn[j].y; P[j][2] = nn[j].z; }
         float pabcd[4];
         FPH(2);  // neighbours loaded
-        const bool ok = HALF ? esti_plane_half<ORD>(P, thr, pabcd) : esti_plane<ORD>(P, thr, pabcd);  // :678
+        bool ok;
+        if (PM == 2) {  // compile-time: this instantiation has no fit in it
+            pabcd[0] = pc.x; pabcd[1] = pc.y; pabcd[2] = pc.z; pabcd[3] = pc.w;
+            ok = true;
+        } else {
+            ok = HALF ? esti_plane_half<ORD>(P, thr, pabcd) : esti_plane<ORD>(P, thr, pabcd);  // :678
+            if (PM == 1 && ok) plane_cache[i] = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
+        }
         FPH(3);  // plane fit
         bool sel = false;
         float pd2 = 0.f;
@@ -1358,15 +1377,25 @@ int reduce1_blocks(int nblk, int* per_out) {
 hipError_t launch_fit(int order, int half_fit, const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
                       uint8_t* selected, float4* normvec, float4* world, double* partials, double* part2,
                       double* out256, double seq, uint32_t* tickets, uint32_t* slow_count, double* gran, int red1, int store_aux,
-                      hipStream_t st) {
+                      hipStream_t st, float4* plane_cache, int plane_mode) {
     const int nblk = fit_blocks(N);
     const int ncol = ext ? 12 : 6;
+    if (!plane_cache || half_fit || order != 1) plane_mode = 0;  // the experiment exists for the default summation order only
+    if (plane_mode == 1 || plane_mode == 2) {
+        if (plane_mode == 1)
+            hipLaunchKernelGGL((k_fit<1, false, 1>), dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world,
+                               partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux, plane_cache);
+        else
+            hipLaunchKernelGGL((k_fit<1, false, 2>), dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world,
+                               partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux, plane_cache);
+        return hipGetLastError();
+    }
 #define FLH_FIT(O)                                                                                                      \
     hipLaunchKernelGGL((k_fit<O, false>), dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world, \
-                       partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux)
+                       partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux, plane_cache)
     if (half_fit) {  // the fp16 ablation exists for the default summation order only
         hipLaunchKernelGGL((k_fit<1, true>), dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world,
-                           partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux);
+                           partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux, plane_cache);
         return hipGetLastError();
     }
     switch (order) {

@@ -47,7 +47,7 @@ int reduce1_blocks(int nblk, int* per_out);
 hipError_t launch_fit(int order, int half_fit, const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
                       uint8_t* selected, float4* normvec, float4* world, double* partials, double* part2,
                       double* out256, double seq, uint32_t* tickets, uint32_t* slow_count, double* gran, int red1, int store_aux,
-                      hipStream_t st);
+                      hipStream_t st, float4* plane_cache = nullptr, int plane_mode = 0);
 hipError_t launch_fill_d2(const StateDev& s_search, const float4* body, const float4* nn_pts, int N, float* nn_d2, hipStream_t st);
 int gram_slots_host(int ncol);
 int gram_slot_host(int r, int c, int ncol);

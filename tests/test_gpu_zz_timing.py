@@ -60,3 +60,47 @@ def test_more_pending_samples_than_the_pool_holds(setup):
     c = h.counters(reset=True)
     assert c["n_fit"] == (n + 1) // 2 + 3 and c["n_search"] == 1
     h.set_timing_stride(1)
+
+
+def test_plane_cache_experiment_changes_no_bit(monkeypatch):
+    """FLH_PLANE_CACHE=1 (off by default): no-search passes take each point's plane from the last searching pass instead of
+    re-fitting it from the same five neighbours.  Every output must keep its bits: normal equations of a search / no-search /
+    no-search sequence at three different states, flags, planes, and a whole iterated update."""
+    pr = synth.make_problem(200000, 20000, "avia", cfg=1)
+    xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
+    x2 = np.array(xp, dtype=np.float64)
+    x2[:3] += [0.02, -0.015, 0.01]
+    x3 = np.array(pr.x_true, dtype=np.float64)
+    got = []
+    for on in (False, True):
+        if on:
+            monkeypatch.setenv("FLH_PLANE_CACHE", "1")
+        else:
+            monkeypatch.delenv("FLH_PLANE_CACHE", raising=False)
+        h = capi.Handle()
+        h.map_build(pr.map_xyz)
+        h.scan_upload(pr.body)
+        seq = []
+        for ext in (False, True):
+            for x, search in ((xp, True), (x2, False), (x3, False), (x3, True), (xp, False)):
+                HTH, HTh, n_eff, tres = h.eval(x, search, ext)
+                seq.append((HTH.copy(), HTh.copy(), n_eff, tres, h.fetch_selected().copy(), h.fetch_normvec().copy()))
+        h.scan_upload(pr.body)
+        kf = capi.Esekf(h, max_iter=3)
+        kf.change_x(xp)
+        kf.change_P(P)
+        st = kf.update(0.001)
+        got.append((seq, kf.get_x().copy(), kf.get_P().copy(), list(st.n_eff)[: st.passes]))
+        kf.close()
+        h.close()
+    (seq0, x0, P0, n0), (seq1, x1, P1, n1) = got
+    assert n0 == n1
+    np.testing.assert_array_equal(x0, x1)
+    np.testing.assert_array_equal(P0, P1)
+    for a, b in zip(seq0, seq1):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        assert a[2] == b[2] and a[3] == b[3]
+        np.testing.assert_array_equal(a[4], b[4])
+        sel = a[4].astype(bool)
+        np.testing.assert_array_equal(a[5][sel].view(np.uint32), b[5][sel].view(np.uint32))
