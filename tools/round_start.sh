@@ -18,4 +18,10 @@ except Exception as e:
 PY
 done
 unset FLH_SYNC_EVENTS
+FLH_PLANE_CACHE=1 timeout 240 python bench.py --gpus 1 --steps 300 --warmup 30 --cpu-scans 0 --no-extra-legs 2>/dev/null | python -c "
+import json, sys
+try:
+    d = json.loads(sys.stdin.read()); print('plane cache on :', {k: d[k] for k in ('value', 'ms_search_pass', 'ms_nosearch_pass', 'device_resident_scans_per_s')}, d['roofline']['fit_kernel_us'])
+except Exception as e:
+    print('plane cache run: no line', e)"
 timeout 400 python bench.py > $O/bench300.json 2> $O/bench300.err; echo "bench300 rc=$?"; cut -c1-400 $O/bench300.json; tail -3 $O/bench300.err
