@@ -1260,7 +1260,12 @@ static int search_plan(const flh_handle* h, bool host_granules) {
 // would make more than kGranGroups groups; 0 = too many points for the granule path.
 static int gran_group_size(size_t N) {
     const int nblk = flh::fit_blocks((int)N);
-    int red = 16;
+    static const int red0 = [] {  // experiment knob: blocks per group (16, 32, 64 or 128); unset = 16
+        const char* e = std::getenv("FLH_GRAN_GROUP");
+        const int v = e ? std::atoi(e) : 16;
+        return (v == 32 || v == 64 || v == 128) ? v : 16;
+    }();
+    int red = red0;
     while ((nblk + red - 1) / red > kGranGroups) red *= 2;
     return red <= 128 ? red : 0;
 }
