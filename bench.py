@@ -450,8 +450,17 @@ def run_main_in_child(attempts=2):
             rc, out = r.returncode, r.stdout
         except subprocess.TimeoutExpired as e:
             rc, out = -9, (e.stdout or b"")
-        lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{")]
-        if rc == 0 and lines:
+        lines = []
+        for ln in out.decode(errors="replace").splitlines():
+            if ln.startswith("{"):
+                try:
+                    if "metric" in json.loads(ln):
+                        lines.append(ln)
+                except ValueError:
+                    pass
+        if lines:  # the line is printed once, after every measurement: it stands even if the process then died while tearing down
+            if rc != 0:
+                log(f"[bench] the measuring process printed its line and then exited with {rc}")
             print(lines[-1], flush=True)
             return 0
         log(f"[bench] attempt {k + 1}/{attempts}: the measuring process exited with {rc} and no result line")
