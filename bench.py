@@ -481,8 +481,11 @@ def run_extra_legs_in_child(args):
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
         lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
-        if r.returncode == 0 and lines:
-            return json.loads(lines[-1])
+        if lines:
+            try:
+                return json.loads(lines[-1])
+            except ValueError:
+                pass
         return {"extra_legs_error": f"child exited with {r.returncode}: {r.stderr.decode()[-300:]}"}
     except Exception as e:  # timeout, spawn failure
         return {"extra_legs_error": repr(e)[:300]}
