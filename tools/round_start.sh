@@ -24,4 +24,12 @@ try:
     d = json.loads(sys.stdin.read()); print('plane cache on :', {k: d[k] for k in ('value', 'ms_search_pass', 'ms_nosearch_pass', 'device_resident_scans_per_s')}, d['roofline']['fit_kernel_us'])
 except Exception as e:
     print('plane cache run: no line', e)"
+for knob in FLH_STAGE_AHEAD=2 FLH_GRAN_GROUP=32; do
+  env $knob timeout 240 python bench.py --gpus 1 --steps 300 --warmup 30 --cpu-scans 0 --no-extra-legs 2>/dev/null | python -c "
+import json, sys
+try:
+    d = json.loads(sys.stdin.read()); print('$knob :', {k: d[k] for k in ('value', 'ms_search_pass', 'ms_nosearch_pass', 'device_resident_scans_per_s')}, d['roofline']['fit_kernel_us'])
+except Exception as e:
+    print('$knob: no line', e)"
+done
 timeout 400 python bench.py > $O/bench300.json 2> $O/bench300.err; echo "bench300 rc=$?"; cut -c1-400 $O/bench300.json; tail -3 $O/bench300.err
