@@ -1,7 +1,7 @@
 #!/bin/bash
-# First GPU call of a round (one gpurun call, ~4 minutes): the GPU suite, then the driver's bench command with the roofline
+# First GPU call of a round (one gpurun call, ~12 minutes): the GPU suite, then the driver's bench command with the roofline
 # events read both ways, then the default 300-step bench.  Everything under its own timeout; outputs in gpurun_out/round_start/.
-#   gpurun --timeout 900 -- tools/round_start.sh
+#   gpurun --timeout 1500 -- tools/round_start.sh
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/round_start; mkdir -p $O; cd $R
 timeout 420 python -m pytest tests -q -m gpu -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -6 | tee $O/gpu_tests.txt
