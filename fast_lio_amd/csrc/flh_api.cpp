@@ -249,7 +249,7 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.plane_threshold <= 0) cfg.plane_threshold = 0.1f;
     if (cfg.max_sqdist <= 0) cfg.max_sqdist = 5.0f;
     if (cfg.sort_queries < 0) cfg.sort_queries = 1;
-    if (cfg.first_stage < 0 || cfg.first_stage > 2) cfg.first_stage = 0;
+    if (cfg.first_stage < 0 || cfg.first_stage > 3) cfg.first_stage = 0;
     if (cfg.eigen_order < 0 || cfg.eigen_order > 3) cfg.eigen_order = FLH_ORDER_SSE;
     if (cfg.plane_fit_dtype != 1) cfg.plane_fit_dtype = 0;
     {

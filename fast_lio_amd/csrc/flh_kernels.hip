@@ -323,379 +323,7 @@ k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, 
               uint32_t* __restrict__ out_list, uint32_t* __restrict__ out_count, uint32_t stripe_cap,
               const float* ub_in, float* ub_out /* may alias ub_in */, int rmax, u64* __restrict__ cand_counter, int own_axis,
               float own_lo, float own_hi) {
-    // own_axis >= 0 (map partitioned over ranks, flh_set_owned_interval): a query whose world coordinate lies outside
-    // [own_lo, own_hi) belongs to another rank: its flag is cleared and it is not searched here.
-    // FINAL: a query this stage cannot settle is finished on the spot by its group with the general exact search
-    // (exact_query) instead of being listed for one more kernel -- each extra kernel costs ~6 us of fixed latency per pass.
-    // CACHED (first stage, later searches of a scan): the five neighbours the PREVIOUS search of this scan left in the cache
-    // are map points, so the largest of their distances to the query's new position bounds its true 5th distance from above:
-    // rows and row ends outside that ball are not visited (the state moves by centimetres between searches, so the ball is
-    // a fraction of the 3x3x3 block: ~25 candidates instead of ~80, and most segment look-ups masked off).
-    // BOUNDED: the query comes with an upper bound ub of its true 5th squared distance (found by a smaller
-    // ring); rows and row ends that lie entirely outside that ball are not visited.
-    // Work lists are striped kStripes ways (stripe = blockIdx & (kStripes-1)) and appended to with one global
-    // atomic per WAVE: thousands of returning atomics on a single word serialise at ~11 ns each and were the
-    // whole runtime of an earlier version of this kernel.  No block-level barrier anywhere: waves run free.
-    // OCT (RING == 1 only): instead of the 3x3x3 block, the 2x2x2 block of cells nearest to the query (per axis the
-    // cell's neighbour on the side of the half the query sits in): 8 cells instead of 27, guaranteed radius
-    // c * min over the axes of max(f, 1 - f) >= c / 2.
-    constexpr int W = OCT ? 2 : 2 * RING + 1;      // block edge in cells
-    constexpr int NR = W * W;                      // (y,z) rows: each an x-run of W consecutive cells
-    constexpr int NSEG = NR * 2;                   // a run crosses at most one brick boundary -> two segments
-    constexpr int SPL = (NSEG + LPQ - 1) / LPQ;    // segments resolved per lane
-    constexpr int GPB = 256 / LPQ;                 // query groups per block
-    constexpr int UNR = 8;                         // independent point loads in flight per lane
-    // seg: (first point, length); after the prefix step: (first point - flat start, flat end), so that flat
-    // candidate t of the group lives at pts[seg.x + t] for t < seg.y
-    __shared__ uint2 seg[GPB][NSEG + 2];  // + sentinel + one slot the walk's look-ahead may touch
-    const int grp = threadIdx.x / LPQ;
-    const int lane = threadIdx.x & (LPQ - 1);
-    const uint32_t stripe = blockIdx.x & (kStripes - 1);
-    const uint32_t sub = blockIdx.x / kStripes, nsub = gridDim.x / kStripes;  // position among the stripe's blocks
-    if (in_list) in_list += (size_t)stripe * stripe_cap;
-    out_list += (size_t)stripe * stripe_cap;
-    const uint32_t total = in_list ? in_count[stripe] : (uint32_t)N;
-    const uint32_t first_base = in_list ? sub * GPB : blockIdx.x * GPB;
-    const uint32_t step_base = in_list ? nsub * GPB : gridDim.x * GPB;
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)g.pts, 0, (int)(map_points * 16u), 0x00020000);
-    const u64* __restrict__ hash64 = reinterpret_cast<const u64*>(g.hash);
-    PH_DECL
-    PH_MARK(0);  // 0: start
-
-    // A1 (no input list) launches one block per GPB queries and makes a single trip: the state and grid scalars die
-    // after the transform instead of staying pinned in SGPRs around a loop.
-    for (uint32_t base = first_base; base < total; base += step_base) {
-        const uint32_t gi = base + grp;
-        bool live = gi < total;
-        const int q = in_list ? (int)in_list[live ? gi : total - 1] : (int)(live ? gi : total - 1);
-        const float4 b = body[q];
-        float qx, qy, qz;
-        body_to_world(s, b.x, b.y, b.z, qx, qy, qz);
-        if (!in_list && own_axis >= 0) {
-            const float oc = own_axis == 0 ? qx : (own_axis == 1 ? qy : qz);
-            if (live && !(oc >= own_lo && oc < own_hi)) {
-                if (lane == 0) { selected[q] = 0; nn_cnt[q] = 0; }
-                live = false;
-            }
-        }
-        int cx, cy, cz;
-        float fx, fy, fz;
-        cell_of(g, qx, qy, qz, cx, cy, cz, fx, fy, fz);
-        const float minfrac = fminf(fminf(fminf(fx, 1.f - fx), fminf(fy, 1.f - fy)), fminf(fz, 1.f - fz));
-        PH_MARK(1);  // 1: query loaded + transformed
-
-        // ---- phase 1: directory probes of this lane's segments
-        float ubq = INFINITY, ub_raw = INFINITY;
-        if (BOUNDED) ubq = fminf(ub_in[q], max_sqdist) * 1.0001f + 1e-6f;
-        if (CACHED) {
-            // lane l holds cached ranks l, l + LPQ, ...; the group's maximum is the bound (only when all five were found)
-            float dm = 0.f;
-#pragma unroll
-            for (int r = 0; r < (5 + LPQ - 1) / LPQ; ++r) {
-                const int j = lane + r * LPQ;
-                if (j < 5) {
-                    const float4 c = nn_pts[(size_t)j * N + q];
-                    dm = fmaxf(dm, dist2(qx, qy, qz, c.x, c.y, c.z));
-                }
-            }
-            if (LPQ >= 2) dm = fmaxf(dm, __uint_as_float(dpp_u32<0xB1>(__float_as_uint(dm))));
-            if (LPQ >= 4) dm = fmaxf(dm, __uint_as_float(dpp_u32<0x4E>(__float_as_uint(dm))));
-            if (LPQ >= 8) dm = fmaxf(dm, __uint_as_float(dpp_u32<0x141>(__float_as_uint(dm))));
-            if (LPQ >= 16) dm = fmaxf(dm, __uint_as_float(dpp_u32<0x140>(__float_as_uint(dm))));
-            ub_raw = (nn_cnt[q] == 5) ? dm : INFINITY;
-            ubq = fminf(ub_raw, max_sqdist * 4.f) * 1.0001f + 1e-6f;  // beyond twice the gate radius the whole block is inside anyway
-        }
-        const float inv_c2 = g.inv_c * g.inv_c;
-        uint32_t key[SPL], i0[SPL], i1[SPL];
-        u64 he[SPL];
-#pragma unroll
-        for (int u = 0; u < SPL; ++u) {
-            const int sl = lane + u * LPQ;
-            const int half = sl / NR, r = sl - half * NR;  // slots [0,NR): first segments, [NR,2NR): second (split rows)
-            const int rz = r / W, ry = r - rz * W;
-            const int dy = OCT ? ry - (fy < 0.5f ? 1 : 0) : ry - RING, dz = OCT ? rz - (fz < 0.5f ? 1 : 0) : rz - RING;
-            const int y = cy + dy, z = cz + dz;
-            int xlo = OCT ? cx - (fx < 0.5f ? 1 : 0) : cx - RING, xhi = OCT ? xlo + 1 : cx + RING;
-            bool inball = true;
-            if (BOUNDED || CACHED) {
-                // distance (in cells) from the query to the row's (y,z) slab; what is left of the ball bounds x
-                const float gy = dy > 0 ? (float)dy - fy : (dy < 0 ? fy - (float)(dy + 1) : 0.f);
-                const float gz = dz > 0 ? (float)dz - fz : (dz < 0 ? fz - (float)(dz + 1) : 0.f);
-                const float rem = ubq * inv_c2 * 1.01f + 1e-4f - (gy * gy + gz * gz);
-                inball = rem >= 0.f;
-                const float gmax = sqrtf(fmaxf(rem, 0.f));
-                xlo = max(xlo, cx - (int)(gmax - fx + 1.f));  // dx < 0: gap = fx - (dx + 1) <= gmax
-                xhi = min(xhi, cx + (int)(gmax + fx));        // dx > 0: gap = dx - fx       <= gmax
-            }
-            const int x0 = max(xlo, 0), x1 = min(xhi, g.nx - 1);
-            const bool split = (x0 >> 2) != (x1 >> 2);
-            bool valid = (sl < NSEG) && inball && x0 <= x1 && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
-            int xa, xb;
-            if (half == 0) { xa = x0; xb = split ? (x0 | 3) : x1; }
-            else { xa = x1 & ~3; xb = x1; valid = valid && split; }
-            key[u] = brick_key(xa, y, z);
-            i0[u] = cell_local(xa, y, z);
-            i1[u] = cell_local(xb, y, z) + 1;
-            he[u] = valid ? hash64[hash_slot(key[u], g.hash_shift)] : (u64)kEmptyKey;
-        }
-        PH_MARK(2);  // 2: directory entries arrived
-        // ---- phase 2: directory entries -> point ranges.  Collisions first (rare, one branch for all segments), then
-        // every prefix-table read of the lane in one batch: a miss reads brick 0's table and is masked afterwards.
-        {
-            bool coll = false;
-#pragma unroll
-            for (int u = 0; u < SPL; ++u) coll = coll || ((uint32_t)he[u] != key[u] && (uint32_t)he[u] != kEmptyKey);
-            if (coll) {
-#pragma unroll
-                for (int u = 0; u < SPL; ++u) {
-                    u64 e = he[u];
-                    uint32_t sl_ = hash_slot(key[u], g.hash_shift);
-                    while ((uint32_t)e != key[u] && (uint32_t)e != kEmptyKey) {  // linear probing
-                        sl_ = (sl_ + 1) & g.hash_mask;
-                        e = hash64[sl_];
-                    }
-                    he[u] = e;
-                }
-            }
-        }
-        uint32_t la[SPL], nseg[SPL];
-        if (RING == 1) {
-            // a ring-1 run covers at most three cells of one brick row, so its start and its end sit within four consecutive
-            // table entries: ONE 16-byte load per segment (the table rows are padded so that a z-slab's 16 entries share
-            // a 64-byte line -- the three rows of one z that neighbouring lanes resolve hit the same line)
-            typedef u32x4 __attribute__((aligned(4))) u32x4_u;
-            u32x4 tb[SPL];
-#pragma unroll
-            for (int u = 0; u < SPL; ++u) {
-                const bool hit = (uint32_t)he[u] == key[u];
-                const uint32_t* st = g.starts + (size_t)(hit ? (uint32_t)(he[u] >> 32) : 0u) * kBrickStride + i0[u];
-                tb[u] = *reinterpret_cast<const u32x4_u*>(st);
-            }
-#pragma unroll
-            for (int u = 0; u < SPL; ++u) {
-                const bool hit = (uint32_t)he[u] == key[u];
-                const uint32_t len = i1[u] - i0[u];  // 1..3 cells
-                la[u] = tb[u].x;
-                const uint32_t lb = len == 1 ? tb[u].y : (len == 2 ? tb[u].z : tb[u].w);
-                nseg[u] = hit ? min(lb - la[u], 1u << 18) : 0u;  // cap: keeps the packed sums below exact (> 2^PB is unsettled anyway)
-            }
-        } else {
-            uint32_t lb[SPL];
-#pragma unroll
-            for (int u = 0; u < SPL; ++u) {
-                const bool hit = (uint32_t)he[u] == key[u];
-                const uint32_t* st = g.starts + (size_t)(hit ? (uint32_t)(he[u] >> 32) : 0u) * kBrickStride;
-                la[u] = st[i0[u]];
-                lb[u] = st[i1[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < SPL; ++u) {
-                const bool hit = (uint32_t)he[u] == key[u];
-                nseg[u] = hit ? min(lb[u] - la[u], 1u << 18) : 0u;
-            }
-        }
-        PH_MARK(3);  // 3: prefix tables read
-        // ---- flat candidate list of the group: exclusive prefix over its segments in slot order (slot = lane + u*LPQ),
-        // in registers: a DPP scan across the group's lanes per u, running totals across u.  Empty segments are dropped,
-        // so the table holds (first point - flat start, flat end) of the non-empty ones, then a sentinel.
-        uint32_t T = 0;
-        {
-            uint32_t run = 0;  // bits 0..23: candidates so far, 24..31: non-empty segments so far
-#pragma unroll
-            for (int u = 0; u < SPL; ++u) {
-                const uint32_t mine = nseg[u] | (nseg[u] ? (1u << 24) : 0u);
-                uint32_t inc = mine;
-                if (LPQ >= 2) { const uint32_t up = dpp_u32z<0x111>(inc); inc += (lane >= 1) ? up : 0u; }
-                if (LPQ >= 4) { const uint32_t up = dpp_u32z<0x112>(inc); inc += (lane >= 2) ? up : 0u; }
-                if (LPQ >= 8) { const uint32_t up = dpp_u32z<0x114>(inc); inc += (lane >= 4) ? up : 0u; }
-                if (LPQ >= 16) { const uint32_t up = dpp_u32z<0x118>(inc); inc += (lane >= 8) ? up : 0u; }
-                uint32_t tot;
-                if (LPQ == 2) tot = dpp_u32<0xF5>(inc);        // quad_perm [1,1,3,3]
-                else if (LPQ == 4) tot = dpp_u32<0xFF>(inc);   // quad_perm [3,3,3,3]
-                else tot = (uint32_t)__shfl((int)inc, LPQ - 1, LPQ);
-                const uint32_t ex = run + inc - mine;
-                const uint32_t exT = ex & 0xFFFFFFu;
-                if (nseg[u]) seg[grp][ex >> 24] = make_uint2(la[u] - exT, exT + nseg[u]);
-                run += tot;
-            }
-            T = run & 0xFFFFFFu;
-            if (lane == 0) seg[grp][run >> 24] = make_uint2(0u, 0xFFFFFFFFu);  // sentinel: the walk never runs off the end
-        }
-        wave_sync();
-        PH_MARK(4);  // 4: prefix done
-        // ---- one pass over the candidates: the group's T candidates are dealt round-robin to its lanes
-        constexpr uint32_t PMASK = (1u << PB) - 1u;
-        uint32_t K[kTop];
-#pragma unroll
-        for (int j = 0; j < kTop; ++j) K[j] = kEmptyPacked;
-        int cur = 0;
-        uint2 sg = seg[grp][0];
-        uint2 nx = seg[grp][1];  // the entry after the current one is always in flight before it is needed
-        for (uint32_t t0 = lane; t0 < T; t0 += LPQ * UNR) {
-            u32x3 v[UNR];
-#pragma unroll
-            for (int w = 0; w < UNR; ++w) {
-                const uint32_t t = t0 + (uint32_t)(w * LPQ);
-                if (t >= sg.y) {  // one step is the common case; its look-ahead read is not waited for here
-                    sg = nx; ++cur; nx = seg[grp][cur + 1];
-                    while (t >= sg.y) { sg = nx; ++cur; nx = seg[grp][cur + 1]; }
-                }
-                v[w] = load_xyz(rsrc, (t < T) ? sg.x + t : 0xFFFFFFFu);  // past the end: out-of-range -> zeros, masked below
-            }
-#pragma unroll
-            for (int w = 0; w < UNR; ++w) {
-                const uint32_t t = t0 + (uint32_t)(w * LPQ);
-                const float d = dist2(qx, qy, qz, __uint_as_float(v[w].x), __uint_as_float(v[w].y), __uint_as_float(v[w].z));
-                const uint32_t key = (__float_as_uint(d) & ~PMASK) | (t & PMASK);
-                ins8(K, (t < T) ? key : kEmptyPacked);
-            }
-        }
-        PH_MARK(5);  // 5: candidates
-        merge_group8<LPQ>(K);
-        int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) cnt += (K[j] < kEmptyPacked) ? 1 : 0;
-        // The packed order decides WHICH candidates can be among the five nearest: with v = the 5th key above the packed
-        // bits, every candidate whose key exceeds v there is farther than five others, and those at or below v are all
-        // among the best eight as long as the 8th key is above v.  Their exact (d2, map index) -- known once their points
-        // are loaded -- then picks and orders the five.  Only an 8th key at v (four neighbours within 2^-15 relative, or
-        // equal distances) or a list longer than the packed index can name leaves the set open: next stage / general path.
-        const uint32_t v5 = K[4] >> PB;
-        int m = cnt;  // candidates to load: the found ones among the first five + the ties of the fifth
-#pragma unroll
-        for (int j = 5; j < kTop - 1; ++j) m += (cnt == 5 && K[j] < kEmptyPacked && (K[j] >> PB) == v5) ? 1 : 0;
-        const bool amb = T > PMASK + 1u || (cnt == 5 && K[kTop - 1] < kEmptyPacked && (K[kTop - 1] >> PB) == v5);
-        const float d5hi = (cnt == 5) ? __uint_as_float(K[4] | PMASK) : INFINITY;  // >= the true 5th distance
-        const float octfrac = fminf(fminf(fmaxf(fx, 1.f - fx), fmaxf(fy, 1.f - fy)), fmaxf(fz, 1.f - fz));
-        const float gr = (OCT ? octfrac : (float)RING + minfrac) * g.c - 2e-3f * g.c;  // guaranteed-complete radius (fp margin)
-        const float gr2 = gr * gr;
-        const bool covered = (cnt == 5 && d5hi <= gr2) || gr2 >= max_sqdist;
-        const bool done = !amb && covered;
-#ifndef FLH_PHASES
-        if (cand_counter && live && lane == 0) atomicAdd(cand_counter, (u64)T);
-#endif
-        PH_MARK(6);  // 6: merged
-        // ---- results: lane l loads ranks l, l + LPQ, ... (< m): flat index -> map position (table walk) -> one point load
-        // each, all issued before the first is consumed; the exact squared distance is recomputed from the point (same
-        // formula, same bits as the scan saw before packing).  The group then exchanges the (d2, map index) pairs and every
-        // lane places its points at their exact rank; ranks beyond the fifth are dropped.
-        if (done && live) {
-            constexpr int NL = kTop - 1;                 // at most seven candidates are loaded
-            constexpr int RPL = (NL + LPQ - 1) / LPQ;    // per lane
-            float4 pv[RPL];
-            float dv[RPL];
-#pragma unroll
-            for (int r = 0; r < RPL; ++r) {
-                const int j = lane + r * LPQ;
-                uint32_t kj = K[0];
-#pragma unroll
-                for (int jj = 1; jj < NL; ++jj) kj = (j == jj) ? K[jj] : kj;
-                pv[r] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-                if (j < m) {
-                    const uint32_t t = kj & PMASK;
-                    int c2 = 0;
-                    uint2 s2 = seg[grp][0];
-                    while (t >= s2.y) s2 = seg[grp][++c2];
-                    pv[r] = load_pt(rsrc, s2.x + t);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < RPL; ++r)
-                dv[r] = (lane + r * LPQ < m) ? dist2(qx, qy, qz, pv[r].x, pv[r].y, pv[r].z) : INFINITY;
-            // every lane sees all (d2, id): candidate i lives in slot i / LPQ of lane i % LPQ
-            float da[NL];
-            uint32_t ia[NL];
-#pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                da[i] = group_bcast<LPQ>(dv[i / LPQ], i % LPQ);
-                ia[i] = __float_as_uint(group_bcast<LPQ>(pv[i / LPQ].w, i % LPQ));
-            }
-#pragma unroll
-            for (int r = 0; r < RPL; ++r) {
-                const int j = lane + r * LPQ;
-                if (j < NL) {
-                    int e = j;  // rows past the found ones (j >= m, only when fewer than five were found) are written empty
-                    if (j < m) {  // exact rank among the loaded ones (ids are distinct: a strict total order)
-                        const uint32_t myid = __float_as_uint(pv[r].w);
-                        e = 0;
-#pragma unroll
-                        for (int i = 0; i < NL; ++i)
-                            e += (i < m && (da[i] < dv[r] || (da[i] == dv[r] && ia[i] < myid))) ? 1 : 0;
-                    }
-                    if (e < 5) {
-                        nn_pts[(size_t)e * N + q] = pv[r];  // the squared distances are not stored: k_fill_d2 recomputes them on demand
-                        if (e == 4) selected[q] = (j < m && !(dv[r] > max_sqdist)) ? 1 : 0;  // laserMapping.cpp:671
-                    }
-                }
-            }
-            if (lane == 0) nn_cnt[q] = (uint8_t)cnt;
-        }
-        PH_MARK(7);  // 7: results written
-        bool done2 = done;
-        if (FINAL) {
-            // Last stage only.  The block provably holds the five nearest (5th distance inside the guaranteed radius) but
-            // the packed keys left the set open (5th and 6th agree above the packed bits -- equal distances included -- or
-            // the list is longer than the packed index can name): one more pass over the SAME candidates with 64-bit
-            // (d2, map index) keys settles it.
-            if (live && !done && covered) {
-                Top5 L;
-                L.reset();
-                int c2 = 0;
-                uint2 s2 = seg[grp][0];
-                constexpr int RU = 8;  // loads in flight per lane
-                for (uint32_t t0 = lane; t0 < T; t0 += LPQ * RU) {
-                    float4 pv[RU];
-                    uint32_t pos[RU];
-#pragma unroll
-                    for (int w = 0; w < RU; ++w) {
-                        const uint32_t t = t0 + (uint32_t)(w * LPQ);
-                        while (t >= s2.y) s2 = seg[grp][++c2];
-                        pos[w] = (t < T) ? s2.x + t : 0xFFFFFFFu;
-                        pv[w] = load_pt(rsrc, pos[w]);
-                    }
-#pragma unroll
-                    for (int w = 0; w < RU; ++w)
-                        if (t0 + (uint32_t)(w * LPQ) < T)
-                            L.insert(make_key(dist2(qx, qy, qz, pv[w].x, pv[w].y, pv[w].z), pv[w].w), pos[w]);
-                }
-                top5_finish<LPQ>(L, g, q, N, lane, max_sqdist, nn_pts, nn_d2, nn_cnt, selected);
-                done2 = true;
-            }
-        }
-        if (FINAL) {
-            if (live && !done2) {
-                const float ubx = fminf(BOUNDED ? fminf(d5hi, ub_in[q]) : (CACHED ? fminf(d5hi, ub_raw) : d5hi), max_sqdist);
-                const uint32_t nc = exact_query<LPQ>(g, q, N, qx, qy, qz, cx, cy, cz, fx, fy, fz, ubx, rmax, max_sqdist, lane, nn_pts,
-                                                     nn_d2, nn_cnt, selected);
-                if (cand_counter && lane == 0) atomicAdd(cand_counter, (u64)nc);
-            }
-        }
-        if (FINAL && !in_list) {  // first stage finishing alone: only count the queries that took the slow path (for the host's
-                                  // choice of the launch plan of the next search pass), one atomic per wave
-            const u64 bslow = __ballot(live && !done && lane == 0);
-            if (bslow && (threadIdx.x & 63) == (__ffsll((long long)bslow) - 1)) atomicAdd(out_count + stripe, (uint32_t)__popcll(bslow));
-        }
-        // ---- unsettled queries go to the next stage's list: one global atomic per wave, 64 striped counters
-        const bool append = !FINAL && live && !done2 && lane == 0;
-        const u64 bal = __ballot(append);
-        if (bal) {
-            const int wlane = threadIdx.x & 63;
-            const int leader = __ffsll((long long)bal) - 1;
-            uint32_t wbase = 0;
-            if (wlane == leader) wbase = atomicAdd(out_count + stripe, (uint32_t)__popcll(bal));
-            wbase = __shfl(wbase, leader, 64);
-            if (append) {
-                out_list[wbase + (uint32_t)__popcll(bal & ((1ull << wlane) - 1ull))] = (uint32_t)q;
-                ub_out[q] = BOUNDED ? fminf(d5hi, ub_in[q]) : (CACHED ? fminf(d5hi, ub_raw) : d5hi);  // the true 5th distance is <= either bound
-            }
-        }
-        PH_MARK(8);  // 8: appended
-        PH_NEXT_TRIP();
-        if (!BOUNDED) break;  // no input list: single trip (see above)
-        wave_sync();  // seg[] is rewritten by the next trip
-    }
-    PH_DUMP(RING == 1 ? 0 : 8);
+#include "flh_ring_body.inc"
 }
 
 // Group-wide merge of the lanes' sorted (d2, map index) lists and the query's result rows: 5 x (min butterfly, ballot, pop).
@@ -831,6 +459,8 @@ k_search_exact(GridParams g, StateDev s, const float4* __restrict__ body, int N,
         if (cand_counter && ncand) atomicAdd(cand_counter, (u64)ncand);
     }
 }
+
+#include "flh_search_tile.inc"
 
 // ------------------------------------------------------------------------------------------------
 // B: one thread per scan point: plane fit, residual gate, Jacobian row; then the wave's 64 rows are
@@ -1260,6 +890,11 @@ hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const St
                            nn_pts, nn_d2, nn_cnt, selected, list1, counts, cap, ub, 1, cand_counter, own_axis, own_lo, own_hi);
         return hipGetLastError();
     }
+    // experiment (first_stage = 3): the first stage with a block-shared LDS tile (flh_search_tile.inc), every search of a scan
+    const bool tile_stage = first_stage == 3 && lpq == 4 && rmax >= 2;
+    if (tile_stage)
+        hipLaunchKernelGGL(k_search_tile, dim3(cdiv(N, 64)), blk, 0, st, g, s, body, N, map_points, max_sqdist, nn_pts, nn_d2, nn_cnt,
+                           selected, list1, counts, cap, ub, rmax, cand_counter, own_axis, own_lo, own_hi);
     // A1: ring 1, every query
 #define FLH_A1(L, O)                                                                                                     \
     if (cache_bound == 2 && L == 4 && !O)                                                                                \
@@ -1277,7 +912,8 @@ hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const St
                        map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,                \
                        (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter, own_axis,     \
                        own_lo, own_hi)
-    if (first_stage == 2 && rmax >= 2) {
+    if (tile_stage) {
+    } else if (first_stage == 2 && rmax >= 2) {
         switch (lpq) {
             case 1: FLH_A1(1, true); break;
             case 2: FLH_A1(2, true); break;
@@ -1293,7 +929,7 @@ hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const St
         }
     }
 #undef FLH_A1
-    if (cache_bound == 2 && lpq == 4 && !(first_stage == 2 && rmax >= 2)) return hipGetLastError();  // the first stage finished everything
+    if (!tile_stage && cache_bound == 2 && lpq == 4 && !(first_stage == 2 && rmax >= 2)) return hipGetLastError();  // the first stage finished everything
     if (rmax >= 2) {
         // A2: ring 2 over list 1, inside the ball A1's 5th distance defines; whatever it cannot settle (distance ties, a
         // 5th neighbour beyond the 5x5x5 block) it finishes itself with the general exact search

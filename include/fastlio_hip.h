@@ -54,7 +54,9 @@ typedef struct flh_config {
     int sort_queries;       /* 1: Morton-sort scan points at upload for cache locality (default 1 if <0) */
     int first_stage;        /* block of cells the first search stage scans: 1 = the 3x3x3 block around the query's cell,
                                2 = the 2x2x2 block nearest to the query (8 cells instead of 27; more queries go on to the
-                               second stage), 0 = default.  Performance only: every setting returns the same exact 5-NN */
+                               second stage), 0 = default; 3 = EXPERIMENT, not validated on hardware when it was written: the 3x3x3 block
+                               served from a block-shared LDS tile (flh_search_tile.inc).  Performance only: every setting is
+                               meant to return the same exact 5-NN */
     int eigen_order;        /* fp32 summation order of esti_plane's reductions (include/common_lib.h:241 runs Eigen's
                                ColPivHouseholderQR, whose reduction order depends on how Eigen was vectorised):
                                FLH_ORDER_SEQ / _SSE / _PAIRWISE / _NOVEC; <0 -> FLH_ORDER_SSE (Eigen 3.3.x, x86-64 + SSE2:

@@ -32,4 +32,10 @@ try:
 except Exception as e:
     print('$knob: no line', e)"
 done
+timeout 240 python bench.py --gpus 1 --steps 300 --warmup 30 --cpu-scans 0 --no-extra-legs --first-stage 3 2>/dev/null | python -c "
+import json, sys
+try:
+    d = json.loads(sys.stdin.read()); print('first_stage 3 (LDS tile):', {k: d[k] for k in ('value', 'ms_search_pass', 'ms_nosearch_pass', 'device_resident_scans_per_s')}, d['roofline']['avg_kernel_us'])
+except Exception as e:
+    print('first_stage 3: no line', e)"
 timeout 400 python bench.py > $O/bench300.json 2> $O/bench300.err; echo "bench300 rc=$?"; cut -c1-400 $O/bench300.json; tail -3 $O/bench300.err
