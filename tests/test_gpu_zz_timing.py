@@ -159,7 +159,7 @@ def _experiment_tile_stage():
 # ---- experiments that are OFF by default and had not run on hardware when they were written.  Each runs in a child process under a
 # time limit, so that a device fault or a hang in unvalidated device code cannot take the suite down; a failure is reported as an
 # expected failure with the child's last lines in the warnings summary (the product's default path is not involved either way).
-def _run_experiment(fn_name, limit=420):
+def _run_experiment(fn_name, limit=240):
     import subprocess
     import sys
     import warnings
