@@ -177,9 +177,15 @@ def _run_experiment(fn_name, limit=240):
     pytest.xfail("experiment %s: see the warnings summary" % fn_name)
 
 
+_experiments = pytest.mark.skipif(not os.environ.get("FLH_RUN_EXPERIMENTS"),
+                                  reason="unvalidated device code: run with FLH_RUN_EXPERIMENTS=1 (tools/round_start.sh does)")
+
+
+@_experiments
 def test_plane_cache_experiment_changes_no_bit():
     _run_experiment("_experiment_plane_cache")
 
 
+@_experiments
 def test_tile_first_stage_experiment_equals_the_default_stage():
     _run_experiment("_experiment_tile_stage")

@@ -4,7 +4,7 @@
 #   gpurun --timeout 1500 -- tools/round_start.sh
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/round_start; mkdir -p $O; cd $R
-timeout 420 python -m pytest tests -q -m gpu -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -6 | tee $O/gpu_tests.txt
+FLH_RUN_EXPERIMENTS=1 timeout 600 python -m pytest tests -q -m gpu -x -rxX 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -6 | tee $O/gpu_tests.txt
 for mode in deferred sync; do
   if [ $mode = sync ]; then export FLH_SYNC_EVENTS=1; else unset FLH_SYNC_EVENTS; fi
   timeout 240 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-scans 0 --no-extra-legs > $O/bench20_$mode.json 2> $O/bench20_$mode.err
