@@ -107,7 +107,8 @@ def main():
                     help="evaluations of the timed region whose kernels are bracketed by HIP events (>= 16; half of them "
                          "are searching evaluations, so the default gives >= 16 samples of the search kernels from 20 steps on)")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the headline + roofline (profiling runs)")
-    ap.add_argument("--cpu-scans", type=int, default=3, help="scans timed on the CPU oracle per thread count (0 = skip)")
+    ap.add_argument("--cpu-scans", type=int, default=96,
+                    help="upper bound of the scans timed on the CPU oracle at --cpu-threads (it stops after ~12 s; 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=3, help="OpenMP threads (reference MP_PROC_NUM = 3)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo for debugging")
     ap.add_argument("--single-device", type=int, default=0, help="debug: every rank uses cuda:0 (needs --backend gloo)")
@@ -147,8 +148,12 @@ def main():
             dist.init_process_group(args.backend)
     mode = args.mode
     if mode == "auto":
-        mode = "streams"
+        # one GPU: the pipelined scan stream.  N > 1: BASELINE's split -- ONE scan's points sharded over the ranks (configs with a
+        # map <= 20M points: map replicated) or the map partitioned (config 5), the 16x16 normal-equation block all-reduced by RCCL
+        # inside every pass.  N independent replicas (no collective) are reported beside it, never as `value`.
+        mode = "streams" if G == 1 else ("partition" if args.config == 5 else "shard")
     run_shard_leg = (G > 1 or args.force_shard_leg) and args.mode in ("auto", "shard", "partition")
+    run_replica_leg = G > 1 and args.mode == "auto"
 
     from fast_lio_amd import dist as fdist
 
@@ -157,10 +162,14 @@ def main():
     with_map_inserts = args.config == 3  # "Velodyne scan stream ... incremental map inserts"
     t0 = time.time()
     scene = synth.make_scene(M, synth.CONFIG_SEED_BASE + args.config)
-    S = max(1, min(args.scans, args.steps + args.warmup))
+    S = max(1, args.scans)  # >= 100 distinct seeded scans whatever --steps is; they are cycled through
 
     def gen(seed_base, count):
-        pr = [synth.make_problem(M, N, sensor, cfg=args.config, scan_seed=seed_base + s, scene=scene) for s in range(count)]
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:  # numpy releases the GIL in the heavy parts
+            pr = list(ex.map(lambda s_: synth.make_problem(M, N, sensor, cfg=args.config, scan_seed=seed_base + s_, scene=scene),
+                             range(count)))
         pri = [synth.propagate_prior_cov(capi.predict_fn, p.x_prior) for p in pr]
         return pr, [(np.ascontiguousarray(x, np.float64), np.ascontiguousarray(P, np.float64)) for x, P in pri]
 
@@ -213,7 +222,10 @@ def main():
         gc.collect()
         gc.disable()
         sync()
-        hx.set_timing_stride(max(2, (n_steps * 4) // max(args.timing_samples, 16)))  # >= 2: sampled evaluations do not wait
+        # sampled evaluations record HIP events and do not wait (stride >= 2); an ODD stride walks through all four positions
+        # of the pass schedule (search, no-search, search, no-search), so first and later searches are sampled alike
+        stride = max(3, (n_steps * 4) // max(args.timing_samples, 16))
+        hx.set_timing_stride(stride + 1 - (stride & 1))
         hx.counters(reset=True)
         t1 = time.perf_counter()
         rs = kfx.run_scans(jobs, n_warm, n_steps, ring=RING, map_incremental=with_map_inserts, first_staged=n_warm > 0)
@@ -225,7 +237,9 @@ def main():
             tt = torch.tensor([dt_], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_ = float(tt.item())
-        return dt_, Acc(rs), hx.counters()
+        c_ = hx.counters()
+        c_.update(hx.search_counters())
+        return dt_, Acc(rs), c_
 
     # ---------------- headline leg: the pipelined loop.  Scan i+1 is handed to the staging thread (host buffer -> H2D ->
     # re-stride + Morton sort on the copy stream) before the update of scan i starts; the update waits for ITS staging
@@ -235,10 +249,17 @@ def main():
     shard_out = None
     if mode in ("shard", "partition") and G == 1 and not args.force_shard_leg:
         mode = "streams"  # one rank: nothing to shard
+    replicas_out = None
     if mode == "streams":
         dt, acc, ctr = run(kf, h, jobs_pipe, args.warmup, args.steps)
         units = args.steps * G
         n_pts = N
+    elif run_replica_leg:
+        k1 = max(10, min(60, args.steps // 2))
+        dt1, _a1, _c1 = run(kf, h, jobs_pipe, max(3, args.warmup // 2), k1)
+        replicas_out = {"value": round(k1 * G / dt1, 3), "unit": "scans/s", "steps": k1, "scaling": "weak",
+                        "note": f"{G} independent scan streams (one per rank), replicated map, NO collective in the data path: "
+                                "replicas, not the sharded path"}
     # ---------------- sharded leg (north_star C1): ONE scan's points split over the ranks Morton-first, map replicated (or,
     # --mode partition / config 5, the map cut into slabs with a halo and every rank holding the whole scan); per pass each
     # rank reduces its part to the 16x16 Gram block in device memory and RCCL sums the blocks INSIDE flh_eval (native
@@ -267,8 +288,8 @@ def main():
                 pts_here = hi - lo
             kfs = capi.Esekf(hs, max_iter=3, extrinsic_est_en=ext)
             jobs_sh = capi.Esekf.make_jobs([np.zeros((1, 3), np.float32)] * S_sh, sh_priors, slots=list(range(S_sh)))
-            k2 = args.steps if mode in ("shard", "partition") else max(10, min(60, args.steps // 4))
-            dt2, acc2, ctr2 = run(kfs, hs, jobs_sh, max(3, args.warmup // 4), k2)
+            k2 = args.steps if mode in ("shard", "partition") else max(10, min(60, args.steps // 4))  # (side leg only with --force-shard-leg)
+            dt2, acc2, ctr2 = run(kfs, hs, jobs_sh, args.warmup if mode in ("shard", "partition") else max(3, args.warmup // 4), k2)
             # every rank must have produced the same posterior
             xs = [kfs.get_x()] * G
             if dist is not None:
@@ -305,7 +326,11 @@ def main():
                 "kernel": f"5-NN search of one pass = k_search_ring<{args.lpq},1> (every query) + k_search_ring<16,2> (the rest, incl. the exact fallback)",
                 "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                 "traffic": None, "avg_kernel_us": round(dur_s * 1e6, 2), "alg_bytes_per_launch": ALG_BYTES_SEARCH * n_pts,
-                "events_sampled": int(ctr["n_search"]), "fit_kernel_us": round(fit_s * 1e6, 2),
+                "events_sampled": int(ctr["n_search"]),
+                "events_sampled_by_kind": {"first_search_of_scan": int(ctr.get("n_first", 0)), "later_search": int(ctr.get("n_later", 0))},
+                "first_search_us": round(ctr["first_ms"] / ctr["n_first"] * 1e3, 2) if ctr.get("n_first") else None,
+                "later_search_us": round(ctr["later_ms"] / ctr["n_later"] * 1e3, 2) if ctr.get("n_later") else None,
+                "fit_kernel_us": round(fit_s * 1e6, 2),
                 "fit_events_sampled": int(ctr["n_fit"]),
                 "fit_alg_bytes_per_launch": ALG_BYTES_NOSEARCH * n_pts,
                 "fit_achieved_GBs": round(ALG_BYTES_NOSEARCH * n_pts / fit_s / 1e9, 2),
@@ -337,7 +362,7 @@ def main():
                                     f"per pass" if mode in ("shard", "partition") else
                                     f"{G} independent scan streams (one per rank), replicated map, no collective in the data path")),
                    "distinct_scans": S, "cell_size_m": args.cell, "lanes_per_query": args.lpq, "first_stage": args.first_stage,
-                   "event_reading": "synchronous" if os.environ.get("FLH_SYNC_EVENTS") else "deferred"},
+                   "event_reading": "deferred (recorded inside the timed region, read after it)"},
         "ms_per_iekf_pass": round((acc.ms_s + acc.ms_n) / max(acc.passes, 1), 4),
         "ms_search_pass": round(acc.ms_s / max(acc.n_s, 1), 4),
         "ms_nosearch_pass": round(acc.ms_n / max(acc.n_n, 1), 4),
@@ -381,34 +406,49 @@ def main():
         out["roofline"] = roof
     if shard_out is not None and mode not in ("shard", "partition"):
         out["shard_mode"] = shard_out
+    if shard_out is not None and mode in ("shard", "partition"):
+        out["sharded_path"] = {k: shard_out[k] for k in ("layout", "points_per_rank", "map_points_this_rank", "collective",
+                                                          "ranks_in_communicator", "max_abs_state_disagreement_across_ranks")}
+    if replicas_out is not None:
+        out["replicas_no_collective"] = replicas_out
 
-    # ---- CPU baseline: the oracle's restated reference path on this box's host cores (rank 0, N=1 only), at the
-    # reference's own thread count (MP_PROC_NUM = 3, CMakeLists.txt:21-24) and at all host cores
+    # ---- CPU baseline: the oracle's restated reference path on this box's host cores (rank 0, N=1 only): a bounded sample
+    # (~10-30 s of CPU work) at the reference's own thread count (MP_PROC_NUM = 3, CMakeLists.txt:21-24), and the best of a
+    # small thread sweep -- the restated k-d tree path stops scaling long before "all cores" on a many-core host
     if rank == 0 and G == 1 and args.cpu_scans > 0:
         from oracle import pyoracle as po
 
         m = po.Map(scene.map_xyz)  # k-d tree build is outside the reference's t_update window too
-        ncpu = min(args.cpu_scans, S)
-
-        def cpu_rate(threads):
-            tot = 0.0
-            for s in range(ncpu):
-                sc = po.Scan(probs[s].body, nthreads=threads)
-                t1 = time.perf_counter()
-                sc.update_iterated(m, priors[s][0], priors[s][1], extrinsic_est_en=ext)
-                tot += time.perf_counter() - t1
-            return ncpu / tot
-
-        r3 = cpu_rate(args.cpu_threads)
         ncores = os.cpu_count() or 1
-        rall = cpu_rate(ncores)
+
+        def cpu_rate(threads, budget_s, max_scans):
+            tot, n = 0.0, 0
+            while n < max_scans and (n < 2 or tot < budget_s):
+                s_ = n % S
+                sc = po.Scan(probs[s_].body, nthreads=threads)
+                t1 = time.perf_counter()
+                sc.update_iterated(m, priors[s_][0], priors[s_][1], extrinsic_est_en=ext)
+                tot += time.perf_counter() - t1
+                n += 1
+            return n / tot, n
+
+        r3, n3 = cpu_rate(args.cpu_threads, 12.0, args.cpu_scans)
+        sweep = {}
+        for th in (8, 16, 32, 64):
+            if th <= ncores:
+                sweep[th] = cpu_rate(th, 2.5, max(2, args.cpu_scans // 4))
+        best_th = max(sweep, key=lambda k_: sweep[k_][0]) if sweep else None
         out["cpu_baseline"] = {"value": round(r3, 4), "unit": "scans/s", "cores": args.cpu_threads, "kind": "port",
-                               "sample": f"{ncpu} full updates of the same {N}-pt scans vs the same {M}-pt map "
+                               "sample": f"{n3} full updates of the same {N}-pt scans vs the same {M}-pt map "
                                          f"(restated reference path: k-d tree 5-NN + plane fit + IEKF, OpenMP "
                                          f"{args.cpu_threads} threads = the reference's MP_PROC_NUM); host has "
                                          f"{ncores} logical cores",
-                               "speedup_vs_cpu": round(value / r3, 1),
-                               "all_cores": {"value": round(rall, 4), "cores": ncores, "speedup_vs_cpu": round(value / rall, 1)}}
+                               "speedup_vs_cpu": round(value / r3, 1)}
+        if best_th is not None:
+            out["cpu_baseline"]["best_of_thread_sweep"] = {
+                "value": round(sweep[best_th][0], 4), "cores": best_th, "speedup_vs_cpu": round(value / sweep[best_th][0], 1),
+                "sweep_scans_per_s": {str(k_): round(v_[0], 3) for k_, v_ in sweep.items()},
+                "sample": f"{sweep[best_th][1]} updates per thread count"}
 
     # ---- the legs beside the headline (map_incremental, the raw-scan front end incl. frame_world, optionally two scan
     # streams on one GPU) run in a CHILD process after this one has finished its own GPU work: they are reported beside
@@ -439,29 +479,29 @@ def run_main_in_child(attempts=2):
     big = any(a in ("4", "5") and i > 0 and sys.argv[i] == "--config" for i, a in enumerate(sys.argv[1:]))  # 20M / 50M maps: generation alone takes minutes
     limit = 3000 if big else 800  # a healthy run of the default configuration takes one to three minutes
     rc = 1
+    history = []
     for k in range(attempts):
-        env = dict(os.environ)
-        if k > 0:
-            # the second attempt reads its roofline events synchronously (the library's older, longer-proven way); it costs
-            # throughput in short runs -- the line says so in config.event_reading
-            env["FLH_SYNC_EVENTS"] = "1"
         try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, timeout=limit)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=limit)
             rc, out = r.returncode, r.stdout
         except subprocess.TimeoutExpired as e:
             rc, out = -9, (e.stdout or b"")
-        lines = []
+        history.append(rc)
+        line = None
         for ln in out.decode(errors="replace").splitlines():
             if ln.startswith("{"):
                 try:
-                    if "metric" in json.loads(ln):
-                        lines.append(ln)
+                    d = json.loads(ln)
+                    if "metric" in d:
+                        line = d
                 except ValueError:
                     pass
-        if lines:  # the line is printed once, after every measurement: it stands even if the process then died while tearing down
+        if line is not None:  # printed once, after every measurement: it stands even if the process then died while tearing down
+            # nothing is hidden: the line says how many attempts it took and how each measuring process ended
+            line["measuring_process"] = {"attempts": k + 1, "exit_codes": history}
             if rc != 0:
                 log(f"[bench] the measuring process printed its line and then exited with {rc}")
-            print(lines[-1], flush=True)
+            print(json.dumps(line), flush=True)
             return 0
         log(f"[bench] attempt {k + 1}/{attempts}: the measuring process exited with {rc} and no result line")
         if rc == 3:  # no GPU: a second try changes nothing

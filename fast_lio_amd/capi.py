@@ -31,6 +31,7 @@ class FlhConfig(C.Structure):
         ("first_stage", C.c_int),
         ("eigen_order", C.c_int),
         ("plane_fit_dtype", C.c_int),
+        ("undistort_first_point", C.c_int),
     ]
 
 
@@ -91,7 +92,7 @@ EXPORTS = [
     "flh_scan_stage_undistorted", "flh_esekf_update_scan", "flh_map_stats",
     "flh_scan_stage_async", "flh_scan_wait", "flh_host_alloc", "flh_host_free", "flh_frame_world", "flh_points_body_to_world",
     "flh_esekf_last_error", "flh_rccl_unique_id", "flh_rccl_init_rank", "flh_rccl_init_all", "flh_rccl_destroy", "flh_rccl_size",
-    "flh_rccl_rank", "flh_eval_group", "flh_set_owned_interval", "flh_esekf_run_scans",
+    "flh_rccl_rank", "flh_eval_group", "flh_set_owned_interval", "flh_esekf_run_scans", "flh_get_search_counters",
 ]
 
 _lib = None
@@ -204,6 +205,7 @@ def lib():
                                              C.c_int, _f64p, C.c_float, C.c_void_p, C.POINTER(C.c_size_t)]
     L.flh_get_counters.argtypes = [C.c_void_p, _f64p, C.c_int]
     L.flh_set_timing_stride.argtypes = [C.c_void_p, C.c_int]
+    L.flh_get_search_counters.argtypes = [C.c_void_p, _f64p]
     L.flh_eval.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, C.c_int, C.c_int, _f64p, _f64p,
                            C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.flh_eval_device.argtypes = [C.c_void_p, _f64p, C.c_int, C.c_int, C.c_void_p]
@@ -245,7 +247,7 @@ class Handle:
 
     def __init__(self, cell_size: float = 1.5, lanes_per_query: int = 4, device: int = -1, stream: int | None = None,
                  plane_threshold: float = 0.1, max_sqdist: float = 5.0, sort_queries: int = -1, first_stage: int = 0,
-                 eigen_order: int = -1, plane_fit_dtype: int = 0):
+                 eigen_order: int = -1, plane_fit_dtype: int = 0, undistort_first_point: int = -1):
         L = lib()
         cfg = FlhConfig()
         L.flh_default_config(C.byref(cfg))
@@ -259,6 +261,7 @@ class Handle:
         cfg.first_stage = first_stage
         cfg.eigen_order = eigen_order
         cfg.plane_fit_dtype = plane_fit_dtype
+        cfg.undistort_first_point = undistort_first_point
         self._h = C.c_void_p()
         _chk(L.flh_create(C.byref(cfg), C.byref(self._h)), "flh_create")
         self._keep = []
@@ -416,6 +419,12 @@ class Handle:
         _chk(lib().flh_get_counters(self._h, out, int(reset)), "flh_get_counters")
         return {"search_ms": out[0], "n_search": int(out[1]), "fit_ms": out[2], "n_fit": int(out[3]),
                 "eval_ms": out[4], "n_eval": int(out[5])}
+
+    def search_counters(self):
+        """Search-kernel time split by kind: a scan's first search / its later (cache-bounded) searches."""
+        out = np.zeros(4)
+        _chk(lib().flh_get_search_counters(self._h, out), "flh_get_search_counters")
+        return {"first_ms": out[0], "n_first": int(out[1]), "later_ms": out[2], "n_later": int(out[3])}
 
     @property
     def N(self):

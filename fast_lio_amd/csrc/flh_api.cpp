@@ -124,6 +124,7 @@ struct flh_handle {
     DevBuf<float4> world, nn_pts, normvec;
     DevBuf<float4> plane;     // experiment (FLH_PLANE_CACHE=1): (a, b, c, d) of the last searching pass's fits, reused by no-search passes
     bool plane_cache = false;
+    bool planes_valid = false;  // `plane` holds the fits of the CURRENT neighbour cache (written by the fit that followed the last search)
     DevBuf<float> nn_d2;
     DevBuf<uint8_t> nn_cnt, selected;
     DevBuf<double> partials, part2, gram, gather_buf;
@@ -165,6 +166,7 @@ struct flh_handle {
     bool evp_ready = false;   // the pool's events exist
     uint64_t seq = 0;        // sequence number of the last flh_eval (published by k_fit next to the result)
     double acc[6] = {0, 0, 0, 0, 0, 0};
+    double acc_kind[4] = {0, 0, 0, 0};  // search-kernel ms / launches of a scan's FIRST search, of its LATER searches (bounded by the cache)
     // staging ring
     struct Slot {
         DevBuf<float4> body;            // Morton-ordered (internal order); .w = original index
@@ -185,6 +187,7 @@ struct flh_handle {
     struct StageJob { int slot; const void* pts; size_t stride; size_t N; };
     std::thread stager;                 // flh_scan_stage_async's worker
     std::mutex st_mu;
+    std::mutex stage_mu;                // one staging at a time: the stager and the synchronous entry points share the scratch buffers below and the copy stream
     std::condition_variable st_cv, st_done;
     std::deque<StageJob> st_queue;
     bool st_quit = false;
@@ -202,6 +205,7 @@ struct flh_handle {
     // staging scratch (copy stream)
     DevBuf<float4> st_raw, ds_raw, ds_und; // ds_*: undistortion / voxel-grid down-sampling of a raw scan
     DevBuf<double> ds_poses;
+    DevBuf<u64> ds_blockmin;               // k_undistort's per-block (time, index) minima
     DevBuf<uint32_t> ds_flags, ds_incl;
     DevBuf<u64> st_k0, st_k1;
     DevBuf<uint32_t> st_v0, st_v1;
@@ -235,6 +239,7 @@ void flh_default_config(flh_config* c) {
     c->first_stage = 0;
     c->eigen_order = -1;
     c->plane_fit_dtype = 0;
+    c->undistort_first_point = -1;
 }
 
 int flh_create(const flh_config* cfg_in, flh_handle** out) {
@@ -252,6 +257,7 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.first_stage < 0 || cfg.first_stage > 3) cfg.first_stage = 0;
     if (cfg.eigen_order < 0 || cfg.eigen_order > 3) cfg.eigen_order = FLH_ORDER_SSE;
     if (cfg.plane_fit_dtype != 1) cfg.plane_fit_dtype = 0;
+    if (cfg.undistort_first_point != 0) cfg.undistort_first_point = 1;
     {
         const int l = cfg.lanes_per_query;  // 0 = exact kernel for every query
         if (l != 0 && l != 1 && l != 2 && l != 8 && l != 16) cfg.lanes_per_query = 4;
@@ -328,7 +334,7 @@ void flh_destroy(flh_handle* h) {
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->h_small) (void)hipHostFree(h->h_small);
     h->st_bytes.release(); h->fw_bytes.release(); h->fw_in.release(); h->fw_out.release();
-    h->ds_raw.release(); h->ds_und.release(); h->ds_poses.release(); h->ds_flags.release(); h->ds_incl.release();
+    h->ds_raw.release(); h->ds_und.release(); h->ds_poses.release(); h->ds_blockmin.release(); h->ds_flags.release(); h->ds_incl.release();
     h->st_raw.release(); h->st_k0.release(); h->st_k1.release(); h->st_v0.release(); h->st_v1.release(); h->st_tmp.release();
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->h_gram) (void)hipHostFree(h->h_gram);
@@ -763,6 +769,7 @@ static int prepare_scan_buffers(flh_handle* h, size_t N, bool full_clear) {
     h->searched_once = false;
     h->d2_valid = false;
     h->aux_valid = false;
+    h->planes_valid = false;
     h->mi_valid_N = (size_t)-1;
     return 0;
 }
@@ -931,7 +938,12 @@ static int stage_raw(flh_handle* h, flh_handle::Slot& sl, const char* who, const
             static_assert(sizeof(flh_pose6d) == 22 * sizeof(double), "flh_pose6d must be 22 packed doubles");
             HIPC(hipMemcpyAsync(h->ds_poses.p, und->poses, sizeof(flh_pose6d) * und->n_pose, hipMemcpyHostToDevice, cs));
             const StateDev se = make_state(und->x_end + 3, und->x_end + 0, und->x_end + 7, und->x_end + 11);
-            HIPC(flh::launch_undistort(se, h->ds_poses.p, und->n_pose, h->ds_raw.p, nu, sl.dense.p, cs));
+            u64* bmin = nullptr;
+            if (h->cfg.undistort_first_point) {  // the reference's repeated compensation of the earliest point (IMU_Processing.hpp:345)
+                HIPC(h->ds_blockmin.reserve(flh::undistort_blocks(nu)));
+                bmin = h->ds_blockmin.p;
+            }
+            HIPC(flh::launch_undistort(se, h->ds_poses.p, und->n_pose, h->ds_raw.p, nu, sl.dense.p, bmin, cs));
         }
         sl.n_dense = n;
         const float4* srcd = sl.dense.p;
@@ -1028,7 +1040,11 @@ static void stager_main(flh_handle* h) {
         lk.unlock();
         flh_handle::Slot& sl = h->slots[job.slot];
         g_err.clear();
-        const int rc = stage_into(h, sl, job.pts, job.stride, job.N, true);
+        int rc;
+        {
+            std::lock_guard<std::mutex> sg(h->stage_mu);
+            rc = stage_into(h, sl, job.pts, job.stride, job.N, true);
+        }
         lk.lock();
         sl.async_rc = rc;
         sl.async_err = rc ? g_err : std::string();
@@ -1070,7 +1086,10 @@ static int activate(flh_handle* h, flh_handle::Slot& sl, bool full_clear) {
 int flh_scan_upload(flh_handle* h, const void* pts, size_t stride_bytes, size_t N) {
     if (!h) return fail("flh_scan_upload: null handle");
     flh_handle::Slot& sl = h->slots[FLH_MAX_SLOTS];
-    if (stage_into(h, sl, pts, stride_bytes, N, true) != 0) return -1;
+    {
+        std::lock_guard<std::mutex> sg(h->stage_mu);  // a staging the worker thread has under way finishes first (shared scratch)
+        if (stage_into(h, sl, pts, stride_bytes, N, true) != 0) return -1;
+    }
     if (activate(h, sl, true) != 0) return -1;
     HIPC(hipStreamSynchronize(h->stream));
     return 0;
@@ -1085,6 +1104,7 @@ int flh_scan_stage(flh_handle* h, int slot, const void* pts, size_t stride_bytes
         h->cur_body = nullptr;
         h->have_eval = false;
     }
+    std::lock_guard<std::mutex> sg(h->stage_mu);
     return stage_into(h, h->slots[slot], pts, stride_bytes, N, true);
 }
 
@@ -1131,6 +1151,7 @@ int flh_scan_stage_downsampled(flh_handle* h, int slot, const void* pts, size_t 
     if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_stage_downsampled: bad slot");
     if (!(leaf_size > 0.f)) return fail("flh_scan_stage_downsampled: leaf size must be > 0");
     if (wait_slot(h, h->slots[slot]) != 0) return -1;
+    std::lock_guard<std::mutex> sg(h->stage_mu);
     return stage_raw(h, h->slots[slot], "flh_scan_stage_downsampled", pts, stride_bytes, n, nullptr, leaf_size, n_out);
 }
 
@@ -1147,6 +1168,7 @@ int flh_scan_stage_undistorted(flh_handle* h, int slot, const void* pts, size_t 
     u.x_end = x_end;
     u.time_offset_bytes = time_offset_bytes;
     u.undistorted_out = undistorted_xyz;
+    std::lock_guard<std::mutex> sg(h->stage_mu);
     return stage_raw(h, h->slots[slot], "flh_scan_stage_undistorted", pts, stride_bytes, n, &u, leaf_size, n_out);
 }
 
@@ -1296,7 +1318,7 @@ static void drain_events(flh_handle* h) {
             continue;  // a sample that cannot be read is dropped, not guessed
         }
         const bool srch = h->evp_search[k] != 0;
-        if (srch) { h->acc[0] += a; h->acc[1] += 1; }
+        if (srch) { h->acc[0] += a; h->acc[1] += 1; h->acc_kind[h->evp_search[k] == 2 ? 2 : 0] += a; h->acc_kind[h->evp_search[k] == 2 ? 3 : 1] += 1; }
         h->acc[2] += b; h->acc[3] += 1;
         h->acc[4] += c; h->acc[5] += 1;
         h->timing.search_ms = srch ? a : 0.f;
@@ -1330,7 +1352,8 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
     HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
                          h->world.p, h->partials.p, h->part2.p, d_out, seq, h->tickets.p, h->slow_count.p,
                          host_granules ? h->h_gran : nullptr, host_granules ? gran_group_size(h->N) : 0, 0, st,
-                         h->plane_cache ? h->plane.p : nullptr, do_search ? 1 : 2));
+                         h->plane_cache ? h->plane.p : nullptr, (do_search || !h->planes_valid) ? 1 : 2));
+    h->planes_valid = h->plane_cache;
     h->aux_valid = false;
     if (timed) HIPC(hipEventRecord(ev3[2], st));
     h->last_state = s;
@@ -1459,7 +1482,7 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     // timed evaluations: three event records on the stream (before the first launch, after the search kernels, after the
     // fit kernel); the last one completes when k_fit retires, a moment after the flag
     if (deferred) {  // recorded, not awaited: read by drain_events
-        h->evp_search[h->evp_n] = do_search ? 1 : 0;
+        h->evp_search[h->evp_n] = do_search ? (h->last_search_was_later ? 2 : 1) : 0;
         h->evp_n++;
     } else if (timed) {
         HIPC(hipEventSynchronize(h->ev[2]));
@@ -1530,7 +1553,7 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     }
 #endif
     if (timed && !deferred) {
-        if (do_search) { h->acc[0] += a; h->acc[1] += 1; }
+        if (do_search) { h->acc[0] += a; h->acc[1] += 1; h->acc_kind[h->last_search_was_later ? 2 : 0] += a; h->acc_kind[h->last_search_was_later ? 3 : 1] += 1; }
         h->acc[2] += b; h->acc[3] += 1;
         h->acc[4] += c; h->acc[5] += 1;
     }
@@ -1541,8 +1564,16 @@ int flh_get_counters(flh_handle* h, double out[6], int reset) {
     if (!h || !out) return fail("flh_get_counters: null argument");
     drain_events(h);
     for (int i = 0; i < 6; ++i) out[i] = h->acc[i];
-    if (reset)
+    if (reset) {
         for (int i = 0; i < 6; ++i) h->acc[i] = 0;
+        for (int i = 0; i < 4; ++i) h->acc_kind[i] = 0;
+    }
+    return 0;
+}
+int flh_get_search_counters(flh_handle* h, double out[4]) {
+    if (!h || !out) return fail("flh_get_search_counters: null argument");
+    drain_events(h);
+    for (int i = 0; i < 4; ++i) out[i] = h->acc_kind[i];
     return 0;
 }
 
@@ -1659,6 +1690,8 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
             HIPC(hipMemsetAsync(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t), st));
             h->searched_once = true;
             h->search_state = s;
+            h->d2_valid = false;   // pointSearchSqDis on demand (ensure_d2) must be recomputed for the new neighbours
+            h->planes_valid = false;
         } else {
             HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p,
                                  h->normvec.p, h->world.p, h->partials.p, h->part2.p, h->gram.p, 0.0, h->tickets.p, h->slow_count.p,

@@ -166,8 +166,15 @@ int flh_esekf_run_scans(flh_esekf* e, const flh_scan_job* jobs, int n_jobs, int6
     const int ahead = (ahead_env == 2 && ring >= 3) ? 2 : 1;
     const int64_t last = first + count;  // one past the last scan of this call; `last` itself is staged only with FLH_RUN_STAGE_NEXT
     auto may_stage = [&](int64_t k) { return k < last || (k == last && (flags & FLH_RUN_STAGE_NEXT)); };
-    if (count > 0 && !(flags & FLH_RUN_FIRST_STAGED) && stage(first) != 0) return -1;
-    if (ahead == 2 && count > 0 && may_stage(first + 1) && stage(first + 1) != 0) return -1;
+    // an error return must not leave the staging thread reading the caller's buffers: wait for every slot of the ring first
+    auto bail = [&]() -> int {
+        const std::string keep = e->err;
+        for (int sidx = 0; sidx < ring; ++sidx) (void)flh_scan_wait(h, sidx);
+        e->err = keep;
+        return -1;
+    };
+    if (count > 0 && !(flags & FLH_RUN_FIRST_STAGED) && stage(first) != 0) return bail();
+    if (ahead == 2 && count > 0 && may_stage(first + 1) && stage(first + 1) != 0) return bail();
     static const bool trace = std::getenv("FLH_RUN_TRACE") != nullptr;  // developer aid: per-scan wall times on stderr
     auto t_prev = clk::now();
     for (int64_t i = first; i < first + count; ++i) {
@@ -179,12 +186,12 @@ int flh_esekf_run_scans(flh_esekf* e, const flh_scan_job* jobs, int n_jobs, int6
             t_prev = t_now;
         }
         if (ahead == 2) {
-            if (may_stage(i + 2) && stage(i + 2) != 0) return -1;  // scans i+1 (already under way) and i+2 cross PCIe while scan i updates
+            if (may_stage(i + 2) && stage(i + 2) != 0) return bail();  // scans i+1 (already under way) and i+2 cross PCIe while scan i updates
         } else if ((i + 1 < first + count || (flags & FLH_RUN_STAGE_NEXT)) && stage(i + 1) != 0) {
-            return -1;  // scan i+1 crosses PCIe while scan i updates
+            return bail();  // scan i+1 crosses PCIe while scan i updates
         }
         flh_update_stats st;
-        if (flh_esekf_update_scan(e, j.slot >= 0 ? j.slot : (int)(i % ring), j.x, j.P, R, &st) != 0) return -1;
+        if (flh_esekf_update_scan(e, j.slot >= 0 ? j.slot : (int)(i % ring), j.x, j.P, R, &st) != 0) return bail();
         rs.scans++;
         rs.passes += st.passes;
         rs.searches += st.searches;
@@ -198,7 +205,7 @@ int flh_esekf_run_scans(flh_esekf* e, const flh_scan_job* jobs, int n_jobs, int6
             e->kf.get_x().to_flat(x26);
             if (flh_map_incremental(h, x26, filter_size_map, 1, 1, nullptr, nullptr) != 0) {
                 e->err = std::string("flh_map_incremental: ") + flh_last_error();
-                return -1;
+                return bail();
             }
             rs.ms_map_incremental += std::chrono::duration<double, std::milli>(clk::now() - t0).count();
         }

@@ -81,8 +81,9 @@ hipError_t launch_live_compact(const float4* map_orig, const uint32_t* flags, co
                                hipStream_t st);
 
 // ---- flh_scanprep.hip: pcl::VoxelGrid of the scan ----
+uint32_t undistort_blocks(uint32_t n);
 hipError_t launch_undistort(const StateDev& s_end, const double* poses, int n_pose, const float4* raw, uint32_t n, float4* out,
-                            hipStream_t st);
+                            unsigned long long* block_min, hipStream_t st);
 hipError_t launch_cloud_body_to_world(const StateDev& s, const float4* in, uint32_t n, float4* out, hipStream_t st);
 hipError_t launch_vg_keys(const float4* raw, uint32_t n, float inv, const int min_b[3], int mul1, int mul2,
                           unsigned long long* keys, uint32_t* vals, hipStream_t st);

@@ -63,6 +63,9 @@ typedef struct flh_config {
                                the reference's own build).  See DESIGN.md "Eigen summation order" */
     int plane_fit_dtype;    /* 0 = fp32, exactly as the reference (esti_plane<float>); 1 = ABLATION ONLY: the plane fit in
                                fp16 on query-centred coordinates (BASELINE configs[4]); not bit-exact, never the default */
+    int undistort_first_point; /* flh_scan_stage_undistorted: 1 (default, also for < 0) = as the reference, whose sweep compensates the
+                               EARLIEST point of the cloud once per segment older than it (src/IMU_Processing.hpp:345); 0 = every
+                               point once */
 } flh_config;
 enum { FLH_ORDER_SEQ = 0, FLH_ORDER_SSE = 1, FLH_ORDER_PAIRWISE = 2, FLH_ORDER_NOVEC = 3 };
 
@@ -163,9 +166,10 @@ int flh_scan_stage_downsampled(flh_handle* h, int slot, const void* pts, size_t 
  * A point at time t is carried to the scan-end frame with the LAST segment k <= n_pose-2 whose offset_time is < t
  * (what the reference's back-to-front sweep over the time-sorted cloud amounts to, also when the first IMU sample
  * precedes the first point and offset_time[1] < offset_time[0] = 0); a point no segment claims is left as it is.  The cloud
- * is NOT re-ordered by time (the reference's sort only serves its sweep).  One deliberate deviation: the reference's loop
- * (:326-346) compensates the EARLIEST point of the cloud once more per earlier segment when that point is younger than
- * IMUpose[1] (it breaks at begin() without stepping past it); here that point is carried once, like every other.
+ * is NOT re-ordered by time (the reference's sort only serves its sweep).  The reference's loop (:326-346) breaks at begin()
+ * without stepping past it, so the EARLIEST point of the cloud (lowest index among equal times here; the reference's
+ * std::sort leaves that unspecified) is compensated again by every earlier segment older than it, each time on its moved
+ * coordinates: reproduced by default, flh_config.undistort_first_point = 0 carries it once like every other point.
  * leaf_size <= 0 skips the down-sampling; undistorted_xyz (optional, 3*n floats) receives feats_undistort. */
 typedef struct flh_pose6d {
     double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9];
@@ -255,6 +259,10 @@ int flh_last_timing(flh_handle* h, flh_timing* t);
  * out[0] = sum of search-kernel ms, out[1] = number of search launches, out[2] = sum of fit(+reduce) ms,
  * out[3] = number of fit launches, out[4] = sum of first-launch-to-host-visible ms, out[5] = evaluations. */
 int flh_get_counters(flh_handle* h, double out[6], int reset);
+/* The search part of the same, split by kind: out[0], out[1] = ms and launches of a scan's FIRST search (every query over its
+ * whole 3x3x3 block), out[2], out[3] = of its LATER searches (bounded by the neighbours the previous search cached).  Reset
+ * together with flh_get_counters(reset != 0). */
+int flh_get_search_counters(flh_handle* h, double out[4]);
 /* The HIP events behind flh_last_timing / flh_get_counters: recorded on every n-th flh_eval (1 = always, the default;
  * 0 = never).  With every_n == 1 the evaluation waits for its last event and reads the three times at once (tens of
  * microseconds of host time per evaluation).  With every_n >= 2 -- sampling inside a running stream -- a sampled evaluation
@@ -340,7 +348,10 @@ typedef struct flh_run_stats {
     double ms_map_incremental;
 } flh_run_stats;
 #define FLH_RUN_FIRST_STAGED 1 /* scan `first` was staged by the previous call (which had FLH_RUN_STAGE_NEXT) */
-#define FLH_RUN_STAGE_NEXT 2   /* while the last scan updates, stage scan first + count for the next call: a continuous stream */
+#define FLH_RUN_STAGE_NEXT 2   /* while the last scan updates, stage scan first + count for the next call: a continuous stream.
+                                  The call may return while that staging is still under way: the buffer of jobs[(first + count) %
+                                  n_jobs] must stay valid and unchanged until the next flh_esekf_run_scans call activates it or
+                                  flh_scan_wait((first + count) % ring) returns.  On an error return no staging is left in flight. */
 int flh_esekf_run_scans(flh_esekf* kf, const flh_scan_job* jobs, int n_jobs, int64_t first, int64_t count, int ring, double R,
                         int with_map_incremental, double filter_size_map, int flags, flh_run_stats* stats,
                         double x_last[FLH_NSTATE], double P_last[FLH_NDOF * FLH_NDOF]);

@@ -194,6 +194,8 @@ size_t orc_voxel_grid(const float* in, size_t stride_floats, size_t n, float lea
 
 /* ImuProcess::UndistortPcl, per-point half (src/IMU_Processing.hpp:307-349); poses = IMUpose (msg/Pose6D.msg). */
 typedef struct { double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]; } orc_pose6d;
+/* 1 (default): the reference's re-compensation of the earliest point (IMU_Processing.hpp:345) is reproduced; 0: every point once */
+void orc_set_undistort_first(int on);
 void orc_undistort(const orc_pose6d* poses, int n_pose, const double x_end[ORC_NSTATE], const float* pts, size_t stride_floats,
                    size_t time_off_floats, size_t n, float* out_xyz);
 

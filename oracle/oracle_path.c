@@ -1056,14 +1056,16 @@ size_t orc_voxel_grid(const float* in, size_t stride, size_t n, float leaf, floa
    since every point is handled independently the sweep reduces to: segment k = the LAST k <= n_pose-2 with
    poses[k].offset_time < t (a segment skipped for a later point has offset_time >= that point's time, hence >= every
    earlier point's too); a point no segment claims is left untouched, as the sweep never reaches it.
-   ONE DELIBERATE DEVIATION: the reference's inner loop leaves through `if (it_pcl == begin) break` WITHOUT
-   stepping past the first point (:345), so the earliest point of the cloud -- and only that one -- is compensated AGAIN by
-   every earlier segment whose head is older than it, each time on its already-moved coordinates.  That happens only when the
-   earliest point is younger than IMUpose[1] (> ~5 ms into the scan at 200 Hz); it is an artefact of the loop, not a model
-   of anything, concerns one point per scan, and is NOT reproduced here nor in the product (fast_lio_amd/csrc/flh_scanprep.hip:
-   k_undistort): that point is carried once, with its own segment, like every other point.  No ordering of the
-   offset_times is assumed: IMUpose[1] precedes IMUpose[0] = 0 whenever the first IMU sample is older than the first point.  The order of the output is the order of the input: the
-   reference's (unstable) sort order is not reproduced.
+   THE FIRST POINT (:345): the reference's inner loop leaves through `if (it_pcl == begin) break` WITHOUT stepping past the
+   first point, so the earliest point of the (time-sorted) cloud -- and only that one -- is compensated AGAIN by every earlier
+   segment whose head is older than it, each time on its already-moved float coordinates: it ends up carried by every segment
+   k = n_pose-2 .. 0 with poses[k].offset_time < t, in that order.  That happens only when the earliest point is younger than
+   IMUpose[1] (> ~5 ms into the scan at 200 Hz); it is an artefact of the loop, but the contract is "identical to the
+   reference on the same inputs", so it is reproduced by default (orc_set_undistort_first(0) switches it off: every point
+   carried once).  "Earliest" = the smallest time offset; among equal ones the lowest input index (the reference's sort is
+   std::sort, whose order of equal keys is unspecified).  No ordering of the offset_times is assumed: IMUpose[1] precedes
+   IMUpose[0] = 0 whenever the first IMU sample is older than the first point.  The order of the output is the order of the
+   input: the reference's sort order is not reproduced.
    Exp() is so3_math.h:36-58.  Double arithmetic in source order; Eigen's internal evaluation order of the 3x3
    products is not modelled (it moves results by ~1e-16 before the final narrowing to float). */
 static void und_exp(const double w[3], double dt, double R[9]) {
@@ -1081,44 +1083,53 @@ static void und_exp(const double w[3], double dt, double R[9]) {
             }
     }
 }
-void orc_undistort(const orc_pose6d* poses, int n_pose, const double x_end[ORC_NSTATE], const float* pts, size_t stride,
-                   size_t time_off, size_t n, float* out_xyz) {
+static int g_undistort_first = 1;
+void orc_set_undistort_first(int on) { g_undistort_first = on ? 1 : 0; }
+/* one pass of the inner loop's body (:326-343) for a point at time t with segment k; xyz are float members of the point */
+static void und_apply(const orc_pose6d* poses, int k, const double x_end[ORC_NSTATE], double t, float xyz[3]) {
     const double* pos_e = x_end + X_POS;
     const double* rot_e = x_end + X_ROT;
     const double* offR = x_end + X_OFFR;
     const double* offT = x_end + X_OFFT;
     const double rot_c[4] = {-rot_e[0], -rot_e[1], -rot_e[2], rot_e[3]};
     const double offR_c[4] = {-offR[0], -offR[1], -offR[2], offR[3]};
+    const orc_pose6d* head = poses + k;
+    const orc_pose6d* tail = poses + k + 1;
+    const double dt = t - head->offset_time;
+    double E[9], R_i[9];
+    und_exp(tail->gyr, dt, E); /* angvel_avr = tail->gyr */
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double a = 0.0;
+            for (int m = 0; m < 3; m++) a = a + head->rot[3 * r + m] * E[3 * m + c];
+            R_i[3 * r + c] = a;
+        }
+    const double P_i[3] = {xyz[0], xyz[1], xyz[2]};
+    double T_ei[3], q1[3], q2[3], q3[3], q4[3];
+    for (int d = 0; d < 3; d++)
+        T_ei[d] = ((head->pos[d] + head->vel[d] * dt) + ((0.5 * tail->acc[d]) * dt) * dt) - pos_e[d];
+    orc_quat_rot(offR, P_i, q1);
+    for (int d = 0; d < 3; d++) q1[d] = q1[d] + offT[d];
+    for (int r = 0; r < 3; r++) q2[r] = ((R_i[3 * r] * q1[0] + R_i[3 * r + 1] * q1[1]) + R_i[3 * r + 2] * q1[2]) + T_ei[r];
+    orc_quat_rot(rot_c, q2, q3);
+    for (int d = 0; d < 3; d++) q3[d] = q3[d] - offT[d];
+    orc_quat_rot(offR_c, q3, q4);
+    for (int d = 0; d < 3; d++) xyz[d] = (float)q4[d];
+}
+void orc_undistort(const orc_pose6d* poses, int n_pose, const double x_end[ORC_NSTATE], const float* pts, size_t stride,
+                   size_t time_off, size_t n, float* out_xyz) {
+    size_t first = 0; /* the earliest point (lowest index among equal times) */
+    for (size_t i = 1; i < n; i++)
+        if (pts[i * stride + time_off] < pts[first * stride + time_off]) first = i;
     for (size_t i = 0; i < n; i++) {
         const float* p = pts + i * stride;
         out_xyz[3 * i] = p[0]; out_xyz[3 * i + 1] = p[1]; out_xyz[3 * i + 2] = p[2];
         const double t = (double)p[time_off] / (double)1000; /* it_pcl->curvature / double(1000) */
-        int k = -1;
         for (int j = n_pose - 2; j >= 0; j--)
-            if (t > poses[j].offset_time) { k = j; break; }
-        if (k < 0) continue;
-        const orc_pose6d* head = poses + k;
-        const orc_pose6d* tail = poses + k + 1;
-        const double dt = t - head->offset_time;
-        double E[9], R_i[9];
-        und_exp(tail->gyr, dt, E); /* angvel_avr = tail->gyr */
-        for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 3; c++) {
-                double a = 0.0;
-                for (int m = 0; m < 3; m++) a = a + head->rot[3 * r + m] * E[3 * m + c];
-                R_i[3 * r + c] = a;
+            if (t > poses[j].offset_time) {
+                und_apply(poses, j, x_end, t, out_xyz + 3 * i);
+                if (!(g_undistort_first && i == first)) break; /* every point but the first leaves the sweep here (:326, :345) */
             }
-        const double P_i[3] = {p[0], p[1], p[2]};
-        double T_ei[3], q1[3], q2[3], q3[3], q4[3];
-        for (int d = 0; d < 3; d++)
-            T_ei[d] = ((head->pos[d] + head->vel[d] * dt) + ((0.5 * tail->acc[d]) * dt) * dt) - pos_e[d];
-        orc_quat_rot(offR, P_i, q1);
-        for (int d = 0; d < 3; d++) q1[d] = q1[d] + offT[d];
-        for (int r = 0; r < 3; r++) q2[r] = ((R_i[3 * r] * q1[0] + R_i[3 * r + 1] * q1[1]) + R_i[3 * r + 2] * q1[2]) + T_ei[r];
-        orc_quat_rot(rot_c, q2, q3);
-        for (int d = 0; d < 3; d++) q3[d] = q3[d] - offT[d];
-        orc_quat_rot(offR_c, q3, q4);
-        for (int d = 0; d < 3; d++) out_xyz[3 * i + d] = (float)q4[d];
     }
 }
 

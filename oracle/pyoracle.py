@@ -514,15 +514,20 @@ def make_poses(rows):
     return arr
 
 
-def undistort(poses, x_end, pts_xyzt):
-    """Per-point half of UndistortPcl: pts_xyzt = n x 4 float32 (x, y, z, time offset in ms)."""
+def undistort(poses, x_end, pts_xyzt, first_point=True):
+    """Per-point half of UndistortPcl: pts_xyzt = n x 4 float32 (x, y, z, time offset in ms).  first_point: reproduce the
+    reference's repeated compensation of the earliest point (IMU_Processing.hpp:345), the default."""
     a = _c32(pts_xyzt).reshape(-1, 4)
     L = lib()
+    L.orc_set_undistort_first.restype = None
+    L.orc_set_undistort_first.argtypes = [C.c_int]
+    L.orc_set_undistort_first(1 if first_point else 0)
     L.orc_undistort.restype = None
     L.orc_undistort.argtypes = [C.c_void_p, C.c_int, np.ctypeslib.ndpointer(np.float64), np.ctypeslib.ndpointer(np.float32),
                                 C.c_size_t, C.c_size_t, C.c_size_t, np.ctypeslib.ndpointer(np.float32)]
     out = np.zeros((max(len(a), 1), 3), np.float32)
     L.orc_undistort(C.cast(poses, C.c_void_p), len(poses), _c64(x_end), a, 4, 3, len(a), out)
+    L.orc_set_undistort_first(1)
     return out[: len(a)].copy()
 
 

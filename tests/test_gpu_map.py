@@ -393,6 +393,37 @@ def test_undistortion_matches_oracle(prob):
         h.scan_stage_undistorted(0, pts[:10], poses, x_end)
 
 
+def test_undistortion_earliest_point_younger_than_the_second_imu_pose(prob):
+    """src/IMU_Processing.hpp:345: the reference's sweep compensates the earliest point of the cloud once per segment older than
+    it.  Every point of this cloud is younger than IMUpose[3], so the earliest one is carried four times; the device must do
+    the same (default) or carry it once (flh_config.undistort_first_point = 0), as the oracle does either way."""
+    pr = prob
+    x0 = pr.x_true.copy()
+    x0[14:17] = (8.0, -3.0, 0.5)
+    poses, x_end = imu_poses_for_test(x0)
+    rng = np.random.default_rng(16)
+    raw = raw_scan(pr, 20000, 2)
+    t3 = 1000.0 * poses[3].offset_time
+    tms = rng.uniform(t3 + 0.5, 104.0, len(raw)).astype(np.float32)
+    first = 1234
+    tms[first] = np.float32(t3 + 0.25)
+    tms[first + 4000] = tms[first]           # an equal time at a higher index: not "the first point"
+    pts = np.c_[raw, tms].astype(np.float32)
+    want = po.undistort(poses, x_end, pts)
+    once = po.undistort(poses, x_end, pts, first_point=False)
+    assert (np.abs(want - once).max(axis=1) > 0).sum() == 1 and np.abs(want[first] - once[first]).max() > 1e-3
+    scale = np.abs(want).max()
+    for flag, ref in ((-1, want), (0, once)):
+        h = capi.Handle(undistort_first_point=flag)
+        h.map_build(pr.map_xyz[:1000])
+        n, und = h.scan_stage_undistorted(1, pts, poses, x_end, leaf_size=0.0)
+        assert n == len(pts)
+        assert np.abs(und - ref).max() <= 2.0 * np.spacing(np.float32(scale))
+        assert (und.view(np.uint32) == ref.view(np.uint32)).mean() > 0.999
+        assert np.abs(und[first] - ref[first]).max() <= 4.0 * np.spacing(np.float32(scale))  # four passes, one ulp each at most
+        h.close()
+
+
 def test_velodyne_stream_with_incremental_map():
     """BASELINE configs[2] in miniature: a Velodyne-16 scan stream whose points are inserted into the map after every
     update (laserMapping.cpp:879-927 loop body, five times over): the device map must stay bit-identical to the

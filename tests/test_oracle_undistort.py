@@ -89,3 +89,23 @@ def test_first_imu_sample_older_than_the_first_point():
     for i in (1, 2, 3):                                                                # segment 1: tail gyr -2 rad/s
         np.testing.assert_allclose(out[i], rz(-2.0 * (tms[i] / 1000.0 + 0.002)) @ p, atol=2e-6)
     np.testing.assert_allclose(out[4], rz(3.0 * (0.005 - 0.003)) @ p, atol=2e-6)      # segment 2: tail gyr 3 rad/s
+
+
+def test_the_earliest_point_is_carried_again_by_every_earlier_segment():
+    # IMU_Processing.hpp:345: the sweep leaves its inner loop at begin() WITHOUT stepping past the first point, so the earliest
+    # point -- when it is younger than IMUpose[1] -- is compensated once more per earlier segment, on its moved coordinates
+    rows = [(0.0, (0,) * 3, (0, 0, 9.0), (0,) * 3, (0,) * 3, I9), (0.01, (0,) * 3, (0, 0, 1.0), (0,) * 3, (0,) * 3, I9),
+            (0.02, (0,) * 3, (0, 0, -2.0), (0,) * 3, (0,) * 3, I9), (0.03, (0,) * 3, (0, 0, 3.0), (0,) * 3, (0,) * 3, I9)]
+    poses = po.make_poses(rows)
+    p = np.array([10.0, 0, 0])
+    tms = np.array([25.0, 15.0, 35.0, 15.0], np.float32)   # the earliest time twice: the lower index is "the first point"
+    pts = np.c_[np.tile(p, (4, 1)), tms].astype(np.float32)
+    out = po.undistort(poses, state(), pts)
+    once = po.undistort(poses, state(), pts, first_point=False)
+    # segment 1 (tail gyr -2 rad/s, dt = 5 ms), then segment 0 (tail gyr +1 rad/s, dt = 15 ms) on the moved float coordinates
+    s1 = (rz(-2.0 * 0.005) @ p).astype(np.float32)
+    np.testing.assert_allclose(once[1], s1, atol=2e-6)
+    np.testing.assert_allclose(out[1], rz(1.0 * 0.015) @ s1.astype(np.float64), atol=2e-6)
+    assert np.abs(out[1] - once[1]).max() > 0.05
+    np.testing.assert_array_equal(out[[0, 2, 3]], once[[0, 2, 3]])   # every other point (an equal time included) once
+    np.testing.assert_allclose(out[3], s1, atol=2e-6)

@@ -23,6 +23,8 @@ class FakeHandle:
     def set_timing_stride(self, n): self.stride = n
     def counters(self, reset=False):
         return {"search_ms": 0.5, "n_search": 10, "fit_ms": 0.3, "n_fit": 20, "eval_ms": 1.0, "n_eval": 20}
+    def search_counters(self):
+        return {"first_ms": 0.3, "n_first": 5, "later_ms": 0.2, "n_later": 5}
     def scan_stage(self, slot, body): assert 0 <= slot < 64
     def scan_upload(self, body): pass
     def enable_stats(self, on): pass
