@@ -122,7 +122,7 @@ struct flh_handle {
     // scan
     size_t N = 0;
     DevBuf<float4> world, nn_pts, normvec;
-    DevBuf<float4> plane;     // experiment (FLH_PLANE_CACHE=1): (a, b, c, d) of the last searching pass's fits, reused by no-search passes
+    DevBuf<float4> plane;     // flh_config.plane_cache: (a, b, c, d) of the last searching pass's fits, reused by no-search passes
     bool plane_cache = false;
     bool planes_valid = false;  // `plane` holds the fits of the CURRENT neighbour cache (written by the fit that followed the last search)
     DevBuf<float> nn_d2;
@@ -240,6 +240,7 @@ void flh_default_config(flh_config* c) {
     c->eigen_order = -1;
     c->plane_fit_dtype = 0;
     c->undistort_first_point = -1;
+    c->plane_cache = -1;
 }
 
 int flh_create(const flh_config* cfg_in, flh_handle** out) {
@@ -254,10 +255,11 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.plane_threshold <= 0) cfg.plane_threshold = 0.1f;
     if (cfg.max_sqdist <= 0) cfg.max_sqdist = 5.0f;
     if (cfg.sort_queries < 0) cfg.sort_queries = 1;
-    if (cfg.first_stage < 0 || cfg.first_stage > 3) cfg.first_stage = 0;
+    if (cfg.first_stage < 0 || cfg.first_stage > 4) cfg.first_stage = 0;
     if (cfg.eigen_order < 0 || cfg.eigen_order > 3) cfg.eigen_order = FLH_ORDER_SSE;
     if (cfg.plane_fit_dtype != 1) cfg.plane_fit_dtype = 0;
     if (cfg.undistort_first_point != 0) cfg.undistort_first_point = 1;
+    if (cfg.plane_cache != 0) cfg.plane_cache = 1;
     {
         const int l = cfg.lanes_per_query;  // 0 = exact kernel for every query
         if (l != 0 && l != 1 && l != 2 && l != 8 && l != 16) cfg.lanes_per_query = 4;
@@ -298,8 +300,7 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
         flh_destroy(h);
         return fail("hipMalloc failed");
     }
-    if (const char* e = std::getenv("FLH_TIMING_STRIDE")) h->timing_stride = std::max(0, std::atoi(e));
-    h->plane_cache = std::getenv("FLH_PLANE_CACHE") != nullptr;  // off by default: not yet validated on hardware
+    h->plane_cache = cfg.plane_cache != 0;
     h->rmax = (int)std::ceil((std::sqrt((double)cfg.max_sqdist) + 2e-3 * cfg.cell_size) / cfg.cell_size);
     if (h->rmax < 1) h->rmax = 1;
     *out = h;
@@ -617,9 +618,6 @@ static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size
     h->M = h->M + n_alive - h->h_ctr[3];
     h->id_pos_valid = false;
     h->searched_once = false;  // cached neighbours refer to the previous map
-    if (std::getenv("FLH_TRACE_MAP"))
-        std::fprintf(stderr, "[map] +%u -%u -> M=%zu ids=%zu bricks=%u top=%u/%zu flags=%u%s\n", n_alive, h->h_ctr[3], h->M, h->n_ids,
-                     h->h_ctr[1], h->h_ctr[0], h->pts_cap, h->h_ctr[2], h->h_ctr[2] ? " (re-index)" : "");
     if (h->h_ctr[2] != 0) return reindex_from_ids(h);
     ++h->n_inplace;
     h->alloc_top = h->h_ctr[0];
@@ -1267,14 +1265,10 @@ static StateDev make_state(const double rot[4], const double pos[3], const doubl
     return s;
 }
 
-// 0: first stage + second stage; 1: the same with the first stage bounded by the cached neighbours (a later search of the scan);
-// 2 (experiment, FLH_SOLO=1 only): bounded first stage that finishes its few leftovers itself, no second-stage launch, when
-// the last later search left at most N/512 queries unsettled.  Measured on BASELINE configs[1]: the leftovers lengthen the
-// first stage's slowest waves by more than the second stage's launch costs (search pass 63.5 vs 61.7 us) -- hence off.
-static int search_plan(const flh_handle* h, bool host_granules) {
-    static const bool no_bound = std::getenv("FLH_NO_CACHE_BOUND") != nullptr, solo = std::getenv("FLH_SOLO") != nullptr;
-    if (!h->searched_once || h->own_axis >= 0 || no_bound) return 0;
-    if (host_granules && solo && h->later_unsettled >= 0 && h->later_unsettled * 512 <= (int64_t)h->N) return 2;
+// 0: first stage + second stage; 1: the same with the ring first stage bounded by the cached neighbours (a later search of the
+// scan; only the ring stage, flh_config.first_stage = 1, has that variant).
+static int search_plan(const flh_handle* h) {
+    if (!h->searched_once || h->own_axis >= 0) return 0;
     return 1;
 }
 
@@ -1282,12 +1276,7 @@ static int search_plan(const flh_handle* h, bool host_granules) {
 // would make more than kGranGroups groups; 0 = too many points for the granule path.
 static int gran_group_size(size_t N) {
     const int nblk = flh::fit_blocks((int)N);
-    static const int red0 = [] {  // experiment knob: blocks per group (16, 32, 64 or 128); unset = 16
-        const char* e = std::getenv("FLH_GRAN_GROUP");
-        const int v = e ? std::atoi(e) : 16;
-        return (v == 32 || v == 64 || v == 128) ? v : 16;
-    }();
-    int red = red0;
+    int red = 16;
     while ((nblk + red - 1) / red > kGranGroups) red *= 2;
     return red <= 128 ? red : 0;
 }
@@ -1342,7 +1331,7 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
         HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
                                 h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
                                 h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr,
-                                h->own_axis, h->own_lo, h->own_hi, search_plan(h, host_granules), st));
+                                h->own_axis, h->own_lo, h->own_hi, search_plan(h), st));
         h->last_search_was_later = h->searched_once;
         h->searched_once = true;
         h->d2_valid = false;
@@ -1403,15 +1392,12 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     bool deferred = false;
     hipEvent_t* ev3 = nullptr;
     if (timed) {
-        static const bool sync_events = std::getenv("FLH_SYNC_EVENTS") != nullptr;  // force the synchronous reading
-        deferred = h->timing_stride >= 2 && !sync_events && ensure_event_pool(h);
+        deferred = h->timing_stride >= 2 && ensure_event_pool(h);
         if (deferred && h->evp_n == flh_handle::kEvPool) drain_events(h);
         ev3 = deferred ? h->evp[h->evp_n] : h->ev;
     }
     const double seq = (double)(++h->seq);
     hipStream_t st = h->stream;
-    static const bool host_prof = std::getenv("FLH_HOST_PROFILE") != nullptr;
-    const auto tp0 = std::chrono::steady_clock::now();
     const int gran_red = (!h->comm && !h->stats && h->N > 0) ? gran_group_size(h->N) : 0;
     if (h->comm) {
         // this rank's partial block stays in device memory, RCCL sums the ranks' blocks in place (256 doubles: latency-bound,
@@ -1422,7 +1408,6 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
         return -1;
     }
     if (h->stats && do_search) HIPC(hipMemcpyAsync(h->h_counter, h->counter.p, sizeof(u64), hipMemcpyDeviceToHost, st));
-    const auto tp1 = std::chrono::steady_clock::now();
     if (gran_red > 0) {
         // k_fit's group reducers write {value, sequence} granules straight into pinned memory: wait until every granule of
         // every group carries this evaluation's sequence number, then add the groups up in group order (fixed order ->
@@ -1490,21 +1475,6 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     if (h->h_gram[255] != seq) return fail("flh_eval: result sequence mismatch");
     h->h_gram[255] = 0.0;  // G[15][15] is structurally zero
     flh_unpack_gram(h->h_gram, HTH, HTh, n_eff, total_residual);
-    if (host_prof) {  // developer aid: where the host's share of a pass goes (enqueue / wait for the device / unpack)
-        const auto tp2 = std::chrono::steady_clock::now();
-        static thread_local double acc_[2][3] = {{0, 0, 0}, {0, 0, 0}};
-        static thread_local uint64_t n_[2] = {0, 0};
-        static thread_local std::chrono::steady_clock::time_point last_end_;
-        static thread_local double gap_[2] = {0, 0};
-        const int k = do_search ? 1 : 0;
-        acc_[k][0] += std::chrono::duration<double, std::micro>(tp1 - tp0).count();
-        acc_[k][1] += std::chrono::duration<double, std::micro>(tp2 - tp1).count();
-        if (n_[0] + n_[1] > 0) gap_[k] += std::chrono::duration<double, std::micro>(tp0 - last_end_).count();
-        last_end_ = tp2;
-        if (++n_[k] % 2000 == 0)
-            std::fprintf(stderr, "[host] %s pass: enqueue %.2f us, wait+sum %.2f us, host time before it (algebra, caller) %.2f us (n=%llu)\n",
-                         k ? "search" : "no-search", acc_[k][0] / n_[k], acc_[k][1] / n_[k], gap_[k] / n_[k], (unsigned long long)n_[k]);
-    }
     float a = 0, b = 0, c = 0;
     if (timed && !deferred) {
         (void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);

@@ -160,10 +160,6 @@ int flh_esekf_run_scans(flh_esekf* e, const flh_scan_job* jobs, int n_jobs, int6
         }
         return 0;
     };
-    // experiment knob FLH_STAGE_AHEAD=2 (unset = 1): keep two scans in flight on the staging thread instead of one, so that a late
-    // staging thread (a wake-up, a slow copy) is absorbed instead of stalling the next update.  Needs ring >= 3.
-    static const int ahead_env = [] { const char* e = std::getenv("FLH_STAGE_AHEAD"); return (e && std::atoi(e) == 2) ? 2 : 1; }();
-    const int ahead = (ahead_env == 2 && ring >= 3) ? 2 : 1;
     const int64_t last = first + count;  // one past the last scan of this call; `last` itself is staged only with FLH_RUN_STAGE_NEXT
     auto may_stage = [&](int64_t k) { return k < last || (k == last && (flags & FLH_RUN_STAGE_NEXT)); };
     // an error return must not leave the staging thread reading the caller's buffers: wait for every slot of the ring first
@@ -174,22 +170,9 @@ int flh_esekf_run_scans(flh_esekf* e, const flh_scan_job* jobs, int n_jobs, int6
         return -1;
     };
     if (count > 0 && !(flags & FLH_RUN_FIRST_STAGED) && stage(first) != 0) return bail();
-    if (ahead == 2 && count > 0 && may_stage(first + 1) && stage(first + 1) != 0) return bail();
-    static const bool trace = std::getenv("FLH_RUN_TRACE") != nullptr;  // developer aid: per-scan wall times on stderr
-    auto t_prev = clk::now();
     for (int64_t i = first; i < first + count; ++i) {
         const flh_scan_job& j = jobs[i % n_jobs];
-        if (trace) {
-            const auto t_now = clk::now();
-            if (i > first && i - first <= 40) std::fprintf(stderr, "%s%.0f", (i - first == 1) ? "[run_scans] us/scan:" : " ", std::chrono::duration<double, std::micro>(t_now - t_prev).count());
-            if (i - first == 40 || i + 1 == first + count) std::fprintf(stderr, "\n");
-            t_prev = t_now;
-        }
-        if (ahead == 2) {
-            if (may_stage(i + 2) && stage(i + 2) != 0) return bail();  // scans i+1 (already under way) and i+2 cross PCIe while scan i updates
-        } else if ((i + 1 < first + count || (flags & FLH_RUN_STAGE_NEXT)) && stage(i + 1) != 0) {
-            return bail();  // scan i+1 crosses PCIe while scan i updates
-        }
+        if (may_stage(i + 1) && stage(i + 1) != 0) return bail();  // scan i+1 crosses PCIe while scan i updates
         flh_update_stats st;
         if (flh_esekf_update_scan(e, j.slot >= 0 ? j.slot : (int)(i % ring), j.x, j.P, R, &st) != 0) return bail();
         rs.scans++;

@@ -1,8 +1,7 @@
 // flh_kernels.hip -- the HIP kernels of the hot path, written for gfx950 (CDNA4, wave64) only.
 //
 //   K0  map index build     keys -> (radix sort) -> bricks, per-brick cell tables, directory            [setup]
-//   A1  k_search_ring<4,1>  body->world transform + 5-NN over the 3x3x3 cell block, 4 lanes per query    [search passes]
-//                           (later searches of a scan: the ball of the cached neighbours bounds the rows it visits)
+//   A1  k_search_wtile<2|4> / k_search_ring<4,1>  body->world transform + 5-NN over the 3x3x3 cell block  [search passes]
 //   A2  k_search_ring<16,2> the queries A1 could not settle: 5x5x5 block inside A1's bound, 16 lanes per
 //                           query, finishing leftovers itself with the general exact search (exact_query)
 //   A3  k_search_exact      the general exact search as a kernel (lanes_per_query = 0, grids without ring 2)
@@ -31,7 +30,8 @@ constexpr u64 kInfKey = ~0ull;
 constexpr int kStripes = 64;  // work-list stripes (one counter + one list segment each)
 
 // ------------------------------------------------------------------------------------------------
-// K0: map index
+// K0: map index: points keyed by (brick, local cell), sorted, laid out per brick with slack behind its points; per brick a
+// prefix table of absolute storage positions; an open-addressing directory brick key -> brick rank.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_map_keys(GridParams g, const float4* __restrict__ pts, uint32_t M,
                                                   u64* __restrict__ keys, uint32_t* __restrict__ vals) {
@@ -130,28 +130,32 @@ __global__ void __launch_bounds__(256) k_map_place(const float4* __restrict__ pt
 }
 
 // ------------------------------------------------------------------------------------------------
-// A: exact 5-NN, three kernels chained through two work lists.
+// A: exact 5-NN: a first stage over every query, a second stage over the queries the first could not settle.
 //
-// A1 k_search_ring<4,1>     every query, the 3x3x3 cells around its cell: settles every query whose 5th
-//                           neighbour is provably inside that block and free of distance ties
-// A2 k_search_ring<16,2>    the queries A1 listed, 5x5x5 cells clipped to the ball of A1's 5th distance
-// A3 k_search_exact         whatever is left (distance ties, 5th neighbour beyond the 5x5x5 block): one pass over
-//                           the cells intersecting the ball of the best bound so far -- never beyond the gate
-//                           radius sqrt(max_sqdist) of src/laserMapping.cpp:671 -- with 64-bit (d2, map index)
-//                           keys, 32 lanes per query.
+// A1 first stage, every query, the 3x3x3 cells around its cell.  Two implementations of the same search:
+//      k_search_wtile<2|4>   (flh_search_wtile.inc) a wave of 32 / 16 Morton-neighbouring queries shares one LDS tile of the map
+//      k_search_ring<4,1>    four lanes per query gather their own candidates through 18 row segments; also the code a wave of
+//                            the tile kernel runs when its neighbourhoods do not fit the tile
+//    settles every query whose 5th neighbour is provably inside that block and free of near-ties
+// A2 k_search_ring<16,2>     the queries A1 listed: 5x5x5 cells clipped to the ball of A1's 5th distance; whatever it cannot
+//                            settle either (a true tie, a list longer than the packed index can name) it finishes itself with
+//                            64-bit (d2, map index) keys, and a 5th neighbour beyond its block with the general search
+// A3 k_search_exact          the general exact search as a kernel: lanes_per_query = 0 (the tests' cross-check), grids whose
+//                            cells are as large as the gate radius
 //
-// k_search_ring: LPQ lanes per query.  Each (y,z) row of the (2R+1)^3 block is an x-run of consecutive
-// local cells, i.e. ONE contiguous range of the cell-sorted map (two if the run crosses a brick boundary).
-// The 2(2R+1)^2 segment slots are resolved in parallel by the group's lanes (directory probe, then two
-// reads of the brick's prefix table), parked in LDS and prefix-summed, so that the group's T candidates
-// form one flat list dealt round-robin to its lanes, eight independent loads in flight per lane.
-// One pass over the candidates: exact fp32 d2 (the oracle's op order) and a sorted top-6 in registers -- the
-// distances by K0' = min(K0,t), Kj' = med3(K(j-1),Kj,t), the positions riding on the six compares t < Kj;
-// the lanes' lists are merged over DPP with a bitonic half-cleaner + 12-comparator network.  The sixth
-// entry exists only to see a tie at the boundary.  Five point loads per query then write the result rows.
-// A query is settled when its 5th distance lies within the block's guaranteed radius
-// (R + distance to the nearest face of the centre cell) * c and all distances involved are distinct
-// (equal distances need the oracle's (d2, map index) order); otherwise it goes to the next list.
+// k_search_ring: LPQ lanes per query.  Each (y,z) row of the (2R+1)^3 block is an x-run of consecutive local cells, i.e. ONE
+// contiguous range of the cell-sorted map (two if the run crosses a brick boundary).  The 2(2R+1)^2 segment slots are resolved in
+// parallel by the group's lanes (one directory probe, then ONE 16-byte read of the brick's prefix table for a ring-1 run), parked
+// in LDS and prefix-summed, so that the group's T candidates form one flat list dealt round-robin to its lanes, eight independent
+// loads in flight per lane.  One pass over the candidates: exact fp32 d2 (the oracle's op order) packed into a 32-bit key (the
+// distance with its low PB mantissa bits replaced by the candidate's flat index) and kept in a SORTED TOP-8 per lane --
+// K0' = min(K0,t), Kj' = med3(K(j-1),Kj,t): eight VALU ops per candidate, no payload registers; the lanes' lists are merged over
+// DPP with a bitonic half-cleaner + three-stage bitonic merge.  The packed keys only decide WHICH candidates can be among the
+// five nearest (those whose key does not exceed the 5th's above the packed bits: at hand among the eight unless four neighbours
+// agree to 2^-15 relative); the group loads those points, exchanges their exact (d2, map index) and every lane places its points
+// at their exact rank.  A query is settled when its 5th distance lies within the block's guaranteed radius
+// (R + distance to the nearest face of the centre cell) * c and the packed keys left the set closed; otherwise it goes to the
+// next list.
 // ------------------------------------------------------------------------------------------------
 struct Top5 {
     u64 k[5];
@@ -460,7 +464,7 @@ k_search_exact(GridParams g, StateDev s, const float4* __restrict__ body, int N,
     }
 }
 
-#include "flh_search_tile.inc"
+#include "flh_search_wtile.inc"
 
 // ------------------------------------------------------------------------------------------------
 // B: one thread per scan point: plane fit, residual gate, Jacobian row; then the wave's 64 rows are
@@ -504,7 +508,7 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
       double* __restrict__ partials, double* __restrict__ part2, double* __restrict__ out256, double seq,
       uint32_t* __restrict__ tickets, uint32_t* __restrict__ slow_count, double* __restrict__ gran, int red1, int ncol,
       int store_aux, float4* __restrict__ plane_cache) {
-    // PM (experimental, FLH_PLANE_CACHE=1; 0 = off, the product's default -- its code is untouched by the other two): a plane depends on the five neighbours only, not on the state, and a
+    // PM (flh_config.plane_cache, on by default; 0 = off and the fetch path): a plane depends on the five neighbours only, not on the state, and a
     // point that enters a no-search pass with its flag set was fitted successfully on the pass before, from the very same
     // neighbours.  1 (searching pass): fit as always and keep (a, b, c, d) per point; 2 (no-search pass): take the plane from there
     // -- same bits -- instead of re-reading 80 B of neighbours and repeating the QR.  The gate and the Jacobian row are
@@ -890,19 +894,17 @@ hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const St
                            nn_pts, nn_d2, nn_cnt, selected, list1, counts, cap, ub, 1, cand_counter, own_axis, own_lo, own_hi);
         return hipGetLastError();
     }
-    // experiment (first_stage = 3): the first stage with a block-shared LDS tile (flh_search_tile.inc), every search of a scan
-    const bool tile_stage = first_stage == 3 && lpq == 4 && rmax >= 2;
-    if (tile_stage)
-        hipLaunchKernelGGL(k_search_tile, dim3(cdiv(N, 64)), blk, 0, st, g, s, body, N, map_points, max_sqdist, nn_pts, nn_d2, nn_cnt,
+    // first_stage = 3 / 4: the first stage with a wave-shared LDS tile (flh_search_wtile.inc), 4 / 2 lanes per query, every search of a scan
+    const bool tile_stage = (first_stage == 3 || first_stage == 4) && lpq == 4 && rmax >= 2;
+    if (tile_stage && first_stage == 3)
+        hipLaunchKernelGGL((k_search_wtile<4>), dim3(cdiv(N, 16)), dim3(64), 0, st, g, s, body, N, map_points, max_sqdist, nn_pts, nn_d2, nn_cnt,
+                           selected, list1, counts, cap, ub, rmax, cand_counter, own_axis, own_lo, own_hi);
+    else if (tile_stage)
+        hipLaunchKernelGGL((k_search_wtile<2>), dim3(cdiv(N, 32)), dim3(64), 0, st, g, s, body, N, map_points, max_sqdist, nn_pts, nn_d2, nn_cnt,
                            selected, list1, counts, cap, ub, rmax, cand_counter, own_axis, own_lo, own_hi);
     // A1: ring 1, every query
 #define FLH_A1(L, O)                                                                                                     \
-    if (cache_bound == 2 && L == 4 && !O)                                                                                \
-        hipLaunchKernelGGL((k_search_ring<4, 1, false, 8, true, false, true>), dim3(cdiv(N, 64)), blk, 0, st, g, s, body, N, \
-                           map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,            \
-                           (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter,  \
-                           own_axis, own_lo, own_hi);                                                                    \
-    else if (cache_bound && L == 4 && !O)                                                                                \
+    if (cache_bound && L == 4 && !O)                                                                                     \
         hipLaunchKernelGGL((k_search_ring<4, 1, false, 8, false, false, true>), dim3(cdiv(N, 64)), blk, 0, st, g, s, body, N, \
                            map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,            \
                            (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter,  \
@@ -929,7 +931,6 @@ hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const St
         }
     }
 #undef FLH_A1
-    if (!tile_stage && cache_bound == 2 && lpq == 4 && !(first_stage == 2 && rmax >= 2)) return hipGetLastError();  // the first stage finished everything
     if (rmax >= 2) {
         // A2: ring 2 over list 1, inside the ball A1's 5th distance defines; whatever it cannot settle (distance ties, a
         // 5th neighbour beyond the 5x5x5 block) it finishes itself with the general exact search

@@ -52,11 +52,13 @@ typedef struct flh_config {
     int lanes_per_query;    /* fast search kernel: lanes cooperating on one query, 2/4/8/16 (default 4);
                                0 = run the general exact kernel for every query */
     int sort_queries;       /* 1: Morton-sort scan points at upload for cache locality (default 1 if <0) */
-    int first_stage;        /* block of cells the first search stage scans: 1 = the 3x3x3 block around the query's cell,
-                               2 = the 2x2x2 block nearest to the query (8 cells instead of 27; more queries go on to the
-                               second stage), 0 = default; 3 = EXPERIMENT, not validated on hardware when it was written: the 3x3x3 block
-                               served from a block-shared LDS tile (flh_search_tile.inc).  Performance only: every setting is
-                               meant to return the same exact 5-NN */
+    int first_stage;        /* how the first search stage (every query, the 3x3x3 cells around its cell) is run: 1 = four lanes per
+                               query gather their own candidates through 18 row segments (k_search_ring); 2 = the same over the 2x2x2
+                               block of cells nearest to the query (8 cells instead of 27; more queries go on to the second stage);
+                               3 / 4 = a WAVE of 16 / 32 Morton-neighbouring queries shares one LDS tile of the map (its bounding box
+                               of cells, each map point loaded once per wave), 4 / 2 lanes per query scan it (k_search_wtile); a
+                               wave whose box does not fit runs 1's code.  0 = default.  Performance only: every setting returns
+                               the same exact 5-NN */
     int eigen_order;        /* fp32 summation order of esti_plane's reductions (include/common_lib.h:241 runs Eigen's
                                ColPivHouseholderQR, whose reduction order depends on how Eigen was vectorised):
                                FLH_ORDER_SEQ / _SSE / _PAIRWISE / _NOVEC; <0 -> FLH_ORDER_SSE (Eigen 3.3.x, x86-64 + SSE2:
@@ -66,6 +68,9 @@ typedef struct flh_config {
     int undistort_first_point; /* flh_scan_stage_undistorted: 1 (default, also for < 0) = as the reference, whose sweep compensates the
                                EARLIEST point of the cloud once per segment older than it (src/IMU_Processing.hpp:345); 0 = every
                                point once */
+    int plane_cache;        /* 1 (default, also for < 0): a pass that does not search takes each point's plane from the fit of the last
+                               searching pass instead of re-reading five neighbours and repeating the QR (a plane depends on the
+                               neighbours only, not on the state: same bits); 0: re-fit on every pass */
 } flh_config;
 enum { FLH_ORDER_SEQ = 0, FLH_ORDER_SSE = 1, FLH_ORDER_PAIRWISE = 2, FLH_ORDER_NOVEC = 3 };
 
@@ -267,8 +272,7 @@ int flh_get_search_counters(flh_handle* h, double out[4]);
  * 0 = never).  With every_n == 1 the evaluation waits for its last event and reads the three times at once (tens of
  * microseconds of host time per evaluation).  With every_n >= 2 -- sampling inside a running stream -- a sampled evaluation
  * only RECORDS its events; they are read when flh_get_counters / flh_last_timing / flh_set_timing_stride is called next
- * (or when 64 samples are pending).  flh_last_timing then reports the most recent sample.  The environment variable
- * FLH_SYNC_EVENTS=1 forces the waiting behaviour for every stride. */
+ * (or when 64 samples are pending).  flh_last_timing then reports the most recent sample. */
 int flh_set_timing_stride(flh_handle* h, int every_n);
 int flh_enable_stats(flh_handle* h, int on); /* count candidate points examined (slower) */
 /* Run one kernel of the hot path `iters` times back-to-back on the handle's stream and return the

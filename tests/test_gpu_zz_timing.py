@@ -1,8 +1,6 @@
 """The roofline events of bench.py: with a timing stride >= 2 a timed evaluation records its three HIP events and does not wait
 for them; the elapsed times are read when the counters are asked for.  The sampling must not change any result, must count
 exactly the evaluations it was asked to, and must survive more pending samples than the event pool holds."""
-import os
-
 import numpy as np
 import pytest
 
@@ -64,8 +62,8 @@ def test_more_pending_samples_than_the_pool_holds(setup):
     h.set_timing_stride(1)
 
 
-def _experiment_plane_cache():
-    """FLH_PLANE_CACHE=1 (off by default): no-search passes take each point's plane from the last searching pass instead of
+def test_plane_cache_changes_no_bit():
+    """flh_config.plane_cache (default on): no-search passes take each point's plane from the last searching pass instead of
     re-fitting it from the same five neighbours.  Every output must keep its bits: normal equations of a search / no-search /
     no-search sequence at three different states, flags, planes, and a whole iterated update."""
     pr = synth.make_problem(200000, 20000, "avia", cfg=1)
@@ -74,12 +72,8 @@ def _experiment_plane_cache():
     x2[:3] += [0.02, -0.015, 0.01]
     x3 = np.array(pr.x_true, dtype=np.float64)
     got = []
-    for on in (False, True):
-        if on:
-            os.environ["FLH_PLANE_CACHE"] = "1"
-        else:
-            os.environ.pop("FLH_PLANE_CACHE", None)
-        h = capi.Handle()
+    for on in (0, 1):
+        h = capi.Handle(plane_cache=on)
         h.map_build(pr.map_xyz)
         h.scan_upload(pr.body)
         seq = []
@@ -87,6 +81,10 @@ def _experiment_plane_cache():
             for x, search in ((xp, True), (x2, False), (x3, False), (x3, True), (xp, False)):
                 HTH, HTh, n_eff, tres = h.eval(x, search, ext)
                 seq.append((HTH.copy(), HTh.copy(), n_eff, tres, h.fetch_selected().copy(), h.fetch_normvec().copy()))
+        # flh_time_kernel re-runs the search WITHOUT a fit: the planes of the old neighbours must not be reused afterwards
+        h.time_kernel(0, x3, False, 1)
+        HTH, HTh, n_eff, tres = h.eval(x3, False, False)
+        seq.append((HTH.copy(), HTh.copy(), n_eff, tres, h.fetch_selected().copy(), h.fetch_normvec().copy()))
         h.scan_upload(pr.body)
         kf = capi.Esekf(h, max_iter=3)
         kf.change_x(xp)
@@ -108,11 +106,12 @@ def _experiment_plane_cache():
         np.testing.assert_array_equal(a[5][sel].view(np.uint32), b[5][sel].view(np.uint32))
 
 
-def _experiment_tile_stage():
-    """first_stage = 3 (experiment, off by default): the first search stage with a block-shared LDS tile.  It examines the same
-    27 cells per query as the default stage, so flags, neighbour ids in rank order, planes and the whole update must be identical
-    -- on a dense scan (blocks that fit the tile), on a scan thinned out so that blocks do NOT fit (the ring code inside the tile
-    kernel), and on a short scan whose last block is partly empty."""
+@pytest.mark.parametrize("stage", [3, 4])
+def test_wave_tile_first_stage_equals_the_ring_stage(stage):
+    """first_stage = 3 / 4: the first search stage with a wave-shared LDS tile, 4 / 2 lanes per query.  It examines the same 27
+    cells per query as the ring stage (first_stage = 1), so flags, neighbour ids in rank order, planes and the whole update must
+    be identical -- on a dense scan (waves that fit the tile), on a scan thinned out so that waves do NOT fit (the ring code
+    inside the tile kernel), and on a short scan whose last wave is partly empty."""
     from oracle import pyoracle as po
 
     pr = synth.make_problem(200000, 20000, "avia", cfg=1)
@@ -121,8 +120,8 @@ def _experiment_tile_stage():
     m = po.Map(pr.map_xyz)
     for name, body in scans.items():
         out = []
-        for stage in (0, 3):
-            h = capi.Handle(first_stage=stage)
+        for fs in (1, stage):
+            h = capi.Handle(first_stage=fs)
             h.map_build(pr.map_xyz)
             h.scan_upload(body)
             res = []
@@ -154,38 +153,3 @@ def _experiment_tile_stage():
         sc = po.Scan(body, nthreads=8)
         sc.h_share_model(m, xp, True, False)
         np.testing.assert_array_equal(r3[0][4], sc.selected, err_msg=name + ": flags vs oracle")
-
-
-# ---- experiments that are OFF by default and had not run on hardware when they were written.  Each runs in a child process under a
-# time limit, so that a device fault or a hang in unvalidated device code cannot take the suite down; a failure is reported as an
-# expected failure with the child's last lines in the warnings summary (the product's default path is not involved either way).
-def _run_experiment(fn_name, limit=240):
-    import subprocess
-    import sys
-    import warnings
-
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_zz_timing as t; t.%s(); print('EXPERIMENT-OK')"
-            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), fn_name))
-    try:
-        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=limit)
-        out, rc = r.stdout.decode(errors="replace"), r.returncode
-    except subprocess.TimeoutExpired as e:
-        out, rc = (e.stdout or b"").decode(errors="replace") + "\n[time limit]", -9
-    if rc == 0 and "EXPERIMENT-OK" in out:
-        return
-    warnings.warn("experiment %s did not pass (rc %s): %s" % (fn_name, rc, out[-1500:]))
-    pytest.xfail("experiment %s: see the warnings summary" % fn_name)
-
-
-_experiments = pytest.mark.skipif(not os.environ.get("FLH_RUN_EXPERIMENTS"),
-                                  reason="unvalidated device code: run with FLH_RUN_EXPERIMENTS=1 (tools/round_start.sh does)")
-
-
-@_experiments
-def test_plane_cache_experiment_changes_no_bit():
-    _run_experiment("_experiment_plane_cache")
-
-
-@_experiments
-def test_tile_first_stage_experiment_equals_the_default_stage():
-    _run_experiment("_experiment_tile_stage")
