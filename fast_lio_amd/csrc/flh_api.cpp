@@ -101,6 +101,14 @@ struct flh_handle {
     DevBuf<uint32_t> mb_cap, mb_capincl;
     DevBuf<uint32_t> ctr;                  // device counters: [0] storage top, [1] bricks, [2] re-index flags, [3] removed
     uint32_t* h_ctr = nullptr;             // pinned mirror
+    // A map change (flh_map_incremental with apply, flh_map_add) is ENQUEUED and returns; its counters come back as granules in
+    // pinned memory (h_mi: [0..3] list lengths of map_incremental, [4..7] storage top / bricks / re-index flags / removed,
+    // [8..11] inserted + sequence) and are folded into the host's bookkeeping by map_settle() when somebody needs them -- by
+    // then the device has long finished, so nothing waits.
+    uint32_t* h_mi = nullptr;
+    uint32_t mi_seq = 0;
+    bool map_pending = false;
+    uint32_t map_pending_seq = 0;
     size_t pts_cap = 0, rows_cap = 0, alloc_top = 0;
     DevBuf<float4> ins;                    // points being inserted, with their ids
     std::vector<uint32_t> id_pos;          // id -> position among the live points (flh_fetch_neighbors), built on demand
@@ -288,12 +296,14 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (hipHostMalloc((void**)&h->h_gram, 256 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_counter, sizeof(u64), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_ctr, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_mi, 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_small, 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_gran, ((size_t)kGranGroups * kGranSlots + 1) * 16, hipHostMallocDefault) != hipSuccess) {
         flh_destroy(h);
         return fail("hipHostMalloc failed");
     }
     std::memset(h->h_gram, 0, 256 * sizeof(double));
+    std::memset(h->h_mi, 0, 16 * sizeof(uint32_t));
     std::memset(h->h_gran, 0, ((size_t)kGranGroups * kGranSlots + 1) * 16);
     if (h->gram.reserve(256) != hipSuccess || h->counter.reserve(FLH_COUNTER_WORDS) != hipSuccess || h->slow_count.reserve(2 * flh::list_stripes()) != hipSuccess ||
         hipMemset(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t)) != hipSuccess) {
@@ -318,6 +328,7 @@ void flh_destroy(flh_handle* h) {
     h->dead_id.release(); h->cap_end.release(); h->live.release(); h->mb_cap.release(); h->mb_capincl.release(); h->ctr.release();
     h->ins.release();
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
+    if (h->h_mi) (void)hipHostFree(h->h_mi);
     h->map_orig.release(); h->map_next.release(); h->mb_aabb.release(); h->mu_add.release(); h->mi_world.release();
     h->mu_alive.release(); h->mi_cls.release(); h->mu_flags.release(); h->mu_incl.release(); h->mu_boxes.release();
     h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_list2.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
@@ -350,7 +361,12 @@ void flh_destroy(flh_handle* h) {
     delete h;
 }
 
-size_t flh_map_size(const flh_handle* h) { return h ? h->M : 0; }
+static int map_settle(flh_handle* h);
+size_t flh_map_size(const flh_handle* h) {
+    if (!h) return 0;
+    (void)map_settle(const_cast<flh_handle*>(h));  // a map change still under way on the device decides the size
+    return h->M;
+}
 size_t flh_scan_size(const flh_handle* h) { return h ? h->N : 0; }
 
 // ---------------------------------------------------------------------------------------------
@@ -515,6 +531,10 @@ int flh_map_build(flh_handle* h, const void* xyz, size_t stride_bytes, size_t M)
     if (!h) return fail("flh_map_build: null handle");
     if (M >= (1ull << 31)) return fail("flh_map_build: M too large");
     HIPC(hipSetDevice(h->device));
+    if (h->map_pending) {  // a change of the map that is being replaced: let it finish, its counters no longer matter
+        HIPC(hipStreamSynchronize(h->stream));
+        h->map_pending = false;
+    }
     if (upload_points(h, "flh_map_build", xyz, stride_bytes, M, h->map_next) != 0) return -1;
     const int rc = rebuild_index(h, h->map_next, M);
     if (rc != 0) {  // Build replaces the map: a failed build leaves none
@@ -555,75 +575,97 @@ static int reindex_from_ids(flh_handle* h) {
     return rebuild_index(h, h->map_next, total);
 }
 
-// d_add holds n1 points to insert WITH down-sampling followed by n2 points to insert as they are.
+// Waits until the granule at h_mi[off .. off+3] carries `seq` in its last word (written by one 16-byte system-scope store of a
+// kernel on the handle's stream); a stream that finished or failed without publishing is an error, not a hang.
+static int wait_granule(flh_handle* h, int off, uint32_t seq, const char* who) {
+    const volatile uint32_t* g = h->h_mi + off;
+    uint64_t spins = 0;
+    while (g[3] != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFFu) == 0 && hipStreamQuery(h->stream) != hipErrorNotReady) {
+            HIPC(hipStreamSynchronize(h->stream));
+            if (g[3] != seq) return fail(std::string(who) + ": the device finished without publishing its counters");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return 0;
+}
+
+// Folds the counters of the map change that is under way (if any) into the host's bookkeeping; re-indexes when the change
+// said so.  Called by everything that reads the map's size / ids / tables or launches a search.
+static int map_settle(flh_handle* h) {
+    if (!h->map_pending) return 0;
+    HIPC(hipSetDevice(h->device));
+    if (wait_granule(h, 8, h->map_pending_seq, "map change") != 0) return -1;
+    h->map_pending = false;
+    const uint32_t top = h->h_mi[4], bricks = h->h_mi[5], flags = h->h_mi[6], removed = h->h_mi[7], n_alive = h->h_mi[8];
+    h->n_ids += n_alive;
+    h->M = h->M + n_alive - removed;
+    h->id_pos_valid = false;
+    if (flags != 0) return reindex_from_ids(h);
+    ++h->n_inplace;
+    h->alloc_top = top;
+    h->nbricks = bricks;
+    // ids (and the id-ordered array) only grow between re-indexings: renumber once the removed ones outweigh half the map
+    if (h->n_ids > h->M + h->M / 2 + (1u << 20)) return reindex_from_ids(h);
+    return 0;
+}
+
+// d_add holds n1 points to insert WITH down-sampling followed by n2 points to insert as they are.  Everything is enqueued on
+// the handle's stream with launch sizes the host knows (n1, n2; the number of points that survive the down-sampling stays on the
+// device: n bounds it, and entries beyond it carry a sentinel key); the change's counters are collected by map_settle().
 static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size_t n2, double ds) {
     hipStream_t st = h->stream;
+    if (map_settle(h) != 0) return -1;
     const size_t n = n1 + n2;
     if (h->n_ids + n >= (1ull << 31)) return fail("map update: too many points");
     if (!h->grid.hash) {  // no map yet: index an empty one so there are tables to insert into
         if (rebuild_index(h, h->map_orig, 0) != 0) return -1;
     }
     if (n == 0) return 0;
-    HIPC(hipMemsetAsync(h->ctr.p + 2, 0, 2 * sizeof(uint32_t), st));
+    const uint32_t nu = (uint32_t)n;
     HIPC(h->mu_alive.reserve(n));
-    if (n1 > 0) HIPC(hipMemsetAsync(h->mu_alive.p, 0, n1, st));
-    if (n2 > 0) HIPC(hipMemsetAsync(h->mu_alive.p + n1, 1, n2, st));
+    HIPC(h->mb_k0.reserve(n)); HIPC(h->mb_k1.reserve(n)); HIPC(h->mb_v0.reserve(n)); HIPC(h->mb_v1.reserve(n));
+    HIPC(h->mu_flags.reserve(n)); HIPC(h->mu_incl.reserve(n));
+    size_t tb_sort = 0, tb_scan = 0;
+    HIPC(flh::sort_vox_pairs(nullptr, tb_sort, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, nu, st));
+    HIPC(flh::inclusive_sum(nullptr, tb_scan, h->mu_flags.p, h->mu_incl.p, nu, st));
+    HIPC(h->mb_tmp.reserve(std::max(tb_sort, tb_scan)));
+    // room for every point of the change (the survivors are at most n): allocated up front, nothing to wait for in between
+    HIPC(h->map_orig.grow(h->n_ids + n, h->n_ids, st));
+    {
+        const size_t before = h->dead_id.cap;
+        HIPC(h->dead_id.grow(h->n_ids + n, h->n_ids, st));
+        if (h->dead_id.cap != before) HIPC(hipMemsetAsync(h->dead_id.p + h->n_ids, 0, h->dead_id.cap - h->n_ids, st));
+    }
+    HIPC(h->ins.reserve(n));
+    HIPC(flh::launch_add_keys(d_add, (uint32_t)n1, nu, ds, h->mb_k0.p, h->mb_v0.p, h->mu_alive.p, h->ctr.p, st));
     if (n1 > 0) {
-        const uint32_t nu = (uint32_t)n1;
-        HIPC(h->mb_k0.reserve(n)); HIPC(h->mb_k1.reserve(n)); HIPC(h->mb_v0.reserve(n)); HIPC(h->mb_v1.reserve(n));
-        HIPC(flh::launch_add_keys(d_add, nu, ds, h->mb_k0.p, h->mb_v0.p, st));
-        size_t tb = 0;
-        HIPC(flh::sort_vox_pairs(nullptr, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, nu, st));
-        HIPC(h->mb_tmp.reserve(tb));
-        tb = h->mb_tmp.cap;
-        HIPC(flh::sort_vox_pairs(h->mb_tmp.p, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, nu, st));
-        HIPC(flh::launch_add_resolve(h->grid, h->map_sorted.p, d_add, h->mb_k1.p, h->mb_v1.p, nu, ds, h->dead_id.p, h->live.p,
+        size_t tb = h->mb_tmp.cap;
+        HIPC(flh::sort_vox_pairs(h->mb_tmp.p, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, (uint32_t)n1, st));
+        HIPC(flh::launch_add_resolve(h->grid, h->map_sorted.p, d_add, h->mb_k1.p, h->mb_v1.p, (uint32_t)n1, ds, h->dead_id.p, h->live.p,
                                      h->ctr.p, h->mu_alive.p, st));
     }
-    // ids of the survivors, in input order
-    HIPC(h->mu_flags.reserve(n)); HIPC(h->mu_incl.reserve(n));
-    HIPC(flh::launch_byte_flags(h->mu_alive.p, (uint32_t)n, 0, h->mu_flags.p, st));
+    // ids of the survivors, in input order; the brick keys start as sentinels
+    HIPC(flh::launch_byte_flags(h->mu_alive.p, nu, 0, h->mu_flags.p, st, h->mb_k0.p));
     {
-        size_t tb = 0;
-        HIPC(flh::inclusive_sum(nullptr, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)n, st));
-        HIPC(h->mb_tmp.reserve(tb));
-        tb = h->mb_tmp.cap;
-        HIPC(flh::inclusive_sum(h->mb_tmp.p, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)n, st));
+        size_t tb = h->mb_tmp.cap;
+        HIPC(flh::inclusive_sum(h->mb_tmp.p, tb, h->mu_flags.p, h->mu_incl.p, nu, st));
     }
-    uint32_t n_alive = 0;
-    HIPC(hipMemcpyAsync(&n_alive, h->mu_incl.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIPC(hipStreamSynchronize(st));
-    if (n_alive > 0) {
-        HIPC(h->map_orig.grow(h->n_ids + n_alive, h->n_ids, st));
-        {
-            const size_t before = h->dead_id.cap;
-            HIPC(h->dead_id.grow(h->n_ids + n_alive, h->n_ids, st));
-            if (h->dead_id.cap != before) HIPC(hipMemsetAsync(h->dead_id.p + h->n_ids, 0, h->dead_id.cap - h->n_ids, st));
-        }
-        HIPC(h->ins.reserve(n_alive));
-        HIPC(h->mb_k0.reserve(n_alive)); HIPC(h->mb_k1.reserve(n_alive)); HIPC(h->mb_v0.reserve(n_alive)); HIPC(h->mb_v1.reserve(n_alive));
-        HIPC(flh::launch_ins_prepare(h->grid, d_add, h->mu_alive.p, h->mu_incl.p, (uint32_t)n, (uint32_t)h->n_ids, h->map_orig.p,
-                                     h->dead_id.p, h->ins.p, h->mb_k0.p, h->mb_v0.p, h->ctr.p, st));
-        size_t tb = 0;
-        HIPC(flh::sort_vox_pairs(nullptr, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, n_alive, st));
-        HIPC(h->mb_tmp.reserve(tb));
-        tb = h->mb_tmp.cap;
-        HIPC(flh::sort_vox_pairs(h->mb_tmp.p, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, n_alive, st));
-        HIPC(flh::launch_brick_rewrite(h->grid, h->map_sorted.p, h->starts.p, h->hash.p, h->cap_end.p, h->live.p, h->ctr.p, h->ins.p,
-                                       h->mb_k1.p, h->mb_v1.p, n_alive, (uint32_t)h->pts_cap, (uint32_t)h->rows_cap, st));
+    HIPC(flh::launch_ins_prepare(h->grid, d_add, h->mu_alive.p, h->mu_incl.p, nu, (uint32_t)h->n_ids, h->map_orig.p,
+                                 h->dead_id.p, h->ins.p, h->mb_k0.p, h->mb_v0.p, h->ctr.p, st));
+    {
+        size_t tb = h->mb_tmp.cap;
+        HIPC(flh::sort_vox_pairs(h->mb_tmp.p, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, nu, st));
     }
-    HIPC(hipMemcpyAsync(h->h_ctr, h->ctr.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIPC(hipStreamSynchronize(st));
-    h->n_ids += n_alive;
-    h->M = h->M + n_alive - h->h_ctr[3];
+    HIPC(flh::launch_brick_rewrite(h->grid, h->map_sorted.p, h->starts.p, h->hash.p, h->cap_end.p, h->live.p, h->ctr.p, h->ins.p,
+                                   h->mb_k1.p, h->mb_v1.p, nu, (uint32_t)h->pts_cap, (uint32_t)h->rows_cap, st));
+    const uint32_t seq = ++h->mi_seq;
+    HIPC(flh::launch_map_publish(h->ctr.p, h->mu_incl.p + (n - 1), h->h_mi + 4, seq, st));
+    h->map_pending = true;
+    h->map_pending_seq = seq;
     h->id_pos_valid = false;
     h->searched_once = false;  // cached neighbours refer to the previous map
-    if (h->h_ctr[2] != 0) return reindex_from_ids(h);
-    ++h->n_inplace;
-    h->alloc_top = h->h_ctr[0];
-    h->nbricks = h->h_ctr[1];
-    // ids (and the id-ordered array) only grow between re-indexings: renumber once the removed ones outweigh half the map
-    if (h->n_ids > h->M + h->M / 2 + (1u << 20)) return reindex_from_ids(h);
     return 0;
 }
 
@@ -633,6 +675,7 @@ int flh_map_add(flh_handle* h, const void* xyz, size_t stride_bytes, size_t n, i
     if (!h) return fail("flh_map_add: null handle");
     if (downsample && !(downsample_size > 0)) return fail("flh_map_add: downsample_size must be > 0");
     HIPC(hipSetDevice(h->device));
+    if (map_settle(h) != 0) return -1;
     if (upload_points(h, "flh_map_add", xyz, stride_bytes, n, h->mu_add) != 0) return -1;
     return apply_map_changes(h, h->mu_add.p, downsample ? n : 0, downsample ? 0 : n, downsample_size);
 }
@@ -642,6 +685,7 @@ int flh_map_add(flh_handle* h, const void* xyz, size_t stride_bytes, size_t n, i
 int flh_map_delete_boxes(flh_handle* h, const float* boxes, size_t nb) {
     if (!h) return fail("flh_map_delete_boxes: null handle");
     if (nb > 0 && !boxes) return fail("flh_map_delete_boxes: null boxes");
+    if (map_settle(h) != 0) return -1;
     if (nb == 0 || h->M == 0) return 0;
     HIPC(hipSetDevice(h->device));
     hipStream_t st = h->stream;
@@ -684,6 +728,7 @@ int flh_fov_segment(flh_handle* h, flh_local_map* lm, const double pos_lid[3], d
         }
     if (boxes_out) std::memcpy(boxes_out, boxes, sizeof(float) * 6 * cub_needrm.size());
     if (n_boxes) *n_boxes = (int)cub_needrm.size();
+    if (map_settle(h) != 0) return -1;
     const size_t before = h->M;
     if (!cub_needrm.empty() && flh_map_delete_boxes(h, boxes, cub_needrm.size()) != 0) return -1;
     if (kdtree_delete_counter) *kdtree_delete_counter = (int64_t)(before - h->M);
@@ -694,6 +739,7 @@ int flh_fov_segment(flh_handle* h, flh_local_map* lm, const double pos_lid[3], d
 // ids handed out since the last re-indexing, bricks}.
 int flh_map_stats(const flh_handle* h, uint64_t out[6]) {
     if (!h || !out) return fail("flh_map_stats: null argument");
+    if (map_settle(const_cast<flh_handle*>(h)) != 0) return -1;
     out[0] = h->n_reindex; out[1] = h->n_inplace; out[2] = h->alloc_top; out[3] = h->pts_cap; out[4] = h->n_ids; out[5] = h->nbricks;
     return 0;
 }
@@ -701,6 +747,7 @@ int flh_map_stats(const flh_handle* h, uint64_t out[6]) {
 // The map in index order (what PCL_Storage / flatten would hand back, src/laserMapping.cpp:406-411): the live points by id.
 int flh_map_download(flh_handle* h, float* xyz, size_t capacity_points) {
     if (!h) return fail("flh_map_download: null handle");
+    if (map_settle(h) != 0) return -1;
     if (capacity_points < h->M) return fail("flh_map_download: buffer too small");
     if (h->M == 0) return 0;
     if (!xyz) return fail("flh_map_download: null buffer");
@@ -1321,6 +1368,7 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
                         bool host_granules = false) {
     const bool timed = ev3 != nullptr;  // three records: before the first launch, after the search kernels, after the fit kernel
     hipStream_t st = h->stream;
+    if (h->map_pending && map_settle(h) != 0) return -1;  // a map change under way: its counters (and a re-index it asked for) first
     if (!h->cur_body || !h->selected.p) return fail("flh_eval: no active scan (flh_scan_upload / flh_scan_activate first)");
     if (!h->grid.hash && h->N > 0) return fail("flh_eval: no map (flh_map_build / flh_map_add first)");
     if (!do_search && !h->searched_once && h->N > 0)
@@ -1562,6 +1610,7 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
     if (!h || !x) return fail("flh_map_incremental: null argument");
     if (!(filter_size_map > 0)) return fail("flh_map_incremental: filter_size_map must be > 0");
     if (!h->cur_body) return fail("flh_map_incremental: no active scan");
+    if (map_settle(h) != 0) return -1;
     if (h->N > 0 && !h->searched_once)
         return fail("flh_map_incremental: the active scan has not been searched against the current map");
     HIPC(hipSetDevice(h->device));
@@ -1582,14 +1631,14 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
         HIPC(h->mb_tmp.reserve(tb));
         tb = h->mb_tmp.cap;
         HIPC(flh::inclusive_sum(h->mb_tmp.p, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)(2 * N), st));
-        uint32_t e1 = 0, e2 = 0;
-        HIPC(hipMemcpyAsync(&e1, h->mu_incl.p + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIPC(hipMemcpyAsync(&e2, h->mu_incl.p + (2 * N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIPC(hipStreamSynchronize(st));
-        c1 = e1;
-        c2 = e2 - e1;
-        HIPC(h->mu_add.reserve((size_t)c1 + c2 + 1));
-        HIPC(flh::launch_cls_compact(h->mi_world.p, h->mi_cls.p, h->mu_incl.p, (int)N, h->mu_add.p, st));
+        // the two lists hold at most N points together: compacted without knowing their lengths; the kernel hands the lengths to
+        // the host as a granule in pinned memory (no copy, no stream synchronisation)
+        HIPC(h->mu_add.reserve(N + 1));
+        const uint32_t seq = ++h->mi_seq;
+        HIPC(flh::launch_cls_compact(h->mi_world.p, h->mi_cls.p, h->mu_incl.p, (int)N, h->mu_add.p, h->h_mi, seq, st));
+        if (wait_granule(h, 0, seq, "flh_map_incremental") != 0) return -1;
+        c1 = h->h_mi[0];
+        c2 = h->h_mi[1] - h->h_mi[0];
     }
     if (n_add) *n_add = c1;
     if (n_no_downsample) *n_no_downsample = c2;
@@ -1650,6 +1699,7 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
     HIPC(hipSetDevice(h->device));
     hipStream_t st = h->stream;
     const StateDev s = make_state(x + 3, x + 0, x + 7, x + 11);
+    if (map_settle(h) != 0) return -1;
     if (which != 0 && !h->searched_once) return fail("flh_time_kernel: fit kernel timed before any search");
     HIPC(hipEventRecord(h->ev[0], st));
     for (int it = 0; it < iters; ++it) {
@@ -1700,6 +1750,7 @@ int flh_fetch_selected(flh_handle* h, uint8_t* flags) {
 int flh_fetch_neighbors(flh_handle* h, int32_t* idx, float* d2, uint8_t* cnt) {
     if (!h || !idx || !d2) return fail("flh_fetch_neighbors: null argument");
     if (!h->cur) return fail("flh_fetch_neighbors: no active scan");
+    if (map_settle(h) != 0) return -1;
     const size_t N = h->N;
     if (N == 0) return 0;
     HIPC(hipSetDevice(h->device));

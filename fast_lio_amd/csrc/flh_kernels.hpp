@@ -59,10 +59,11 @@ hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t 
                               float4* world_out, uint8_t* cls, hipStream_t st);
 hipError_t launch_cls_flags(const uint8_t* cls, int N, uint32_t* flags, hipStream_t st);
 hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* incl, int N, float4* out,
-                              hipStream_t st);
+                              uint32_t* host_counts, uint32_t seq, hipStream_t st);
+hipError_t launch_map_publish(const uint32_t* ctr, const uint32_t* n_alive, uint32_t* host_out, uint32_t seq, hipStream_t st);
 hipError_t launch_aabb(const float4* pts, uint32_t M, uint32_t* out6, hipStream_t st);
-hipError_t launch_add_keys(const float4* add, uint32_t n, double ds, unsigned long long* keys, uint32_t* vals,
-                           hipStream_t st);
+hipError_t launch_add_keys(const float4* add, uint32_t n1, uint32_t n, double ds, unsigned long long* keys, uint32_t* vals,
+                           uint8_t* alive_new, uint32_t* ctr, hipStream_t st);
 hipError_t sort_vox_pairs(void* tmp, size_t& tmp_bytes, const unsigned long long* kin, unsigned long long* kout,
                           const uint32_t* vin, uint32_t* vout, uint32_t n, hipStream_t st);
 hipError_t launch_add_resolve(const GridParams& g, float4* pts_rw, const float4* add, const unsigned long long* ks,
@@ -76,7 +77,8 @@ hipError_t launch_ins_prepare(const GridParams& g, const float4* add, const uint
 hipError_t launch_brick_rewrite(const GridParams& g, float4* pts, uint32_t* starts, uint2* hash, uint32_t* cap_end, uint32_t* live,
                                 uint32_t* ctr, const float4* ins, const unsigned long long* ks, const uint32_t* perm, uint32_t n,
                                 uint32_t pts_cap, uint32_t rows_cap, hipStream_t st);
-hipError_t launch_byte_flags(const uint8_t* in, uint32_t n, int invert, uint32_t* flags, hipStream_t st);
+hipError_t launch_byte_flags(const uint8_t* in, uint32_t n, int invert, uint32_t* flags, hipStream_t st,
+                             unsigned long long* keys_sentinel = nullptr);
 hipError_t launch_live_compact(const float4* map_orig, const uint32_t* flags, const uint32_t* incl, uint32_t n_ids, float4* out,
                                hipStream_t st);
 

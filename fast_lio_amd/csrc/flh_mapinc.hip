@@ -148,9 +148,20 @@ __global__ void __launch_bounds__(256) k_cls_flags(const uint8_t* __restrict__ c
     flags[i] = c == 1 ? 1u : 0u;
     flags[N + i] = c == 2 ? 1u : 0u;
 }
+// One 16-byte system-scope store: {a, b, c, sequence} lands in pinned host memory as one granule (the host polls the sequence word
+// and then trusts the other three -- the hand-off k_fit's group reducers use, MI355X_MICROARCH.md "granule").
+typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void publish_granule(uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t seq) {
+    const u32x4g v = {a, b, c, seq};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+}
+// Also hands the two list lengths to the host (granule {PointToAdd, PointToAdd + PointNoNeedDownsample, 0, seq}): the host needs
+// them to size the launches of Add_Points, and a copy + stream synchronisation would cost more than this whole kernel.
 __global__ void __launch_bounds__(256) k_cls_compact(const float4* __restrict__ world, const uint8_t* __restrict__ cls,
-                                                     const uint32_t* __restrict__ incl, int N, float4* __restrict__ out) {
+                                                     const uint32_t* __restrict__ incl, int N, float4* __restrict__ out,
+                                                     uint32_t* __restrict__ host_counts, uint32_t seq) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && host_counts) publish_granule(host_counts, incl[N - 1], incl[2 * N - 1], 0u, seq);
     if (i >= N) return;
     const uint8_t c = cls[i];
     if (c == 1) out[incl[i] - 1] = world[i];
@@ -211,10 +222,16 @@ __device__ __forceinline__ u64 pack_vox(long long kx, long long ky, long long kz
            ((u64)(kz + (1ll << 20)) & 0x1FFFFFull);
 }
 
-__global__ void __launch_bounds__(256) k_add_keys(const float4* __restrict__ add, uint32_t n, double ds,
-                                                  u64* __restrict__ keys, uint32_t* __restrict__ vals) {
+// First kernel of a map change: the voxel keys of the n1 points inserted WITH down-sampling; alive_new = 0 for them (k_add_resolve
+// decides), 1 for the n - n1 points inserted as they are; the change's counters (re-index flags, removed points) start at zero.
+__global__ void __launch_bounds__(256) k_add_keys(const float4* __restrict__ add, uint32_t n1, uint32_t n, double ds,
+                                                  u64* __restrict__ keys, uint32_t* __restrict__ vals, uint8_t* __restrict__ alive_new,
+                                                  uint32_t* __restrict__ ctr) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { ctr[2] = 0u; ctr[3] = 0u; }
     if (i >= n) return;
+    alive_new[i] = i < n1 ? 0 : 1;
+    if (i >= n1) return;
     const float4 p = add[i];
     long long kx, ky, kz;
     vox_of(p.x, p.y, p.z, ds, kx, ky, kz);
@@ -402,6 +419,7 @@ k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g
     const int tid = threadIdx.x;
     if (j >= n) return;
     const u64 key = ks[j];
+    if (key == ~0ull) return;               // beyond the surviving points (n is the host's upper bound of their number)
     if (j > 0 && ks[j - 1] == key) return;  // block-uniform: not the head of its brick's run
     uint32_t e = j + 1;
     while (e < n && ks[e] == key) ++e;
@@ -502,9 +520,12 @@ k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g
 }
 
 // index-ordered array -> contiguous array of the live points, in order (download, full re-index)
-__global__ void __launch_bounds__(256) k_byte_flags(const uint8_t* __restrict__ in, uint32_t n, int invert, uint32_t* __restrict__ flags) {
+__global__ void __launch_bounds__(256) k_byte_flags(const uint8_t* __restrict__ in, uint32_t n, int invert, uint32_t* __restrict__ flags,
+                                                    u64* __restrict__ keys_sentinel) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) flags[i] = ((in[i] != 0) != (invert != 0)) ? 1u : 0u;
+    if (i >= n) return;
+    flags[i] = ((in[i] != 0) != (invert != 0)) ? 1u : 0u;
+    if (keys_sentinel) keys_sentinel[i] = ~0ull;  // k_ins_prepare overwrites the first n_alive of them
 }
 __global__ void __launch_bounds__(256) k_live_compact(const float4* __restrict__ map_orig, const uint32_t* __restrict__ flags,
                                                       const uint32_t* __restrict__ incl, uint32_t n_ids, float4* __restrict__ out) {
@@ -534,9 +555,24 @@ hipError_t launch_cls_flags(const uint8_t* cls, int N, uint32_t* flags, hipStrea
     return hipGetLastError();
 }
 hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* incl, int N, float4* out,
-                              hipStream_t st) {
+                              uint32_t* host_counts, uint32_t seq, hipStream_t st) {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_cls_compact, dim3(cdiv2(N, 256)), dim3(256), 0, st, world, cls, incl, N, out);
+    hipLaunchKernelGGL(k_cls_compact, dim3(cdiv2(N, 256)), dim3(256), 0, st, world, cls, incl, N, out, host_counts, seq);
+    return hipGetLastError();
+}
+// the counters of a map change and the number of points it inserted, as two granules behind each other:
+// {storage top, bricks, re-index flags, removed} with seq in a second granule {inserted, 0, 0, seq}
+__global__ void k_map_publish(const uint32_t* __restrict__ ctr, const uint32_t* __restrict__ n_alive, uint32_t* __restrict__ host_out,
+                              uint32_t seq) {
+    if (threadIdx.x != 0) return;
+    const uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    const uint32_t na = n_alive ? *n_alive : 0u;
+    publish_granule(host_out, c0, c1, c2, c3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first granule carries no sequence word of its own: it lands before the second
+    publish_granule(host_out + 4, na, 0u, 0u, seq);
+}
+hipError_t launch_map_publish(const uint32_t* ctr, const uint32_t* n_alive, uint32_t* host_out, uint32_t seq, hipStream_t st) {
+    hipLaunchKernelGGL(k_map_publish, dim3(1), dim3(64), 0, st, ctr, n_alive, host_out, seq);
     return hipGetLastError();
 }
 hipError_t launch_aabb(const float4* pts, uint32_t M, uint32_t* out6, hipStream_t st) {
@@ -546,9 +582,10 @@ hipError_t launch_aabb(const float4* pts, uint32_t M, uint32_t* out6, hipStream_
     hipLaunchKernelGGL(k_aabb, dim3(blocks), dim3(256), 0, st, pts, M, out6);
     return hipGetLastError();
 }
-hipError_t launch_add_keys(const float4* add, uint32_t n, double ds, u64* keys, uint32_t* vals, hipStream_t st) {
+hipError_t launch_add_keys(const float4* add, uint32_t n1, uint32_t n, double ds, u64* keys, uint32_t* vals, uint8_t* alive_new,
+                           uint32_t* ctr, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_add_keys, dim3(cdiv2(n, 256)), dim3(256), 0, st, add, n, ds, keys, vals);
+    hipLaunchKernelGGL(k_add_keys, dim3(cdiv2(n, 256)), dim3(256), 0, st, add, n1, n, ds, keys, vals, alive_new, ctr);
     return hipGetLastError();
 }
 hipError_t sort_vox_pairs(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, const uint32_t* vin, uint32_t* vout,
@@ -584,9 +621,9 @@ hipError_t launch_brick_rewrite(const GridParams& g, float4* pts, uint32_t* star
                        rows_cap);
     return hipGetLastError();
 }
-hipError_t launch_byte_flags(const uint8_t* in, uint32_t n, int invert, uint32_t* flags, hipStream_t st) {
+hipError_t launch_byte_flags(const uint8_t* in, uint32_t n, int invert, uint32_t* flags, hipStream_t st, u64* keys_sentinel) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_byte_flags, dim3(cdiv2(n, 256)), dim3(256), 0, st, in, n, invert, flags);
+    hipLaunchKernelGGL(k_byte_flags, dim3(cdiv2(n, 256)), dim3(256), 0, st, in, n, invert, flags, keys_sentinel);
     return hipGetLastError();
 }
 hipError_t launch_live_compact(const float4* map_orig, const uint32_t* flags, const uint32_t* incl, uint32_t n_ids, float4* out,

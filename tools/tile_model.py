@@ -108,13 +108,30 @@ def check(Q, TP, TC, IT):
         cstart[:TC] = np.concatenate([[0], np.cumsum(cnt)])[:TC]
         cstart[TC] = P
         nfit += 1
+        # segments in tile order, their first tile positions as a bitmap, the copy by popcount (flh_search_wtile.inc)
+        seg_tab = [(gpos, int(cstart[t0])) for gpos, t0, n in item if n > 0]
+        assert all(seg_tab[i][1] < seg_tab[i + 1][1] for i in range(len(seg_tab) - 1))
+        PPL = TP // 64
+        bits = [0] * PPL
+        for gpos, toff in seg_tab:
+            bits[toff >> 6] |= 1 << (toff & 63)
+        before = [0] * PPL
+        for k in range(1, PPL):
+            before[k] = before[k - 1] + bin(bits[k - 1]).count("1")
         tile = -np.ones(P, np.int64)
+        for lane in range(64):
+            for k in range(PPL):
+                pp = lane + 64 * k
+                if pp < P:
+                    si = before[k] + bin(bits[k] & ((1 << (lane + 1)) - 1)).count("1") - 1
+                    gpos, toff = seg_tab[si]
+                    tile[pp] = gpos + (pp - toff)
+        ref = -np.ones(P, np.int64)
         for gpos, t0, n in item:
             toff = cstart[t0]
             for j in range(n):
-                assert tile[toff + j] == -1
-                tile[toff + j] = gpos + j
-        assert (tile >= 0).all()
+                ref[toff + j] = gpos + j
+        assert (tile == ref).all() and (tile >= 0).all()
         for j, q in enumerate(qs):
             got = []
             cx, cy, cz = qc[q]
