@@ -57,15 +57,29 @@ def pmc_traffic(args):
     """HBM bytes per search pass from the committed rocprofv3 --pmc summary of this round (profiles/, made by
     tools/pmc_summary.py from separate FETCH_SIZE and WRITE_SIZE passes of this same command).  FETCH_SIZE/WRITE_SIZE
     are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled (MI355X_MICROARCH.md, HBM
-    section).  Only valid for the workload the summary was taken on (default kernel settings)."""
+    section).  Only valid for the workload AND the code the summary was taken on: the summary's side file records the hash of the
+    library's sources (tools/src_hash.py) and the first-stage setting; a mismatch with the running code drops the figure."""
     import csv
-
     import glob
 
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_summary_config{args.config}.csv")))
-    if not found or args.lpq != 4 or args.cell != 1.5 or args.first_stage != 0:
+    if not found or args.lpq != 4 or args.cell != 1.5:
         return None
     path = found[-1]  # the latest round's
+    meta = {}
+    try:
+        meta = json.load(open(path[:-4] + ".meta.json"))
+    except (OSError, ValueError):
+        pass
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from src_hash import src_hash
+
+        here = src_hash()
+    except Exception:  # noqa: BLE001
+        here = None
+    if not meta or meta.get("src_hash") != here or int(meta.get("first_stage", -1)) != int(args.first_stage):
+        return {"stale": True, "source": os.path.relpath(path, ROOT), "summary_src_hash": meta.get("src_hash"), "running_src_hash": here}
     fetch, write, calls = {}, {}, {}
     with open(path) as f:
         for r in csv.DictReader(f):
@@ -77,12 +91,38 @@ def pmc_traffic(args):
                 calls[k] = int(r["dispatches"])
             elif r["counter"] == "WRITE_SIZE":
                 write[k] = float(r["sum"])
-    a1 = [k for k in calls if k.startswith("k_search_ring<4, 1")]
-    if not a1 or not fetch:
+    second = [k for k in calls if k.startswith("k_search_ring<16, 2")]
+    if not second or not fetch:
         return None
-    passes = sum(calls[k] for k in a1)  # every search pass launches exactly one first-stage variant (first / later search)
+    passes = sum(calls[k] for k in second)  # every search pass launches the second stage exactly once
     total = (2.0 * sum(fetch.values()) + sum(write.values())) * 1024.0 / passes
-    return {"bytes_per_search_pass": int(total), "source": os.path.relpath(path, ROOT) + " (FETCH_SIZE x2 + WRITE_SIZE, KiB)"}
+    return {"bytes_per_search_pass": int(total), "src_hash": here, "commit": meta.get("commit"),
+            "source": os.path.relpath(path, ROOT) + " (FETCH_SIZE x2 + WRITE_SIZE, KiB)"}
+
+
+def load_scene(args, M):
+    """The seeded scene; the big ones (>= 10M points: tens of seconds of numpy) are kept in --cache-dir between runs."""
+    seed = synth.CONFIG_SEED_BASE + args.config
+    path = os.path.join(args.cache_dir, f"scene_cfg{args.config}_M{M}.npz") if (args.cache_dir and M >= 10_000_000) else None
+    if path and os.path.exists(path):
+        try:
+            z = np.load(path)
+            sc = synth.Scene(L=float(z["L"]), walls=z["walls"], seed=seed)
+            sc.map_xyz = np.ascontiguousarray(z["map_xyz"])
+            if sc.map_xyz.shape == (M, 3):
+                return sc
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] cache {path} unreadable ({e!r}): regenerating")
+    sc = synth.make_scene(M, seed)
+    if path:
+        try:
+            os.makedirs(args.cache_dir, exist_ok=True)
+            tmp = path + f".tmp{os.getpid()}.npz"
+            np.savez(tmp, L=sc.L, walls=sc.walls, map_xyz=sc.map_xyz)
+            os.replace(tmp, path)
+        except OSError as e:
+            log(f"[bench] could not write {path}: {e!r}")
+    return sc
 
 
 def main():
@@ -103,9 +143,12 @@ def main():
     ap.add_argument("--first-stage", type=int, default=0)
     ap.add_argument("--sort", type=int, default=1, help="Morton-order the scan at staging (0 = keep input order)")
     ap.add_argument("--extrinsic-est", type=int, default=0)
+    ap.add_argument("--plane-cache", type=int, default=-1, help="flh_config.plane_cache (-1 = the library's default: on)")
+    ap.add_argument("--plane-fit-dtype", type=int, default=0,
+                    help="1 = the fp16 plane-fit ABLATION of BASELINE configs[4] (not bit-exact, never a parity claim)")
     ap.add_argument("--timing-samples", type=int, default=32,
-                    help="evaluations of the timed region whose kernels are bracketed by HIP events (>= 16; half of them "
-                         "are searching evaluations, so the default gives >= 16 samples of the search kernels from 20 steps on)")
+                    help="evaluations of the timed region whose kernels carry HIP events (start / stop time stamps of the kernels "
+                         "themselves); half of them are searching evaluations: >= 16 samples of the search kernels from 20 steps on")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the headline + roofline (profiling runs)")
     ap.add_argument("--cpu-scans", type=int, default=96,
                     help="upper bound of the scans timed on the CPU oracle at --cpu-threads (it stops after ~12 s; 0 = skip)")
@@ -114,6 +157,8 @@ def main():
     ap.add_argument("--single-device", type=int, default=0, help="debug: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--leg", default="", help="internal: run only the named group of side legs (used by the child process)")
     ap.add_argument("--two-streams", action="store_true", help="side legs: also time two scan streams on one GPU")
+    ap.add_argument("--cache-dir", default=os.path.join(ROOT, ".bench_cache"),
+                    help="where generated scans + priors are kept between runs ('' = do not cache)")
     ap.add_argument("--in-process", action="store_true",
                     help="one GPU: do the GPU work in this process (default: in a child that is started once more if it dies, "
                          "so that a transient device fault costs a retry and not the line); profilers want this flag")
@@ -161,17 +206,46 @@ def main():
     ext = bool(args.extrinsic_est)
     with_map_inserts = args.config == 3  # "Velodyne scan stream ... incremental map inserts"
     t0 = time.time()
-    scene = synth.make_scene(M, synth.CONFIG_SEED_BASE + args.config)
+    scene = load_scene(args, M)
     S = max(1, args.scans)  # >= 100 distinct seeded scans whatever --steps is; they are cycled through
 
+    class _Scan:  # what the legs need of a synth.Problem
+        def __init__(self, body, x_prior):
+            self.body, self.x_prior = body, x_prior
+
     def gen(seed_base, count):
+        """`count` seeded scans + propagated priors.  Generating a scan ray-casts against every wall of the scene (tens of
+        seconds per scan for the 20M / 50M-point scenes), so the result is kept in --cache-dir (deterministic: same seeds, same
+        bytes) -- the rocprofv3 passes of the same command do not generate it again."""
         from concurrent.futures import ThreadPoolExecutor
 
+        cache = None
+        if args.cache_dir:
+            os.makedirs(args.cache_dir, exist_ok=True)
+            cache = os.path.join(args.cache_dir, f"scans_cfg{args.config}_n{count}_b{seed_base}.npz")
+            if os.path.exists(cache):
+                try:
+                    z = np.load(cache)
+                    if z["body"].shape == (count, N, 3):
+                        pr = [_Scan(np.ascontiguousarray(z["body"][i]), z["x_prior"][i]) for i in range(count)]
+                        return pr, [(np.ascontiguousarray(z["x"][i]), np.ascontiguousarray(z["P"][i])) for i in range(count)]
+                except Exception as e:  # a torn file: generate again
+                    log(f"[bench] cache {cache} unreadable ({e!r}): regenerating")
         with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:  # numpy releases the GIL in the heavy parts
-            pr = list(ex.map(lambda s_: synth.make_problem(M, N, sensor, cfg=args.config, scan_seed=seed_base + s_, scene=scene),
-                             range(count)))
+            full = list(ex.map(lambda s_: synth.make_problem(M, N, sensor, cfg=args.config, scan_seed=seed_base + s_, scene=scene),
+                               range(count)))
+        pr = [_Scan(p.body, p.x_prior) for p in full]
         pri = [synth.propagate_prior_cov(capi.predict_fn, p.x_prior) for p in pr]
-        return pr, [(np.ascontiguousarray(x, np.float64), np.ascontiguousarray(P, np.float64)) for x, P in pri]
+        pri = [(np.ascontiguousarray(x, np.float64), np.ascontiguousarray(P, np.float64)) for x, P in pri]
+        if cache:
+            try:
+                tmp = cache + f".tmp{os.getpid()}.npz"
+                np.savez(tmp, body=np.stack([p.body for p in pr]), x_prior=np.stack([p.x_prior for p in pr]),
+                         x=np.stack([x for x, _ in pri]), P=np.stack([P for _, P in pri]))
+                os.replace(tmp, cache)
+            except OSError as e:
+                log(f"[bench] could not write {cache}: {e!r}")
+        return pr, pri
 
     # streams: every rank follows its own scan stream; the shard leg uses scans common to all ranks
     probs, priors = gen(1000 * rank if G > 1 else 0, S)
@@ -188,7 +262,7 @@ def main():
             f"gen {time.time() - t0:.1f}s")
 
     h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
-                    first_stage=args.first_stage)
+                    first_stage=args.first_stage, plane_cache=args.plane_cache, plane_fit_dtype=args.plane_fit_dtype)
     t0 = time.time()
     h.map_build(scene.map_xyz)
     t_build = time.time() - t0
@@ -326,6 +400,7 @@ def main():
                 "kernel": f"5-NN search of one pass = k_search_ring<{args.lpq},1> (every query) + k_search_ring<16,2> (the rest, incl. the exact fallback)",
                 "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                 "traffic": None, "avg_kernel_us": round(dur_s * 1e6, 2), "alg_bytes_per_launch": ALG_BYTES_SEARCH * n_pts,
+                "event_bracket": "start of the first search kernel -> end of the last one (hipExtLaunchKernelGGL time stamps)",
                 "events_sampled": int(ctr["n_search"]),
                 "events_sampled_by_kind": {"first_search_of_scan": int(ctr.get("n_first", 0)), "later_search": int(ctr.get("n_later", 0))},
                 "first_search_us": round(ctr["first_ms"] / ctr["n_first"] * 1e3, 2) if ctr.get("n_first") else None,
@@ -362,6 +437,7 @@ def main():
                                     f"per pass" if mode in ("shard", "partition") else
                                     f"{G} independent scan streams (one per rank), replicated map, no collective in the data path")),
                    "distinct_scans": S, "cell_size_m": args.cell, "lanes_per_query": args.lpq, "first_stage": args.first_stage,
+                   "plane_cache": args.plane_cache, "plane_fit": "fp16 ABLATION (not bit-exact)" if args.plane_fit_dtype else "fp32 (reference-exact)",
                    "event_reading": "deferred (recorded inside the timed region, read after it)"},
         "ms_per_iekf_pass": round((acc.ms_s + acc.ms_n) / max(acc.passes, 1), 4),
         "ms_search_pass": round(acc.ms_s / max(acc.n_s, 1), 4),
@@ -400,9 +476,14 @@ def main():
     h.set_timing_stride(0)
     if roof is not None:
         tr = pmc_traffic(args)
-        if tr is not None:
+        if tr is not None and not tr.get("stale"):
             roof["traffic"] = tr["bytes_per_search_pass"]
             roof["traffic_source"] = tr["source"]
+            roof["traffic_src_hash"] = tr["src_hash"]
+            roof["traffic_commit"] = tr["commit"]
+        elif tr is not None:
+            roof["traffic_note"] = (f"dropped: {tr['source']} was taken on other code (sources {tr['summary_src_hash']}, running "
+                                    f"{tr['running_src_hash']})")
         roof["candidates_per_query"] = round(cand_per_query, 2)
         roof["candidate_traffic_GBs"] = round(cand_per_query * 16 * n_pts / (roof["avg_kernel_us"] * 1e-6) / 1e9, 2)
         out["roofline"] = roof

@@ -12,7 +12,7 @@ LIB = os.path.join(LIBDIR, "libfastlio_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SOURCES = ["flh_kernels.hip", "flh_mapinc.hip", "flh_scanprep.hip", "flh_api.cpp", "flh_esekf.cpp"]
-DEPS = SOURCES + ["flh_device.hpp", "flh_kernels.hpp", "flh_ring_body.inc", "flh_search_wtile.inc"]
+DEPS = SOURCES + ["flh_device.hpp", "flh_kernels.hpp", "flh_ring_body.inc"]
 HDRS = ["fastlio_hip.h", "fastlio_amd/esekfom.hpp", "fastlio_amd/mtk.hpp", "fastlio_amd/smallmat.hpp",
         "fastlio_amd/use-ikfom.hpp", "fastlio_amd/h_share_model.hpp", "fastlio_amd/local_map.hpp", "fastlio_amd/imu_processing.hpp"]
 

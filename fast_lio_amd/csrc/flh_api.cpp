@@ -89,7 +89,7 @@ struct flh_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev[4]{};  // start, after search, after fit, end
+    hipEvent_t ev[4]{};  // a timed evaluation: search start, search end, fit start, fit end (time stamps of the kernels themselves)
     // map
     size_t M = 0;
     GridParams grid{};
@@ -168,7 +168,7 @@ struct flh_handle {
     // triple and does NOT wait for it -- waiting on an event costs the host tens of microseconds, more than a whole pass; the
     // elapsed times are read when somebody asks for them (drain_events).  timing_stride == 1 keeps the synchronous reading.
     static constexpr int kEvPool = 64;
-    hipEvent_t evp[kEvPool][3]{};
+    hipEvent_t evp[kEvPool][4]{};
     uint8_t evp_search[kEvPool]{};
     int evp_n = 0;            // triples recorded and not yet read
     bool evp_ready = false;   // the pool's events exist
@@ -215,7 +215,8 @@ struct flh_handle {
     DevBuf<double> ds_poses;
     DevBuf<u64> ds_blockmin;               // k_undistort's per-block (time, index) minima
     DevBuf<uint32_t> ds_flags, ds_incl;
-    DevBuf<u64> st_k0, st_k1;
+    DevBuf<u64> st_k0, st_k1;              // voxel keys of the scan's down-sampling
+    DevBuf<uint32_t> st_m0, st_m1;          // Morton keys of the staging sort
     DevBuf<uint32_t> st_v0, st_v1;
     DevBuf<unsigned char> st_tmp;
 };
@@ -263,7 +264,7 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.plane_threshold <= 0) cfg.plane_threshold = 0.1f;
     if (cfg.max_sqdist <= 0) cfg.max_sqdist = 5.0f;
     if (cfg.sort_queries < 0) cfg.sort_queries = 1;
-    if (cfg.first_stage < 0 || cfg.first_stage > 4) cfg.first_stage = 0;
+    if (cfg.first_stage < 0 || cfg.first_stage > 2) cfg.first_stage = 0;
     if (cfg.eigen_order < 0 || cfg.eigen_order > 3) cfg.eigen_order = FLH_ORDER_SSE;
     if (cfg.plane_fit_dtype != 1) cfg.plane_fit_dtype = 0;
     if (cfg.undistort_first_point != 0) cfg.undistort_first_point = 1;
@@ -347,7 +348,7 @@ void flh_destroy(flh_handle* h) {
     if (h->h_small) (void)hipHostFree(h->h_small);
     h->st_bytes.release(); h->fw_bytes.release(); h->fw_in.release(); h->fw_out.release();
     h->ds_raw.release(); h->ds_und.release(); h->ds_poses.release(); h->ds_blockmin.release(); h->ds_flags.release(); h->ds_incl.release();
-    h->st_raw.release(); h->st_k0.release(); h->st_k1.release(); h->st_v0.release(); h->st_v1.release(); h->st_tmp.release();
+    h->st_raw.release(); h->st_k0.release(); h->st_k1.release(); h->st_m0.release(); h->st_m1.release(); h->st_v0.release(); h->st_v1.release(); h->st_tmp.release();
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->h_gram) (void)hipHostFree(h->h_gram);
     if (h->h_gran) (void)hipHostFree(h->h_gran);
@@ -863,13 +864,13 @@ static int stage_sorted(flh_handle* h, flh_handle::Slot& sl, size_t N, bool have
     const bool do_sort = h->cfg.sort_queries != 0 && N > 1;
     if (do_sort) {
         const uint32_t Nu = (uint32_t)N;
-        HIPC(h->st_k0.reserve(N)); HIPC(h->st_k1.reserve(N)); HIPC(h->st_v0.reserve(N)); HIPC(h->st_v1.reserve(N));
-        if (!have_keys) HIPC(flh::launch_scan_keys(h->st_raw.p, Nu, 0.25f, h->st_k0.p, h->st_v0.p, cs));
+        HIPC(h->st_m0.reserve(N)); HIPC(h->st_m1.reserve(N)); HIPC(h->st_v0.reserve(N)); HIPC(h->st_v1.reserve(N));
+        if (!have_keys) HIPC(flh::launch_scan_keys(h->st_raw.p, Nu, 0.5f, h->st_m0.p, h->st_v0.p, cs));
         size_t tb = 0;
-        HIPC(flh::sort_scan_pairs(nullptr, tb, h->st_k0.p, h->st_k1.p, h->st_v0.p, h->st_v1.p, Nu, cs));
+        HIPC(flh::sort_scan_pairs(nullptr, tb, h->st_m0.p, h->st_m1.p, h->st_v0.p, h->st_v1.p, Nu, cs));
         HIPC(h->st_tmp.reserve(tb));
         tb = h->st_tmp.cap;
-        HIPC(flh::sort_scan_pairs(h->st_tmp.p, tb, h->st_k0.p, h->st_k1.p, h->st_v0.p, h->st_v1.p, Nu, cs));
+        HIPC(flh::sort_scan_pairs(h->st_tmp.p, tb, h->st_m0.p, h->st_m1.p, h->st_v0.p, h->st_v1.p, Nu, cs));
         HIPC(flh::launch_scan_gather(h->st_raw.p, h->st_v1.p, Nu, sl.body.p, cs));
     } else {
         HIPC(flh::launch_scan_gather(h->st_raw.p, nullptr, (uint32_t)N, sl.body.p, cs));
@@ -904,9 +905,9 @@ static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size
         HIPC(hipEventRecord(sl.h2d_done, cs));
     }
     const bool do_sort = h->cfg.sort_queries != 0 && N > 1;
-    if (do_sort) { HIPC(h->st_k0.reserve(N)); HIPC(h->st_v0.reserve(N)); }
-    HIPC(flh::launch_scan_restride(h->st_bytes.p, (uint32_t)stride_bytes, 0, 0, (uint32_t)N, 0.25f, h->st_raw.p,
-                                   do_sort ? h->st_k0.p : nullptr, do_sort ? h->st_v0.p : nullptr, nullptr, cs));
+    if (do_sort) { HIPC(h->st_m0.reserve(N)); HIPC(h->st_v0.reserve(N)); }
+    HIPC(flh::launch_scan_restride(h->st_bytes.p, (uint32_t)stride_bytes, 0, 0, (uint32_t)N, 0.5f, h->st_raw.p,
+                                   do_sort ? h->st_m0.p : nullptr, do_sort ? h->st_v0.p : nullptr, nullptr, cs));
     if (stage_sorted(h, sl, N, do_sort) != 0) return -1;
     if (direct && wait_reusable && N > 0) HIPC(hipEventSynchronize(sl.h2d_done));
     return 0;
@@ -1332,11 +1333,11 @@ static int gran_group_size(size_t N) {
 static bool ensure_event_pool(flh_handle* h) {
     if (h->evp_ready) return true;
     for (int k = 0; k < flh_handle::kEvPool; ++k)
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < 4; ++j)
             if (hipEventCreate(&h->evp[k][j]) != hipSuccess) {
                 (void)hipGetLastError();
                 for (int k2 = 0; k2 <= k; ++k2)
-                    for (int j2 = 0; j2 < 3; ++j2)
+                    for (int j2 = 0; j2 < 4; ++j2)
                         if (h->evp[k2][j2]) { (void)hipEventDestroy(h->evp[k2][j2]); h->evp[k2][j2] = nullptr; }
                 return false;  // the caller falls back to the synchronous reading
             }
@@ -1348,12 +1349,15 @@ static void drain_events(flh_handle* h) {
     (void)hipSetDevice(h->device);
     for (int k = 0; k < h->evp_n; ++k) {
         float a = 0, b = 0, c = 0;
-        if (hipEventSynchronize(h->evp[k][2]) != hipSuccess || hipEventElapsedTime(&a, h->evp[k][0], h->evp[k][1]) != hipSuccess ||
-            hipEventElapsedTime(&b, h->evp[k][1], h->evp[k][2]) != hipSuccess || hipEventElapsedTime(&c, h->evp[k][0], h->evp[k][2]) != hipSuccess) {
+        const bool srch = h->evp_search[k] != 0;
+        hipError_t e = hipEventSynchronize(h->evp[k][3]);
+        if (e == hipSuccess && srch) e = hipEventElapsedTime(&a, h->evp[k][0], h->evp[k][1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&b, h->evp[k][2], h->evp[k][3]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&c, h->evp[k][srch ? 0 : 2], h->evp[k][3]);
+        if (e != hipSuccess) {
             (void)hipGetLastError();
             continue;  // a sample that cannot be read is dropped, not guessed
         }
-        const bool srch = h->evp_search[k] != 0;
         if (srch) { h->acc[0] += a; h->acc[1] += 1; h->acc_kind[h->evp_search[k] == 2 ? 2 : 0] += a; h->acc_kind[h->evp_search[k] == 2 ? 3 : 1] += 1; }
         h->acc[2] += b; h->acc[3] += 1;
         h->acc[4] += c; h->acc[5] += 1;
@@ -1366,33 +1370,31 @@ static void drain_events(flh_handle* h) {
 
 static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext, double* d_out, double seq, hipEvent_t* ev3,
                         bool host_granules = false) {
-    const bool timed = ev3 != nullptr;  // three records: before the first launch, after the search kernels, after the fit kernel
+    const bool timed = ev3 != nullptr;  // four time stamps: first search kernel's start, last one's end, fit kernel's start and end
     hipStream_t st = h->stream;
     if (h->map_pending && map_settle(h) != 0) return -1;  // a map change under way: its counters (and a re-index it asked for) first
     if (!h->cur_body || !h->selected.p) return fail("flh_eval: no active scan (flh_scan_upload / flh_scan_activate first)");
     if (!h->grid.hash && h->N > 0) return fail("flh_eval: no map (flh_map_build / flh_map_add first)");
     if (!do_search && !h->searched_once && h->N > 0)
         return fail("flh_eval: do_search == 0 before any search on this scan (the reference always searches on the first pass)");
-    if (timed) HIPC(hipEventRecord(ev3[0], st));
     if (do_search) {
         if (h->stats) HIPC(hipMemsetAsync(h->counter.p, 0, FLH_COUNTER_WORDS * sizeof(u64), st));
         HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
                                 h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
                                 h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr,
-                                h->own_axis, h->own_lo, h->own_hi, search_plan(h), st));
+                                h->own_axis, h->own_lo, h->own_hi, search_plan(h), st, timed ? ev3[0] : nullptr, timed ? ev3[1] : nullptr));
         h->last_search_was_later = h->searched_once;
         h->searched_once = true;
         h->d2_valid = false;
         h->search_state = s;
     }
-    if (timed) HIPC(hipEventRecord(ev3[1], st));
     HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
                          h->world.p, h->partials.p, h->part2.p, d_out, seq, h->tickets.p, h->slow_count.p,
                          host_granules ? h->h_gran : nullptr, host_granules ? gran_group_size(h->N) : 0, 0, st,
-                         h->plane_cache ? h->plane.p : nullptr, (do_search || !h->planes_valid) ? 1 : 2));
+                         h->plane_cache ? h->plane.p : nullptr, (do_search || !h->planes_valid) ? 1 : 2, timed ? ev3[2] : nullptr,
+                         timed ? ev3[3] : nullptr));
     h->planes_valid = h->plane_cache;
     h->aux_valid = false;
-    if (timed) HIPC(hipEventRecord(ev3[2], st));
     h->last_state = s;
     h->last_ext = ext;
     h->have_eval = true;
@@ -1515,19 +1517,19 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     // timed evaluations: three event records on the stream (before the first launch, after the search kernels, after the
     // fit kernel); the last one completes when k_fit retires, a moment after the flag
     if (deferred) {  // recorded, not awaited: read by drain_events
-        h->evp_search[h->evp_n] = do_search ? (h->last_search_was_later ? 2 : 1) : 0;
+        h->evp_search[h->evp_n] = (do_search && h->N > 0) ? (h->last_search_was_later ? 2 : 1) : 0;  // N == 0: no search kernel ran
         h->evp_n++;
     } else if (timed) {
-        HIPC(hipEventSynchronize(h->ev[2]));
+        HIPC(hipEventSynchronize(h->ev[3]));
     }
     if (h->h_gram[255] != seq) return fail("flh_eval: result sequence mismatch");
     h->h_gram[255] = 0.0;  // G[15][15] is structurally zero
     flh_unpack_gram(h->h_gram, HTH, HTh, n_eff, total_residual);
     float a = 0, b = 0, c = 0;
     if (timed && !deferred) {
-        (void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
-        (void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
-        (void)hipEventElapsedTime(&c, h->ev[0], h->ev[2]);
+        if (do_search && h->N > 0) (void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
+        (void)hipEventElapsedTime(&b, h->ev[2], h->ev[3]);
+        (void)hipEventElapsedTime(&c, h->ev[(do_search && h->N > 0) ? 0 : 2], h->ev[3]);
     }
     if (!deferred && h->evp_n == 0) {  // (with samples pending the last timing is whatever drain_events reads last)
         h->timing.search_ms = do_search ? a : 0.f;
@@ -1571,7 +1573,7 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     }
 #endif
     if (timed && !deferred) {
-        if (do_search) { h->acc[0] += a; h->acc[1] += 1; h->acc_kind[h->last_search_was_later ? 2 : 0] += a; h->acc_kind[h->last_search_was_later ? 3 : 1] += 1; }
+        if (do_search && h->N > 0) { h->acc[0] += a; h->acc[1] += 1; h->acc_kind[h->last_search_was_later ? 2 : 0] += a; h->acc_kind[h->last_search_was_later ? 3 : 1] += 1; }
         h->acc[2] += b; h->acc[3] += 1;
         h->acc[4] += c; h->acc[5] += 1;
     }

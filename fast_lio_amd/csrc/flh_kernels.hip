@@ -1,7 +1,7 @@
 // flh_kernels.hip -- the HIP kernels of the hot path, written for gfx950 (CDNA4, wave64) only.
 //
 //   K0  map index build     keys -> (radix sort) -> bricks, per-brick cell tables, directory            [setup]
-//   A1  k_search_wtile<2|4> / k_search_ring<4,1>  body->world transform + 5-NN over the 3x3x3 cell block  [search passes]
+//   A1  k_search_ring<4,1>  body->world transform + 5-NN over the 3x3x3 cell block, 4 lanes per query    [search passes]
 //   A2  k_search_ring<16,2> the queries A1 could not settle: 5x5x5 block inside A1's bound, 16 lanes per
 //                           query, finishing leftovers itself with the general exact search (exact_query)
 //   A3  k_search_exact      the general exact search as a kernel (lanes_per_query = 0, grids without ring 2)
@@ -14,6 +14,7 @@
 #include "flh_kernels.hpp"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -132,11 +133,11 @@ __global__ void __launch_bounds__(256) k_map_place(const float4* __restrict__ pt
 // ------------------------------------------------------------------------------------------------
 // A: exact 5-NN: a first stage over every query, a second stage over the queries the first could not settle.
 //
-// A1 first stage, every query, the 3x3x3 cells around its cell.  Two implementations of the same search:
-//      k_search_wtile<2|4>   (flh_search_wtile.inc) a wave of 32 / 16 Morton-neighbouring queries shares one LDS tile of the map
-//      k_search_ring<4,1>    four lanes per query gather their own candidates through 18 row segments; also the code a wave of
-//                            the tile kernel runs when its neighbourhoods do not fit the tile
-//    settles every query whose 5th neighbour is provably inside that block and free of near-ties
+// A1 k_search_ring<4,1>     every query, the 3x3x3 cells around its cell: four lanes per query gather their candidates through
+//                            18 row segments; settles every query whose 5th neighbour is provably inside that block and free
+//                            of near-ties.  (An LDS-tile variant -- a block, later a wave, of Morton-neighbouring queries sharing
+//                            one tile of the map -- was built, validated bit for bit and measured 1.6-2.2x SLOWER in three
+//                            versions; see profiles/r03_wtile_experiment/ and DESIGN.md for why.  It is not in the product.)
 // A2 k_search_ring<16,2>     the queries A1 listed: 5x5x5 cells clipped to the ball of A1's 5th distance; whatever it cannot
 //                            settle either (a true tie, a list longer than the packed index can name) it finishes itself with
 //                            64-bit (d2, map index) keys, and a 5th neighbour beyond its block with the general search
@@ -464,8 +465,6 @@ k_search_exact(GridParams g, StateDev s, const float4* __restrict__ body, int N,
     }
 }
 
-#include "flh_search_wtile.inc"
-
 // ------------------------------------------------------------------------------------------------
 // B: one thread per scan point: plane fit, residual gate, Jacobian row; then the wave's 64 rows are
 // contracted into a 16x16 Gram block on the f64 matrix core.  v = [row(12) | h=-pd2 | 1 | |pd2| | 0]:
@@ -749,23 +748,26 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
 // so one sort per scan serves every IEKF pass).  Neighbouring lanes then walk the same bricks, cells
 // and map points, which is what turns the search from line-traffic-bound into cache-resident.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 spread3(uint32_t v) {  // 14 bits -> every third bit
-    u64 x = v & 0x3FFFu;
-    x = (x | (x << 16)) & 0x0000FF0000FFull;
-    x = (x | (x << 8)) & 0x00F00F00F00Full;
-    x = (x | (x << 4)) & 0x0C30C30C30C3ull;
-    x = (x | (x << 2)) & 0x249249249249ull;
+// 32-bit key: 0.5 m quantum (the leaf of the down-sampling that produced the scan: finer would order nothing), x and y 11 bits
+// (+-512 m), z 10 bits (+-256 m); the low 10 bits of the three interleaved, the 11th bits of x and y on top.  32-bit keys
+// halve what the sort moves per pass next to the 42-bit keys of round 2 (rocPRIM merge-sorts arrays of this size: block
+// sort + 7 merge passes, all on the copy stream beside the previous scan's update).
+__device__ __forceinline__ uint32_t spread3_10(uint32_t v) {  // 10 bits -> every third bit
+    uint32_t x = v & 0x3FFu;
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
     return x;
 }
-__device__ __forceinline__ u64 scan_morton(float x, float y, float z, float inv_q) {
-    const float lim = 16383.f;
-    const uint32_t ix = (uint32_t)fminf(fmaxf(x * inv_q + 8192.f, 0.f), lim);
-    const uint32_t iy = (uint32_t)fminf(fmaxf(y * inv_q + 8192.f, 0.f), lim);
-    const uint32_t iz = (uint32_t)fminf(fmaxf(z * inv_q + 8192.f, 0.f), lim);
-    return spread3(ix) | (spread3(iy) << 1) | (spread3(iz) << 2);
+__device__ __forceinline__ uint32_t scan_morton(float x, float y, float z, float inv_q) {
+    const uint32_t ix = (uint32_t)fminf(fmaxf(x * inv_q + 1024.f, 0.f), 2047.f);
+    const uint32_t iy = (uint32_t)fminf(fmaxf(y * inv_q + 1024.f, 0.f), 2047.f);
+    const uint32_t iz = (uint32_t)fminf(fmaxf(z * inv_q + 512.f, 0.f), 1023.f);
+    return spread3_10(ix) | (spread3_10(iy) << 1) | (spread3_10(iz) << 2) | ((ix >> 10) << 30) | ((iy >> 10) << 31);
 }
 __global__ void __launch_bounds__(256) k_scan_keys(const float4* __restrict__ raw, uint32_t N, float inv_q,
-                                                   u64* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const float4 p = raw[i];
@@ -778,7 +780,7 @@ __global__ void __launch_bounds__(256) k_scan_keys(const float4* __restrict__ ra
 // plain staging path -- the Morton key in the same pass.  bad (optional) counts non-finite input.
 __global__ void __launch_bounds__(256) k_scan_restride(const uint32_t* __restrict__ words, uint32_t stride_words, uint32_t w_off,
                                                        int has_w, uint32_t N, float inv_q, float4* __restrict__ raw,
-                                                       u64* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                                                        uint32_t* __restrict__ bad) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
@@ -810,6 +812,16 @@ __global__ void __launch_bounds__(256) k_scan_gather(const float4* __restrict__ 
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+// A launch that may carry the timing events of a sampled evaluation: hipExtLaunchKernelGGL takes the kernel's own start / stop
+// time stamps from its dispatch packet -- no extra barrier packets on the stream (three hipEventRecord per sampled evaluation
+// cost ~10 us of it, a sixth of a pass) and the bracket is the kernels' time, what rocprofv3 reports.
+#define FLH_LAUNCH_EV(kernel, grid, block, st, evA, evB, ...)                                           \
+    do {                                                                                                \
+        if ((evA) != nullptr || (evB) != nullptr)                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, st, evA, evB, 0, __VA_ARGS__);                \
+        else                                                                                            \
+            hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                \
+    } while (0)
 
 hipError_t launch_map_keys(const GridParams& g, const float4* pts, uint32_t M, u64* keys, uint32_t* vals, hipStream_t st) {
     hipLaunchKernelGGL(k_map_keys, dim3(cdiv(M, 256)), dim3(256), 0, st, g, pts, M, keys, vals);
@@ -857,21 +869,21 @@ hipError_t launch_map_place(const float4* pts, const uint32_t* vs, const uint32_
     return hipGetLastError();
 }
 
-hipError_t launch_scan_keys(const float4* raw, uint32_t N, float quantum, u64* keys, uint32_t* vals, hipStream_t st) {
+hipError_t launch_scan_keys(const float4* raw, uint32_t N, float quantum, uint32_t* keys, uint32_t* vals, hipStream_t st) {
     if (N == 0) return hipSuccess;
     hipLaunchKernelGGL(k_scan_keys, dim3(cdiv(N, 256)), dim3(256), 0, st, raw, N, 1.0f / quantum, keys, vals);
     return hipGetLastError();
 }
 hipError_t launch_scan_restride(const void* bytes, uint32_t stride_bytes, uint32_t w_off_bytes, int has_w, uint32_t N, float quantum,
-                                float4* raw, u64* keys, uint32_t* vals, uint32_t* bad, hipStream_t st) {
+                                float4* raw, uint32_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t st) {
     if (N == 0) return hipSuccess;
     hipLaunchKernelGGL(k_scan_restride, dim3(cdiv(N, 256)), dim3(256), 0, st, (const uint32_t*)bytes, stride_bytes / 4u,
                        w_off_bytes / 4u, has_w, N, 1.0f / quantum, raw, keys, vals, bad);
     return hipGetLastError();
 }
-hipError_t sort_scan_pairs(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, const uint32_t* vin, uint32_t* vout,
+hipError_t sort_scan_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
                            uint32_t N, hipStream_t st) {
-    return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kin, kout, vin, vout, (int)N, 0, 42, st);
+    return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kin, kout, vin, vout, (int)N, 0, 32, st);
 }
 hipError_t launch_scan_gather(const float4* raw, const uint32_t* perm, uint32_t N, float4* body, hipStream_t st) {
     if (N == 0) return hipSuccess;
@@ -885,37 +897,30 @@ uint32_t list_stripe_cap(int N) { return (uint32_t)(cdiv(cdiv(N > 0 ? N : 1, 16)
 hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points,
                          float max_sqdist, int rmax, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
                          uint32_t* list1, uint32_t* list2, float* ub, uint32_t* counts /* [2 * kStripes] */,
-                         u64* cand_counter, int own_axis, float own_lo, float own_hi, int cache_bound, hipStream_t st) {
+                         u64* cand_counter, int own_axis, float own_lo, float own_hi, int cache_bound, hipStream_t st,
+                         hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (N <= 0) return hipSuccess;
     const dim3 blk(256);
     const uint32_t cap = list_stripe_cap(N);
+    const hipEvent_t ev_none = nullptr;
     if (lpq == 0) {  // exact path for every query (validation / fallback)
-        hipLaunchKernelGGL(k_search_exact, dim3(std::min(cdiv(N, 8), 4096)), blk, 0, st, g, s, body, N, max_sqdist, rmax,
-                           nn_pts, nn_d2, nn_cnt, selected, list1, counts, cap, ub, 1, cand_counter, own_axis, own_lo, own_hi);
+        FLH_LAUNCH_EV(k_search_exact, dim3(std::min(cdiv(N, 8), 4096)), blk, st, ev_start, ev_stop, g, s, body, N, max_sqdist, rmax,
+                      nn_pts, nn_d2, nn_cnt, selected, list1, counts, cap, ub, 1, cand_counter, own_axis, own_lo, own_hi);
         return hipGetLastError();
     }
-    // first_stage = 3 / 4: the first stage with a wave-shared LDS tile (flh_search_wtile.inc), 4 / 2 lanes per query, every search of a scan
-    const bool tile_stage = (first_stage == 3 || first_stage == 4) && lpq == 4 && rmax >= 2;
-    if (tile_stage && first_stage == 3)
-        hipLaunchKernelGGL((k_search_wtile<4>), dim3(cdiv(N, 16)), dim3(64), 0, st, g, s, body, N, map_points, max_sqdist, nn_pts, nn_d2, nn_cnt,
-                           selected, list1, counts, cap, ub, rmax, cand_counter, own_axis, own_lo, own_hi);
-    else if (tile_stage)
-        hipLaunchKernelGGL((k_search_wtile<2>), dim3(cdiv(N, 32)), dim3(64), 0, st, g, s, body, N, map_points, max_sqdist, nn_pts, nn_d2, nn_cnt,
-                           selected, list1, counts, cap, ub, rmax, cand_counter, own_axis, own_lo, own_hi);
     // A1: ring 1, every query
 #define FLH_A1(L, O)                                                                                                     \
-    if (cache_bound && L == 4 && !O)                                                                                     \
-        hipLaunchKernelGGL((k_search_ring<4, 1, false, 8, false, false, true>), dim3(cdiv(N, 64)), blk, 0, st, g, s, body, N, \
-                           map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,            \
-                           (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter,  \
-                           own_axis, own_lo, own_hi);                                                                    \
+    if (cache_bound && first_stage == 0 && L == 4 && !O)                                                                 \
+        FLH_LAUNCH_EV((k_search_ring<4, 1, false, 8, false, false, true>), dim3(cdiv(N, 64)), blk, st, ev_start, ev_none, g, s, body, N, \
+                      map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,                 \
+                      (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter,       \
+                      own_axis, own_lo, own_hi);                                                                         \
     else                                                                                                                 \
-    hipLaunchKernelGGL((k_search_ring<L, 1, false, 8, false, O>), dim3(cdiv(N, 256 / L)), blk, 0, st, g, s, body, N, \
-                       map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,                \
-                       (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter, own_axis,     \
-                       own_lo, own_hi)
-    if (tile_stage) {
-    } else if (first_stage == 2 && rmax >= 2) {
+        FLH_LAUNCH_EV((k_search_ring<L, 1, false, 8, false, O>), dim3(cdiv(N, 256 / L)), blk, st, ev_start, ev_none, g, s, body, N, \
+                      map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,                 \
+                      (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter, own_axis,      \
+                      own_lo, own_hi)
+    if (first_stage == 2 && rmax >= 2) {
         switch (lpq) {
             case 1: FLH_A1(1, true); break;
             case 2: FLH_A1(2, true); break;
@@ -934,13 +939,13 @@ hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const St
     if (rmax >= 2) {
         // A2: ring 2 over list 1, inside the ball A1's 5th distance defines; whatever it cannot settle (distance ties, a
         // 5th neighbour beyond the 5x5x5 block) it finishes itself with the general exact search
-        hipLaunchKernelGGL((k_search_ring<16, 2, true, 11, true>), dim3(kStripes * 16), blk, 0, st, g, s, body, N, map_points,
-                           max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)list1, (const uint32_t*)counts, list2,
-                           counts + kStripes, cap, (const float*)ub, ub, rmax, cand_counter, -1, 0.f, 0.f);
+        FLH_LAUNCH_EV((k_search_ring<16, 2, true, 11, true>), dim3(kStripes * 16), blk, st, ev_none, ev_stop, g, s, body, N, map_points,
+                      max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)list1, (const uint32_t*)counts, list2,
+                      counts + kStripes, cap, (const float*)ub, ub, rmax, cand_counter, -1, 0.f, 0.f);
     } else {
         // cells as large as the gate radius: the general search drains list 1 directly
-        hipLaunchKernelGGL(k_search_exact, dim3(kStripes * 8), blk, 0, st, g, s, body, N, max_sqdist, rmax, nn_pts, nn_d2,
-                           nn_cnt, selected, (const uint32_t*)list1, (const uint32_t*)counts, cap, ub, 0, cand_counter, -1, 0.f, 0.f);
+        FLH_LAUNCH_EV(k_search_exact, dim3(kStripes * 8), blk, st, ev_none, ev_stop, g, s, body, N, max_sqdist, rmax, nn_pts, nn_d2,
+                      nn_cnt, selected, (const uint32_t*)list1, (const uint32_t*)counts, cap, ub, 0, cand_counter, -1, 0.f, 0.f);
     }
     return hipGetLastError();
 }
@@ -1014,25 +1019,25 @@ int reduce1_blocks(int nblk, int* per_out) {
 hipError_t launch_fit(int order, int half_fit, const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
                       uint8_t* selected, float4* normvec, float4* world, double* partials, double* part2,
                       double* out256, double seq, uint32_t* tickets, uint32_t* slow_count, double* gran, int red1, int store_aux,
-                      hipStream_t st, float4* plane_cache, int plane_mode) {
+                      hipStream_t st, float4* plane_cache, int plane_mode, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int nblk = fit_blocks(N);
     const int ncol = ext ? 12 : 6;
     if (!plane_cache || half_fit || order != 1) plane_mode = 0;  // the experiment exists for the default summation order only
     if (plane_mode == 1 || plane_mode == 2) {
         if (plane_mode == 1)
-            hipLaunchKernelGGL((k_fit<1, false, 1>), dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world,
-                               partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux, plane_cache);
+            FLH_LAUNCH_EV((k_fit<1, false, 1>), dim3(nblk), dim3(256), st, ev_start, ev_stop, s, body, nn_pts, N, ext, thr, selected, normvec, world,
+                          partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux, plane_cache);
         else
-            hipLaunchKernelGGL((k_fit<1, false, 2>), dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world,
-                               partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux, plane_cache);
+            FLH_LAUNCH_EV((k_fit<1, false, 2>), dim3(nblk), dim3(256), st, ev_start, ev_stop, s, body, nn_pts, N, ext, thr, selected, normvec, world,
+                          partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux, plane_cache);
         return hipGetLastError();
     }
 #define FLH_FIT(O)                                                                                                      \
-    hipLaunchKernelGGL((k_fit<O, false>), dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world, \
-                       partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux, plane_cache)
+    FLH_LAUNCH_EV((k_fit<O, false>), dim3(nblk), dim3(256), st, ev_start, ev_stop, s, body, nn_pts, N, ext, thr, selected, normvec, world, \
+                  partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux, plane_cache)
     if (half_fit) {  // the fp16 ablation exists for the default summation order only
-        hipLaunchKernelGGL((k_fit<1, true>), dim3(nblk), dim3(256), 0, st, s, body, nn_pts, N, ext, thr, selected, normvec, world,
-                           partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux, plane_cache);
+        FLH_LAUNCH_EV((k_fit<1, true>), dim3(nblk), dim3(256), st, ev_start, ev_stop, s, body, nn_pts, N, ext, thr, selected, normvec, world,
+                      partials, part2, out256, seq, tickets, slow_count, gran, red1, ncol, store_aux, plane_cache);
         return hipGetLastError();
     }
     switch (order) {

@@ -23,12 +23,11 @@ hipError_t launch_brick_tables(const unsigned long long* ks, const uint32_t* bri
                                const uint32_t* cap_incl, const uint32_t* cap, uint32_t* starts, uint32_t* cap_end, uint32_t* live,
                                uint2* hash, uint32_t hash_mask, int hash_shift, hipStream_t st);
 
-hipError_t launch_scan_keys(const float4* raw, uint32_t N, float quantum, unsigned long long* keys, uint32_t* vals,
-                            hipStream_t st);
+hipError_t launch_scan_keys(const float4* raw, uint32_t N, float quantum, uint32_t* keys, uint32_t* vals, hipStream_t st);
 hipError_t launch_scan_restride(const void* bytes, uint32_t stride_bytes, uint32_t w_off_bytes, int has_w, uint32_t N, float quantum,
-                                float4* raw, unsigned long long* keys, uint32_t* vals, uint32_t* bad, hipStream_t st);
-hipError_t sort_scan_pairs(void* tmp, size_t& tmp_bytes, const unsigned long long* kin, unsigned long long* kout,
-                           const uint32_t* vin, uint32_t* vout, uint32_t N, hipStream_t st);
+                                float4* raw, uint32_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t st);
+hipError_t sort_scan_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
+                           uint32_t N, hipStream_t st);
 hipError_t launch_scan_gather(const float4* raw, const uint32_t* perm, uint32_t N, float4* body, hipStream_t st);
 
 int list_stripes();
@@ -36,7 +35,8 @@ uint32_t list_stripe_cap(int N);
 hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points,
                          float max_sqdist, int rmax, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
                          uint32_t* list1, uint32_t* list2, float* ub, uint32_t* counts, unsigned long long* cand_counter,
-                         int own_axis, float own_lo, float own_hi, int cache_bound, hipStream_t st);
+                         int own_axis, float own_lo, float own_hi, int cache_bound, hipStream_t st,
+                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);  // optional: time stamps of the first kernel's start / the last one's end
 hipError_t launch_publish256(const double* src, double* out256, double seq, hipStream_t st);
 
 #ifdef FLH_PHASES
@@ -47,7 +47,8 @@ int reduce1_blocks(int nblk, int* per_out);
 hipError_t launch_fit(int order, int half_fit, const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
                       uint8_t* selected, float4* normvec, float4* world, double* partials, double* part2,
                       double* out256, double seq, uint32_t* tickets, uint32_t* slow_count, double* gran, int red1, int store_aux,
-                      hipStream_t st, float4* plane_cache = nullptr, int plane_mode = 0);
+                      hipStream_t st, float4* plane_cache = nullptr, int plane_mode = 0, hipEvent_t ev_start = nullptr,
+                      hipEvent_t ev_stop = nullptr);
 hipError_t launch_fill_d2(const StateDev& s_search, const float4* body, const float4* nn_pts, int N, float* nn_d2, hipStream_t st);
 int gram_slots_host(int ncol);
 int gram_slot_host(int r, int c, int ncol);

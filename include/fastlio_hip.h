@@ -52,13 +52,9 @@ typedef struct flh_config {
     int lanes_per_query;    /* fast search kernel: lanes cooperating on one query, 2/4/8/16 (default 4);
                                0 = run the general exact kernel for every query */
     int sort_queries;       /* 1: Morton-sort scan points at upload for cache locality (default 1 if <0) */
-    int first_stage;        /* how the first search stage (every query, the 3x3x3 cells around its cell) is run: 1 = four lanes per
-                               query gather their own candidates through 18 row segments (k_search_ring); 2 = the same over the 2x2x2
-                               block of cells nearest to the query (8 cells instead of 27; more queries go on to the second stage);
-                               3 / 4 = a WAVE of 16 / 32 Morton-neighbouring queries shares one LDS tile of the map (its bounding box
-                               of cells, each map point loaded once per wave), 4 / 2 lanes per query scan it (k_search_wtile); a
-                               wave whose box does not fit runs 1's code.  0 = default.  Performance only: every setting returns
-                               the same exact 5-NN */
+    int first_stage;        /* block of cells the first search stage scans: 1 (and 0 = default) = the 3x3x3 block around the
+                               query's cell, 2 = the 2x2x2 block nearest to the query (8 cells instead of 27; more queries go on
+                               to the second stage).  Performance only: either setting returns the same exact 5-NN */
     int eigen_order;        /* fp32 summation order of esti_plane's reductions (include/common_lib.h:241 runs Eigen's
                                ColPivHouseholderQR, whose reduction order depends on how Eigen was vectorised):
                                FLH_ORDER_SEQ / _SSE / _PAIRWISE / _NOVEC; <0 -> FLH_ORDER_SSE (Eigen 3.3.x, x86-64 + SSE2:

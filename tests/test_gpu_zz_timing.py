@@ -104,52 +104,3 @@ def test_plane_cache_changes_no_bit():
         np.testing.assert_array_equal(a[4], b[4])
         sel = a[4].astype(bool)
         np.testing.assert_array_equal(a[5][sel].view(np.uint32), b[5][sel].view(np.uint32))
-
-
-@pytest.mark.parametrize("stage", [3, 4])
-def test_wave_tile_first_stage_equals_the_ring_stage(stage):
-    """first_stage = 3 / 4: the first search stage with a wave-shared LDS tile, 4 / 2 lanes per query.  It examines the same 27
-    cells per query as the ring stage (first_stage = 1), so flags, neighbour ids in rank order, planes and the whole update must
-    be identical -- on a dense scan (waves that fit the tile), on a scan thinned out so that waves do NOT fit (the ring code
-    inside the tile kernel), and on a short scan whose last wave is partly empty."""
-    from oracle import pyoracle as po
-
-    pr = synth.make_problem(200000, 20000, "avia", cfg=1)
-    xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
-    scans = {"dense": pr.body, "sparse": np.ascontiguousarray(pr.body[::37]), "ragged": np.ascontiguousarray(pr.body[:5003])}
-    m = po.Map(pr.map_xyz)
-    for name, body in scans.items():
-        out = []
-        for fs in (1, stage):
-            h = capi.Handle(first_stage=fs)
-            h.map_build(pr.map_xyz)
-            h.scan_upload(body)
-            res = []
-            for x, search in ((xp, True), (pr.x_true, False), (pr.x_true, True)):
-                HTH, HTh, n_eff, tres = h.eval(x, search, False)
-                idx, d2, cnt = h.fetch_neighbors()
-                res.append((HTH.copy(), HTh.copy(), n_eff, tres, h.fetch_selected().copy(), idx.copy(), cnt.copy(), h.fetch_normvec().copy()))
-            h.scan_upload(body)
-            kf = capi.Esekf(h, max_iter=3)
-            kf.change_x(xp)
-            kf.change_P(P)
-            st = kf.update(0.001)
-            out.append((res, kf.get_x().copy(), kf.get_P().copy(), list(st.n_eff)[: st.passes]))
-            kf.close()
-            h.close()
-        (r0, x0, P0, n0), (r3, x3, P3, n3) = out
-        assert n0 == n3, name
-        np.testing.assert_array_equal(x0, x3, err_msg=name)
-        np.testing.assert_array_equal(P0, P3, err_msg=name)
-        for a, b in zip(r0, r3):
-            np.testing.assert_array_equal(a[4], b[4], err_msg=name + ": flags")
-            sel = a[4].astype(bool)
-            np.testing.assert_array_equal(a[5][sel], b[5][sel], err_msg=name + ": neighbour ids")
-            np.testing.assert_array_equal(a[7][sel].view(np.uint32), b[7][sel].view(np.uint32), err_msg=name + ": planes")
-            np.testing.assert_array_equal(a[0], b[0], err_msg=name)
-            np.testing.assert_array_equal(a[1], b[1], err_msg=name)
-            assert a[2] == b[2] and a[3] == b[3], name
-        # and against the oracle, for the tile stage on its own
-        sc = po.Scan(body, nthreads=8)
-        sc.h_share_model(m, xp, True, False)
-        np.testing.assert_array_equal(r3[0][4], sc.selected, err_msg=name + ": flags vs oracle")
