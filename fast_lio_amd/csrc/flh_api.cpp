@@ -1313,13 +1313,6 @@ static StateDev make_state(const double rot[4], const double pos[3], const doubl
     return s;
 }
 
-// 0: first stage + second stage; 1: the same with the ring first stage bounded by the cached neighbours (a later search of the
-// scan; only the ring stage, flh_config.first_stage = 1, has that variant).
-static int search_plan(const flh_handle* h) {
-    if (!h->searched_once || h->own_axis >= 0) return 0;
-    return 1;
-}
-
 // Group size of k_fit's first-level reduction when the group sums go to the host as granules: 16 blocks, more when that
 // would make more than kGranGroups groups; 0 = too many points for the granule path.
 static int gran_group_size(size_t N) {
@@ -1382,7 +1375,7 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
         HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
                                 h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
                                 h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr,
-                                h->own_axis, h->own_lo, h->own_hi, search_plan(h), st, timed ? ev3[0] : nullptr, timed ? ev3[1] : nullptr));
+                                h->own_axis, h->own_lo, h->own_hi, st, timed ? ev3[0] : nullptr, timed ? ev3[1] : nullptr));
         h->last_search_was_later = h->searched_once;
         h->searched_once = true;
         h->d2_valid = false;
@@ -1708,7 +1701,7 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
         if (which == 0) {
             HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
                                     h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
-                                    h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, nullptr, h->own_axis, h->own_lo, h->own_hi, 0, st));
+                                    h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, nullptr, h->own_axis, h->own_lo, h->own_hi, st));
             HIPC(hipMemsetAsync(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t), st));
             h->searched_once = true;
             h->search_state = s;

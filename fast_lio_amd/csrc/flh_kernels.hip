@@ -320,7 +320,7 @@ __device__ __forceinline__ void top5_finish(Top5& L, const GridParams& g, int q,
                                             float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
                                             uint8_t* __restrict__ selected);
 
-template <int LPQ, int RING, bool BOUNDED, int PB, bool FINAL, bool OCT = false, bool CACHED = false>
+template <int LPQ, int RING, bool BOUNDED, int PB, bool FINAL, bool OCT = false>
 __global__ void __launch_bounds__(256)
 k_search_ring(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist,
               float4* __restrict__ nn_pts, float* __restrict__ nn_d2, uint8_t* __restrict__ nn_cnt,
@@ -897,7 +897,7 @@ uint32_t list_stripe_cap(int N) { return (uint32_t)(cdiv(cdiv(N > 0 ? N : 1, 16)
 hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points,
                          float max_sqdist, int rmax, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
                          uint32_t* list1, uint32_t* list2, float* ub, uint32_t* counts /* [2 * kStripes] */,
-                         u64* cand_counter, int own_axis, float own_lo, float own_hi, int cache_bound, hipStream_t st,
+                         u64* cand_counter, int own_axis, float own_lo, float own_hi, hipStream_t st,
                          hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (N <= 0) return hipSuccess;
     const dim3 blk(256);
@@ -910,16 +910,10 @@ hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const St
     }
     // A1: ring 1, every query
 #define FLH_A1(L, O)                                                                                                     \
-    if (cache_bound && first_stage == 0 && L == 4 && !O)                                                                 \
-        FLH_LAUNCH_EV((k_search_ring<4, 1, false, 8, false, false, true>), dim3(cdiv(N, 64)), blk, st, ev_start, ev_none, g, s, body, N, \
-                      map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,                 \
-                      (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter,       \
-                      own_axis, own_lo, own_hi);                                                                         \
-    else                                                                                                                 \
-        FLH_LAUNCH_EV((k_search_ring<L, 1, false, 8, false, O>), dim3(cdiv(N, 256 / L)), blk, st, ev_start, ev_none, g, s, body, N, \
-                      map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,                 \
-                      (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter, own_axis,      \
-                      own_lo, own_hi)
+    FLH_LAUNCH_EV((k_search_ring<L, 1, false, 8, false, O>), dim3(cdiv(N, 256 / L)), blk, st, ev_start, ev_none, g, s, body, N, \
+                  map_points, max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)nullptr,                     \
+                  (const uint32_t*)nullptr, list1, counts, cap, (const float*)nullptr, ub, rmax, cand_counter, own_axis,          \
+                  own_lo, own_hi)
     if (first_stage == 2 && rmax >= 2) {
         switch (lpq) {
             case 1: FLH_A1(1, true); break;
