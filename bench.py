@@ -146,9 +146,9 @@ def main():
     ap.add_argument("--plane-cache", type=int, default=-1, help="flh_config.plane_cache (-1 = the library's default: on)")
     ap.add_argument("--plane-fit-dtype", type=int, default=0,
                     help="1 = the fp16 plane-fit ABLATION of BASELINE configs[4] (not bit-exact, never a parity claim)")
-    ap.add_argument("--timing-samples", type=int, default=32,
-                    help="evaluations of the timed region whose kernels carry HIP events (start / stop time stamps of the kernels "
-                         "themselves); half of them are searching evaluations: >= 16 samples of the search kernels from 20 steps on")
+    ap.add_argument("--timing-samples", type=int, default=16,
+                    help="searching evaluations of the timed region whose kernels carry HIP events (start / stop time stamps of "
+                         "the kernels themselves); at 20 steps (40 searches) every third one: 14 samples, both kinds of search")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the headline + roofline (profiling runs)")
     ap.add_argument("--cpu-scans", type=int, default=96,
                     help="upper bound of the scans timed on the CPU oracle at --cpu-threads (it stops after ~12 s; 0 = skip)")
@@ -296,10 +296,11 @@ def main():
         gc.collect()
         gc.disable()
         sync()
-        # sampled evaluations record HIP events and do not wait (stride >= 2); an ODD stride walks through all four positions
-        # of the pass schedule (search, no-search, search, no-search), so first and later searches are sampled alike
-        stride = max(3, (n_steps * 4) // max(args.timing_samples, 16))
-        hx.set_timing_stride(stride + 1 - (stride & 1))
+        # The kernels of a sampled evaluation carry HIP events (read after the timed region); that costs the host ~10 us per
+        # sampled evaluation, so only SEARCHING evaluations are sampled -- the roofline is the search's -- every n-th of them,
+        # n odd: a scan's first and later searches alternate, an odd stride samples both kinds alike
+        stride = max(3, (n_steps * 2) // max(args.timing_samples, 8))
+        hx.set_timing_sampling(stride + 1 - (stride & 1), True)
         hx.counters(reset=True)
         t1 = time.perf_counter()
         rs = kfx.run_scans(jobs, n_warm, n_steps, ring=RING, map_incremental=with_map_inserts, first_staged=n_warm > 0)
@@ -407,6 +408,7 @@ def main():
                 "later_search_us": round(ctr["later_ms"] / ctr["n_later"] * 1e3, 2) if ctr.get("n_later") else None,
                 "fit_kernel_us": round(fit_s * 1e6, 2),
                 "fit_events_sampled": int(ctr["n_fit"]),
+                "fit_note": "the fit kernel behind a sampled search (it also writes the plane cache); the no-search passes' fit reads that cache and is shorter (profiles/: k_fit<1,false,2>)",
                 "fit_alg_bytes_per_launch": ALG_BYTES_NOSEARCH * n_pts,
                 "fit_achieved_GBs": round(ALG_BYTES_NOSEARCH * n_pts / fit_s / 1e9, 2),
                 "fit_frac": round(ALG_BYTES_NOSEARCH * n_pts / fit_s / 1e9 / HBM_PEAK_GBS, 5)}

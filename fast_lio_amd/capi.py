@@ -93,7 +93,7 @@ EXPORTS = [
     "flh_scan_stage_undistorted", "flh_esekf_update_scan", "flh_map_stats",
     "flh_scan_stage_async", "flh_scan_wait", "flh_host_alloc", "flh_host_free", "flh_frame_world", "flh_points_body_to_world",
     "flh_esekf_last_error", "flh_rccl_unique_id", "flh_rccl_init_rank", "flh_rccl_init_all", "flh_rccl_destroy", "flh_rccl_size",
-    "flh_rccl_rank", "flh_eval_group", "flh_set_owned_interval", "flh_esekf_run_scans", "flh_get_search_counters",
+    "flh_rccl_rank", "flh_eval_group", "flh_set_owned_interval", "flh_esekf_run_scans", "flh_get_search_counters", "flh_set_timing_sampling",
 ]
 
 _lib = None
@@ -207,6 +207,7 @@ def lib():
     L.flh_get_counters.argtypes = [C.c_void_p, _f64p, C.c_int]
     L.flh_set_timing_stride.argtypes = [C.c_void_p, C.c_int]
     L.flh_get_search_counters.argtypes = [C.c_void_p, _f64p]
+    L.flh_set_timing_sampling.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.flh_eval.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, C.c_int, C.c_int, _f64p, _f64p,
                            C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.flh_eval_device.argtypes = [C.c_void_p, _f64p, C.c_int, C.c_int, C.c_void_p]
@@ -490,6 +491,9 @@ class Handle:
 
     def set_timing_stride(self, every_n: int):
         _chk(lib().flh_set_timing_stride(self._h, int(every_n)), "flh_set_timing_stride")
+
+    def set_timing_sampling(self, every_n: int, search_only: bool):
+        _chk(lib().flh_set_timing_sampling(self._h, int(every_n), int(search_only)), "flh_set_timing_sampling")
 
     def enable_stats(self, on=True):
         _chk(lib().flh_enable_stats(self._h, int(on)), "flh_enable_stats")

@@ -163,6 +163,7 @@ struct flh_handle {
     bool d2_valid = false;    // nn_d2 holds the distances of the current neighbour cache (filled on demand, ensure_d2)
     bool aux_valid = false;   // world / normvec hold the last evaluation's (filled on demand, ensure_aux)
     int timing_stride = 1;   // record HIP events on every n-th evaluation (0 = never)
+    bool timing_search_only = false;  // count (and time) SEARCHING evaluations only
     uint64_t eval_no = 0;
     // timing_stride >= 2 (sampling inside a running stream, bench.py): a timed evaluation records into the next free event
     // triple and does NOT wait for it -- waiting on an event costs the host tens of microseconds, more than a whole pass; the
@@ -1431,7 +1432,7 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     const StateDev s = make_state(rot, pos, offR, offT);
     // the final reduce kernel writes the 16x16 block straight into pinned, device-mapped host memory:
     // no copy kernel, no extra boundary -- the stream sync below is the only wait
-    const bool timed = h->timing_stride > 0 && (h->eval_no++ % (uint64_t)h->timing_stride) == 0;
+    const bool timed = h->timing_stride > 0 && (!h->timing_search_only || do_search) && (h->eval_no++ % (uint64_t)h->timing_stride) == 0;
     bool deferred = false;
     hipEvent_t* ev3 = nullptr;
     if (timed) {
@@ -1675,11 +1676,18 @@ int flh_set_timing_stride(flh_handle* h, int every_n) {
     if (!h) return fail("flh_set_timing_stride: null handle");
     drain_events(h);
     h->timing_stride = every_n < 0 ? 0 : every_n;
+    h->timing_search_only = false;
     h->eval_no = 0;
     if (h->timing_stride >= 2) {  // create the event pool here, not inside the caller's timed region
         (void)hipSetDevice(h->device);
         (void)ensure_event_pool(h);
     }
+    return 0;
+}
+int flh_set_timing_sampling(flh_handle* h, int every_n, int search_only) {
+    if (!h) return fail("flh_set_timing_sampling: null handle");
+    if (flh_set_timing_stride(h, every_n) != 0) return -1;
+    h->timing_search_only = search_only != 0;
     return 0;
 }
 int flh_enable_stats(flh_handle* h, int on) {

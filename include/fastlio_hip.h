@@ -270,6 +270,10 @@ int flh_get_search_counters(flh_handle* h, double out[4]);
  * only RECORDS its events; they are read when flh_get_counters / flh_last_timing / flh_set_timing_stride is called next
  * (or when 64 samples are pending).  flh_last_timing then reports the most recent sample. */
 int flh_set_timing_stride(flh_handle* h, int every_n);
+/* The same with search_only != 0: only SEARCHING evaluations are counted and timed (every every_n-th of them): a sampled
+ * evaluation costs the host ~10 us (its launches carry events), so a short measurement samples the kernels it is after -- the
+ * 5-NN search, and the fit kernel behind it -- and leaves the no-search evaluations alone. */
+int flh_set_timing_sampling(flh_handle* h, int every_n, int search_only);
 int flh_enable_stats(flh_handle* h, int on); /* count candidate points examined (slower) */
 /* Run one kernel of the hot path `iters` times back-to-back on the handle's stream and return the
  * mean duration in ms, measured with HIP events on that stream (bench.py's roofline leg).

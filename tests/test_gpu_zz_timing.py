@@ -104,3 +104,25 @@ def test_plane_cache_changes_no_bit():
         np.testing.assert_array_equal(a[4], b[4])
         sel = a[4].astype(bool)
         np.testing.assert_array_equal(a[5][sel].view(np.uint32), b[5][sel].view(np.uint32))
+
+
+def test_search_only_sampling_counts_searching_evaluations(setup):
+    """flh_set_timing_sampling(n, search_only=1): only searching evaluations are counted and timed, every n-th of them; a scan's
+    first and later searches are told apart; results are untouched."""
+    pr, xp, h = setup
+    h.set_timing_stride(0)
+    h.scan_upload(pr.body)
+    ref_s = h.eval(xp, True, False)
+    h.scan_upload(pr.body)
+    h.set_timing_sampling(3, True)
+    h.counters(reset=True)
+    for k in range(14):  # searches at k = 0, 2, 4, ... (seven of them): the 1st, 4th and 7th are sampled
+        o = h.eval(xp, k % 2 == 0, False)
+        if k == 0:
+            np.testing.assert_array_equal(o[0], ref_s[0])
+    c = h.counters()
+    sc = h.search_counters()
+    assert c["n_search"] == 3 and c["n_fit"] == 3
+    assert sc["n_first"] == 1 and sc["n_later"] == 2   # only the very first search of the scan is a "first search"
+    assert 0.0 < c["search_ms"] / c["n_search"] < 20.0 and 0.0 < c["fit_ms"] / c["n_fit"] < 5.0
+    h.set_timing_stride(1)

@@ -21,6 +21,7 @@ class FakeHandle:
         self.kw = kw; self.M = 0; self._n = 0; self.stride = 1
     def map_build(self, xyz): self.M = len(xyz)
     def set_timing_stride(self, n): self.stride = n
+    def set_timing_sampling(self, n, search_only): self.stride = n
     def counters(self, reset=False):
         return {"search_ms": 0.5, "n_search": 10, "fit_ms": 0.3, "n_fit": 20, "eval_ms": 1.0, "n_eval": 20}
     def search_counters(self):
