@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--first-stage", type=int, default=0)
     ap.add_argument("--sort", type=int, default=1, help="Morton-order the scan at staging (0 = keep input order)")
     ap.add_argument("--extrinsic-est", type=int, default=0)
+    ap.add_argument("--second-stage-lanes", type=int, default=0, help="flh_config.second_stage_lanes (0 = the library's default)")
     ap.add_argument("--plane-cache", type=int, default=-1, help="flh_config.plane_cache (-1 = the library's default: on)")
     ap.add_argument("--plane-fit-dtype", type=int, default=0,
                     help="1 = the fp16 plane-fit ABLATION of BASELINE configs[4] (not bit-exact, never a parity claim)")
@@ -262,7 +263,8 @@ def main():
             f"gen {time.time() - t0:.1f}s")
 
     h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
-                    first_stage=args.first_stage, plane_cache=args.plane_cache, plane_fit_dtype=args.plane_fit_dtype)
+                    first_stage=args.first_stage, plane_cache=args.plane_cache, plane_fit_dtype=args.plane_fit_dtype,
+                    second_stage_lanes=args.second_stage_lanes)
     t0 = time.time()
     h.map_build(scene.map_xyz)
     t_build = time.time() - t0

@@ -251,6 +251,7 @@ void flh_default_config(flh_config* c) {
     c->plane_fit_dtype = 0;
     c->undistort_first_point = -1;
     c->plane_cache = -1;
+    c->second_stage_lanes = 0;
 }
 
 int flh_create(const flh_config* cfg_in, flh_handle** out) {
@@ -270,6 +271,7 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.plane_fit_dtype != 1) cfg.plane_fit_dtype = 0;
     if (cfg.undistort_first_point != 0) cfg.undistort_first_point = 1;
     if (cfg.plane_cache != 0) cfg.plane_cache = 1;
+    if (cfg.second_stage_lanes != 16 && cfg.second_stage_lanes != 32) cfg.second_stage_lanes = 8;
     {
         const int l = cfg.lanes_per_query;  // 0 = exact kernel for every query
         if (l != 0 && l != 1 && l != 2 && l != 8 && l != 16) cfg.lanes_per_query = 4;
@@ -1376,7 +1378,7 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
         HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
                                 h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
                                 h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr,
-                                h->own_axis, h->own_lo, h->own_hi, st, timed ? ev3[0] : nullptr, timed ? ev3[1] : nullptr));
+                                h->own_axis, h->own_lo, h->own_hi, st, timed ? ev3[0] : nullptr, timed ? ev3[1] : nullptr, h->cfg.second_stage_lanes));
         h->last_search_was_later = h->searched_once;
         h->searched_once = true;
         h->d2_valid = false;
@@ -1709,7 +1711,7 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
         if (which == 0) {
             HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
                                     h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
-                                    h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, nullptr, h->own_axis, h->own_lo, h->own_hi, st));
+                                    h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, nullptr, h->own_axis, h->own_lo, h->own_hi, st, nullptr, nullptr, h->cfg.second_stage_lanes));
             HIPC(hipMemsetAsync(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t), st));
             h->searched_once = true;
             h->search_state = s;

@@ -234,12 +234,26 @@ __device__ __forceinline__ void merge8(uint32_t (&K)[kTop]) {
     cex2(K[0], K[2]); cex2(K[1], K[3]); cex2(K[4], K[6]); cex2(K[5], K[7]);
     cex2(K[0], K[1]); cex2(K[2], K[3]); cex2(K[4], K[5]); cex2(K[6], K[7]);
 }
+// the same with the partner at lane ^ XOR reached through the LDS crossbar (groups wider than a 16-lane DPP row)
+template <int XOR>
+__device__ __forceinline__ void merge8_xor(uint32_t (&K)[kTop]) {
+    uint32_t B[kTop];
+#pragma unroll
+    for (int j = 0; j < kTop; ++j) B[j] = (uint32_t)__shfl_xor((int)K[j], XOR, 64);
+#pragma unroll
+    for (int j = 0; j < kTop; ++j) K[j] = min(K[j], B[kTop - 1 - j]);
+    cex2(K[0], K[4]); cex2(K[1], K[5]); cex2(K[2], K[6]); cex2(K[3], K[7]);
+    cex2(K[0], K[2]); cex2(K[1], K[3]); cex2(K[4], K[6]); cex2(K[5], K[7]);
+    cex2(K[0], K[1]); cex2(K[2], K[3]); cex2(K[4], K[5]); cex2(K[6], K[7]);
+}
 template <int LPQ>
 __device__ __forceinline__ void merge_group8(uint32_t (&K)[kTop]) {
     if (LPQ >= 2) merge8<0xB1>(K);    // quad_perm [1,0,3,2]
     if (LPQ >= 4) merge8<0x4E>(K);    // quad_perm [2,3,0,1]
     if (LPQ >= 8) merge8<0x141>(K);   // row_half_mirror
     if (LPQ >= 16) merge8<0x140>(K);  // row_mirror
+    if (LPQ >= 32) merge8_xor<16>(K);
+    if (LPQ >= 64) merge8_xor<32>(K);
 }
 
 // value of lane `src` of the LPQ-lane query group (src is a compile-time constant at every call site after unrolling)
@@ -898,7 +912,7 @@ hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const St
                          float max_sqdist, int rmax, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
                          uint32_t* list1, uint32_t* list2, float* ub, uint32_t* counts /* [2 * kStripes] */,
                          u64* cand_counter, int own_axis, float own_lo, float own_hi, hipStream_t st,
-                         hipEvent_t ev_start, hipEvent_t ev_stop) {
+                         hipEvent_t ev_start, hipEvent_t ev_stop, int lpq2) {
     if (N <= 0) return hipSuccess;
     const dim3 blk(256);
     const uint32_t cap = list_stripe_cap(N);
@@ -933,9 +947,18 @@ hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const St
     if (rmax >= 2) {
         // A2: ring 2 over list 1, inside the ball A1's 5th distance defines; whatever it cannot settle (distance ties, a
         // 5th neighbour beyond the 5x5x5 block) it finishes itself with the general exact search
-        FLH_LAUNCH_EV((k_search_ring<16, 2, true, 11, true>), dim3(kStripes * 16), blk, st, ev_none, ev_stop, g, s, body, N, map_points,
-                      max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)list1, (const uint32_t*)counts, list2,
-                      counts + kStripes, cap, (const float*)ub, ub, rmax, cand_counter, -1, 0.f, 0.f);
+#define FLH_A2(L2, BPS)                                                                                                          \
+        FLH_LAUNCH_EV((k_search_ring<L2, 2, true, 11, true>), dim3(kStripes * BPS), blk, st, ev_none, ev_stop, g, s, body, N, map_points, \
+                      max_sqdist, nn_pts, nn_d2, nn_cnt, selected, (const uint32_t*)list1, (const uint32_t*)counts, list2,       \
+                      counts + kStripes, cap, (const float*)ub, ub, rmax, cand_counter, -1, 0.f, 0.f)
+        // lanes per query of the second stage (flh_config.second_stage_lanes) and blocks per stripe so that a stripe's share of
+        // ~10 % of the queries is one trip of its blocks
+        // measured on BASELINE configs[1] (rocprofv3 mean over first and later searches): 4 lanes 15.5 us, 8 lanes 12.3, 16 lanes 13.3,
+        // 32 lanes 16.3, 64 lanes 24.2
+        if (lpq2 == 32) FLH_A2(32, 32);
+        else if (lpq2 == 16) FLH_A2(16, 16);
+        else FLH_A2(8, 8);
+#undef FLH_A2
     } else {
         // cells as large as the gate radius: the general search drains list 1 directly
         FLH_LAUNCH_EV(k_search_exact, dim3(kStripes * 8), blk, st, ev_none, ev_stop, g, s, body, N, max_sqdist, rmax, nn_pts, nn_d2,

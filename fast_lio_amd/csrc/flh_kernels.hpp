@@ -36,7 +36,8 @@ hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const St
                          float max_sqdist, int rmax, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
                          uint32_t* list1, uint32_t* list2, float* ub, uint32_t* counts, unsigned long long* cand_counter,
                          int own_axis, float own_lo, float own_hi, hipStream_t st,
-                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);  // optional: time stamps of the first kernel's start / the last one's end
+                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,  // optional: time stamps of the first kernel's start / the last one's end
+                         int lpq2 = 8);
 hipError_t launch_publish256(const double* src, double* out256, double seq, hipStream_t st);
 
 #ifdef FLH_PHASES

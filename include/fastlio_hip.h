@@ -67,6 +67,9 @@ typedef struct flh_config {
     int plane_cache;        /* 1 (default, also for < 0): a pass that does not search takes each point's plane from the fit of the last
                                searching pass instead of re-reading five neighbours and repeating the QR (a plane depends on the
                                neighbours only, not on the state: same bits); 0: re-fit on every pass */
+    int second_stage_lanes; /* lanes cooperating on one query of the second search stage (the queries the first stage could not
+                               settle: 5x5x5 cells inside the first stage's bound): 8 (default, also for any other value), 16
+                               or 32.  Performance only */
 } flh_config;
 enum { FLH_ORDER_SEQ = 0, FLH_ORDER_SSE = 1, FLH_ORDER_PAIRWISE = 2, FLH_ORDER_NOVEC = 3 };
 

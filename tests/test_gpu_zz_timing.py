@@ -126,3 +126,47 @@ def test_search_only_sampling_counts_searching_evaluations(setup):
     assert sc["n_first"] == 1 and sc["n_later"] == 2   # only the very first search of the scan is a "first search"
     assert 0.0 < c["search_ms"] / c["n_search"] < 20.0 and 0.0 < c["fit_ms"] / c["n_fit"] < 5.0
     h.set_timing_stride(1)
+
+
+@pytest.mark.parametrize("lanes", [16, 32])
+def test_second_stage_lanes_change_no_result(lanes):
+    """flh_config.second_stage_lanes: the second search stage with 16 / 32 lanes per query examines the same cells as with 8 (the default), so
+    flags, neighbour ids in rank order, planes and the whole update must be identical -- on a dense scan, on a thinned-out scan
+    (many queries reach the second stage) and with a prior so far off that most queries do."""
+    pr = synth.make_problem(200000, 20000, "avia", cfg=1)
+    xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
+    x_far = np.array(xp, dtype=np.float64)
+    x_far[:3] += [0.9, -0.7, 0.8]          # metres off: 5th neighbours beyond the first stage's guaranteed radius
+    scans = {"dense": pr.body, "sparse": np.ascontiguousarray(pr.body[::37]), "ragged": np.ascontiguousarray(pr.body[:5003])}
+    for name, body in scans.items():
+        out = []
+        for ln in (8, lanes):
+            h = capi.Handle(second_stage_lanes=ln)
+            h.map_build(pr.map_xyz)
+            h.scan_upload(body)
+            res = []
+            for x, search in ((xp, True), (x_far, True), (pr.x_true, False), (pr.x_true, True)):
+                HTH, HTh, n_eff, tres = h.eval(x, search, False)
+                idx, d2, cnt = h.fetch_neighbors()
+                res.append((HTH.copy(), HTh.copy(), n_eff, tres, h.fetch_selected().copy(), idx.copy(), cnt.copy(), d2.copy()))
+            h.scan_upload(body)
+            kf = capi.Esekf(h, max_iter=3)
+            kf.change_x(xp)
+            kf.change_P(P)
+            st = kf.update(0.001)
+            out.append((res, kf.get_x().copy(), kf.get_P().copy(), list(st.n_eff)[: st.passes]))
+            kf.close()
+            h.close()
+        (r0, x0, P0, n0), (r1, x1, P1, n1) = out
+        assert n0 == n1, name
+        np.testing.assert_array_equal(x0, x1, err_msg=name)
+        np.testing.assert_array_equal(P0, P1, err_msg=name)
+        for a, b in zip(r0, r1):
+            np.testing.assert_array_equal(a[4], b[4], err_msg=name + ": flags")
+            np.testing.assert_array_equal(a[6], b[6], err_msg=name + ": neighbour counts")
+            inside = a[7] <= 5.0                     # inside the gate the two must agree entry for entry
+            np.testing.assert_array_equal(a[5][inside], b[5][inside], err_msg=name + ": neighbour ids")
+            np.testing.assert_array_equal(a[7][inside].view(np.uint32), b[7][inside].view(np.uint32), err_msg=name + ": distances")
+            np.testing.assert_array_equal(a[0], b[0], err_msg=name)
+            np.testing.assert_array_equal(a[1], b[1], err_msg=name)
+            assert a[2] == b[2] and a[3] == b[3], name
