@@ -170,3 +170,30 @@ def test_second_stage_lanes_change_no_result(lanes):
             np.testing.assert_array_equal(a[0], b[0], err_msg=name)
             np.testing.assert_array_equal(a[1], b[1], err_msg=name)
             assert a[2] == b[2] and a[3] == b[3], name
+
+
+def test_synchronous_and_asynchronous_staging_do_not_share_scratch_unguarded():
+    """The staging thread and the synchronous entry points use the same scratch buffers and the same copy stream.  Round 2's
+    unexplained `Memory access fault by GPU` fits this picture: a synchronous staging that grows a scratch buffer (free + new
+    allocation) while the worker's staging of another slot still reads it.  Every staging now holds one mutex; this test hammers
+    the pair with growing sizes and checks every staged scan byte for byte."""
+    pr = synth.make_problem(200000, 20000, "avia", cfg=1)
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    rng = np.random.default_rng(3)
+    big = np.ascontiguousarray(np.tile(pr.body, (12, 1)) + rng.normal(0, 0.01, (12 * len(pr.body), 3)).astype(np.float32))
+    assert len(big) >= 20000 + 7000 * 11 + 9000 + 9000 * 11
+    for rep in range(12):
+        n_async = 20000 + 7000 * rep          # both sizes grow: every round re-allocates some scratch buffer
+        n_sync = 9000 + 9000 * rep
+        a = np.ascontiguousarray(big[:n_async])
+        b = np.ascontiguousarray(big[n_async: n_async + n_sync])
+        h.scan_stage_async(0, a)
+        h.scan_stage(1, b)                    # synchronous, while slot 0 may still be under way on the worker
+        h.scan_upload(b[: 1000 + rep])        # the third path (its own slot, the same scratch)
+        h.scan_wait(0)
+        for slot, want in ((0, a), (1, b)):
+            h.scan_activate(slot)
+            got = h.fetch_scan()
+            np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+    h.close()
