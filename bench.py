@@ -91,7 +91,9 @@ def pmc_traffic(args):
                 calls[k] = int(r["dispatches"])
             elif r["counter"] == "WRITE_SIZE":
                 write[k] = float(r["sum"])
-    second = [k for k in calls if k.startswith("k_search_ring<16, 2")]
+    import re
+
+    second = [k for k in calls if re.match(r"k_search_ring<\d+, 2,", k)]
     if not second or not fetch:
         return None
     passes = sum(calls[k] for k in second)  # every search pass launches the second stage exactly once
