@@ -9,6 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfastlio_hip.so")
+if os.environ.get("FLH_LIB"):  # developer tools only (tools/variant.py builds): another build of the same ABI; never rebuilt from here
+    LIB = os.environ["FLH_LIB"]
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SOURCES = ["flh_kernels.hip", "flh_mapinc.hip", "flh_scanprep.hip", "flh_api.cpp", "flh_esekf.cpp"]
@@ -32,6 +34,8 @@ def hipcc() -> str:
 
 
 def needs_build() -> bool:
+    if os.environ.get("FLH_LIB"):
+        return False
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)

@@ -34,6 +34,7 @@ class FlhConfig(C.Structure):
         ("undistort_first_point", C.c_int),
         ("plane_cache", C.c_int),
         ("second_stage_lanes", C.c_int),
+        ("fused_small_changes", C.c_int),
     ]
 
 
@@ -250,7 +251,8 @@ class Handle:
 
     def __init__(self, cell_size: float = 1.5, lanes_per_query: int = 4, device: int = -1, stream: int | None = None,
                  plane_threshold: float = 0.1, max_sqdist: float = 5.0, sort_queries: int = -1, first_stage: int = 0,
-                 eigen_order: int = -1, plane_fit_dtype: int = 0, undistort_first_point: int = -1, plane_cache: int = -1, second_stage_lanes: int = 0):
+                 eigen_order: int = -1, plane_fit_dtype: int = 0, undistort_first_point: int = -1, plane_cache: int = -1, second_stage_lanes: int = 0,
+                 fused_small_changes: int = -1):
         L = lib()
         cfg = FlhConfig()
         L.flh_default_config(C.byref(cfg))
@@ -267,6 +269,7 @@ class Handle:
         cfg.undistort_first_point = undistort_first_point
         cfg.plane_cache = plane_cache
         cfg.second_stage_lanes = second_stage_lanes
+        cfg.fused_small_changes = fused_small_changes
         self._h = C.c_void_p()
         _chk(L.flh_create(C.byref(cfg), C.byref(self._h)), "flh_create")
         self._keep = []

@@ -115,6 +115,7 @@ struct flh_handle {
     bool id_pos_valid = false;
     uint64_t n_reindex = 0, n_inplace = 0; // full re-indexings / changes applied brick-wise since creation
     DevBuf<u64> mb_k0, mb_k1;              // sort scratch of the index build and of the map updates (kept allocated)
+    DevBuf<u64> vox_tab;                   // voxel hash table of a map change (key, best new point) x slots
     DevBuf<uint32_t> mb_v0, mb_v1, mb_bh, mb_br, mb_bstart, mb_aabb;
     DevBuf<unsigned char> mb_tmp;
     DevBuf<float4> mu_add, mi_world;       // incremental update: points to insert; map_incremental's world points
@@ -252,6 +253,7 @@ void flh_default_config(flh_config* c) {
     c->undistort_first_point = -1;
     c->plane_cache = -1;
     c->second_stage_lanes = 0;
+    c->fused_small_changes = -1;
 }
 
 int flh_create(const flh_config* cfg_in, flh_handle** out) {
@@ -272,6 +274,7 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.undistort_first_point != 0) cfg.undistort_first_point = 1;
     if (cfg.plane_cache != 0) cfg.plane_cache = 1;
     if (cfg.second_stage_lanes != 16 && cfg.second_stage_lanes != 32) cfg.second_stage_lanes = 8;
+    if (cfg.fused_small_changes != 0) cfg.fused_small_changes = 1;
     {
         const int l = cfg.lanes_per_query;  // 0 = exact kernel for every query
         if (l != 0 && l != 1 && l != 2 && l != 8 && l != 16) cfg.lanes_per_query = 4;
@@ -632,7 +635,9 @@ static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size
     HIPC(h->mb_k0.reserve(n)); HIPC(h->mb_k1.reserve(n)); HIPC(h->mb_v0.reserve(n)); HIPC(h->mb_v1.reserve(n));
     HIPC(h->mu_flags.reserve(n)); HIPC(h->mu_incl.reserve(n));
     size_t tb_sort = 0, tb_scan = 0;
-    HIPC(flh::sort_vox_pairs(nullptr, tb_sort, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, nu, st));
+    uint32_t* const bk0 = reinterpret_cast<uint32_t*>(h->mb_k0.p);  // the brick keys of the surviving points are 32-bit
+    uint32_t* const bk1 = reinterpret_cast<uint32_t*>(h->mb_k1.p);
+    HIPC(flh::sort_brick_pairs(nullptr, tb_sort, bk0, bk1, h->mb_v0.p, h->mb_v1.p, nu, st));
     HIPC(flh::inclusive_sum(nullptr, tb_scan, h->mu_flags.p, h->mu_incl.p, nu, st));
     HIPC(h->mb_tmp.reserve(std::max(tb_sort, tb_scan)));
     // room for every point of the change (the survivors are at most n): allocated up front, nothing to wait for in between
@@ -643,27 +648,37 @@ static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size
         if (h->dead_id.cap != before) HIPC(hipMemsetAsync(h->dead_id.p + h->n_ids, 0, h->dead_id.cap - h->n_ids, st));
     }
     HIPC(h->ins.reserve(n));
-    HIPC(flh::launch_add_keys(d_add, (uint32_t)n1, nu, ds, h->mb_k0.p, h->mb_v0.p, h->mu_alive.p, h->ctr.p, st));
+    // the points inserted with down-sampling are grouped by voxel in a hash table (no sort): per voxel the best new point, which
+    // then meets the points the map already holds there
+    const uint32_t vcap = flh::vox_table_slots((uint32_t)n1);
     if (n1 > 0) {
-        size_t tb = h->mb_tmp.cap;
-        HIPC(flh::sort_vox_pairs(h->mb_tmp.p, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, (uint32_t)n1, st));
-        HIPC(flh::launch_add_resolve(h->grid, h->map_sorted.p, d_add, h->mb_k1.p, h->mb_v1.p, (uint32_t)n1, ds, h->dead_id.p, h->live.p,
+        HIPC(h->vox_tab.reserve(2 * (size_t)vcap));
+        HIPC(hipMemsetAsync(h->vox_tab.p, 0xFF, 2 * (size_t)vcap * sizeof(unsigned long long), st));
+    }
+    HIPC(flh::launch_add_insert(d_add, (uint32_t)n1, nu, ds, h->vox_tab.p, vcap, h->mu_alive.p, h->ctr.p, st));
+    if (n1 > 0)
+        HIPC(flh::launch_add_resolve(h->grid, h->map_sorted.p, d_add, h->vox_tab.p, vcap, (uint32_t)n1, ds, h->dead_id.p, h->live.p,
                                      h->ctr.p, h->mu_alive.p, st));
-    }
-    // ids of the survivors, in input order; the brick keys start as sentinels
-    HIPC(flh::launch_byte_flags(h->mu_alive.p, nu, 0, h->mu_flags.p, st, h->mb_k0.p));
-    {
-        size_t tb = h->mb_tmp.cap;
-        HIPC(flh::inclusive_sum(h->mb_tmp.p, tb, h->mu_flags.p, h->mu_incl.p, nu, st));
-    }
-    HIPC(flh::launch_ins_prepare(h->grid, d_add, h->mu_alive.p, h->mu_incl.p, nu, (uint32_t)h->n_ids, h->map_orig.p,
-                                 h->dead_id.p, h->ins.p, h->mb_k0.p, h->mb_v0.p, h->ctr.p, st));
-    {
-        size_t tb = h->mb_tmp.cap;
-        HIPC(flh::sort_vox_pairs(h->mb_tmp.p, tb, h->mb_k0.p, h->mb_k1.p, h->mb_v0.p, h->mb_v1.p, nu, st));
+    if (h->cfg.fused_small_changes != 0 && nu <= flh::small_change_max()) {
+        // a scan's worth of points: ids, brick keys and their sort in one workgroup (one launch instead of eight)
+        HIPC(flh::launch_ins_sort_small(h->grid, d_add, h->mu_alive.p, nu, (uint32_t)h->n_ids, h->map_orig.p, h->dead_id.p, h->ins.p, bk0,
+                                        bk1, h->mb_v1.p, h->ctr.p, h->mu_incl.p + (n - 1), st));
+    } else {
+        // ids of the survivors, in input order; the brick keys start as sentinels
+        HIPC(flh::launch_byte_flags(h->mu_alive.p, nu, 0, h->mu_flags.p, st, bk0));
+        {
+            size_t tb = h->mb_tmp.cap;
+            HIPC(flh::inclusive_sum(h->mb_tmp.p, tb, h->mu_flags.p, h->mu_incl.p, nu, st));
+        }
+        HIPC(flh::launch_ins_prepare(h->grid, d_add, h->mu_alive.p, h->mu_incl.p, nu, (uint32_t)h->n_ids, h->map_orig.p,
+                                     h->dead_id.p, h->ins.p, bk0, h->mb_v0.p, h->ctr.p, st));
+        {
+            size_t tb = h->mb_tmp.cap;
+            HIPC(flh::sort_brick_pairs(h->mb_tmp.p, tb, bk0, bk1, h->mb_v0.p, h->mb_v1.p, nu, st));
+        }
     }
     HIPC(flh::launch_brick_rewrite(h->grid, h->map_sorted.p, h->starts.p, h->hash.p, h->cap_end.p, h->live.p, h->ctr.p, h->ins.p,
-                                   h->mb_k1.p, h->mb_v1.p, nu, (uint32_t)h->pts_cap, (uint32_t)h->rows_cap, st));
+                                   bk1, h->mb_v1.p, nu, (uint32_t)h->pts_cap, (uint32_t)h->rows_cap, st));
     const uint32_t seq = ++h->mi_seq;
     HIPC(flh::launch_map_publish(h->ctr.p, h->mu_incl.p + (n - 1), h->h_mi + 4, seq, st));
     h->map_pending = true;

@@ -64,23 +64,28 @@ hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uin
                               uint32_t* host_counts, uint32_t seq, hipStream_t st);
 hipError_t launch_map_publish(const uint32_t* ctr, const uint32_t* n_alive, uint32_t* host_out, uint32_t seq, hipStream_t st);
 hipError_t launch_aabb(const float4* pts, uint32_t M, uint32_t* out6, hipStream_t st);
-hipError_t launch_add_keys(const float4* add, uint32_t n1, uint32_t n, double ds, unsigned long long* keys, uint32_t* vals,
-                           uint8_t* alive_new, uint32_t* ctr, hipStream_t st);
-hipError_t sort_vox_pairs(void* tmp, size_t& tmp_bytes, const unsigned long long* kin, unsigned long long* kout,
-                          const uint32_t* vin, uint32_t* vout, uint32_t n, hipStream_t st);
-hipError_t launch_add_resolve(const GridParams& g, float4* pts_rw, const float4* add, const unsigned long long* ks,
-                              const uint32_t* vs, uint32_t n, double ds, uint8_t* dead_id, uint32_t* live, uint32_t* ctr,
-                              uint8_t* alive_new, hipStream_t st);
+uint32_t vox_table_slots(uint32_t n1);
+hipError_t launch_add_insert(const float4* add, uint32_t n1, uint32_t n, double ds, unsigned long long* tab, uint32_t cap,
+                             uint8_t* alive_new, uint32_t* ctr, hipStream_t st);
+// map changes of at most small_change_max() points: ids, brick keys and their sort in one workgroup (flh_mapinc.hip)
+uint32_t small_change_max();
+hipError_t launch_ins_sort_small(const GridParams& g, const float4* add, const uint8_t* alive_new, uint32_t n, uint32_t n_ids,
+                                 float4* map_orig, uint8_t* dead_id, float4* ins, uint32_t* keys_tmp, uint32_t* ks, uint32_t* perm,
+                                 uint32_t* ctr, uint32_t* n_alive_out, hipStream_t st);
+hipError_t sort_brick_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
+                            uint32_t n, hipStream_t st);
+hipError_t launch_add_resolve(const GridParams& g, float4* pts_rw, const float4* add, const unsigned long long* tab, uint32_t cap,
+                              uint32_t n, double ds, uint8_t* dead_id, uint32_t* live, uint32_t* ctr, uint8_t* alive_new, hipStream_t st);
 hipError_t launch_delete_boxes(const GridParams& g, float4* pts_rw, uint32_t n_slots, const float* boxes, int nb, uint8_t* dead_id,
                                uint32_t* live, uint32_t* ctr, hipStream_t st);
 hipError_t launch_ins_prepare(const GridParams& g, const float4* add, const uint8_t* alive_new, const uint32_t* incl, uint32_t n,
-                              uint32_t n_ids, float4* map_orig, uint8_t* dead_id, float4* ins, unsigned long long* keys,
+                              uint32_t n_ids, float4* map_orig, uint8_t* dead_id, float4* ins, uint32_t* keys,
                               uint32_t* vals, uint32_t* ctr, hipStream_t st);
 hipError_t launch_brick_rewrite(const GridParams& g, float4* pts, uint32_t* starts, uint2* hash, uint32_t* cap_end, uint32_t* live,
-                                uint32_t* ctr, const float4* ins, const unsigned long long* ks, const uint32_t* perm, uint32_t n,
+                                uint32_t* ctr, const float4* ins, const uint32_t* ks, const uint32_t* perm, uint32_t n,
                                 uint32_t pts_cap, uint32_t rows_cap, hipStream_t st);
 hipError_t launch_byte_flags(const uint8_t* in, uint32_t n, int invert, uint32_t* flags, hipStream_t st,
-                             unsigned long long* keys_sentinel = nullptr);
+                             uint32_t* keys_sentinel = nullptr);
 hipError_t launch_live_compact(const float4* map_orig, const uint32_t* flags, const uint32_t* incl, uint32_t n_ids, float4* out,
                                hipStream_t st);
 

@@ -2,17 +2,20 @@
 //
 //   k_mi_classify     map_incremental's add/skip decision per scan point (src/laserMapping.cpp:427-474), fed
 //                     from the device-resident neighbour cache the last search left behind
-//   k_add_keys/...    ikdtree.Add_Points(points, downsample) (:470-471): per filter_size_map voxel the point
+//   k_far_nearest     points_near[0] of the few scan points with no map point inside the search bound (shell search over bricks)
+//   k_add_insert / k_add_resolve   ikdtree.Add_Points(points, downsample) (:470-471): per filter_size_map voxel the point
 //                     nearest to the voxel centre survives [ikd-Tree semantics, recalled-upstream; the oracle
-//                     (oracle_path.c: orc_map_add) states them]
+//                     (oracle_path.c: orc_map_add) states them]; the new points are grouped by voxel in a hash table (no sort)
 //   k_delete_boxes    ikdtree.Delete_Point_Boxes (:275)
 //
-//   k_ins_prepare / k_brick_rewrite   the surviving new points enter the brick storage: only the bricks that receive points
-//                     are rewritten (LDS counting sort, in place while they fit their slack, else relocated); the whole
-//                     index is rebuilt only when something no longer fits (flh_api.cpp: apply_map_changes)
+//   k_ins_prepare (k_ins_sort_small for a scan's worth of points) / k_brick_rewrite   the surviving new points enter the brick
+//                     storage: only the bricks that receive points are rewritten (LDS counting sort, in place while they fit
+//                     their slack, else relocated); the whole index is rebuilt only when something no longer fits
+//                     (flh_api.cpp: apply_map_changes)
 // Built with -ffp-contract=off like the rest.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include "flh_device.hpp"
 #include "flh_kernels.hpp"
@@ -31,6 +34,11 @@ static inline int cdiv2(long long a, long long b) { return (int)((a + b - 1) / b
 // unbounded.  The two still agree on every decision below: a neighbour that can veto the insert lies within
 // sqrt(3)*fsm of the point (well inside the bound), and the one case that needs a neighbour outside the bound --
 // points_near[0] of a point with NO map point inside it -- is served by k_far_nearest first.
+// One wave per query.  Bricks are visited in cubic shells around the query's brick (shell r = the bricks at Chebyshev distance
+// r): after shell r everything within the cube of (2r+1)^3 bricks is known, so the search ends as soon as the best distance
+// found is smaller than the distance from the query to that cube's faces -- a few hundred directory probes when the nearest
+// point is some tens of metres away.  Only when the shells grow past the directory itself (a query very far from everything)
+// the remaining work is done by scanning the whole directory twice (bound, then exact).
 __global__ void __launch_bounds__(256)
 k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, const uint8_t* __restrict__ nn_cnt,
               const float* __restrict__ nn_d2, float max_sqdist, int N, uint32_t hash_size, const uint32_t* __restrict__ live,
@@ -44,43 +52,29 @@ k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, 
     body_to_world(s_search, b.x, b.y, b.z, wx, wy, wz);  // the world position the last search used
     const unsigned long long* __restrict__ hash64 = reinterpret_cast<const unsigned long long*>(g.hash);
     const float bw = 4.0f * g.c;
+    const float w[3] = {wx, wy, wz};
+    const float org[3] = {g.ox, g.oy, g.oz};
+    float marg[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) marg[d] = 1e-3f * g.c + 1e-5f * fabsf(w[d]);
     auto box = [&](uint32_t key, float& lb2, float& ub2) {
-        const float bx = (float)(key & 1023u), by = (float)((key >> 10) & 1023u), bz = (float)(key >> 20);
-        const float lo[3] = {g.ox + bx * bw, g.oy + by * bw, g.oz + bz * bw};
-        const float w[3] = {wx, wy, wz};
+        const float bc[3] = {(float)(key & 1023u), (float)((key >> 10) & 1023u), (float)(key >> 20)};
         lb2 = 0.f; ub2 = 0.f;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const float m = 1e-3f * g.c + 1e-5f * fabsf(w[d]);
-            const float l = lo[d] - m, h = lo[d] + bw + m;
+            const float l = org[d] + bc[d] * bw - marg[d], h = org[d] + bc[d] * bw + bw + marg[d];
             const float dmin = fmaxf(0.f, fmaxf(l - w[d], w[d] - h));
             const float dmax = fmaxf(fabsf(w[d] - l), fabsf(w[d] - h));
             lb2 += dmin * dmin;
             ub2 += dmax * dmax;
         }
     };
-    // pass 1: a brick with a live point holds one within its far corner, so the min over such bricks bounds the answer
-    float best_ub = INFINITY;
-    for (uint32_t slot = lane; slot < hash_size; slot += 64) {
-        const unsigned long long e = hash64[slot];
-        if ((uint32_t)e == kEmptyKey || live[(uint32_t)(e >> 32)] == 0u) continue;
-        float lb2, ub2;
-        box((uint32_t)e, lb2, ub2);
-        best_ub = fminf(best_ub, ub2);
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) best_ub = fminf(best_ub, __shfl_xor(best_ub, o, 64));
-    best_ub *= 1.0001f;
-    // pass 2: exact distances in the bricks that can hold it; key = (d2 bits, original index) so ties go to the lower index
+    // exact distances over a brick's points; key = (d2 bits, original index) so ties go to the lower index
     u64 best = ~0ull;
     float4 best_p = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t slot = lane; slot < hash_size; slot += 64) {
-        const unsigned long long e = hash64[slot];
-        if ((uint32_t)e == kEmptyKey) continue;
-        float lb2, ub2;
-        box((uint32_t)e, lb2, ub2);
-        if (lb2 * 0.9999f > best_ub) continue;
-        const uint32_t* stt = g.starts + (size_t)(uint32_t)(e >> 32) * kBrickStride;
+    float best_ub = INFINITY;  // >= the squared distance of the nearest point, with a rounding margin
+    auto scan_brick = [&](uint32_t rank) {
+        const uint32_t* stt = g.starts + (size_t)rank * kBrickStride;
         const uint32_t i0 = stt[0], i1 = stt[64];
         for (uint32_t i = i0; i < i1; ++i) {
             const float4 p = g.pts[i];
@@ -89,6 +83,82 @@ k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, 
             const u64 k = ((u64)__float_as_uint(d) << 32) | (u64)__float_as_uint(p.w);
             if (k < best) { best = k; best_p = p; }
             best_ub = fminf(best_ub, d * 1.0001f);
+        }
+    };
+    // the query's brick (it may lie outside the grid) and the grid's extent in bricks
+    int bq[3], nb[3] = {(g.nx + 3) >> 2, (g.ny + 3) >> 2, (g.nz + 3) >> 2};
+    int r0 = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float f = floorf((w[d] - org[d]) / bw);
+        bq[d] = (int)fminf(fmaxf(f, -1.0e6f), 1.0e6f);
+        r0 = max(r0, max(-bq[d], bq[d] - (nb[d] - 1)));  // shells nearer than this hold no brick of the grid
+    }
+    bool finished = false;
+    for (int r = r0;; ++r) {
+        const long long side = 2ll * r + 1;
+        if (side * side * side > (long long)hash_size) break;  // block-uniform: the directory itself is the shorter list
+        const uint32_t face = (uint32_t)(side * side);
+        const uint32_t total = r == 0 ? 1u : 2u * face + (uint32_t)(2 * r - 1) * (uint32_t)(8 * r);
+        for (uint32_t t = lane; t < total; t += 64) {
+            int dx, dy, dz;
+            if (r == 0) { dx = dy = dz = 0; }
+            else if (t < 2u * face) {
+                const uint32_t rem = t < face ? t : t - face;
+                dz = t < face ? -r : r;
+                dy = (int)(rem / (uint32_t)side) - r;
+                dx = (int)(rem % (uint32_t)side) - r;
+            } else {
+                const uint32_t t2 = t - 2u * face;
+                dz = (int)(t2 / (uint32_t)(8 * r)) - (r - 1);
+                const uint32_t u = t2 % (uint32_t)(8 * r), e = u / (uint32_t)(2 * r);
+                const int k = (int)(u % (uint32_t)(2 * r));
+                dx = e == 0 ? -r + k : (e == 1 ? r : (e == 2 ? r - k : -r));
+                dy = e == 0 ? -r : (e == 1 ? -r + k : (e == 2 ? r : r - k));
+            }
+            const int x = bq[0] + dx, y = bq[1] + dy, z = bq[2] + dz;
+            if ((unsigned)x >= (unsigned)nb[0] || (unsigned)y >= (unsigned)nb[1] || (unsigned)z >= (unsigned)nb[2]) continue;
+            const uint32_t key = ((uint32_t)z << 20) | ((uint32_t)y << 10) | (uint32_t)x;
+            const uint32_t rank = lookup_brick(g, key);
+            if (rank == kEmptyKey || live[rank] == 0u) continue;
+            float lb2, ub2;
+            box(key, lb2, ub2);
+            if (lb2 * 0.9999f > best_ub) continue;
+            scan_brick(rank);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) best_ub = fminf(best_ub, __shfl_xor(best_ub, o, 64));
+        // every brick inside the cube [bq - r, bq + r]^3 has been seen: what lies outside is at least this far away
+        float dout = INFINITY;
+        bool all = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float lo = org[d] + (float)(bq[d] - r) * bw, hi = org[d] + (float)(bq[d] + r + 1) * bw;
+            dout = fminf(dout, fminf(w[d] - lo, hi - w[d]) - marg[d]);
+            all = all && bq[d] - r <= 0 && bq[d] + r >= nb[d] - 1;
+        }
+        dout = fmaxf(dout, 0.f);
+        if (all || best_ub < dout * dout * 0.9999f) { finished = true; break; }
+    }
+    if (!finished) {
+        // pass 1: a brick with a live point holds one within its far corner, so the min over such bricks bounds the answer
+        for (uint32_t slot = lane; slot < hash_size; slot += 64) {
+            const unsigned long long e = hash64[slot];
+            if ((uint32_t)e == kEmptyKey || live[(uint32_t)(e >> 32)] == 0u) continue;
+            float lb2, ub2;
+            box((uint32_t)e, lb2, ub2);
+            best_ub = fminf(best_ub, ub2 * 1.0001f);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) best_ub = fminf(best_ub, __shfl_xor(best_ub, o, 64));
+        // pass 2: exact distances in the bricks that can hold it (a brick seen by a shell before is simply seen again)
+        for (uint32_t slot = lane; slot < hash_size; slot += 64) {
+            const unsigned long long e = hash64[slot];
+            if ((uint32_t)e == kEmptyKey) continue;
+            float lb2, ub2;
+            box((uint32_t)e, lb2, ub2);
+            if (lb2 * 0.9999f > best_ub) continue;
+            scan_brick((uint32_t)(e >> 32));
         }
     }
     u64 gbest = best;
@@ -222,11 +292,16 @@ __device__ __forceinline__ u64 pack_vox(long long kx, long long ky, long long kz
            ((u64)(kz + (1ll << 20)) & 0x1FFFFFull);
 }
 
-// First kernel of a map change: the voxel keys of the n1 points inserted WITH down-sampling; alive_new = 0 for them (k_add_resolve
-// decides), 1 for the n - n1 points inserted as they are; the change's counters (re-index flags, removed points) start at zero.
-__global__ void __launch_bounds__(256) k_add_keys(const float4* __restrict__ add, uint32_t n1, uint32_t n, double ds,
-                                                  u64* __restrict__ keys, uint32_t* __restrict__ vals, uint8_t* __restrict__ alive_new,
-                                                  uint32_t* __restrict__ ctr) {
+// First kernel of a map change.  The n1 points inserted WITH down-sampling are grouped by voxel in a hash table (open addressing,
+// 2 x u64 per slot: the packed voxel key, and the best new point of the voxel so far as (fp32 distance to the voxel centre << 32)
+// | ~index -- an unsigned minimum over it picks the nearest point and, among equally near ones, the LATEST, which is the order
+// Add_Points processes them in).  Order-independent, so the outcome does not depend on which thread gets where first.
+// alive_new = 0 for these points (k_add_resolve decides), 1 for the n - n1 points inserted as they are; the change's counters
+// (re-index flags, removed points) start at zero.  The table arrives filled with 0xFF (empty keys, maximal values).
+__device__ __forceinline__ uint32_t vox_slot(u64 key, int shift) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> shift); }
+__global__ void __launch_bounds__(256) k_add_insert(const float4* __restrict__ add, uint32_t n1, uint32_t n, double ds,
+                                                    u64* __restrict__ tab, uint32_t mask, int shift, uint8_t* __restrict__ alive_new,
+                                                    uint32_t* __restrict__ ctr) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) { ctr[2] = 0u; ctr[3] = 0u; }
     if (i >= n) return;
@@ -235,8 +310,15 @@ __global__ void __launch_bounds__(256) k_add_keys(const float4* __restrict__ add
     const float4 p = add[i];
     long long kx, ky, kz;
     vox_of(p.x, p.y, p.z, ds, kx, ky, kz);
-    keys[i] = pack_vox(kx, ky, kz);
-    vals[i] = i;
+    const u64 key = pack_vox(kx, ky, kz);
+    const u64 val = ((u64)__float_as_uint(dist_to_center(p.x, p.y, p.z, kx, ky, kz, ds)) << 32) | (u64)(~i);
+    uint32_t slot = vox_slot(key, shift);
+    for (;;) {
+        const u64 prev = atomicCAS(tab + 2 * (size_t)slot, ~0ull, key);
+        if (prev == ~0ull || prev == key) break;
+        slot = (slot + 1) & mask;
+    }
+    atomicMin(tab + 2 * (size_t)slot + 1, val);
 }
 
 // (start, count) of a cell and the rank of its brick
@@ -251,37 +333,32 @@ __device__ __forceinline__ uint2 lookup_cell_rank(const GridParams& g, int cx, i
     return make_uint2(a, b - a);
 }
 
-// One thread per run of new points sharing a voxel (the radix sort is stable, so a run lists them in input
-// order).  Final state of the voxel = the single point nearest to its centre among {points already in the map}
-// U {new points}; ties: a new point beats an existing one, a later new point beats an earlier one; a voxel whose
-// single existing point stays nearest is left untouched.
+// Eight lanes per new point; only the voxel's best new point (k_add_insert's table) goes on.  Final state of the voxel = the
+// single point nearest to its centre among {points already in the map} U {new points}; ties: a new point beats an existing
+// one, a later new point beats an earlier one; a voxel whose single existing point stays nearest is left untouched.
 // A displaced map point is removed on the spot: its identity is marked dead (dead_id), its storage slot becomes a
 // tombstone (no search will ever select it), its brick's live count drops.  Threads of other voxels may read that slot
 // while it changes -- either value lies outside THEIR voxel, so it does not matter which they see.
 __global__ void __launch_bounds__(256)
-k_add_resolve(GridParams g, float4* pts_rw /* = g.pts */, const float4* __restrict__ add, const u64* __restrict__ keys_sorted,
-              const uint32_t* __restrict__ vals_sorted, uint32_t n, double ds, uint8_t* __restrict__ dead_id,
-              uint32_t* __restrict__ live, uint32_t* __restrict__ ctr, uint8_t* __restrict__ alive_new) {
-    // eight lanes per run: the cells the voxel box overlaps are dealt to the lanes, so the directory probe -> prefix table
-    // -> points chain of each cell runs side by side instead of one after the other (it was 106 us with one thread per run)
+k_add_resolve(GridParams g, float4* pts_rw /* = g.pts */, const float4* __restrict__ add, const u64* __restrict__ tab, uint32_t mask,
+              int shift, uint32_t n, double ds, uint8_t* __restrict__ dead_id, uint32_t* __restrict__ live, uint32_t* __restrict__ ctr,
+              uint8_t* __restrict__ alive_new) {
+    // eight lanes per point: the cells the voxel box overlaps are dealt to the lanes, so the directory probe -> prefix table
+    // -> points chain of each cell runs side by side instead of one after the other (it was 106 us with one thread per voxel)
     constexpr int L = 8;
     const uint32_t j = (blockIdx.x * 256 + threadIdx.x) / L;
     const int lane = threadIdx.x & (L - 1);
     if (j >= n) return;
-    const u64 key = keys_sorted[j];
-    if (j > 0 && keys_sorted[j - 1] == key) return;  // group-uniform: not the head of its run
-    const float4 p0 = add[vals_sorted[j]];
+    const float4 p0 = add[j];
     long long kx, ky, kz;
     vox_of(p0.x, p0.y, p0.z, ds, kx, ky, kz);
-    // best new point of the run (every lane, the runs are short)
-    uint32_t best_new = vals_sorted[j];
-    float best_d = dist_to_center(p0.x, p0.y, p0.z, kx, ky, kz, ds);
-    for (uint32_t e = j + 1; e < n && keys_sorted[e] == key; ++e) {
-        const uint32_t id = vals_sorted[e];
-        const float4 p = add[id];
-        const float d = dist_to_center(p.x, p.y, p.z, kx, ky, kz, ds);
-        if (d <= best_d) { best_d = d; best_new = id; }  // later wins a tie
-    }
+    const u64 key = pack_vox(kx, ky, kz);
+    uint32_t slot = vox_slot(key, shift);
+    while (tab[2 * (size_t)slot] != key) slot = (slot + 1) & mask;  // present: k_add_insert put it there
+    const u64 best = tab[2 * (size_t)slot + 1];
+    const uint32_t best_new = ~(uint32_t)best;
+    if (best_new != j) return;  // group-uniform: another new point of this voxel is nearer to the centre (or as near and later)
+    const float best_d = __uint_as_float((uint32_t)(best >> 32));
     // existing points in the voxel: every search cell the voxel box overlaps, exact voxel test per point
     const float bx0 = (float)((double)kx * ds), by0 = (float)((double)ky * ds), bz0 = (float)((double)kz * ds);
     const float bx1 = (float)((double)(kx + 1) * ds), by1 = (float)((double)(ky + 1) * ds), bz1 = (float)((double)(kz + 1) * ds);
@@ -386,7 +463,7 @@ constexpr int kTile = 2048;  // points of one brick that fit the LDS tile
 __global__ void __launch_bounds__(256)
 k_ins_prepare(GridParams g, const float4* __restrict__ add, const uint8_t* __restrict__ alive_new, const uint32_t* __restrict__ incl,
               uint32_t n, uint32_t n_ids, float4* __restrict__ map_orig, uint8_t* __restrict__ dead_id, float4* __restrict__ ins,
-              u64* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ ctr) {
+              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ ctr) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n || !alive_new[i]) return;
     const uint32_t r = incl[i] - 1, id = n_ids + r;
@@ -403,14 +480,14 @@ k_ins_prepare(GridParams g, const float4* __restrict__ add, const uint8_t* __res
     }
     p.w = __uint_as_float(id);
     ins[r] = p;
-    keys[r] = (u64)brick_key(cx, cy, cz);
+    keys[r] = brick_key(cx, cy, cz);
     vals[r] = r;
 }
 
 __global__ void __launch_bounds__(128)
 k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g.starts */, uint2* hash /* = g.hash */,
                 uint32_t* __restrict__ cap_end, uint32_t* __restrict__ live, uint32_t* __restrict__ ctr,
-                const float4* __restrict__ ins, const u64* __restrict__ ks, const uint32_t* __restrict__ perm, uint32_t n,
+                const float4* __restrict__ ins, const uint32_t* __restrict__ ks, const uint32_t* __restrict__ perm, uint32_t n,
                 uint32_t pts_cap, uint32_t rows_cap) {
     __shared__ float4 buf[kTile];
     __shared__ uint32_t hist[64], offs[64];
@@ -418,13 +495,13 @@ k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g
     const uint32_t j = blockIdx.x;
     const int tid = threadIdx.x;
     if (j >= n) return;
-    const u64 key = ks[j];
-    if (key == ~0ull) return;               // beyond the surviving points (n is the host's upper bound of their number)
+    const uint32_t key = ks[j];
+    if (key == kEmptyKey) return;           // beyond the surviving points (n is the host's upper bound of their number)
     if (j > 0 && ks[j - 1] == key) return;  // block-uniform: not the head of its brick's run
     uint32_t e = j + 1;
     while (e < n && ks[e] == key) ++e;
     const uint32_t run = e - j;
-    const uint32_t rank = lookup_brick(g, (uint32_t)key);
+    const uint32_t rank = lookup_brick(g, key);
     uint32_t old_base = 0, old_end = 0, old_cap_end = 0;
     if (rank != kEmptyKey) {
         old_base = starts[(size_t)rank * kBrickStride];
@@ -460,7 +537,7 @@ k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g
                 r = atomicAdd(ctr + 1, 1u);
                 if (r >= rows_cap) { atomicOr(ctr + 2, 8u); s_ok = 0; }
                 else {
-                    const uint32_t k32 = (uint32_t)key;
+                    const uint32_t k32 = key;
                     uint32_t slot = hash_slot(k32, g.hash_shift);
                     bool placed = false;
                     for (uint32_t tries = 0; tries <= g.hash_mask; ++tries) {
@@ -521,11 +598,11 @@ k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g
 
 // index-ordered array -> contiguous array of the live points, in order (download, full re-index)
 __global__ void __launch_bounds__(256) k_byte_flags(const uint8_t* __restrict__ in, uint32_t n, int invert, uint32_t* __restrict__ flags,
-                                                    u64* __restrict__ keys_sentinel) {
+                                                    uint32_t* __restrict__ keys_sentinel) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     flags[i] = ((in[i] != 0) != (invert != 0)) ? 1u : 0u;
-    if (keys_sentinel) keys_sentinel[i] = ~0ull;  // k_ins_prepare overwrites the first n_alive of them
+    if (keys_sentinel) keys_sentinel[i] = kEmptyKey;  // k_ins_prepare overwrites the first n_alive of them
 }
 __global__ void __launch_bounds__(256) k_live_compact(const float4* __restrict__ map_orig, const uint32_t* __restrict__ flags,
                                                       const uint32_t* __restrict__ incl, uint32_t n_ids, float4* __restrict__ out) {
@@ -534,6 +611,130 @@ __global__ void __launch_bounds__(256) k_live_compact(const float4* __restrict__
     float4 p = map_orig[i];
     p.w = 0.f;
     out[incl[i] - 1] = p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small map changes (at most kSmallMax points -- every scan of a running odometry): ONE workgroup gives the surviving points
+// their ids, keys them by brick and sorts the keys -- k_byte_flags + the prefix sum + k_ins_prepare + the device-wide sort of
+// the general path (eight launches) in one.  The sort is rocprim's block radix sort over keys re-packed to the bits that
+// actually differ (per axis: brick coordinate - block minimum, in as many bits as the block's range needs): two or three
+// eight-bit passes.  Same outputs in the same buffers as the general path: stable, ascending key, sentinels behind.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallItems = 8;
+constexpr uint32_t kSmallMax = kSmallThreads * kSmallItems;
+using SmallSort = rocprim::block_radix_sort<uint32_t, kSmallThreads, kSmallItems, uint32_t>;
+using SmallScan = rocprim::block_scan<uint32_t, kSmallThreads>;
+struct SmallShared {
+    union {
+        SmallSort::storage_type sort;
+        SmallScan::storage_type scan;
+    } st;
+    uint32_t red[kSmallThreads / 64][6];
+    uint32_t mn[3];
+    int bits[3];
+};
+uint32_t small_change_max() { return kSmallMax; }
+
+__global__ void __launch_bounds__(kSmallThreads)
+k_ins_sort_small(GridParams g, const float4* __restrict__ add, const uint8_t* __restrict__ alive_new, uint32_t n, uint32_t n_ids,
+                 float4* __restrict__ map_orig, uint8_t* __restrict__ dead_id, float4* __restrict__ ins, uint32_t* __restrict__ keys_tmp,
+                 uint32_t* __restrict__ ks, uint32_t* __restrict__ perm, uint32_t* __restrict__ ctr, uint32_t* __restrict__ n_alive_out) {
+    __shared__ SmallShared sh;
+    const uint32_t tid = threadIdx.x;
+    // items in blocked arrangement: thread t holds points 8t .. 8t+7, so ranks follow the input order
+    bool valid[kSmallItems];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int u = 0; u < kSmallItems; ++u) {
+        const uint32_t i = tid * kSmallItems + u;
+        valid[u] = i < n && alive_new[i] != 0;
+        cnt += valid[u] ? 1u : 0u;
+    }
+    uint32_t base = 0, total = 0;
+    SmallScan().exclusive_scan(cnt, base, 0u, total, sh.st.scan);
+    uint32_t key[kSmallItems], val[kSmallItems];
+    uint32_t mn[3] = {1023u, 1023u, 1023u}, mx[3] = {0u, 0u, 0u};
+    uint32_t r = base;
+#pragma unroll
+    for (int u = 0; u < kSmallItems; ++u) {
+        const uint32_t i = tid * kSmallItems + u;
+        key[u] = 0u;
+        val[u] = 0u;
+        if (valid[u]) {
+            const uint32_t id = n_ids + r;
+            float4 p = add[i];
+            p.w = 0.f;
+            map_orig[id] = p;
+            dead_id[id] = 0;
+            int cx, cy, cz;
+            float fx, fy, fz;
+            cell_of(g, p.x, p.y, p.z, cx, cy, cz, fx, fy, fz);
+            if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cy >= (unsigned)g.ny || (unsigned)cz >= (unsigned)g.nz) {
+                atomicOr(ctr + 2, 1u);
+                cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
+            }
+            p.w = __uint_as_float(id);
+            ins[r] = p;
+            key[u] = brick_key(cx, cy, cz);
+            keys_tmp[r] = key[u];
+            val[u] = r;
+            ++r;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const uint32_t f = (key[u] >> (10 * (2 - d))) & 1023u;
+                mn[d] = min(mn[d], f);
+                mx[d] = max(mx[d], f);
+            }
+        }
+    }
+    // block-wide range of each of the key's three 10-bit fields
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            mn[d] = min(mn[d], (uint32_t)__shfl_xor((int)mn[d], o, 64));
+            mx[d] = max(mx[d], (uint32_t)__shfl_xor((int)mx[d], o, 64));
+        }
+    if ((tid & 63u) == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { sh.red[tid >> 6][d] = mn[d]; sh.red[tid >> 6][3 + d] = mx[d]; }
+    }
+    __syncthreads();  // also: the scan's storage is free for the sort
+    if (tid < 3) {
+        uint32_t a = 1023u, b = 0u;
+        for (int k = 0; k < kSmallThreads / 64; ++k) { a = min(a, sh.red[k][tid]); b = max(b, sh.red[k][3 + tid]); }
+        sh.mn[tid] = a;
+        sh.bits[tid] = b > a ? 32 - __clz((int)(b - a)) : 0;  // no surviving point at all: a = 1023 > b = 0 -> 0 bits
+    }
+    __syncthreads();
+    const int b1 = sh.bits[1], b2 = sh.bits[2], nbits = sh.bits[0] + b1 + b2;  // <= 30
+    uint32_t pk[kSmallItems];
+#pragma unroll
+    for (int u = 0; u < kSmallItems; ++u) {
+        const uint32_t f0 = ((key[u] >> 20) & 1023u) - sh.mn[0], f1 = ((key[u] >> 10) & 1023u) - sh.mn[1], f2 = (key[u] & 1023u) - sh.mn[2];
+        pk[u] = valid[u] ? ((f0 << (b1 + b2)) | (f1 << b2) | f2) : (1u << nbits);  // monotone in (z, y, x) brick order; no point: behind all
+    }
+    SmallSort().sort(pk, val, sh.st.sort, 0u, (unsigned)nbits + 1u);
+    __syncthreads();  // keys_tmp was written by other threads of this block
+#pragma unroll
+    for (int u = 0; u < kSmallItems; ++u) {
+        const uint32_t j = tid * kSmallItems + u;
+        if (j < n) {
+            const bool has = j < total;
+            perm[j] = has ? val[u] : 0u;
+            ks[j] = has ? keys_tmp[val[u]] : kEmptyKey;
+        }
+    }
+    if (tid == 0) *n_alive_out = total;
+}
+hipError_t launch_ins_sort_small(const GridParams& g, const float4* add, const uint8_t* alive_new, uint32_t n, uint32_t n_ids,
+                                 float4* map_orig, uint8_t* dead_id, float4* ins, uint32_t* keys_tmp, uint32_t* ks, uint32_t* perm,
+                                 uint32_t* ctr, uint32_t* n_alive_out, hipStream_t st) {
+    if (n == 0 || n > kSmallMax) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_ins_sort_small, dim3(1), dim3(kSmallThreads), 0, st, g, add, alive_new, n, n_ids, map_orig, dead_id, ins, keys_tmp,
+                       ks, perm, ctr, n_alive_out);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -582,21 +783,29 @@ hipError_t launch_aabb(const float4* pts, uint32_t M, uint32_t* out6, hipStream_
     hipLaunchKernelGGL(k_aabb, dim3(blocks), dim3(256), 0, st, pts, M, out6);
     return hipGetLastError();
 }
-hipError_t launch_add_keys(const float4* add, uint32_t n1, uint32_t n, double ds, u64* keys, uint32_t* vals, uint8_t* alive_new,
-                           uint32_t* ctr, hipStream_t st) {
+// slots of the voxel table of a change that down-samples n1 points: a power of two, at most half full
+uint32_t vox_table_slots(uint32_t n1) {
+    uint32_t cap = 64;
+    while (cap < 2u * n1 && cap < (1u << 31)) cap <<= 1;
+    return cap;
+}
+static int vox_shift(uint32_t cap) { return 64 - (31 - __builtin_clz(cap)); }
+hipError_t launch_add_insert(const float4* add, uint32_t n1, uint32_t n, double ds, u64* tab, uint32_t cap, uint8_t* alive_new,
+                             uint32_t* ctr, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_add_keys, dim3(cdiv2(n, 256)), dim3(256), 0, st, add, n1, n, ds, keys, vals, alive_new, ctr);
+    hipLaunchKernelGGL(k_add_insert, dim3(cdiv2(n, 256)), dim3(256), 0, st, add, n1, n, ds, tab, cap - 1u, vox_shift(cap), alive_new, ctr);
     return hipGetLastError();
 }
-hipError_t sort_vox_pairs(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, const uint32_t* vin, uint32_t* vout,
-                          uint32_t n, hipStream_t st) {
-    return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kin, kout, vin, vout, (int)n, 0, 63, st);
+// the surviving points by brick: 30-bit brick keys (sentinel 0xFFFFFFFF behind them), stable
+hipError_t sort_brick_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
+                            uint32_t n, hipStream_t st) {
+    return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kin, kout, vin, vout, (int)n, 0, 32, st);
 }
-hipError_t launch_add_resolve(const GridParams& g, float4* pts_rw, const float4* add, const u64* ks, const uint32_t* vs, uint32_t n,
+hipError_t launch_add_resolve(const GridParams& g, float4* pts_rw, const float4* add, const u64* tab, uint32_t cap, uint32_t n,
                               double ds, uint8_t* dead_id, uint32_t* live, uint32_t* ctr, uint8_t* alive_new, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_add_resolve, dim3(cdiv2((long long)n * 8, 256)), dim3(256), 0, st, g, pts_rw, add, ks, vs, n, ds, dead_id, live, ctr,
-                       alive_new);
+    hipLaunchKernelGGL(k_add_resolve, dim3(cdiv2((long long)n * 8, 256)), dim3(256), 0, st, g, pts_rw, add, tab, cap - 1u, vox_shift(cap),
+                       n, ds, dead_id, live, ctr, alive_new);
     return hipGetLastError();
 }
 hipError_t launch_delete_boxes(const GridParams& g, float4* pts_rw, uint32_t n_slots, const float* boxes, int nb, uint8_t* dead_id,
@@ -606,7 +815,7 @@ hipError_t launch_delete_boxes(const GridParams& g, float4* pts_rw, uint32_t n_s
     return hipGetLastError();
 }
 hipError_t launch_ins_prepare(const GridParams& g, const float4* add, const uint8_t* alive_new, const uint32_t* incl, uint32_t n,
-                              uint32_t n_ids, float4* map_orig, uint8_t* dead_id, float4* ins, u64* keys, uint32_t* vals,
+                              uint32_t n_ids, float4* map_orig, uint8_t* dead_id, float4* ins, uint32_t* keys, uint32_t* vals,
                               uint32_t* ctr, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_ins_prepare, dim3(cdiv2(n, 256)), dim3(256), 0, st, g, add, alive_new, incl, n, n_ids, map_orig, dead_id, ins,
@@ -614,14 +823,14 @@ hipError_t launch_ins_prepare(const GridParams& g, const float4* add, const uint
     return hipGetLastError();
 }
 hipError_t launch_brick_rewrite(const GridParams& g, float4* pts, uint32_t* starts, uint2* hash, uint32_t* cap_end, uint32_t* live,
-                                uint32_t* ctr, const float4* ins, const u64* ks, const uint32_t* perm, uint32_t n, uint32_t pts_cap,
+                                uint32_t* ctr, const float4* ins, const uint32_t* ks, const uint32_t* perm, uint32_t n, uint32_t pts_cap,
                                 uint32_t rows_cap, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_brick_rewrite, dim3(n), dim3(128), 0, st, g, pts, starts, hash, cap_end, live, ctr, ins, ks, perm, n, pts_cap,
                        rows_cap);
     return hipGetLastError();
 }
-hipError_t launch_byte_flags(const uint8_t* in, uint32_t n, int invert, uint32_t* flags, hipStream_t st, u64* keys_sentinel) {
+hipError_t launch_byte_flags(const uint8_t* in, uint32_t n, int invert, uint32_t* flags, hipStream_t st, uint32_t* keys_sentinel) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_byte_flags, dim3(cdiv2(n, 256)), dim3(256), 0, st, in, n, invert, flags, keys_sentinel);
     return hipGetLastError();

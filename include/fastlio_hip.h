@@ -70,6 +70,10 @@ typedef struct flh_config {
     int second_stage_lanes; /* lanes cooperating on one query of the second search stage (the queries the first stage could not
                                settle: 5x5x5 cells inside the first stage's bound): 8 (default, also for any other value), 16
                                or 32.  Performance only */
+    int fused_small_changes; /* 1 (default, also for < 0): a map change of at most 8192 points (flh_map_add, flh_map_incremental:
+                               every scan of a running odometry) gives the surviving points their ids and sorts them by brick in
+                               one workgroup instead of the general path's scan + device-wide sort (one launch instead of eight,
+                               same results); 0: the general path for every size.  Performance only */
 } flh_config;
 enum { FLH_ORDER_SEQ = 0, FLH_ORDER_SSE = 1, FLH_ORDER_PAIRWISE = 2, FLH_ORDER_NOVEC = 3 };
 

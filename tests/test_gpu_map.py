@@ -131,7 +131,13 @@ def test_map_incremental_matches_oracle(prob, fsm):
     # scan with a tail of points nowhere near the map (no neighbour inside the search bound)
     rng = np.random.default_rng(3)
     tail = (pr.body[:400] * 0.0 + rng.uniform(150, 400, (400, 3))).astype(np.float32)
-    body = np.vstack([pr.body, tail]).astype(np.float32)
+    # ... and of points in the empty space in and around the map, metres to tens of metres from the nearest map point (their
+    # points_near[0] comes from the shell search of k_far_nearest, which must stop at exactly the right shell)
+    lo, hi = pr.map_xyz.min(0) - 30.0, pr.map_xyz.max(0) + 30.0
+    Rw, tw = synth.quat_to_R(pr.x_true[3:7]), pr.x_true[0:3]
+    gaps_world = rng.uniform(lo, hi, (1500, 3))
+    gaps = ((gaps_world - tw) @ Rw).astype(np.float32)   # body frame of the true pose (identity extrinsic in this problem or not: any body point will do)
+    body = np.vstack([pr.body, tail, gaps]).astype(np.float32)
     h.scan_upload(body)
     sc = po.Scan(body, nthreads=8)
     # the passes of one update, driven identically on both sides: search at the prior, two re-linearisations
@@ -531,3 +537,46 @@ def test_brickwise_updates_and_every_fallback(prob):
     assert st["ids"] > h.M == len(cur)
     same_points(h.map_download(), cur, "after Delete_Point_Boxes")
     assert search_matches(h, cur, pr.body, pr.x_true) > 1000
+
+
+# ---------------------------------------------------------------------------------------------- small map changes
+@pytest.mark.parametrize("downsample", [True, False])
+def test_small_changes_in_one_workgroup_equal_the_general_path(prob, downsample):
+    """flh_config.fused_small_changes: a change of at most 8192 points gives its surviving points their ids and sorts them by
+    brick in one workgroup; larger ones (and every one with the option off) take the scan + device-wide sort.  Same map, same
+    bookkeeping, at the size limit and on both sides of it."""
+    pr = prob
+    rng = np.random.default_rng(77)
+    hs = [capi.Handle(fused_small_changes=f) for f in (1, 0)]
+    for h in hs:
+        h.map_build(pr.map_xyz)
+    cur = pr.map_xyz.astype(np.float32)
+    for n in (1, 2, 63, 1000, 8191, 8192, 8193, 5000):
+        add = (cur[rng.integers(0, len(cur), n)] + rng.normal(0, 0.25, (n, 3))).astype(np.float32)
+        if n >= 63:  # crowded voxels, exact duplicates, a few new bricks beside the map
+            add[: n // 8] = add[n // 8: 2 * (n // 8)]
+            add[-(n // 16):] = (cur.max(0) + rng.uniform(2.0, 20.0, (n // 16, 3))).astype(np.float32)
+        cur = po.map_add(cur, add, downsample, DS)
+        stats = []
+        for h in hs:
+            h.map_add(add, downsample, DS)
+            same_points(h.map_download(), cur, f"n={n}")
+            stats.append(h.map_stats())
+        assert stats[0] == stats[1], (n, stats)
+    assert search_matches(hs[0], cur, pr.body, pr.x_true) > 1000
+
+
+def test_map_add_spanning_kilometres():
+    """A change whose points are spread over kilometres: thousands of voxels and bricks with one point each (a voxel table
+    with long probe sequences, brick keys that differ in every bit field), against the oracle, with and without the
+    one-workgroup path."""
+    rng = np.random.default_rng(9)
+    box = np.array([600.0, 600.0, 300.0], np.float32)
+    m = rng.uniform(-box, box, (30000, 3)).astype(np.float32)
+    add = np.vstack([rng.uniform(-box, box, (5000, 3)), m[rng.integers(0, len(m), 2000)] + rng.normal(0, 0.1, (2000, 3))]).astype(np.float32)
+    want = po.map_add(m, add, True, DS)
+    for f in (1, 0):
+        h = capi.Handle(fused_small_changes=f)
+        h.map_build(m)
+        h.map_add(add, True, DS)
+        same_points(h.map_download(), want, f"fused={f}")

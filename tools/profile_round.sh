@@ -19,7 +19,7 @@ args_of() { case $1 in
   5) echo "--steps 60 --warmup 6 --scans 8";;
 esac; }
 cd $R
-timeout 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -3 | tee $O/r${RND}_gpu_tests.txt
+timeout 900 python -m pytest tests -q -m gpu -x 2>&1 | grep -E "passed|failed|error" | tail -3 | tee $O/r${RND}_gpu_tests.txt
 el "gpu suite"
 timeout $T python bench.py --steps 20 --warmup 5 > $O/r${RND}_bench_driver_cmd_config2.json 2> $O/driver.err; echo "driver command rc=$?"; python tools/bench_line.py $O/r${RND}_bench_driver_cmd_config2.json
 el "driver command"
