@@ -196,17 +196,24 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-constexpr int kTop = 8;  // packed keys kept per lane / per group: the five wanted + three to see ties at the boundary
-__device__ __forceinline__ void ins8(uint32_t (&K)[kTop], uint32_t t) {
+constexpr int kTop = 8;  // packed keys kept per lane / per group: the five wanted + up to three to see ties at the boundary
+// KT = how many of them the candidate loop maintains (the rest stay empty): 8, or 6 where a tie at the boundary may simply go to
+// the next stage (the first stage: a 6th neighbour within 2^-15 relative of the 5th is a rarity, two VALU ops per candidate are not)
+template <int KT>
+__device__ __forceinline__ void insK(uint32_t (&K)[kTop], uint32_t t) {
+    static_assert(KT == 6 || KT == 8, "KT");
     const uint32_t n0 = min(K[0], t);
     const uint32_t n1 = umed3(K[0], K[1], t);
     const uint32_t n2 = umed3(K[1], K[2], t);
     const uint32_t n3 = umed3(K[2], K[3], t);
     const uint32_t n4 = umed3(K[3], K[4], t);
     const uint32_t n5 = umed3(K[4], K[5], t);
-    const uint32_t n6 = umed3(K[5], K[6], t);
-    const uint32_t n7 = umed3(K[6], K[7], t);
-    K[0] = n0; K[1] = n1; K[2] = n2; K[3] = n3; K[4] = n4; K[5] = n5; K[6] = n6; K[7] = n7;
+    if (KT == 8) {
+        const uint32_t n6 = umed3(K[5], K[6], t);
+        const uint32_t n7 = umed3(K[6], K[7], t);
+        K[6] = n6; K[7] = n7;
+    }
+    K[0] = n0; K[1] = n1; K[2] = n2; K[3] = n3; K[4] = n4; K[5] = n5;
 }
 __device__ __forceinline__ void cex2(uint32_t& a, uint32_t& b) {  // a <= b after
     const uint32_t lo = min(a, b), hi = max(a, b);
@@ -284,6 +291,13 @@ __device__ __forceinline__ float4 load_pt(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
 }
 
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// c ? a : b as one v_cndmask (the compiler turns chains of ?: on loaded values into jump trees)
+__device__ __forceinline__ uint32_t sel_u32(bool c, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(__builtin_amdgcn_ballot_w64(c)));
+    return r;
+}
 __device__ __forceinline__ u32x3 load_xyz(__amdgpu_buffer_rsrc_t rsrc, uint32_t idx) {  // coordinates only (12 of the 16 B)
     return __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(idx << 4), 0, 0);
 }
