@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--timing-samples", type=int, default=16,
                     help="searching evaluations of the timed region whose kernels carry HIP events (start / stop time stamps of "
                          "the kernels themselves); at 20 steps (40 searches) every third one: 14 samples, both kinds of search")
+    ap.add_argument("--event-stride", type=int, default=0,
+                    help="developer: sample every n-th searching evaluation with events, ALSO under a profiler (0 = the default "
+                         "sampling, none under a profiler)")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the headline + roofline (profiling runs)")
     ap.add_argument("--cpu-scans", type=int, default=96,
                     help="upper bound of the scans timed on the CPU oracle at --cpu-threads (it stops after ~12 s; 0 = skip)")
@@ -305,10 +308,9 @@ def main():
         # sampled evaluation, so only SEARCHING evaluations are sampled -- the roofline is the search's -- every n-th of them,
         # n odd: a scan's first and later searches alternate, an odd stride samples both kinds alike
         stride = max(3, (n_steps * 2) // max(args.timing_samples, 8))
-        # under a profiler (rocprofv3 sets ROCP_TOOL_LIBRARIES) no events: its trace IS the kernel timing, and the one device
-        # fault this round happened in a profiled run whose dispatches carried both the profiler's and our
-        # time-stamp requests
-        hx.set_timing_sampling(0 if PROFILED else stride + 1 - (stride & 1), True)
+        # under a profiler (rocprofv3 sets ROCP_TOOL_LIBRARIES) no events: its trace IS the kernel timing and stays free of the
+        # events' cost (--event-stride forces them: DESIGN.md 6, the fault hunt)
+        hx.set_timing_sampling(args.event_stride if args.event_stride > 0 else (0 if PROFILED else stride + 1 - (stride & 1)), True)
         hx.counters(reset=True)
         t1 = time.perf_counter()
         rs = kfx.run_scans(jobs, n_warm, n_steps, ring=RING, map_incremental=with_map_inserts, first_staged=n_warm > 0)
