@@ -152,7 +152,7 @@ def main():
                     help="1 = the fp16 plane-fit ABLATION of BASELINE configs[4] (not bit-exact, never a parity claim)")
     ap.add_argument("--timing-samples", type=int, default=16,
                     help="searching evaluations of the timed region whose kernels carry HIP events (start / stop time stamps of "
-                         "the kernels themselves); at 20 steps (40 searches) every third one: 14 samples, both kinds of search")
+                         "the kernels themselves); at 20 steps (40 searches) every fifth one: 8 samples, both kinds of search")
     ap.add_argument("--event-stride", type=int, default=0,
                     help="developer: sample every n-th searching evaluation with events, ALSO under a profiler (0 = the default "
                          "sampling, none under a profiler)")
@@ -307,7 +307,7 @@ def main():
         # The kernels of a sampled evaluation carry HIP events (read after the timed region); that costs the host ~10 us per
         # sampled evaluation, so only SEARCHING evaluations are sampled -- the roofline is the search's -- every n-th of them,
         # n odd: a scan's first and later searches alternate, an odd stride samples both kinds alike
-        stride = max(3, (n_steps * 2) // max(args.timing_samples, 8))
+        stride = max(5, (n_steps * 2) // max(args.timing_samples, 8))  # at most one searching evaluation in five carries events
         # under a profiler (rocprofv3 sets ROCP_TOOL_LIBRARIES) no events: its trace IS the kernel timing and stays free of the
         # events' cost (--event-stride forces them: DESIGN.md 6, the fault hunt)
         hx.set_timing_sampling(args.event_stride if args.event_stride > 0 else (0 if PROFILED else stride + 1 - (stride & 1)), True)
