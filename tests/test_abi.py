@@ -40,3 +40,23 @@ def test_no_cpu_fallback_without_gpu():
         pytest.skip("a GPU is visible; the loud-failure path is for CPU-only boxes")
     with pytest.raises(capi.FlhError, match="no HIP device"):
         capi.Handle()
+
+
+def test_config_mirror_matches_the_c_struct():
+    """capi.FlhConfig must lay out exactly as `flh_config` in include/fastlio_hip.h: same fields in the same order (parsed from the
+    header), and flh_default_config's values land in the fields they belong to (a shifted field would show up here, on a
+    CPU-only box, instead of as a wrong kernel choice on the GPU)."""
+    hdr = open(os.path.join(ROOT, "include", "fastlio_hip.h")).read()
+    body = hdr[hdr.index("typedef struct flh_config {"):hdr.index("} flh_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(?:int|float|void\s*\*)\s*([a-z_0-9]+)\s*;", body)
+    assert fields == [f for f, _ in capi.FlhConfig._fields_], (fields, [f for f, _ in capi.FlhConfig._fields_])
+    cfg = capi.FlhConfig()
+    C.memset(C.byref(cfg), 0x5A, C.sizeof(cfg))
+    capi.lib().flh_default_config(C.byref(cfg))
+    assert cfg.device == -1 and cfg.lanes_per_query == 4 and cfg.first_stage == 0 and cfg.plane_fit_dtype == 0
+    assert cfg.cell_size == 1.5 and cfg.max_sqdist == 5.0 and abs(cfg.plane_threshold - 0.1) < 1e-7
+    assert not cfg.stream
+    # "default" markers the library resolves in flh_create
+    assert (cfg.sort_queries, cfg.eigen_order, cfg.undistort_first_point, cfg.plane_cache, cfg.fused_small_changes) == (-1,) * 5
+    assert cfg.second_stage_lanes == 0
