@@ -1,0 +1,129 @@
+"""The CPU oracle against INDEPENDENT implementations (scipy / numpy), not against its own brute-force twin: a third party's
+k-d tree for the 5-NN, scipy's Rotation for SO(3) and the body->world transform, numpy's least squares for the plane, a
+dictionary-based voxel filter for Add_Points.  These do not pin the oracle to the reference's bits (nothing here can: Eigen,
+PCL and ikd-Tree are absent) -- they pin it to the mathematics the cited reference lines implement, through code
+that shares nothing with the restatement.  CPU only."""
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+from scipy.spatial.transform import Rotation
+
+from fast_lio_amd import synth
+from oracle import pyoracle as po
+
+RNG = np.random.default_rng(20240807)
+
+
+def test_knn5_matches_scipy_ckdtree():
+    """ikdtree.Nearest_Search (src/laserMapping.cpp:666): same five neighbours in the same order as scipy's k-d tree (fp64 on the
+    same fp32 coordinates); squared distances equal to fp32 rounding.  Queries on and off the map, clustered and sparse."""
+    pts = np.vstack([RNG.uniform(-30, 30, (20000, 3)), RNG.normal(0, 0.3, (5000, 3)) + [5, 5, 1]]).astype(np.float32)
+    m = po.Map(pts)
+    t = cKDTree(pts.astype(np.float64))
+    q = np.vstack([RNG.uniform(-35, 35, (3000, 3)), RNG.normal(0, 0.5, (1000, 3)) + [5, 5, 1]]).astype(np.float32)
+    idx, d2, cnt = m.knn5_batch(q, nthreads=4)
+    dd, ii = t.query(q.astype(np.float64), k=5)
+    assert np.all(cnt == 5)
+    np.testing.assert_allclose(d2, dd ** 2, rtol=2e-6, atol=1e-9)
+    # indices: identical wherever the five distances (and the sixth) are distinct beyond fp32 resolution
+    d6 = t.query(q.astype(np.float64), k=6)[0] ** 2
+    gaps = np.diff(d6, axis=1).min(axis=1) > 1e-5 * np.maximum(d6[:, 5], 1e-6)
+    assert gaps.mean() > 0.9
+    np.testing.assert_array_equal(idx[gaps], ii[gaps])
+
+
+def test_so3_and_body_to_world_match_scipy_rotation():
+    """SO3::exp / log (IKFoM mtk) and pointBodyToWorld (src/laserMapping.cpp:656-660) against scipy.spatial.transform."""
+    for _ in range(200):
+        v = RNG.normal(size=3) * RNG.choice([1e-6, 1e-2, 1.0, 3.0])
+        q = po.so3_exp(v)
+        r = Rotation.from_rotvec(v)
+        np.testing.assert_allclose(np.abs(q @ r.as_quat()), 1.0, atol=1e-13)   # same rotation (q and -q are one)
+        v2 = po.so3_log(q)
+        np.testing.assert_allclose(Rotation.from_rotvec(v2).as_matrix(), r.as_matrix(), atol=1e-12)
+    x = synth.make_state(pos=(1.5, -2.0, 0.7), rot=Rotation.from_rotvec([0.3, -0.2, 1.1]).as_quat(),
+                         offR=Rotation.from_rotvec([0.01, 0.02, -0.03]).as_quat(), offT=(0.04, 0.02, -0.03))
+    pts = RNG.uniform(-50, 50, (2000, 3)).astype(np.float32)
+    w = po.points_body_to_world(x, pts)
+    R, RL = Rotation.from_quat(x[3:7]), Rotation.from_quat(x[7:11])
+    ref = R.apply(RL.apply(pts.astype(np.float64)) + x[11:14]) + x[0:3]
+    np.testing.assert_allclose(w, ref.astype(np.float32), rtol=0, atol=8e-6)  # one fp32 rounding at |w| <= 100 m
+
+
+def test_esti_plane_matches_numpy_least_squares():
+    """esti_plane (include/common_lib.h:225-257): A n = -1 by QR; the unit normal and offset against numpy.linalg.lstsq, the
+    verdict against the threshold recomputed in fp64."""
+    ok_seen = bad_seen = 0
+    for _ in range(300):
+        n0 = RNG.normal(size=3)
+        n0 /= np.linalg.norm(n0)
+        c = RNG.uniform(-20, 20, 3)
+        u = np.cross(n0, RNG.normal(size=3))
+        u /= np.linalg.norm(u)
+        v = np.cross(n0, u)
+        noise = RNG.choice([0.0, 0.01, 0.2])
+        P = (c + RNG.uniform(-1, 1, (5, 1)) * u + RNG.uniform(-1, 1, (5, 1)) * v + RNG.normal(0, noise, (5, 1)) * n0).astype(np.float32)
+        ok, pabcd = po.esti_plane(P, 0.1)
+        sol = np.linalg.lstsq(P.astype(np.float64), -np.ones(5), rcond=None)[0]
+        nn = np.linalg.norm(sol)
+        ref = np.r_[sol / nn, 1.0 / nn]
+        res = np.abs(P.astype(np.float64) @ ref[:3] + ref[3])
+        if res.max() < 0.09 or res.max() > 0.11:   # away from the threshold the verdict must agree
+            assert ok == (res.max() <= 0.1)
+        if ok:
+            np.testing.assert_allclose(pabcd, ref, rtol=0, atol=5e-4 * max(1.0, abs(ref[3])) + 2e-4)  # fp32 QR at |p| <= 20 m
+            ok_seen += 1
+        else:
+            bad_seen += 1
+    assert ok_seen > 50 and bad_seen > 50
+
+
+def _voxel_filter_reference(map_xyz, add_xyz, ds):
+    """Add_Points(points, downsample_on = true), stated with dictionaries: per voxel touched by a new point, the point nearest
+    to the voxel centre among the map's and the new ones survives (new beats old and later beats earlier at equal distance; a
+    voxel whose single old point stays nearest is left alone); survivors keep the map's order, new ones are appended in input order."""
+    def vox(p):
+        return tuple(np.floor(p.astype(np.float64) / ds).astype(np.int64))
+
+    def dist(p, k):
+        c = (np.array(k, np.float64) * ds + 0.5 * ds).astype(np.float32)
+        d = p - c
+        return np.float32(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+
+    old = {}
+    for i, p in enumerate(map_xyz):
+        old.setdefault(vox(p), []).append(i)
+    new = {}
+    for j, p in enumerate(add_xyz):
+        new.setdefault(vox(p), []).append(j)
+    dead, keep_new = set(), []
+    for k, js in new.items():
+        best_j, best_d = None, None
+        for j in js:
+            d = dist(add_xyz[j], k)
+            if best_d is None or d <= best_d:
+                best_j, best_d = j, d
+        olds = old.get(k, [])
+        if olds:
+            ds_old = [dist(map_xyz[i], k) for i in olds]
+            bi = int(np.argmin(ds_old))  # first (lowest index) among equals
+            if ds_old[bi] < best_d:
+                if len(olds) == 1:
+                    continue
+                dead.update(i for i in olds if i != olds[bi])
+                continue
+            dead.update(olds)
+        keep_new.append(best_j)
+    keep_old = [i for i in range(len(map_xyz)) if i not in dead]
+    return np.vstack([map_xyz[keep_old], add_xyz[sorted(keep_new)]]).astype(np.float32)
+
+
+@pytest.mark.parametrize("ds", [0.5, 0.3])
+def test_map_add_matches_a_dictionary_voxel_filter(ds):
+    m = RNG.uniform(-6, 6, (4000, 3)).astype(np.float32)
+    add = np.vstack([m[RNG.integers(0, len(m), 1500)] + RNG.normal(0, 0.15, (1500, 3)), RNG.uniform(-8, 8, (1500, 3)),
+                     (RNG.integers(-12, 12, (400, 3)) / 4.0)]).astype(np.float32)   # the last block ties exactly
+    got = po.map_add(m, add, True, ds)
+    want = _voxel_filter_reference(m, add, ds)
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
