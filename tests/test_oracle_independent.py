@@ -127,3 +127,90 @@ def test_map_add_matches_a_dictionary_voxel_filter(ds):
     want = _voxel_filter_reference(m, add, ds)
     assert got.shape == want.shape
     np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_map_incremental_decisions_match_a_numpy_restatement_on_scipy_neighbours():
+    """map_incremental (src/laserMapping.cpp:427-474) written again in numpy straight from those lines, fed with scipy's nearest
+    neighbours instead of the oracle's: same add / no-downsample / skip decision for every scan point whose neighbour set is not
+    a tie.  (Nearest_Points come from the LAST search -- at the search state -- while the world point and the voxel centre use the
+    posterior, exactly as in the node.)"""
+    pr = synth.make_problem(60000, 5000, "avia", cfg=1)
+    fsm = 0.5
+    m = po.Map(pr.map_xyz)
+    sc = po.Scan(pr.body, nthreads=4)
+    x_search, x_post = pr.x_prior, pr.x_true
+    sc.h_share_model(m, x_search, True, False)
+    w_ref, c_ref = sc.map_incremental_classify(m, x_post, fsm, True)
+    # ---- the independent side
+    mp = pr.map_xyz.astype(np.float32)
+    tree = cKDTree(mp.astype(np.float64))
+    ws = po.points_body_to_world(x_search, pr.body).astype(np.float64)   # where the last search looked
+    d6, i6 = tree.query(ws, k=6)
+    tie = np.diff(d6 ** 2, axis=1).min(axis=1) <= 1e-5 * np.maximum(d6[:, 5] ** 2, 1e-6)
+    near = mp[i6[:, :5]]                                                 # points_near[0..4], nearest first
+    w = po.points_body_to_world(x_post, pr.body)                         # feats_down_world (float)
+    np.testing.assert_array_equal(w.view(np.uint32), w_ref.view(np.uint32))
+    mid = (np.floor(w.astype(np.float64) / fsm) * fsm + 0.5 * fsm).astype(np.float32)
+
+    def calc_dist(a, b):                                                 # include/common_lib.h: float arithmetic, x, y, z in turn
+        d = (a - b).astype(np.float32)
+        return (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]).astype(np.float32) + d[..., 2] * d[..., 2]
+
+    dist = calc_dist(w, mid)
+    far = np.all(np.abs(near[:, 0].astype(np.float64) - mid.astype(np.float64)) > 0.5 * fsm, axis=1)
+    veto = np.any(calc_dist(near, mid[:, None, :]) < dist[:, None], axis=1)
+    cls = np.where(far, 2, np.where(veto, 0, 1)).astype(np.uint8)
+    ok = ~tie
+    assert ok.mean() > 0.95 and len(set(cls[ok])) == 3                   # all three classes occur
+    np.testing.assert_array_equal(cls[ok], c_ref[ok])
+
+
+@pytest.mark.parametrize("ext", [False, True])
+def test_h_share_model_matches_a_float64_numpy_restatement(ext):
+    """h_share_model (src/laserMapping.cpp:640-756) in numpy / scipy, fp64 throughout: scipy neighbours, lstsq planes, the
+    selection rule, the Jacobian rows.  The oracle works in the reference's mixed fp32 / fp64, so flags are compared away from
+    their thresholds and numbers to fp32 accuracy."""
+    pr = synth.make_problem(60000, 4000, "avia", cfg=1)
+    m = po.Map(pr.map_xyz)
+    sc = po.Scan(pr.body, nthreads=4)
+    x = pr.x_true
+    assert sc.h_share_model(m, x, True, ext)
+    sel = sc.selected.astype(bool)
+    # ---- independent side
+    R, RL, t, tL = Rotation.from_quat(x[3:7]), Rotation.from_quat(x[7:11]), x[0:3], x[11:14]
+    pb = pr.body.astype(np.float64)
+    pw = R.apply(RL.apply(pb) + tL) + t
+    mp = pr.map_xyz.astype(np.float32).astype(np.float64)
+    d, idx = cKDTree(mp).query(pw, k=5)
+    gate = d[:, 4] ** 2 <= 5.0                                                             # :671
+    P = mp[idx]                                                                            # (N, 5, 3)
+    sol = np.stack([np.linalg.lstsq(P[i], -np.ones(5), rcond=None)[0] for i in range(len(pb))])
+    nn = np.linalg.norm(sol, axis=1)
+    nrm, dd = sol / nn[:, None], 1.0 / nn
+    fit_res = np.abs(np.einsum("nkj,nj->nk", P, nrm) + dd[:, None]).max(axis=1)           # esti_plane's 0.1 threshold
+    pd2 = np.einsum("nj,nj->n", nrm, pw) + dd
+    s = 1 - 0.9 * np.abs(pd2) / np.sqrt(np.linalg.norm(pb, axis=1))                        # :693
+    want = gate & (fit_res <= 0.1) & (s > 0.9)
+    clear = (np.abs(d[:, 4] ** 2 - 5.0) > 1e-3) & (np.abs(fit_res - 0.1) > 2e-3) & (np.abs(s - 0.9) > 2e-3)
+    assert clear.mean() > 0.8
+    np.testing.assert_array_equal(sel[clear], want[clear])
+    both = sel & want & clear
+    assert both.sum() > 500 and sc.n_eff == int(sel.sum())
+    # normals, residuals (normvec.intensity = pd2) and Jacobian rows of the selected points, in the oracle's row order
+    nv = sc.normvec
+    np.testing.assert_allclose(nv[both, :3], nrm[both], atol=2e-3)
+    np.testing.assert_allclose(nv[both, 3], pd2[both], atol=2e-3)
+    rows = np.cumsum(sel) - 1
+    hx, h = sc.h_x, sc.h
+    pthis = RL.apply(pb) + tL
+    C_ = R.inv().apply(nv[:, :3].astype(np.float64))                                       # built from the oracle's own normals: tests the algebra
+    A_ = np.cross(pthis, C_)
+    B_ = np.cross(pb, RL.inv().apply(C_))
+    k = np.flatnonzero(both)[:400]
+    for i in k:
+        r = hx[rows[i]]
+        np.testing.assert_allclose(r[0:3], nv[i, :3], atol=1e-7)
+        np.testing.assert_allclose(r[3:6], A_[i], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(r[6:9], B_[i] if ext else 0.0, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(r[9:12], C_[i] if ext else 0.0, rtol=1e-9, atol=1e-9)
+        assert h[rows[i]] == -np.float64(nv[i, 3])
