@@ -302,9 +302,64 @@ def test_iekf_pass_is_a_gauss_newton_step_on_the_manifold(form):
     # position, both rotations, lever arm, velocity, biases: the exact Gauss-Newton step
     np.testing.assert_allclose(dx[:21], d[:21], rtol=0, atol=1e-8 * max(scale, 1e-3))
     # gravity (S2): differs by ~1e-4 of the gravity correction, identically for every finite-difference step and for both
-    # forms of the pass -- IKFoM's closed-form S2 Jacobians (Nx / Mx) are not the exact derivative of its own S2
-    # boxminus(boxplus(.)) away from zero (cf. tests/test_oracle_kat.py::test_S2_Mx_zero_delta_and_quirk); the restatement keeps
-    # the reference's formulas, so this block is the reference's step, not the textbook one
+    # forms of the pass -- IKFoM's S2 Jacobian Mx takes `exp(Bu, scalar_type(1/2))` with 1/2 in integer arithmetic, i.e. the
+    # identity (mtk S2.hpp:277; cf. tests/test_oracle_kat.py::test_S2_Mx_zero_delta_and_quirk), so it is the exact derivative
+    # only at zero; the restatement keeps the reference's formulas, so this block is the reference's step, not the textbook one
     np.testing.assert_allclose(dx[21:], d[21:], rtol=2e-3, atol=1e-8)
     assert np.abs(dx[21:] - d[21:]).max() < 1e-5
     np.testing.assert_allclose(po.state_boxminus(x_new, po.state_boxplus(x, dx)), 0.0, atol=1e-9)
+
+
+def test_predict_matches_scipy_propagation_and_a_finite_difference_covariance():
+    """esekf::predict with FAST-LIO's process model (use-ikfom.hpp get_f / df_dx / df_dw, esekfom.hpp:280-381): the mean against
+    the model written with scipy rotations (exact), the covariance against F P F^T + G Q G^T with F and G taken by central
+    differences of that mean propagation.  The reference's F = F_x1 + f_x dt is first order in dt, so the two covariances differ
+    at most in second order -- in fact not at all, every block being linear in dt -- with ONE exception the independent model
+    exposes: the rotation's own block.  Its true Jacobian is Exp(-(w - bg) dt); esekfom.hpp:312 computes
+    `exp(res.vec(), seg_SO3, scalar_type(1/2))`, and 1/2 is integer division, so the block stays the identity.  The restatement
+    keeps that (oracle_math.c: "quirk, esekfom.hpp:312"), and this test pins it: with the finite-difference block replaced by I the
+    two covariances agree to the noise of the differences; without the replacement they differ in first order (|w| dt)."""
+    rng = np.random.default_rng(8)
+    x = synth.make_state(pos=(1, -2, 0.5), rot=Rotation.from_rotvec([0.2, -0.4, 0.9]).as_quat(), offR=Rotation.from_rotvec([0.01, 0.0, 0.02]).as_quat(),
+                         offT=(0.04, 0.02, -0.03), vel=(1.5, -0.7, 0.2), bg=(0.01, -0.02, 0.005))
+    x[20:23] = (0.05, -0.03, 0.02)                                  # accelerometer bias
+    A_ = rng.normal(size=(23, 23)) * 0.01
+    P = A_ @ A_.T + np.diag(rng.uniform(1e-4, 1e-2, 23))
+    Q = po.process_noise_cov()
+    acc, gyr = np.array([0.3, -0.2, 9.9]), np.array([0.4, -0.1, 0.25])
+
+    def run(dt):
+        def mean(xx, a=acc, g=gyr):
+            R = Rotation.from_quat(xx[3:7])
+            y = xx.copy()
+            y[0:3] = xx[0:3] + xx[14:17] * dt
+            y[3:7] = (R * Rotation.from_rotvec((g - xx[17:20]) * dt)).as_quat()
+            y[14:17] = xx[14:17] + (R.apply(a - xx[20:23]) + xx[23:26]) * dt
+            return y
+
+        x1, P1 = po.predict(x, P, dt, Q, acc, gyr)
+        base = mean(x)
+        np.testing.assert_allclose(po.state_boxminus(x1, base), 0.0, atol=1e-12)
+        eps = 1e-6
+        F = np.stack([(po.state_boxminus(mean(po.state_boxplus(x, eps * np.eye(23)[k])), base)
+                       - po.state_boxminus(mean(po.state_boxplus(x, -eps * np.eye(23)[k])), base)) / (2 * eps) for k in range(23)], axis=1)
+
+        # process noise (n_g, n_a, n_bg, n_ba): gyro and accelerometer noise through the measurement, the bias walks directly
+        def mean_w(w):
+            y = mean(x, acc - w[3:6], gyr - w[0:3])
+            y[17:20] += w[6:9] * dt
+            y[20:23] += w[9:12] * dt
+            return y
+        G = np.stack([(po.state_boxminus(mean_w(eps * np.eye(12)[k]), base) - po.state_boxminus(mean_w(-eps * np.eye(12)[k]), base)) / (2 * eps)
+                      for k in range(12)], axis=1)
+        true_rot_block = F[3:6, 3:6].copy()
+        F[3:6, 3:6] = np.eye(3)                                        # esekfom.hpp:312, scalar_type(1/2) == 0
+        err_quirk = np.abs(P1 - (F @ P @ F.T + G @ Q @ G.T)).max()
+        F[3:6, 3:6] = true_rot_block
+        err_true = np.abs(P1 - (F @ P @ F.T + G @ Q @ G.T)).max()
+        return err_quirk, err_true, np.abs(P1 - P).max()
+
+    e1, t1, step1 = run(0.005)
+    e2, t2, _ = run(0.00125)
+    assert e1 < 1e-10 and e2 < 1e-10 and step1 > 1e-5          # with the identity block: equal to the noise of the finite differences
+    assert t1 > 1e-6 and 3.0 < t1 / t2 < 5.0                   # against the textbook Jacobian: off in FIRST order (4x for dt / 4)
