@@ -79,13 +79,13 @@ def pmc_traffic(args):
         here = src_hash()
     except Exception:  # noqa: BLE001
         here = None
-    if not meta or meta.get("src_hash") != here or int(meta.get("first_stage", -1)) != int(args.first_stage):
+    if not meta or meta.get("src_hash") != here or int(meta.get("pass_kernel", -2)) != int(args.pass_kernel):
         return {"stale": True, "source": os.path.relpath(path, ROOT), "summary_src_hash": meta.get("src_hash"), "running_src_hash": here}
     fetch, write, calls = {}, {}, {}
     with open(path) as f:
         for r in csv.DictReader(f):
             k = r["kernel"]
-            if not k.startswith("k_search"):
+            if not (k.startswith("k_search") or k.startswith("k_pass")):
                 continue
             if r["counter"] == "FETCH_SIZE":
                 fetch[k] = float(r["sum"])
@@ -94,10 +94,10 @@ def pmc_traffic(args):
                 write[k] = float(r["sum"])
     import re
 
-    second = [k for k in calls if re.match(r"k_search_ring<\d+, 2,", k)]
+    second = [k for k in calls if re.match(r"k_search_ring<\d+, 2,", k) or k.startswith("k_pass")]
     if not second or not fetch:
         return None
-    passes = sum(calls[k] for k in second)  # every search pass launches the second stage exactly once
+    passes = sum(calls[k] for k in second)  # every search pass launches k_pass (three-launch pass: the second stage) exactly once
     total = (2.0 * sum(fetch.values()) + sum(write.values())) * 1024.0 / passes
     return {"bytes_per_search_pass": int(total), "src_hash": here, "commit": meta.get("commit"),
             "source": os.path.relpath(path, ROOT) + " (FETCH_SIZE x2 + WRITE_SIZE, KiB)"}
@@ -136,17 +136,21 @@ def main():
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--scans", type=int, default=128, help="distinct seeded scans cycled through (>= 100 by default)")
     ap.add_argument("--mode", default="auto", choices=["auto", "streams", "shard", "partition"],
-                    help="multi-GPU: streams = one independent scan stream per rank, replicated map, no collective "
-                         "(weak scaling; the headline value); shard = ONE scan's points split over the ranks + RCCL "
-                         "all-reduce of the 16x16 normal-equation block per pass (strong scaling); partition = the map cut "
-                         "into one slab per rank, whole scan on every rank (BASELINE configs[4]).  auto = streams, plus a short "
-                         "shard-mode (config 5: partition-mode) leg reported under \"shard_mode\"")
+                    help="multi-GPU: shard = ONE scan's points split over the ranks, the ranks' normal equations summed per "
+                         "pass (--exchange; strong scaling); partition = the map cut into one slab per rank, whole scan on every "
+                         "rank (BASELINE configs[4]); streams = one independent scan stream per rank, replicated map, nothing "
+                         "exchanged (replicas).  auto = one GPU: streams; N > 1: shard (config 5: partition) as the headline "
+                         "value, the replicas as a sub-field")
     ap.add_argument("--lpq", type=int, default=4)
     ap.add_argument("--cell", type=float, default=1.5)
-    ap.add_argument("--first-stage", type=int, default=0)
+    ap.add_argument("--pass-kernel", type=int, default=-1,
+                    help="flh_config.pass_kernel: -1 / 1 = a searching pass is ONE launch (the library's default), 0 = the three-launch pass")
+    ap.add_argument("--exchange", default="peer", choices=["peer", "rccl"],
+                    help="N > 1: how the ranks' normal equations meet -- peer = granules written into every rank's pinned buffer "
+                         "(no collective, no extra launch; the default), rccl = ncclAllReduce of the 16x16 block on the device + a "
+                         "publish kernel.  The other one is timed as a side leg")
     ap.add_argument("--sort", type=int, default=1, help="Morton-order the scan at staging (0 = keep input order)")
     ap.add_argument("--extrinsic-est", type=int, default=0)
-    ap.add_argument("--second-stage-lanes", type=int, default=0, help="flh_config.second_stage_lanes (0 = the library's default)")
     ap.add_argument("--plane-cache", type=int, default=-1, help="flh_config.plane_cache (-1 = the library's default: on)")
     ap.add_argument("--plane-fit-dtype", type=int, default=0,
                     help="1 = the fp16 plane-fit ABLATION of BASELINE configs[4] (not bit-exact, never a parity claim)")
@@ -269,8 +273,7 @@ def main():
             f"gen {time.time() - t0:.1f}s")
 
     h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
-                    first_stage=args.first_stage, plane_cache=args.plane_cache, plane_fit_dtype=args.plane_fit_dtype,
-                    second_stage_lanes=args.second_stage_lanes)
+                    pass_kernel=args.pass_kernel, plane_cache=args.plane_cache, plane_fit_dtype=args.plane_fit_dtype)
     t0 = time.time()
     h.map_build(scene.map_xyz)
     t_build = time.time() - t0
@@ -349,79 +352,105 @@ def main():
     # --mode partition / config 5, the map cut into slabs with a halo and every rank holding the whole scan); per pass each
     # rank reduces its part to the 16x16 Gram block in device memory and RCCL sums the blocks INSIDE flh_eval (native
     # call site, no Python and no D2H in the pass); every rank then runs the identical 23x23 solve.
-    if run_shard_leg:
-        try:
-            partition = args.mode == "partition" or (args.mode == "auto" and args.config == 5)
+    def shard_leg(exchange, n_warm, n_steps):
+        """ONE scan over the ranks with the named exchange; returns (dict for the line, (dt, acc, ctr), points on this rank)."""
+        partition = args.mode == "partition" or (args.mode == "auto" and args.config == 5)
+        hs = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
+                         pass_kernel=args.pass_kernel)
+        if exchange == "rccl":
             uid = [capi.rccl_unique_id() if rank == 0 else None]
             if dist is not None:
                 dist.broadcast_object_list(uid, src=0)
-            hs = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
-                             first_stage=args.first_stage)
             hs.rccl_init_rank(G, uid[0], rank)
-            if partition:
-                axis, edges = fdist.partition_bounds(scene.map_xyz, G)
-                keep = fdist.partition_slab(scene.map_xyz, axis, edges, rank, fdist.HALO_DEFAULT)
-                hs.map_build(scene.map_xyz[keep])
-                hs.set_owned_interval(axis, edges[rank], edges[rank + 1])
-                for s, p in enumerate(sh_probs):
-                    hs.scan_stage(s, p.body)
-                pts_here = N
-            else:
-                hs.map_build(scene.map_xyz)
-                for s, p in enumerate(sh_probs):
-                    hs.scan_stage(s, np.ascontiguousarray(p.body[fdist.morton_shard(p.body, rank, G)]))
-                pts_here = hi - lo
-            kfs = capi.Esekf(hs, max_iter=3, extrinsic_est_en=ext)
-            jobs_sh = capi.Esekf.make_jobs([np.zeros((1, 3), np.float32)] * S_sh, sh_priors, slots=list(range(S_sh)))
-            k2 = args.steps if mode in ("shard", "partition") else max(10, min(60, args.steps // 4))  # (side leg only with --force-shard-leg)
-            dt2, acc2, ctr2 = run(kfs, hs, jobs_sh, args.warmup if mode in ("shard", "partition") else max(3, args.warmup // 4), k2)
-            # every rank must have produced the same posterior
-            xs = [kfs.get_x()] * G
+        else:
+            nm = [f"/flh_bench_{os.getpid()}" if rank == 0 else None]
             if dist is not None:
-                dist.all_gather_object(xs, kfs.get_x())
-            agree = float(max(np.abs(np.asarray(x_) - np.asarray(xs[0])).max() for x_ in xs))
-            shard_out = {"value": round(k2 / dt2, 3), "unit": "scans/s", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 4),
-                         "ms_per_iekf_pass": round(dt2 / max(acc2.passes, 1) * 1e3, 4),
-                         "layout": ("map partitioned into slabs (+%.2f m halo), whole scan on every rank, queries owned by position" % fdist.HALO_DEFAULT
-                                    if partition else "scan sharded Morton-first, map replicated"),
-                         "points_per_rank": pts_here, "map_points_this_rank": hs.M,
-                         "collective": "ncclAllReduce(sum) of 256 f64 per pass, issued by flh_eval on the handle's stream (RCCL over xGMI)",
-                         "ranks_in_communicator": hs.rccl_size(),
-                         "max_abs_state_disagreement_across_ranks": agree, "scaling": "strong"}
-            if mode in ("shard", "partition"):
+                dist.broadcast_object_list(nm, src=0)
+            hs.peer_open(nm[0], G, rank)
+        if partition:
+            axis, edges = fdist.partition_bounds(scene.map_xyz, G)
+            keep = fdist.partition_slab(scene.map_xyz, axis, edges, rank, fdist.HALO_DEFAULT)
+            hs.map_build(scene.map_xyz[keep])
+            hs.set_owned_interval(axis, edges[rank], edges[rank + 1])
+            for s, p in enumerate(sh_probs):
+                hs.scan_stage(s, p.body)
+            pts_here = N
+        else:
+            hs.map_build(scene.map_xyz)
+            for s, p in enumerate(sh_probs):
+                hs.scan_stage(s, np.ascontiguousarray(p.body[fdist.morton_shard(p.body, rank, G)]))
+            pts_here = hi - lo
+        kfs = capi.Esekf(hs, max_iter=3, extrinsic_est_en=ext)
+        jobs_sh = capi.Esekf.make_jobs([np.zeros((1, 3), np.float32)] * S_sh, sh_priors, slots=list(range(S_sh)))
+        dt2, acc2, ctr2 = run(kfs, hs, jobs_sh, n_warm, n_steps)
+        # every rank must have produced the same posterior
+        xs = [kfs.get_x()] * G
+        if dist is not None:
+            dist.all_gather_object(xs, kfs.get_x())
+        agree = float(max(np.abs(np.asarray(x_) - np.asarray(xs[0])).max() for x_ in xs))
+        d = {"value": round(n_steps / dt2, 3), "unit": "scans/s", "steps": n_steps, "ms_per_step": round(dt2 / n_steps * 1e3, 4),
+             "ms_per_iekf_pass": round(dt2 / max(acc2.passes, 1) * 1e3, 4),
+             "ms_search_pass": round(acc2.ms_s / max(acc2.n_s, 1), 4), "ms_nosearch_pass": round(acc2.ms_n / max(acc2.n_n, 1), 4),
+             "layout": ("map partitioned into slabs (+%.2f m halo), whole scan on every rank, queries owned by position" % fdist.HALO_DEFAULT
+                        if partition else "scan sharded Morton-first, map replicated"),
+             "points_per_rank": pts_here, "map_points_this_rank": hs.M,
+             "collective": ("rccl: ncclAllReduce(sum) of 256 f64 per pass, issued by flh_eval on the handle's stream, + a publish kernel"
+                            if exchange == "rccl" else
+                            "peer granules: every rank's group reducers write {value, sequence} granules into every rank's pinned buffer "
+                            "(one shared segment); no collective, no extra launch; every host adds (rank, group) in order"),
+             "ranks_in_communicator": hs.rccl_size() if exchange == "rccl" else hs.peer_size(),
+             "max_abs_state_disagreement_across_ranks": agree, "scaling": "strong"}
+        kfs.close()
+        hs.close()
+        return d, (dt2, acc2, ctr2), pts_here
+
+    other_exchange = None
+    if run_shard_leg:
+        headline = mode in ("shard", "partition")
+        try:
+            k2 = args.steps if headline else max(10, min(60, args.steps // 4))  # (a side leg only with --force-shard-leg)
+            w2 = args.warmup if headline else max(3, args.warmup // 4)
+            shard_out, (dt2, acc2, ctr2), pts_here = shard_leg(args.exchange, w2, k2)
+            if headline:
                 dt, acc, ctr = dt2, acc2, ctr2
                 units = args.steps
                 n_pts = pts_here
-            kfs.close()
-            hs.close()
         except Exception as e:  # the side leg must not cost the headline line (streams mode); in shard / partition mode it IS the headline
-            if mode in ("shard", "partition"):
+            if headline:
                 raise
             shard_out = {"error": repr(e)[:400]}
+        try:  # the other exchange, shorter, for comparison
+            oth = "rccl" if args.exchange == "peer" else "peer"
+            other_exchange, _r, _p = shard_leg(oth, max(3, args.warmup // 4), max(10, min(60, args.steps // 2)))
+        except Exception as e:  # noqa: BLE001
+            other_exchange = {"error": repr(e)[:400]}
     value = units / dt
     ms_per_step = dt / args.steps * 1e3
 
     # ---- roofline of the dominant kernels (the 5-NN search of one pass), HIP events inside the timed region
     roof = None
+    one_launch = args.pass_kernel != 0 and args.lpq == 4 and abs(args.cell - 1.5) < 1e-6 and not args.plane_fit_dtype
     if ctr["n_search"] > 0:
         dur_s = ctr["search_ms"] / ctr["n_search"] * 1e-3
         ach = ALG_BYTES_SEARCH * n_pts / dur_s / 1e9
-        fit_s = ctr["fit_ms"] / max(ctr["n_fit"], 1) * 1e-3
         roof = {"bound": "hbm",
-                "kernel": f"5-NN search of one pass = k_search_ring<{args.lpq},1> (every query) + k_search_ring<{args.second_stage_lanes or 8},2> (the rest, incl. the exact fallback)",
+                "kernel": ("k_pass = a whole searching pass in ONE launch: body->world, 5-NN (both stages), plane fit, residual gate, "
+                           "Jacobian rows, Gram (f64 MFMA), group sums" if one_launch else
+                           "5-NN search of one pass = k_search_ring<4,1> (every query) + k_search_ring<8,2> (the rest, incl. the exact fallback)"),
                 "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                 "traffic": None, "avg_kernel_us": round(dur_s * 1e6, 2), "alg_bytes_per_launch": ALG_BYTES_SEARCH * n_pts,
-                "event_bracket": "start of the first search kernel -> end of the last one (hipExtLaunchKernelGGL time stamps)",
+                "event_bracket": ("start -> end of k_pass (hipExtLaunchKernelGGL time stamps)" if one_launch else
+                                  "start of the first search kernel -> end of the last one (hipExtLaunchKernelGGL time stamps)"),
                 "events_sampled": int(ctr["n_search"]),
                 "events_sampled_by_kind": {"first_search_of_scan": int(ctr.get("n_first", 0)), "later_search": int(ctr.get("n_later", 0))},
                 "first_search_us": round(ctr["first_ms"] / ctr["n_first"] * 1e3, 2) if ctr.get("n_first") else None,
-                "later_search_us": round(ctr["later_ms"] / ctr["n_later"] * 1e3, 2) if ctr.get("n_later") else None,
-                "fit_kernel_us": round(fit_s * 1e6, 2),
-                "fit_events_sampled": int(ctr["n_fit"]),
-                "fit_note": "the fit kernel behind a sampled search (it also writes the plane cache); the no-search passes' fit reads that cache and is shorter (profiles/: k_fit<1,false,2>)",
-                "fit_alg_bytes_per_launch": ALG_BYTES_NOSEARCH * n_pts,
-                "fit_achieved_GBs": round(ALG_BYTES_NOSEARCH * n_pts / fit_s / 1e9, 2),
-                "fit_frac": round(ALG_BYTES_NOSEARCH * n_pts / fit_s / 1e9 / HBM_PEAK_GBS, 5)}
+                "later_search_us": round(ctr["later_ms"] / ctr["n_later"] * 1e3, 2) if ctr.get("n_later") else None}
+        if ctr["n_fit"] > 0:  # the three-launch pass: the fit kernel behind a sampled search
+            fit_s = ctr["fit_ms"] / ctr["n_fit"] * 1e-3
+            roof.update({"fit_kernel_us": round(fit_s * 1e6, 2), "fit_events_sampled": int(ctr["n_fit"]),
+                         "fit_alg_bytes_per_launch": ALG_BYTES_NOSEARCH * n_pts,
+                         "fit_achieved_GBs": round(ALG_BYTES_NOSEARCH * n_pts / fit_s / 1e9, 2),
+                         "fit_frac": round(ALG_BYTES_NOSEARCH * n_pts / fit_s / 1e9 / HBM_PEAK_GBS, 5)})
 
     if with_map_inserts:
         acc_mi = acc.ms_mi / max(args.steps, 1)
@@ -445,10 +474,11 @@ def main():
                                     "copy stream while the previous scan updates, then the full iterated update"
                                     if mode not in ("shard", "partition") else "scan shards resident in HBM, full iterated update"),
                    "parallelism": ("1 GPU" if G == 1 else
-                                   (f"scan points sharded over {G} ranks + all-reduce of the 16x16 normal-equation block "
-                                    f"per pass" if mode in ("shard", "partition") else
+                                   (f"scan points sharded over {G} ranks, normal equations summed per pass ({args.exchange})"
+                                    if mode in ("shard", "partition") else
                                     f"{G} independent scan streams (one per rank), replicated map, no collective in the data path")),
-                   "distinct_scans": S, "cell_size_m": args.cell, "lanes_per_query": args.lpq, "first_stage": args.first_stage,
+                   "distinct_scans": S, "cell_size_m": args.cell, "lanes_per_query": args.lpq,
+                   "searching_pass": "one launch (k_pass)" if one_launch else "three launches (two search stages + fit)",
                    "plane_cache": args.plane_cache, "plane_fit": "fp16 ABLATION (not bit-exact)" if args.plane_fit_dtype else "fp32 (reference-exact)",
                    "event_reading": "deferred (recorded inside the timed region, read after it)"},
         "ms_per_iekf_pass": round((acc.ms_s + acc.ms_n) / max(acc.passes, 1), 4),
@@ -464,7 +494,7 @@ def main():
         out["ms_map_incremental_call_per_scan"] = round(acc_mi, 4)
     if G > 1 and dist is not None:
         out["ranks_seen_by_collective"] = int(dist.get_world_size())
-        out["ranks_in_rccl_communicator"] = shard_out.get("ranks_in_communicator") if shard_out else None
+        out["ranks_exchanging_normal_equations"] = shard_out.get("ranks_in_communicator") if shard_out else None
 
     # ---- the same update with the scans already resident in HBM (staged before the timed loop): what round 1 reported
     # as `value`.  Not PCIe-inclusive, hence a sub-field.
@@ -486,6 +516,8 @@ def main():
     cand_per_query = h.timing()["candidates"] / max(N, 1)
     h.enable_stats(False)
     h.set_timing_stride(0)
+    ps = h.pass_stats()
+    out["second_stage_queries_per_search_pass"] = round(ps["second_stage_queries"] / max(ps["search_passes"], 1), 1)
     if roof is not None:
         tr = pmc_traffic(args)
         if tr is not None and not tr.get("stale"):
@@ -503,7 +535,10 @@ def main():
         out["shard_mode"] = shard_out
     if shard_out is not None and mode in ("shard", "partition"):
         out["sharded_path"] = {k: shard_out[k] for k in ("layout", "points_per_rank", "map_points_this_rank", "collective",
-                                                          "ranks_in_communicator", "max_abs_state_disagreement_across_ranks")}
+                                                          "ranks_in_communicator", "max_abs_state_disagreement_across_ranks",
+                                                          "ms_search_pass", "ms_nosearch_pass")}
+    if other_exchange is not None:
+        out["other_exchange"] = other_exchange
     if replicas_out is not None:
         out["replicas_no_collective"] = replicas_out
 
@@ -609,7 +644,7 @@ def run_extra_legs_in_child(args):
     import subprocess
 
     cmd = [sys.executable, os.path.abspath(__file__), "--leg", "extras", "--config", str(args.config), "--lpq", str(args.lpq),
-           "--cell", str(args.cell), "--first-stage", str(args.first_stage), "--sort", str(args.sort),
+           "--cell", str(args.cell), "--pass-kernel", str(args.pass_kernel), "--sort", str(args.sort),
            "--extrinsic-est", str(args.extrinsic_est), "--steps", str(args.steps)]
     if args.two_streams:
         cmd.append("--two-streams")
@@ -642,7 +677,7 @@ def extra_legs(args):
         a = capi.pinned_empty((N, 3), np.float32)
         a[:] = p.body
         bodies.append(a)
-    h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, sort_queries=args.sort, first_stage=args.first_stage)
+    h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, sort_queries=args.sort, pass_kernel=args.pass_kernel)
     h.map_build(scene.map_xyz)
     h.set_timing_stride(0)
     for s in range(S):
@@ -655,7 +690,7 @@ def extra_legs(args):
         # its 23x23 system the other's kernels run
         import threading
 
-        h2 = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, sort_queries=args.sort, first_stage=args.first_stage)
+        h2 = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, sort_queries=args.sort, pass_kernel=args.pass_kernel)
         h2.map_build(scene.map_xyz)
         h2.set_timing_stride(0)
         for s in range(S):

@@ -28,12 +28,11 @@ class FlhConfig(C.Structure):
         ("stream", C.c_void_p),
         ("lanes_per_query", C.c_int),
         ("sort_queries", C.c_int),
-        ("first_stage", C.c_int),
+        ("pass_kernel", C.c_int),
         ("eigen_order", C.c_int),
         ("plane_fit_dtype", C.c_int),
         ("undistort_first_point", C.c_int),
         ("plane_cache", C.c_int),
-        ("second_stage_lanes", C.c_int),
         ("fused_small_changes", C.c_int),
     ]
 
@@ -96,6 +95,7 @@ EXPORTS = [
     "flh_scan_stage_async", "flh_scan_wait", "flh_host_alloc", "flh_host_free", "flh_frame_world", "flh_points_body_to_world",
     "flh_esekf_last_error", "flh_rccl_unique_id", "flh_rccl_init_rank", "flh_rccl_init_all", "flh_rccl_destroy", "flh_rccl_size",
     "flh_rccl_rank", "flh_eval_group", "flh_set_owned_interval", "flh_esekf_run_scans", "flh_get_search_counters", "flh_set_timing_sampling",
+    "flh_map_sync", "flh_peer_open", "flh_peer_init_all", "flh_peer_close", "flh_peer_size", "flh_peer_rank", "flh_get_pass_stats",
 ]
 
 _lib = None
@@ -120,6 +120,13 @@ def rccl_init_all(handles):
     """One process, one Handle per device: a common communicator (ncclCommInitAll); use eval_group afterwards."""
     arr = (C.c_void_p * len(handles))(*[h.ptr for h in handles])
     _chk(lib().flh_rccl_init_all(arr, len(handles)), "flh_rccl_init_all")
+
+
+def peer_init_all(handles):
+    """One process, several Handles: every handle's passes publish their group sums to every handle's granule buffer
+    (flh_peer_init_all); use eval_group afterwards."""
+    arr = (C.c_void_p * len(handles))(*[h._h for h in handles])
+    _chk(lib().flh_peer_init_all(arr, len(handles)), "flh_peer_init_all")
 
 
 def eval_group(handles, x, do_search: bool, ext: bool = False):
@@ -192,6 +199,14 @@ def lib():
     L.flh_rccl_init_all.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     L.flh_rccl_destroy.argtypes = [C.c_void_p]
     L.flh_rccl_destroy.restype = None
+    L.flh_map_sync.argtypes = [C.c_void_p]
+    L.flh_peer_open.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    L.flh_peer_init_all.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.flh_peer_close.argtypes = [C.c_void_p]
+    L.flh_peer_close.restype = None
+    L.flh_peer_size.argtypes = [C.c_void_p]
+    L.flh_peer_rank.argtypes = [C.c_void_p]
+    L.flh_get_pass_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.flh_rccl_size.argtypes = [C.c_void_p]
     L.flh_rccl_rank.argtypes = [C.c_void_p]
     L.flh_eval_group.argtypes = [C.POINTER(C.c_void_p), C.c_int, _f64p, C.c_int, C.c_int, _f64p, _f64p, C.POINTER(C.c_int64),
@@ -250,8 +265,8 @@ class Handle:
     """flh_handle: the device-resident map + current scan."""
 
     def __init__(self, cell_size: float = 1.5, lanes_per_query: int = 4, device: int = -1, stream: int | None = None,
-                 plane_threshold: float = 0.1, max_sqdist: float = 5.0, sort_queries: int = -1, first_stage: int = 0,
-                 eigen_order: int = -1, plane_fit_dtype: int = 0, undistort_first_point: int = -1, plane_cache: int = -1, second_stage_lanes: int = 0,
+                 plane_threshold: float = 0.1, max_sqdist: float = 5.0, sort_queries: int = -1, pass_kernel: int = -1,
+                 eigen_order: int = -1, plane_fit_dtype: int = 0, undistort_first_point: int = -1, plane_cache: int = -1,
                  fused_small_changes: int = -1):
         L = lib()
         cfg = FlhConfig()
@@ -263,12 +278,11 @@ class Handle:
         cfg.max_sqdist = max_sqdist
         cfg.stream = stream
         cfg.sort_queries = sort_queries
-        cfg.first_stage = first_stage
+        cfg.pass_kernel = pass_kernel
         cfg.eigen_order = eigen_order
         cfg.plane_fit_dtype = plane_fit_dtype
         cfg.undistort_first_point = undistort_first_point
         cfg.plane_cache = plane_cache
-        cfg.second_stage_lanes = second_stage_lanes
         cfg.fused_small_changes = fused_small_changes
         self._h = C.c_void_p()
         _chk(L.flh_create(C.byref(cfg), C.byref(self._h)), "flh_create")
@@ -352,6 +366,22 @@ class Handle:
         """Join the RCCL communicator (one process per GPU); afterwards eval / Esekf.update all-reduce every pass."""
         assert len(unique_id) == 128
         _chk(lib().flh_rccl_init_rank(self._h, nranks, unique_id, rank), "flh_rccl_init_rank")
+
+    def peer_open(self, shm_name: str, nranks: int, rank: int):
+        """One process per GPU: attach to the ranks' shared granule segment (flh_peer_open); rank 0 creates it."""
+        _chk(lib().flh_peer_open(self._h, shm_name.encode(), nranks, rank), "flh_peer_open")
+
+    def peer_close(self):
+        lib().flh_peer_close(self._h)
+
+    def peer_size(self) -> int:
+        return int(lib().flh_peer_size(self._h))
+
+    def pass_stats(self) -> dict:
+        out = (C.c_uint64 * 4)()
+        _chk(lib().flh_get_pass_stats(self._h, out), "flh_get_pass_stats")
+        return {"search_passes": int(out[0]), "one_launch_passes": int(out[1]), "second_stage_queries": int(out[2]),
+                "nosearch_passes": int(out[3])}
 
     def rccl_size(self) -> int:
         return int(lib().flh_rccl_size(self._h))

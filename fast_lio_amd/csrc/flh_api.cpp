@@ -4,6 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <emmintrin.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -29,18 +33,22 @@
 using flh::GridParams;
 using flh::StateDev;
 typedef unsigned long long u64;
-#ifdef FLH_PHASES
-#define FLH_COUNTER_WORDS (128 + 16 * 1024 * 4 * 12)
-#else
 #define FLH_COUNTER_WORDS 1
-#endif
 
 constexpr int kGranGroups = 64;   // at most this many first-level groups go the granule way (else the in-kernel two-level sum)
-constexpr int kGranSlots = 92;    // gram_nslots(12)
+constexpr int kGranSlots = 93;    // gran_section_slots(12): the Gram entries the filter reads + one statistic
+constexpr size_t kGranSect = 1 + (size_t)kGranGroups * kGranSlots;  // granules of one rank's section: header + [group][slot]
 static thread_local std::string g_err;
 static int fail(const std::string& m) {
     g_err = m;
     return -1;
+}
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
 }
 #define HIPC(expr)                                                                                     \
     do {                                                                                               \
@@ -48,6 +56,18 @@ static int fail(const std::string& m) {
         if (e_ != hipSuccess)                                                                          \
             return fail(std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
     } while (0)
+
+// The peers' shared granule segment: [dst rank][parity][src rank][kGranSect granules], then the row records of the gain-form
+// branch [src rank][kPeerRec doubles].  One mapping per process (several handles of one process share it: refs).
+struct PeerSeg {
+    void* host = nullptr;     // mapped (shm) or hipHostMalloc'ed (one process) memory
+    void* dev = nullptr;      // the device-side address of the same bytes
+    size_t bytes = 0;
+    bool shm = false, creator = false;
+    std::string name;
+    int refs = 0;
+    int n = 0;
+};
 
 template <class T>
 struct DevBuf {
@@ -151,7 +171,21 @@ struct flh_handle {
     bool last_search_was_later = false;
     int own_axis = -1;
     float own_lo = -INFINITY, own_hi = INFINITY;
-    double* h_gran = nullptr;  // pinned: [kGranGroups][92] x {value, sequence} granules written by k_fit's group reducers
+    // Granule buffers (pinned host memory, {value, sequence} pairs written by the passes' group reducers): two parities (a
+    // rank may be one pass ahead of a peer that has not read the last one yet) x one section per rank.  h_gran is this
+    // rank's own buffer; gran_dst lists every buffer this rank's kernels write (itself only, or all peers: flh_peer_*).
+    double* h_gran = nullptr;
+    bool gran_owned = true;        // h_gran came from hipHostMalloc (else: a window of the peers' shared segment)
+    double* gran_dst[flh::kPeersMax] = {};
+    int peer_n = 1, peer_rank = 0;
+    void* peer_map = nullptr;      // the mapped (and registered) shared segment
+    size_t peer_map_bytes = 0;
+    std::string peer_name;
+    bool pass_ok = false;          // the one-launch searching pass may run (flh_config.pass_kernel and its requirements)
+    uint64_t n_second_stage = 0;   // queries that needed the second search, summed over the searching passes since creation
+    uint64_t n_search_pass = 0, n_one_launch = 0, n_nosearch_pass = 0;
+    double* h_gran_own = nullptr;  // the handle's own pinned buffer (h_gran points into the peers' segment while attached)
+    struct PeerSeg* peer_seg = nullptr;
     double* h_gram = nullptr;  // pinned 256 doubles
     u64* h_counter = nullptr;  // pinned
     // last evaluation
@@ -247,12 +281,11 @@ void flh_default_config(flh_config* c) {
     c->stream = nullptr;
     c->lanes_per_query = 4;
     c->sort_queries = -1;
-    c->first_stage = 0;
+    c->pass_kernel = -1;
     c->eigen_order = -1;
     c->plane_fit_dtype = 0;
     c->undistort_first_point = -1;
     c->plane_cache = -1;
-    c->second_stage_lanes = 0;
     c->fused_small_changes = -1;
 }
 
@@ -268,17 +301,13 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.plane_threshold <= 0) cfg.plane_threshold = 0.1f;
     if (cfg.max_sqdist <= 0) cfg.max_sqdist = 5.0f;
     if (cfg.sort_queries < 0) cfg.sort_queries = 1;
-    if (cfg.first_stage < 0 || cfg.first_stage > 2) cfg.first_stage = 0;
+    if (cfg.pass_kernel != 0) cfg.pass_kernel = 1;
     if (cfg.eigen_order < 0 || cfg.eigen_order > 3) cfg.eigen_order = FLH_ORDER_SSE;
     if (cfg.plane_fit_dtype != 1) cfg.plane_fit_dtype = 0;
     if (cfg.undistort_first_point != 0) cfg.undistort_first_point = 1;
     if (cfg.plane_cache != 0) cfg.plane_cache = 1;
-    if (cfg.second_stage_lanes != 16 && cfg.second_stage_lanes != 32) cfg.second_stage_lanes = 8;
     if (cfg.fused_small_changes != 0) cfg.fused_small_changes = 1;
-    {
-        const int l = cfg.lanes_per_query;  // 0 = exact kernel for every query
-        if (l != 0 && l != 1 && l != 2 && l != 8 && l != 16) cfg.lanes_per_query = 4;
-    }
+    if (cfg.lanes_per_query != 0) cfg.lanes_per_query = 4;  // 0 = exact kernel for every query
     flh_handle* h = new flh_handle();
     h->cfg = cfg;
     if (cfg.device >= 0) {
@@ -305,13 +334,14 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
         hipHostMalloc((void**)&h->h_ctr, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_mi, 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_small, 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_gran, ((size_t)kGranGroups * kGranSlots + 1) * 16, hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void**)&h->h_gran, 2 * kGranSect * 16, hipHostMallocDefault) != hipSuccess) {
         flh_destroy(h);
         return fail("hipHostMalloc failed");
     }
     std::memset(h->h_gram, 0, 256 * sizeof(double));
     std::memset(h->h_mi, 0, 16 * sizeof(uint32_t));
-    std::memset(h->h_gran, 0, ((size_t)kGranGroups * kGranSlots + 1) * 16);
+    std::memset(h->h_gran, 0, 2 * kGranSect * 16);
+    h->gran_dst[0] = h->h_gran;
     if (h->gram.reserve(256) != hipSuccess || h->counter.reserve(FLH_COUNTER_WORDS) != hipSuccess || h->slow_count.reserve(2 * flh::list_stripes()) != hipSuccess ||
         hipMemset(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t)) != hipSuccess) {
         flh_destroy(h);
@@ -320,6 +350,14 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     h->plane_cache = cfg.plane_cache != 0;
     h->rmax = (int)std::ceil((std::sqrt((double)cfg.max_sqdist) + 2e-3 * cfg.cell_size) / cfg.cell_size);
     if (h->rmax < 1) h->rmax = 1;
+    {
+        // k_pass's second search visits a 4x4 window of rows: enough as long as the ball of a bounded query stays below 1.5
+        // cells (the very expression ring_query clips its rows with, at the largest bound the gate allows)
+        const float inv_c = 1.0f / cfg.cell_size;
+        const float ubq = cfg.max_sqdist * 1.0001f + 1e-6f;
+        const float rcell2 = ubq * (inv_c * inv_c) * 1.01f + 1e-4f;
+        h->pass_ok = cfg.pass_kernel != 0 && cfg.lanes_per_query == 4 && cfg.plane_fit_dtype == 0 && h->rmax <= 2 && rcell2 < 1.499f * 1.499f;
+    }
     *out = h;
     return 0;
 }
@@ -340,7 +378,7 @@ void flh_destroy(flh_handle* h) {
     h->mu_alive.release(); h->mi_cls.release(); h->mu_flags.release(); h->mu_incl.release(); h->mu_boxes.release();
     h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_list2.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
     h->world.release(); h->nn_pts.release(); h->normvec.release(); h->plane.release();
-    h->nn_d2.release(); h->nn_cnt.release(); h->selected.release();
+    h->nn_d2.release(); h->nn_cnt.release(); h->selected.release(); h->vox_tab.release();
     h->partials.release(); h->part2.release(); h->gram.release(); h->gather_buf.release(); h->counter.release();
     for (auto& sl : h->slots) {
         sl.body.release();
@@ -357,7 +395,8 @@ void flh_destroy(flh_handle* h) {
     h->st_raw.release(); h->st_k0.release(); h->st_k1.release(); h->st_m0.release(); h->st_m1.release(); h->st_v0.release(); h->st_v1.release(); h->st_tmp.release();
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->h_gram) (void)hipHostFree(h->h_gram);
-    if (h->h_gran) (void)hipHostFree(h->h_gran);
+    flh_peer_close(h);
+    if (h->h_gran && h->gran_owned) (void)hipHostFree(h->h_gran);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -369,6 +408,10 @@ void flh_destroy(flh_handle* h) {
 }
 
 static int map_settle(flh_handle* h);
+int flh_map_sync(flh_handle* h) {
+    if (!h) return fail("flh_map_sync: null handle");
+    return map_settle(h);
+}
 size_t flh_map_size(const flh_handle* h) {
     if (!h) return 0;
     (void)map_settle(const_cast<flh_handle*>(h));  // a map change still under way on the device decides the size
@@ -463,6 +506,9 @@ static int rebuild_index_impl(flh_handle* h, DevBuf<float4>& pts, size_t M, bool
     const size_t pts_cap = (size_t)used + std::max<size_t>(M / 4, 65536);
     if (pts_cap >= (1ull << 27)) return fail("map index: too many points for one storage range");
     const size_t rows_cap = (size_t)2 * nbricks + 4096;
+    // the search reads the prefix tables through a buffer resource with 32-bit byte offsets (flh_search_dev.hpp: RingRsrc), the
+    // points likewise (pts_cap * 16 < 2^31, checked above)
+    if (rows_cap * flh::kBrickStride * sizeof(uint32_t) >= (1ull << 32)) return fail("map index: too many bricks for 32-bit table offsets");
     uint32_t hs = 1024;
     while (hs < 2 * rows_cap) hs <<= 1;
     int log2hs = 0;
@@ -588,7 +634,7 @@ static int wait_granule(flh_handle* h, int off, uint32_t seq, const char* who) {
     const volatile uint32_t* g = h->h_mi + off;
     uint64_t spins = 0;
     while (g[3] != seq) {
-        __builtin_ia32_pause();
+        cpu_relax();
         if ((++spins & 0xFFFFFu) == 0 && hipStreamQuery(h->stream) != hipErrorNotReady) {
             HIPC(hipStreamSynchronize(h->stream));
             if (g[3] != seq) return fail(std::string(who) + ": the device finished without publishing its counters");
@@ -603,9 +649,11 @@ static int wait_granule(flh_handle* h, int off, uint32_t seq, const char* who) {
 static int map_settle(flh_handle* h) {
     if (!h->map_pending) return 0;
     HIPC(hipSetDevice(h->device));
-    if (wait_granule(h, 8, h->map_pending_seq, "map change") != 0) return -1;
+    // two granules, EACH with the sequence word: {top, bricks, flags, seq} {removed, inserted, 0, seq} (system-scope stores of one
+    // kernel need not reach the host in order)
+    if (wait_granule(h, 4, h->map_pending_seq, "map change") != 0 || wait_granule(h, 8, h->map_pending_seq, "map change") != 0) return -1;
     h->map_pending = false;
-    const uint32_t top = h->h_mi[4], bricks = h->h_mi[5], flags = h->h_mi[6], removed = h->h_mi[7], n_alive = h->h_mi[8];
+    const uint32_t top = h->h_mi[4], bricks = h->h_mi[5], flags = h->h_mi[6], removed = h->h_mi[8], n_alive = h->h_mi[9];
     h->n_ids += n_alive;
     h->M = h->M + n_alive - removed;
     h->id_pos_valid = false;
@@ -806,8 +854,8 @@ static int prepare_scan_buffers(flh_handle* h, size_t N, bool full_clear) {
         HIPC(h->slow_list.reserve(ln)); HIPC(h->slow_list2.reserve(ln)); HIPC(h->slow_ub.reserve(n1));
     }
     const int nblk = flh::fit_blocks((int)N);
-    HIPC(h->partials.reserve((size_t)nblk * 256));
-    const int ngroups = flh::reduce1_blocks(nblk, nullptr);
+    HIPC(h->partials.reserve(std::max((size_t)nblk * 256, (size_t)flh::pass_blocks((int)N) * kGranSlots)));  // k_fit's blocks / k_pass's workgroups
+    const int ngroups = std::max(flh::reduce1_blocks(nblk, nullptr), kGranGroups);
     HIPC(h->part2.reserve((size_t)ngroups * 256));
     {
         const uint32_t* before = h->tickets.p;
@@ -1360,23 +1408,44 @@ static void drain_events(flh_handle* h) {
     (void)hipSetDevice(h->device);
     for (int k = 0; k < h->evp_n; ++k) {
         float a = 0, b = 0, c = 0;
-        const bool srch = h->evp_search[k] != 0;
+        const int kind = h->evp_search[k] & 3;        // 0: no search, 1: a scan's first search, 2: a later one
+        const bool one_launch = (h->evp_search[k] & 4) != 0;  // k_pass: one kernel, stamps in [0] and [3]
+        const bool srch = kind != 0;
         hipError_t e = hipEventSynchronize(h->evp[k][3]);
-        if (e == hipSuccess && srch) e = hipEventElapsedTime(&a, h->evp[k][0], h->evp[k][1]);
-        if (e == hipSuccess) e = hipEventElapsedTime(&b, h->evp[k][2], h->evp[k][3]);
-        if (e == hipSuccess) e = hipEventElapsedTime(&c, h->evp[k][srch ? 0 : 2], h->evp[k][3]);
+        if (one_launch) {
+            if (e == hipSuccess) e = hipEventElapsedTime(&c, h->evp[k][0], h->evp[k][3]);
+            a = c;  // the search is not a kernel of its own: the pass kernel's time is reported as both
+        } else {
+            if (e == hipSuccess && srch) e = hipEventElapsedTime(&a, h->evp[k][0], h->evp[k][1]);
+            if (e == hipSuccess) e = hipEventElapsedTime(&b, h->evp[k][2], h->evp[k][3]);
+            if (e == hipSuccess) e = hipEventElapsedTime(&c, h->evp[k][srch ? 0 : 2], h->evp[k][3]);
+        }
         if (e != hipSuccess) {
             (void)hipGetLastError();
             continue;  // a sample that cannot be read is dropped, not guessed
         }
-        if (srch) { h->acc[0] += a; h->acc[1] += 1; h->acc_kind[h->evp_search[k] == 2 ? 2 : 0] += a; h->acc_kind[h->evp_search[k] == 2 ? 3 : 1] += 1; }
-        h->acc[2] += b; h->acc[3] += 1;
+        if (srch) { h->acc[0] += a; h->acc[1] += 1; h->acc_kind[kind == 2 ? 2 : 0] += a; h->acc_kind[kind == 2 ? 3 : 1] += 1; }
+        if (!one_launch) { h->acc[2] += b; h->acc[3] += 1; }
         h->acc[4] += c; h->acc[5] += 1;
         h->timing.search_ms = srch ? a : 0.f;
         h->timing.fit_ms = b;
         h->timing.total_ms = c;
     }
     h->evp_n = 0;
+}
+
+// The granule buffers an evaluation with sequence number seq publishes to (parity: see flh_handle::h_gran).
+static flh::GranOut gran_out(const flh_handle* h, double seq) {
+    flh::GranOut o{};
+    const size_t par = ((uint64_t)seq & 1u) * (size_t)h->peer_n * kGranSect * 2;
+    for (int d = 0; d < h->peer_n; ++d) o.dst[d] = h->gran_dst[d] + par;
+    o.n_dst = h->peer_n;
+    o.sect_off = (int)((size_t)h->peer_rank * kGranSect);
+    return o;
+}
+// does a searching evaluation of the active scan run as ONE launch?
+static bool use_pass_kernel(const flh_handle* h, bool host_granules) {
+    return h->pass_ok && host_granules && h->N > 0 && flh::pass_group_size((int)h->N, kGranGroups) <= 1024;
 }
 
 static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext, double* d_out, double seq, hipEvent_t* ev3,
@@ -1388,22 +1457,33 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
     if (!h->grid.hash && h->N > 0) return fail("flh_eval: no map (flh_map_build / flh_map_add first)");
     if (!do_search && !h->searched_once && h->N > 0)
         return fail("flh_eval: do_search == 0 before any search on this scan (the reference always searches on the first pass)");
+    flh::GranOut gout{};
+    if (host_granules) gout = gran_out(h, seq);
+    if (do_search && h->stats) HIPC(hipMemsetAsync(h->counter.p, 0, FLH_COUNTER_WORDS * sizeof(u64), st));
+    if (do_search && use_pass_kernel(h, host_granules)) {
+        // the whole searching pass in one launch (flh_pass.hip); timed: the kernel's own start and end stamps in ev3[0] / ev3[3]
+        HIPC(flh::launch_pass(h->cfg.eigen_order, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap, h->cfg.max_sqdist,
+                              h->cfg.plane_threshold, ext, h->nn_pts.p, h->nn_cnt.p, h->selected.p, h->plane_cache ? h->plane.p : nullptr,
+                              h->partials.p, h->tickets.p, gout, seq, flh::pass_group_size((int)h->N, kGranGroups),
+                              h->stats ? h->counter.p : nullptr, h->own_axis, h->own_lo, h->own_hi, st, timed ? ev3[0] : nullptr,
+                              timed ? ev3[3] : nullptr));
+    } else {
+        if (do_search)
+            HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap, h->cfg.max_sqdist,
+                                    h->rmax, h->nn_pts.p, h->nn_cnt.p, h->selected.p, h->slow_list.p, h->slow_list2.p, h->slow_ub.p,
+                                    h->slow_count.p, h->stats ? h->counter.p : nullptr, h->own_axis, h->own_lo, h->own_hi, st,
+                                    timed ? ev3[0] : nullptr, timed ? ev3[1] : nullptr));
+        HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
+                             h->world.p, h->partials.p, h->part2.p, d_out, seq, h->tickets.p, h->slow_count.p, gout,
+                             host_granules ? gran_group_size(h->N) : 0, 0, st, h->plane_cache ? h->plane.p : nullptr,
+                             (do_search || !h->planes_valid) ? 1 : 2, timed ? ev3[2] : nullptr, timed ? ev3[3] : nullptr));
+    }
     if (do_search) {
-        if (h->stats) HIPC(hipMemsetAsync(h->counter.p, 0, FLH_COUNTER_WORDS * sizeof(u64), st));
-        HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
-                                h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
-                                h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, h->stats ? h->counter.p : nullptr,
-                                h->own_axis, h->own_lo, h->own_hi, st, timed ? ev3[0] : nullptr, timed ? ev3[1] : nullptr, h->cfg.second_stage_lanes));
         h->last_search_was_later = h->searched_once;
         h->searched_once = true;
         h->d2_valid = false;
         h->search_state = s;
     }
-    HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
-                         h->world.p, h->partials.p, h->part2.p, d_out, seq, h->tickets.p, h->slow_count.p,
-                         host_granules ? h->h_gran : nullptr, host_granules ? gran_group_size(h->N) : 0, 0, st,
-                         h->plane_cache ? h->plane.p : nullptr, (do_search || !h->planes_valid) ? 1 : 2, timed ? ev3[2] : nullptr,
-                         timed ? ev3[3] : nullptr));
     h->planes_valid = h->plane_cache;
     h->aux_valid = false;
     h->last_state = s;
@@ -1419,7 +1499,7 @@ static int ensure_aux(flh_handle* h) {
     HIPC(hipSetDevice(h->device));
     HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, h->last_state, h->cur_body, h->nn_pts.p, (int)h->N, h->last_ext,
                          h->cfg.plane_threshold, h->selected.p, h->normvec.p, h->world.p, h->partials.p, h->part2.p, h->gram.p, 0.0,
-                         h->tickets.p, h->slow_count.p, nullptr, 0, 1, h->stream));
+                         h->tickets.p, h->slow_count.p, flh::GranOut{}, 0, 1, h->stream));
     h->aux_valid = true;
     return 0;
 }
@@ -1429,6 +1509,67 @@ static int ensure_d2(flh_handle* h) {
     HIPC(hipSetDevice(h->device));
     HIPC(flh::launch_fill_d2(h->search_state, h->cur_body, h->nn_pts.p, (int)h->N, h->nn_d2.p, h->stream));
     h->d2_valid = true;
+    return 0;
+}
+
+// The group reducers of every rank write {value, sequence} granules straight into this rank's pinned buffer: per rank a
+// header (how many granules follow), then [group][slot].  Waits until every granule carries this evaluation's sequence
+// number, adding the groups up in (rank, group) order as they are seen complete (fixed order -> identical bits run to
+// run, and on every rank), and leaves the 16x16 block in h_gram (G[15][15] = seq).  No device-side final sum, no
+// collective, no flag.
+static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
+    hipStream_t st = h->stream;
+    const int ncol = ext ? 12 : 6;
+    const int nslots = flh::gram_slots_host(ncol), nsl = nslots + 1;
+    double sum[kGranSlots];
+    for (int k = 0; k < nsl; ++k) sum[k] = 0.0;
+    const double* base = h->h_gran + ((uint64_t)seq & 1u) * (size_t)h->peer_n * kGranSect * 2;
+    uint64_t spins = 0;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto wait_for = [&](const double* gp, double* value) -> int {
+        for (;;) {
+            const __m128d x = _mm_load_pd(gp);  // one 16-byte read: {value, sequence}
+            if (_mm_cvtsd_f64(_mm_unpackhi_pd(x, x)) == seq) { *value = _mm_cvtsd_f64(x); return 0; }
+            cpu_relax();
+            if ((++spins & 0xFFFFFu) == 0) {
+                if (hipStreamQuery(st) != hipErrorNotReady) {  // this rank's kernel finished or failed
+                    HIPC(hipStreamSynchronize(st));
+                    const __m128d y = _mm_load_pd(gp);
+                    const bool own = gp >= base + (size_t)h->peer_rank * kGranSect * 2 && gp < base + (size_t)(h->peer_rank + 1) * kGranSect * 2;
+                    if (own && _mm_cvtsd_f64(_mm_unpackhi_pd(y, y)) != seq) return fail("flh_eval: kernel retired without publishing its result");
+                }
+                if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30))
+                    return fail("flh_eval: timed out waiting for a peer's granules (ranks out of step?)");
+            }
+        }
+    };
+    for (int r = 0; r < h->peer_n; ++r) {
+        const double* sect = base + (size_t)r * kGranSect * 2;
+        double cnt_d = 0;
+        if (wait_for(sect, &cnt_d) != 0) return -1;
+        const int cnt = (int)cnt_d;
+        if (cnt <= 0 || cnt % nsl != 0 || cnt / nsl > kGranGroups) return fail("flh_eval: malformed granule section");
+        for (int gi = 0; gi < cnt / nsl; ++gi) {
+            const double* gg = sect + 2 * (1 + (size_t)gi * nsl);
+            for (int k = 0; k < nsl; ++k) {
+                double v;
+                if (wait_for(gg + 2 * k, &v) != 0) return -1;
+                sum[k] += v;
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (do_search) h->n_second_stage += (uint64_t)sum[nslots];
+    double* G = h->h_gram;
+    std::memset(G, 0, 256 * sizeof(double));
+    for (int r = 0; r < 16; ++r)
+        for (int c = 0; c < 16; ++c) {
+            const int sl = flh::gram_slot_host(r, c, ncol);
+            if (sl < 0) continue;
+            G[r * 16 + c] = sum[sl];
+            if (c < 12 && r < c) G[c * 16 + r] = sum[sl];  // the block is symmetric bit for bit (same products, same order)
+        }
+    G[255] = seq;
     return 0;
 }
 
@@ -1459,56 +1600,24 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     }
     const double seq = (double)(++h->seq);
     hipStream_t st = h->stream;
-    const int gran_red = (!h->comm && !h->stats && h->N > 0) ? gran_group_size(h->N) : 0;
+    // group sums as granules in pinned memory (this rank's and, with peers, every rank's): not with an RCCL communicator (the
+    // block is all-reduced on the device), not for an empty scan
+    const bool granules = !h->comm && h->N > 0 && (h->peer_n > 1 || gran_group_size(h->N) > 0);
+    const bool one_launch = do_search && use_pass_kernel(h, granules);
+    if (h->peer_n > 1 && !granules) return fail("flh_eval: a scan shard may not be empty when the ranks exchange granules (flh_peer_*)");
     if (h->comm) {
         // this rank's partial block stays in device memory, RCCL sums the ranks' blocks in place (256 doubles: latency-bound,
         // xGMI bandwidth is irrelevant), then one small kernel publishes the sum + sequence word to pinned host memory
         if (enqueue_eval(h, s, do_search, ext, h->gram.p, 0.0, ev3) != 0) return -1;
         if (rccl_allreduce_publish(h, seq) != 0) return -1;
-    } else if (enqueue_eval(h, s, do_search, ext, h->h_gram, seq, ev3, gran_red > 0) != 0) {
+    } else if (enqueue_eval(h, s, do_search, ext, h->h_gram, seq, ev3, granules) != 0) {
         return -1;
     }
     if (h->stats && do_search) HIPC(hipMemcpyAsync(h->h_counter, h->counter.p, sizeof(u64), hipMemcpyDeviceToHost, st));
-    if (gran_red > 0) {
-        // k_fit's group reducers write {value, sequence} granules straight into pinned memory: wait until every granule of
-        // every group carries this evaluation's sequence number, then add the groups up in group order (fixed order ->
-        // run-to-run identical bits).  No device-side final sum, no drain, no flag.
-        const int ncol = ext ? 12 : 6;
-        const int nslots = flh::gram_slots_host(ncol);
-        const int nblk = flh::fit_blocks((int)h->N);
-        const int ngroups = (nblk + gran_red - 1) / gran_red;
-        const int total = ngroups * nslots + 1;  // + the count of first-stage-unsettled queries behind the last group
-        const double* g = h->h_gran;
-        int next = 0;
-        uint64_t spins = 0;
-        while (next < total) {
-            const __m128d x = _mm_load_pd(g + 2 * (size_t)next);  // one 16-byte read: {value, sequence}
-            if (_mm_cvtsd_f64(_mm_unpackhi_pd(x, x)) == seq) { ++next; continue; }
-            __builtin_ia32_pause();
-            if ((++spins & 0xFFFFFu) == 0 && hipStreamQuery(st) != hipErrorNotReady) {  // finished or failed without publishing
-                HIPC(hipStreamSynchronize(st));
-                const __m128d y = _mm_load_pd(g + 2 * (size_t)next);
-                if (_mm_cvtsd_f64(_mm_unpackhi_pd(y, y)) != seq) return fail("flh_eval: kernel retired without publishing its result");
-            }
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        double sum[kGranSlots];
-        for (int k = 0; k < nslots; ++k) sum[k] = 0.0;
-        for (int gi = 0; gi < ngroups; ++gi) {
-            const double* gg = g + 2 * (size_t)gi * nslots;
-            for (int k = 0; k < nslots; ++k) sum[k] += gg[2 * k];
-        }
-        if (do_search && h->last_search_was_later) h->later_unsettled = (int64_t)g[2 * (size_t)ngroups * nslots];
-        double* G = h->h_gram;
-        std::memset(G, 0, 256 * sizeof(double));
-        for (int r = 0; r < 16; ++r)
-            for (int c = 0; c < 16; ++c) {
-                const int sl = flh::gram_slot_host(r, c, ncol);
-                if (sl < 0) continue;
-                G[r * 16 + c] = sum[sl];
-                if (c < 12 && r < c) G[c * 16 + r] = sum[sl];  // the block is symmetric bit for bit (same products, same order)
-            }
-        G[255] = seq;
+    if (do_search) { h->n_search_pass++; if (one_launch) h->n_one_launch++; } else h->n_nosearch_pass++;
+    if (granules) {
+        if (collect_granules(h, seq, do_search, ext) != 0) return -1;
+        if (h->stats) HIPC(hipStreamSynchronize(st));  // the candidate counter's copy
     } else if (h->stats) {
         HIPC(hipStreamSynchronize(st));
     } else {
@@ -1517,7 +1626,7 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
         const volatile double* flag = h->h_gram + 255;
         uint64_t spins = 0;
         while (*flag != seq) {
-            __builtin_ia32_pause();
+            cpu_relax();
             if ((++spins & 0xFFFFFu) == 0 && hipStreamQuery(st) != hipErrorNotReady) {  // finished or failed without publishing
                 HIPC(hipStreamSynchronize(st));
                 if (*flag != seq) return fail("flh_eval: kernel retired without publishing its result");
@@ -1525,10 +1634,10 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
-    // timed evaluations: three event records on the stream (before the first launch, after the search kernels, after the
-    // fit kernel); the last one completes when k_fit retires, a moment after the flag
+    // timed evaluations: the kernels' own start / stop time stamps (four of them: the search's, the fit's; the one-launch pass:
+    // the pass kernel's two); the last one completes when the last kernel retires, a moment after its granules
     if (deferred) {  // recorded, not awaited: read by drain_events
-        h->evp_search[h->evp_n] = (do_search && h->N > 0) ? (h->last_search_was_later ? 2 : 1) : 0;  // N == 0: no search kernel ran
+        h->evp_search[h->evp_n] = (uint8_t)(((do_search && h->N > 0) ? (h->last_search_was_later ? 2 : 1) : 0) | (one_launch ? 4 : 0));  // N == 0: no search kernel ran
         h->evp_n++;
     } else if (timed) {
         HIPC(hipEventSynchronize(h->ev[3]));
@@ -1538,9 +1647,14 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     flh_unpack_gram(h->h_gram, HTH, HTh, n_eff, total_residual);
     float a = 0, b = 0, c = 0;
     if (timed && !deferred) {
-        if (do_search && h->N > 0) (void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
-        (void)hipEventElapsedTime(&b, h->ev[2], h->ev[3]);
-        (void)hipEventElapsedTime(&c, h->ev[(do_search && h->N > 0) ? 0 : 2], h->ev[3]);
+        if (one_launch) {
+            (void)hipEventElapsedTime(&c, h->ev[0], h->ev[3]);
+            a = c;
+        } else {
+            if (do_search && h->N > 0) (void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
+            (void)hipEventElapsedTime(&b, h->ev[2], h->ev[3]);
+            (void)hipEventElapsedTime(&c, h->ev[(do_search && h->N > 0) ? 0 : 2], h->ev[3]);
+        }
     }
     if (!deferred && h->evp_n == 0) {  // (with samples pending the last timing is whatever drain_events reads last)
         h->timing.search_ms = do_search ? a : 0.f;
@@ -1548,44 +1662,9 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
         h->timing.total_ms = c;
     }
     h->timing.candidates = (h->stats && do_search) ? (int64_t)*h->h_counter : 0;
-#ifdef FLH_PHASES
-    if (h->stats) flh::dump_fit_phases();
-    if (h->stats && do_search) {  // developer build only (tools/phases.py): per-wave phase stamps, reduced here
-        const size_t kWaves = 16 * 1024 * 4;
-        std::vector<u64> ph(kWaves * 12);
-        HIPC(hipMemcpy(ph.data(), h->counter.p + 128, ph.size() * sizeof(u64), hipMemcpyDeviceToHost));
-        for (int k = 0; k < 2; ++k) {
-            double sum[9] = {0}, waves = 0, maxw = 0;
-            u64 r0 = ~0ull, r1 = 0;
-            std::vector<double> starts, durs;
-            for (size_t w = (size_t)k * 8 * 1024 * 4; w < (size_t)(k + 1) * 8 * 1024 * 4; ++w) {
-                const u64* o = ph.data() + w * 12;
-                if (o[0] == 0 || o[8] == 0) continue;
-                waves += 1;
-                for (int i = 0; i < 8; ++i) sum[i] += (double)(o[i + 1] - o[i]);
-                maxw = std::max(maxw, (double)(o[8] - o[0]));
-                r0 = std::min(r0, o[10]);
-                r1 = std::max(r1, o[11]);
-                starts.push_back((double)o[10]);
-                durs.push_back((double)(o[11] - o[10]) / 100.0);
-            }
-            if (waves == 0) continue;
-            std::fprintf(stderr, "[phases] %s waves=%.0f mean cycles/phase:", k == 0 ? "A1" : "A2", waves);
-            for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %.0f", sum[i] / waves);
-            std::fprintf(stderr, " | max wave cycles %.0f | first start -> last end %.2f us\n", maxw, (double)(r1 - r0) / 100.0);
-            for (auto& v : starts) v = (v - (double)r0) / 100.0;
-            std::sort(starts.begin(), starts.end());
-            std::sort(durs.begin(), durs.end());
-            auto pc = [](const std::vector<double>& v, double p) { return v[(size_t)(p * (v.size() - 1))]; };
-            std::fprintf(stderr, "[phases]    wave start offset us p0/p25/p50/p75/p95/p100: %.2f %.2f %.2f %.2f %.2f %.2f; wave duration us: %.2f %.2f %.2f %.2f %.2f %.2f\n",
-                         pc(starts, 0), pc(starts, .25), pc(starts, .5), pc(starts, .75), pc(starts, .95), pc(starts, 1), pc(durs, 0),
-                         pc(durs, .25), pc(durs, .5), pc(durs, .75), pc(durs, .95), pc(durs, 1));
-        }
-    }
-#endif
     if (timed && !deferred) {
         if (do_search && h->N > 0) { h->acc[0] += a; h->acc[1] += 1; h->acc_kind[h->last_search_was_later ? 2 : 0] += a; h->acc_kind[h->last_search_was_later ? 3 : 1] += 1; }
-        h->acc[2] += b; h->acc[3] += 1;
+        if (!one_launch) { h->acc[2] += b; h->acc[3] += 1; }
         h->acc[4] += c; h->acc[5] += 1;
     }
     return 0;
@@ -1724,9 +1803,9 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
     HIPC(hipEventRecord(h->ev[0], st));
     for (int it = 0; it < iters; ++it) {
         if (which == 0) {
-            HIPC(flh::launch_search(h->cfg.lanes_per_query, h->cfg.first_stage, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
-                                    h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_d2.p, h->nn_cnt.p, h->selected.p,
-                                    h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, nullptr, h->own_axis, h->own_lo, h->own_hi, st, nullptr, nullptr, h->cfg.second_stage_lanes));
+            HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap,
+                                    h->cfg.max_sqdist, h->rmax, h->nn_pts.p, h->nn_cnt.p, h->selected.p,
+                                    h->slow_list.p, h->slow_list2.p, h->slow_ub.p, h->slow_count.p, nullptr, h->own_axis, h->own_lo, h->own_hi, st));
             HIPC(hipMemsetAsync(h->slow_count.p, 0, 2 * flh::list_stripes() * sizeof(uint32_t), st));
             h->searched_once = true;
             h->search_state = s;
@@ -1735,7 +1814,7 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
         } else {
             HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p,
                                  h->normvec.p, h->world.p, h->partials.p, h->part2.p, h->gram.p, 0.0, h->tickets.p, h->slow_count.p,
-                                 nullptr, 0, 0, st));
+                                 flh::GranOut{}, 0, 0, st));
         }
     }
     HIPC(hipEventRecord(h->ev[3], st));
@@ -1857,10 +1936,12 @@ static void host_quat_rot(const double q[4], const double v[3], double o[3]) {
 // this; the hot path never materialises rows.
 static int fetch_rows_local(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* n_rows);
 static int fetch_rows_gathered(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* n_rows);
+static int fetch_rows_peers(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* n_rows);
 int flh_fetch_rows(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* n_rows) {
     if (!h || !n_rows) return fail("flh_fetch_rows: null argument");
     if (!h->have_eval) return fail("flh_fetch_rows: no evaluation yet");
     if (h->comm && h->comm_size > 1) return fetch_rows_gathered(h, hx, hv, cap, n_rows);
+    if (h->peer_seg && h->peer_n > 1) return fetch_rows_peers(h, hx, hv, cap, n_rows);
     return fetch_rows_local(h, hx, hv, cap, n_rows);
 }
 static int fetch_rows_local(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* n_rows) {
@@ -1978,6 +2059,7 @@ int flh_rccl_init_rank(flh_handle* h, int nranks, const char id[FLH_RCCL_ID_BYTE
     if (!h || !id) return fail("flh_rccl_init_rank: null argument");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail("flh_rccl_init_rank: bad rank / nranks");
     if (h->comm) return fail("flh_rccl_init_rank: the handle already has a communicator");
+    if (h->peer_seg) return fail("flh_rccl_init_rank: the handle is attached to peers (flh_peer_*)");
     if (rccl_load() != 0) return -1;
     HIPC(hipSetDevice(h->device));
     ncclUniqueId u;
@@ -2032,9 +2114,29 @@ static int rccl_allreduce_publish(flh_handle* h, double seq) {
 int flh_eval_group(flh_handle* const* handles, int n, const double state[FLH_NSTATE], int do_search, int ext, double HTH[144],
                    double HTh[12], int64_t* n_eff, double* total_residual) {
     if (!handles || n < 1 || !state || !HTH || !HTh) return fail("flh_eval_group: bad arguments");
-    for (int i = 0; i < n; ++i)
-        if (!handles[i] || !handles[i]->comm || handles[i]->comm_size != n) return fail("flh_eval_group: handles lack a common communicator (flh_rccl_init_all)");
     const StateDev s = make_state(state + 3, state + 0, state + 7, state + 11);
+    if (handles[0] && handles[0]->peer_seg) {
+        // peers (flh_peer_init_all): every handle's pass publishes to every handle's buffer; handle 0's host adds them up
+        for (int i = 0; i < n; ++i)
+            if (!handles[i] || handles[i]->peer_seg != handles[0]->peer_seg || handles[i]->peer_n != n || handles[i]->peer_rank != i)
+                return fail("flh_eval_group: the handles are not the peers of one flh_peer_init_all, in its order");
+        flh_handle* h0 = handles[0];
+        const double seq = (double)(++h0->seq);
+        for (int i = 0; i < n; ++i) {
+            flh_handle* h = handles[i];
+            h->seq = h0->seq;
+            HIPC(hipSetDevice(h->device));
+            if (h->N == 0) return fail("flh_eval_group: a scan shard may not be empty when the ranks exchange granules");
+            if (enqueue_eval(h, s, do_search, ext, h->h_gram, seq, nullptr, true) != 0) return -1;
+        }
+        HIPC(hipSetDevice(h0->device));
+        if (collect_granules(h0, seq, do_search, ext) != 0) return -1;
+        h0->h_gram[255] = 0.0;
+        flh_unpack_gram(h0->h_gram, HTH, HTh, n_eff, total_residual);
+        return 0;
+    }
+    for (int i = 0; i < n; ++i)
+        if (!handles[i] || !handles[i]->comm || handles[i]->comm_size != n) return fail("flh_eval_group: handles lack a common communicator (flh_rccl_init_all / flh_peer_init_all)");
     for (int i = 0; i < n; ++i) {
         flh_handle* h = handles[i];
         HIPC(hipSetDevice(h->device));
@@ -2053,7 +2155,7 @@ int flh_eval_group(flh_handle* const* handles, int n, const double state[FLH_NST
     const volatile double* flag = h0->h_gram + 255;
     uint64_t spins = 0;
     while (*flag != seq) {
-        __builtin_ia32_pause();
+        cpu_relax();
         if ((++spins & 0xFFFFFu) == 0 && hipStreamQuery(h0->stream) != hipErrorNotReady) {
             HIPC(hipStreamSynchronize(h0->stream));
             if (*flag != seq) return fail("flh_eval_group: result not published");
@@ -2101,6 +2203,170 @@ static int fetch_rows_gathered(flh_handle* h, double* hx, double* hv, int64_t ca
         for (int64_t j = 0; j < nr; ++j, ++k) {
             for (int c = 0; c < 12; ++c) hx[(size_t)c * n + k] = a[1 + (size_t)j * 13 + c];
             hv[k] = a[1 + (size_t)j * 13 + 12];
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU without a collective: peer-written granules (see include/fastlio_hip.h).  The sum the reference forms at
+// esekfom.hpp:1784,1804 over all points is formed here by every host over (rank, group) granules.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPeerRowsMax = 64, kPeerRec = 2 + kPeerRowsMax * 13;  // a rank's record of the gathered row fetch: {tag, n, rows}
+static size_t peer_gran_bytes(int n) { return (size_t)n * 2 * (size_t)n * kGranSect * 16; }
+static size_t peer_seg_bytes(int n) { return peer_gran_bytes(n) + (size_t)n * kPeerRec * sizeof(double); }
+static double* peer_rows(const PeerSeg* sg, int src) { return reinterpret_cast<double*>((char*)sg->host + peer_gran_bytes(sg->n)) + (size_t)src * kPeerRec; }
+
+static void peer_attach(flh_handle* h, PeerSeg* sg, int nranks, int rank) {
+    const size_t window = 2 * (size_t)nranks * kGranSect * 2;  // doubles per destination rank: two parities x nranks sections
+    h->peer_seg = sg;
+    sg->refs++;
+    h->peer_n = nranks;
+    h->peer_rank = rank;
+    h->h_gran_own = h->h_gran;
+    h->h_gran = reinterpret_cast<double*>(sg->host) + (size_t)rank * window;
+    h->gran_owned = false;
+    for (int d = 0; d < nranks; ++d) h->gran_dst[d] = reinterpret_cast<double*>(sg->dev) + (size_t)d * window;
+    h->seq = 0;  // the ranks count their evaluations from the same origin
+}
+
+int flh_peer_open(flh_handle* h, const char* shm_name, int nranks, int rank) {
+    if (!h || !shm_name) return fail("flh_peer_open: null argument");
+    if (nranks < 1 || nranks > FLH_MAX_PEERS || rank < 0 || rank >= nranks) return fail("flh_peer_open: bad rank / nranks");
+    if (h->comm) return fail("flh_peer_open: the handle has an RCCL communicator");
+    if (h->peer_seg) return fail("flh_peer_open: the handle is already attached to peers");
+    HIPC(hipSetDevice(h->device));
+    const size_t bytes = peer_seg_bytes(nranks);
+    int fd = -1;
+    if (rank == 0) {
+        (void)shm_unlink(shm_name);  // a stale segment of an earlier run
+        fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) return fail(std::string("flh_peer_open: shm_open(create): ") + std::strerror(errno));
+        if (ftruncate(fd, (off_t)bytes) != 0) {
+            const std::string m = std::string("flh_peer_open: ftruncate: ") + std::strerror(errno);
+            close(fd);
+            (void)shm_unlink(shm_name);
+            return fail(m);
+        }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {  // wait for rank 0's segment at its full size (ftruncate'd memory is zero-filled)
+            fd = shm_open(shm_name, O_RDWR, 0600);
+            if (fd >= 0) {
+                struct stat sb;
+                if (fstat(fd, &sb) == 0 && (size_t)sb.st_size == bytes) break;
+                close(fd);
+                fd = -1;
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return fail("flh_peer_open: rank 0's segment did not appear");
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+    }
+    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return fail(std::string("flh_peer_open: mmap: ") + std::strerror(errno));
+    hipError_t e = hipHostRegister(m, bytes, hipHostRegisterPortable | hipHostRegisterMapped);
+    void* dev = nullptr;
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&dev, m, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        munmap(m, bytes);
+        if (rank == 0) (void)shm_unlink(shm_name);
+        return fail(std::string("flh_peer_open: hipHostRegister: ") + hipGetErrorString(e));
+    }
+    PeerSeg* sg = new PeerSeg();
+    sg->host = m; sg->dev = dev; sg->bytes = bytes; sg->shm = true; sg->creator = rank == 0; sg->name = shm_name; sg->n = nranks;
+    peer_attach(h, sg, nranks, rank);
+    return 0;
+}
+
+int flh_peer_init_all(flh_handle* const* handles, int n) {
+    if (!handles || n < 1 || n > FLH_MAX_PEERS) return fail("flh_peer_init_all: bad arguments");
+    for (int i = 0; i < n; ++i) {
+        if (!handles[i]) return fail("flh_peer_init_all: null handle");
+        if (handles[i]->comm || handles[i]->peer_seg) return fail("flh_peer_init_all: a handle already has a communicator / peers");
+    }
+    HIPC(hipSetDevice(handles[0]->device));
+    const size_t bytes = peer_seg_bytes(n);
+    void* m = nullptr;
+    HIPC(hipHostMalloc(&m, bytes, hipHostMallocPortable | hipHostMallocMapped));
+    std::memset(m, 0, bytes);
+    PeerSeg* sg = new PeerSeg();
+    sg->host = m; sg->dev = m; sg->bytes = bytes; sg->n = n;
+    for (int i = 0; i < n; ++i) peer_attach(handles[i], sg, n, i);
+    return 0;
+}
+
+void flh_peer_close(flh_handle* h) {
+    if (!h || !h->peer_seg) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    PeerSeg* sg = h->peer_seg;
+    h->peer_seg = nullptr;
+    h->h_gran = h->h_gran_own;
+    h->gran_owned = true;
+    h->gran_dst[0] = h->h_gran;
+    h->peer_n = 1;
+    h->peer_rank = 0;
+    if (--sg->refs == 0) {
+        if (sg->shm) {
+            (void)hipHostUnregister(sg->host);
+            munmap(sg->host, sg->bytes);
+            if (sg->creator) (void)shm_unlink(sg->name.c_str());
+        } else {
+            (void)hipHostFree(sg->host);
+        }
+        delete sg;
+    }
+}
+int flh_peer_size(const flh_handle* h) { return h ? h->peer_n : 0; }
+int flh_peer_rank(const flh_handle* h) { return h ? h->peer_rank : -1; }
+int flh_get_pass_stats(const flh_handle* h, uint64_t out[4]) {
+    if (!h || !out) return fail("flh_get_pass_stats: null argument");
+    out[0] = h->n_search_pass; out[1] = h->n_one_launch; out[2] = h->n_second_stage; out[3] = h->n_nosearch_pass;
+    return 0;
+}
+
+// flh_fetch_rows among peers: every rank's host leaves its rows (at most kPeerRowsMax: the gain-form branch runs when the GLOBAL
+// n_eff is below 23) in the shared segment, tagged with the sequence number of the evaluation they belong to, and reads the
+// others'.  Plain host stores and loads; no device work.
+static int fetch_rows_peers(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* n_rows) {
+    int64_t n_local = 0;
+    if (fetch_rows_local(h, nullptr, nullptr, 0, &n_local) != 0) return -1;
+    if (n_local > kPeerRowsMax) return fail("flh_fetch_rows: more rows on this rank than the gathered fetch carries (the information form needs none)");
+    std::vector<double> lhx((size_t)std::max<int64_t>(n_local, 1) * 12), lhv((size_t)std::max<int64_t>(n_local, 1));
+    if (n_local > 0 && fetch_rows_local(h, lhx.data(), lhv.data(), n_local, &n_local) != 0) return -1;
+    const double tag = (double)h->seq;
+    double* mine = peer_rows(h->peer_seg, h->peer_rank);
+    if (mine[0] != tag) {  // (a second fetch after the same evaluation finds the record in place)
+        mine[1] = (double)n_local;
+        for (int64_t k = 0; k < n_local; ++k) {
+            for (int c = 0; c < 12; ++c) mine[2 + (size_t)k * 13 + c] = lhx[(size_t)c * n_local + k];
+            mine[2 + (size_t)k * 13 + 12] = lhv[k];
+        }
+        std::atomic_thread_fence(std::memory_order_release);
+        reinterpret_cast<std::atomic<double>*>(mine)->store(tag, std::memory_order_release);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    int64_t n = 0;
+    for (int r = 0; r < h->peer_n; ++r) {
+        const double* rec = peer_rows(h->peer_seg, r);
+        while (reinterpret_cast<const std::atomic<double>*>(rec)->load(std::memory_order_acquire) != tag) {
+            cpu_relax();
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return fail("flh_fetch_rows: timed out waiting for a peer's rows");
+        }
+        n += (int64_t)rec[1];
+    }
+    *n_rows = n;
+    if (!hx || !hv) return 0;
+    if (cap < n) return fail("flh_fetch_rows: buffers too small");
+    int64_t k = 0;
+    for (int r = 0; r < h->peer_n; ++r) {
+        const double* rec = peer_rows(h->peer_seg, r);
+        const int64_t nr = (int64_t)rec[1];
+        for (int64_t j = 0; j < nr; ++j, ++k) {
+            for (int c = 0; c < 12; ++c) hx[(size_t)c * n + k] = rec[2 + (size_t)j * 13 + c];
+            hv[k] = rec[2 + (size_t)j * 13 + 12];
         }
     }
     return 0;

@@ -1,0 +1,128 @@
+// flh_fit_dev.hpp -- device code of the per-point plane fit / residual gate / Jacobian row and of the 16x16 Gram contraction
+// on the f64 matrix core, shared by k_fit (flh_kernels.hip) and k_pass (flh_pass.hip).  gfx950 / wave64 only.
+// Reference lines replaced: src/laserMapping.cpp:674-691 (fit + gate), :720-752 (rows), esekfom.hpp:1784,1804 (H^T H, H^T h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "flh_device.hpp"
+
+namespace flh {
+
+// ONE scan point that passed the kNN gate: plane through its five neighbours P (laserMapping.cpp:678), point-to-plane residual
+// (:680), the mixed-precision gate (:681-683), and -- if it passes -- its row of the 16-column Gram operand
+//   v = [row(12) | h = -pd2 | 1 | |pd2| | 0]      (v stays as the caller initialised it -- zeros -- otherwise).
+// PM = 2: the plane is taken from pc (the plane cache) instead of being fitted; PM = 0 / 1: fitted (ok = esti_plane's verdict).
+// Returns the point's final point_selected_surf flag.  The expressions are the reference's, operation for operation.
+template <int ORD, bool HALF, int PM>
+__device__ __forceinline__ bool fit_point(const StateDev& s, float bxf, float byf, float bzf, float wx, float wy, float wz,
+                                          const float (&P)[5][3], const float4& pc, int ext, float thr, float (&pabcd)[4], bool& ok,
+                                          float& pd2, double (&v)[16]) {
+    if (PM == 2) {  // compile-time: this instantiation has no fit in it
+        pabcd[0] = pc.x; pabcd[1] = pc.y; pabcd[2] = pc.z; pabcd[3] = pc.w;
+        ok = true;
+    } else {
+        ok = HALF ? esti_plane_half<ORD>(P, thr, pabcd) : esti_plane<ORD>(P, thr, pabcd);  // :678
+    }
+    bool sel = false;
+    pd2 = 0.f;
+    if (ok) {
+        pd2 = ((pabcd[0] * wx + pabcd[1] * wy) + pabcd[2] * wz) + pabcd[3];  // :680
+        const double bx = (double)bxf, by = (double)byf, bz = (double)bzf;
+        const double nb = sqrt((bx * bx + by * by) + bz * bz);
+        const float sg = (float)(1 - 0.9 * (double)fabsf(pd2) / sqrt(nb));  // :681
+        sel = (double)sg > 0.9;                                             // :683
+    }
+    if (sel) {
+        // Jacobian row, fp64 (:723-752)
+        const double bx = (double)bxf, by = (double)byf, bz = (double)bzf;
+        double px, py, pz;
+        quat_rot(s.offR, bx, by, bz, px, py, pz);
+        px = px + s.offT[0]; py = py + s.offT[1]; pz = pz + s.offT[2];
+        const double rotc[4] = {-s.rot[0], -s.rot[1], -s.rot[2], s.rot[3]};
+        const double nx = (double)pabcd[0], ny = (double)pabcd[1], nz = (double)pabcd[2];
+        double Cx, Cy, Cz;
+        quat_rot(rotc, nx, ny, nz, Cx, Cy, Cz);  // C = R^T n
+        v[0] = nx; v[1] = ny; v[2] = nz;
+        v[3] = (-pz) * Cy + py * Cz;             // A = hat(p_I) C
+        v[4] = pz * Cx + (-px) * Cz;
+        v[5] = (-py) * Cx + px * Cy;
+        if (ext) {
+            const double offRc[4] = {-s.offR[0], -s.offR[1], -s.offR[2], s.offR[3]};
+            double Dx, Dy, Dz;
+            quat_rot(offRc, Cx, Cy, Cz, Dx, Dy, Dz);
+            v[6] = (-bz) * Dy + by * Dz;         // B = hat(p_b) R_LI^T C
+            v[7] = bz * Dx + (-bx) * Dz;
+            v[8] = (-by) * Dx + bx * Dy;
+            v[9] = Cx; v[10] = Cy; v[11] = Cz;
+        }
+        v[12] = -(double)pd2;          // h(i) = -norm_p.intensity (:750)
+        v[13] = 1.0;                   // effct_feat_num
+        v[14] = (double)fabsf(pd2);    // res_last -> total_residual (:702)
+    }
+    return sel;
+}
+
+// The wave's 64 rows contracted into a 16x16 Gram block G = sum v v^T:
+//   G[i][j] (i,j<12) = HTH,  G[i][12] = HTh,  G[13][13] = n_eff,  G[14][13] = total_residual.
+// v_mfma_f64_16x16x4_f64 takes A[i][k] in lane (i + 16k) and B[k][j] in lane (j + 16k): with A = B^T = the same register, one
+// LDS transpose ([point][16] -> lane (col, point%4)) feeds both operands.  T: 64 x kTileStride doubles of LDS owned by the wave;
+// the caller orders the wave's earlier LDS traffic before and after.  Result layout (C/D of the f64 MFMA): col = lane & 15,
+// row = (lane >> 4) + 4 * reg.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int kTileStride = 17;  // doubles per row: 16 + 1 pad (conflict-free ds_write_b64 / ds_read_b64)
+__device__ __forceinline__ void tile_store(double* __restrict__ T, int lane, const double (&v)[16]) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) T[lane * kTileStride + c] = v[c];
+}
+__device__ __forceinline__ v4f64 tile_gram(const double* __restrict__ T, int lane) {
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    const int col = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const double a = T[(4 * m + kq) * kTileStride + col];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// Compact layout of the entries of the 16x16 Gram block the filter reads: the upper triangle of the leading ncol x ncol block
+// (ncol = 12 with extrinsic estimation, else 6: the last six columns are structurally zero, laserMapping.cpp:745), then the
+// ncol entries of column 12 (H^T h), then n_eff (G[13][13]) and total_residual (G[14][13]).  -1 = not transmitted.
+__host__ __device__ inline int gram_nslots(int ncol) { return ncol * (ncol + 1) / 2 + ncol + 2; }
+__host__ __device__ inline int gram_slot(int r, int c, int ncol) {
+    const int tri = ncol * (ncol + 1) / 2;
+    if (c < ncol && r <= c) return r * ncol - r * (r - 1) / 2 + (c - r);
+    if (c == 12 && r < ncol) return tri + r;
+    if (r == 13 && c == 13) return tri + ncol;
+    if (r == 14 && c == 13) return tri + ncol + 1;
+    return -1;
+}
+
+// one 16-byte system-scope store of a {value, sequence} granule (the host polls the sequence word of every granule it needs;
+// a 16-byte store is a single PCIe write, so value and tag arrive together)
+__device__ __forceinline__ void store_granule(double* dst, double value, double seq) {
+    typedef double v2f64 __attribute__((ext_vector_type(2)));
+    const v2f64 g2 = {value, seq};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(g2) : "memory");
+}
+
+
+// Where a pass's group sums go: granule buffers in pinned host memory -- this rank's own and, when a scan is sharded over GPUs,
+// every peer's (one shared-memory segment registered with every device: no collective, no extra launch).  A rank's SECTION of a
+// buffer: granule 0 = {number of value granules that follow, sequence}, then [group][slot] with
+// slot < gran_section_slots(ncol) = the Gram entries the filter reads + one statistic (queries that needed the second search).
+constexpr int kPeersMax = 8;
+struct GranOut {
+    double* dst[kPeersMax];
+    int n_dst;     // 0: no granule output
+    int sect_off;  // granules before this rank's section in every buffer
+};
+__host__ __device__ inline int gran_section_slots(int ncol) { return gram_nslots(ncol) + 1; }
+__device__ __forceinline__ void publish_granule(const GranOut& o, size_t idx, double value, double seq) {
+#pragma unroll
+    for (int d = 0; d < kPeersMax; ++d)  // static indices: the pointers stay in SGPRs
+        if (d < o.n_dst) store_granule(o.dst[d] + ((size_t)o.sect_off + idx) * 2, value, seq);
+}
+
+}  // namespace flh

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "flh_device.hpp"
+#include "flh_fit_dev.hpp"
 
 namespace flh {
 
@@ -32,22 +33,28 @@ hipError_t launch_scan_gather(const float4* raw, const uint32_t* perm, uint32_t 
 
 int list_stripes();
 uint32_t list_stripe_cap(int N);
-hipError_t launch_search(int lpq, int first_stage, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points,
-                         float max_sqdist, int rmax, float4* nn_pts, float* nn_d2, uint8_t* nn_cnt, uint8_t* selected,
+// the three-launch searching pass's search: lpq = 4 (first stage, four lanes per query, + second stage) or 0 (the general exact
+// kernel for every query: the tests' cross-check)
+hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points,
+                         float max_sqdist, int rmax, float4* nn_pts, uint8_t* nn_cnt, uint8_t* selected,
                          uint32_t* list1, uint32_t* list2, float* ub, uint32_t* counts, unsigned long long* cand_counter,
                          int own_axis, float own_lo, float own_hi, hipStream_t st,
-                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,  // optional: time stamps of the first kernel's start / the last one's end
-                         int lpq2 = 8);
+                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);  // optional: time stamps of the first kernel's start / the last one's end
+
+// ---- flh_pass.hip: a searching pass as ONE launch (search, fit, Gram, group sums -> granules) ----
+int pass_blocks(int N);                          // workgroups (64 scan points each)
+int pass_group_size(int N, int max_groups);      // workgroups per reduction group
+hipError_t launch_pass(int order, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points, float max_sqdist,
+                       float thr, int ext, float4* nn_pts, uint8_t* nn_cnt, uint8_t* selected, float4* plane_cache, double* partials,
+                       uint32_t* tickets, const GranOut& gran, double seq, int red, unsigned long long* cand_counter,
+                       int own_axis, float own_lo, float own_hi, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t launch_publish256(const double* src, double* out256, double seq, hipStream_t st);
 
-#ifdef FLH_PHASES
-void dump_fit_phases();
-#endif
 int fit_blocks(int N);
 int reduce1_blocks(int nblk, int* per_out);
 hipError_t launch_fit(int order, int half_fit, const StateDev& s, const float4* body, const float4* nn_pts, int N, int ext, float thr,
                       uint8_t* selected, float4* normvec, float4* world, double* partials, double* part2,
-                      double* out256, double seq, uint32_t* tickets, uint32_t* slow_count, double* gran, int red1, int store_aux,
+                      double* out256, double seq, uint32_t* tickets, uint32_t* slow_count, const GranOut& gran, int red1, int store_aux,
                       hipStream_t st, float4* plane_cache = nullptr, int plane_mode = 0, hipEvent_t ev_start = nullptr,
                       hipEvent_t ev_stop = nullptr);
 hipError_t launch_fill_d2(const StateDev& s_search, const float4* body, const float4* nn_pts, int N, float* nn_d2, hipStream_t st);

@@ -761,16 +761,15 @@ hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uin
     hipLaunchKernelGGL(k_cls_compact, dim3(cdiv2(N, 256)), dim3(256), 0, st, world, cls, incl, N, out, host_counts, seq);
     return hipGetLastError();
 }
-// the counters of a map change and the number of points it inserted, as two granules behind each other:
-// {storage top, bricks, re-index flags, removed} with seq in a second granule {inserted, 0, 0, seq}
+// the counters of a map change and the number of points it inserted, as two granules, each carrying the sequence word (system-scope
+// stores need not reach the host in order): {storage top, bricks, re-index flags, seq} {removed, inserted, 0, seq}
 __global__ void k_map_publish(const uint32_t* __restrict__ ctr, const uint32_t* __restrict__ n_alive, uint32_t* __restrict__ host_out,
                               uint32_t seq) {
     if (threadIdx.x != 0) return;
     const uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
     const uint32_t na = n_alive ? *n_alive : 0u;
-    publish_granule(host_out, c0, c1, c2, c3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first granule carries no sequence word of its own: it lands before the second
-    publish_granule(host_out + 4, na, 0u, 0u, seq);
+    publish_granule(host_out, c0, c1, c2, seq);
+    publish_granule(host_out + 4, c3, na, 0u, seq);
 }
 hipError_t launch_map_publish(const uint32_t* ctr, const uint32_t* n_alive, uint32_t* host_out, uint32_t seq, hipStream_t st) {
     hipLaunchKernelGGL(k_map_publish, dim3(1), dim3(64), 0, st, ctr, n_alive, host_out, seq);

@@ -1,0 +1,256 @@
+// flh_pass.hip -- k_pass: a SEARCHING pass of the iterated update as ONE launch (gfx950 / CDNA4, wave64).
+//
+// The reference does everything a scan point needs in one loop body -- transform, Nearest_Search, the kNN gate, esti_plane, the
+// residual gate (src/laserMapping.cpp:650-693) -- then builds the rows (:720-752) and the filter forms H^T H, H^T h
+// (esekfom.hpp:1784,1804).  Rounds 1-3 ran that as three dependent launches (first search stage -> second stage -> fit) with
+// the neighbours written to HBM and read back in between.  Here a workgroup owns 64 consecutive (Morton-ordered) scan points
+// from the transform to their share of the normal equations:
+//
+//   phase A   ring_query<4,1>: four lanes per query over the 3x3x3 cell block, all 64 queries at once.  Results go to the
+//             neighbour cache in HBM (later passes and map_incremental read it) AND stay in LDS for the fit.
+//   phase B   the queries phase A could not settle (5th neighbour not provably inside the block: at the prior, the far field of
+//             the scan; a handful later) are searched again by the same workgroup, eight lanes per query, over the 5x5x5 block
+//             clipped to the ball of phase A's bound (ring_query<8,2>, which also finishes distance ties with 64-bit keys).
+//             Workgroup-local on purpose: no global work list, no second launch, no spin-waits, and the order in which rows
+//             enter the sums does not depend on timing.
+//   fit       ONE wave takes the 64 queries' neighbours from LDS (lane = query): esti_plane, residual, gate, Jacobian row
+//             (fit_point, the reference's expressions), keeps the plane for the no-search passes (plane cache), contracts the
+//             64 rows into a 16x16 Gram block on v_mfma_f64_16x16x4_f64 and stores the entries the filter reads; the other
+//             three waves have retired by then.
+//   reduce    workgroups are grouped `red` at a time; the last one of a group to finish sums the group's partials in workgroup
+//             order and hands them to the host as 16-byte {value, sequence} granules in pinned memory (to every rank's buffer
+//             when the scan is sharded over GPUs); the host adds the groups in group order.  Fixed order -> identical bits
+//             run to run.
+//
+// Requires cells >= sqrt(max_sqdist) / 1.998 (the 5x5x5 block then covers the gate radius, so phase B settles everything it
+// is given; flh_api.cpp checks and otherwise runs the three-launch pass of flh_kernels.hip).
+#include "flh_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "flh_device.hpp"
+#include "flh_search_dev.hpp"
+#include "flh_fit_dev.hpp"
+
+namespace flh {
+
+// Registers: the kernel is held to 72 VGPRs = 7 waves per SIMD (a scan of 100 000 points is 6 252 waves on 1 024 SIMDs: one
+// round); FLH_PASS_WAVES selects another bound for A/B builds (tools/variant.py).
+// phase B keeps four point loads in flight per lane (eight lanes per query: 32 per query, as phase A's 4 x 8); with eight the
+// kernel does not fit 72 registers
+#ifndef FLH_UNR_B
+#define FLH_UNR_B 4
+#endif
+#ifndef FLH_PASS_WAVES
+#define FLH_PASS_WAVES 7
+#endif
+#define PASS_ATTR __attribute__((amdgpu_waves_per_eu(FLH_PASS_WAVES, FLH_PASS_WAVES)))
+constexpr int kPassQueries = 64;                       // scan points per workgroup
+constexpr int kSegA = ring_seg_slots<1>();             // 20 LDS table entries per phase-A group (64 groups)
+constexpr int kSegB = 2 * 16 + 2;                      // 34 per phase-B group (32 groups, 4x4 window)
+constexpr int kSegWords = (64 * kSegA > 32 * kSegB) ? 64 * kSegA : 32 * kSegB;
+static_assert(kSegWords * 8 >= 64 * kTileStride * 8, "the fit's transpose tile reuses the segment tables");
+template <int ORD>
+__global__ void __launch_bounds__(256) PASS_ATTR
+k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist, float thr, int ext,
+       int ncol, float4* __restrict__ nn_pts, uint8_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected,
+       float4* __restrict__ plane_cache, double* __restrict__ partials, uint32_t* __restrict__ tickets, GranOut gout, double seq,
+       int red, u64* __restrict__ cand_counter, int own_axis, float own_lo, float own_hi) {
+    __shared__ uint2 segs[kSegWords];
+    __shared__ float park[kPassQueries * kParkStride];
+    __shared__ uint32_t s_list[64];  // per wave: the slots (0..63) of its queries that go to phase B
+    __shared__ uint32_t s_wcnt[4];
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * kPassQueries;
+    const RingRsrc rs(g, map_points);
+
+    // ---- phase A: every query of the workgroup, four lanes each
+    {
+        const int grp = tid >> 2, lane = tid & 3, wave = tid >> 6, wl = tid & 63;
+        bool live = q0 + grp < N;
+        const int q = live ? q0 + grp : N - 1;
+        const float4 b = body[q];
+        float qx, qy, qz;
+        body_to_world(s, b.x, b.y, b.z, qx, qy, qz);  // src/laserMapping.cpp:656-660
+        if (own_axis >= 0) {  // map partitioned over ranks (flh_set_owned_interval): another rank's query
+            const float oc = own_axis == 0 ? qx : (own_axis == 1 ? qy : qz);
+            if (live && !(oc >= own_lo && oc < own_hi)) {
+                if (lane == 0) nn_cnt[q] = 0;
+                live = false;
+            }
+        }
+        float* pk = park + grp * kParkStride;
+        if (lane == 0) {
+            pk[kParkWorld] = qx; pk[kParkWorld + 1] = qy; pk[kParkWorld + 2] = qz;
+            pk[kParkBody] = b.x; pk[kParkBody + 1] = b.y; pk[kParkBody + 2] = b.z;
+        }
+        float ub_next;
+        const bool done = ring_query<4, 1, false, 8, false, false>(g, rs, segs + grp * kSegA, lane, q, N, live, qx, qy, qz, INFINITY,
+                                                                   max_sqdist, 2, nn_pts, nn_cnt, selected, cand_counter, pk, ub_next);
+        const bool open = live && !done;
+        if (lane == 0 && !(live && done)) {  // a settled query's status was written with its fifth neighbour
+            pk[kParkStatus] = __uint_as_float(open ? kStOpen : kStIdle);
+            pk[kParkUb] = ub_next;
+        }
+        const u64 bal = __ballot(open && lane == 0);
+        if (open && lane == 0) s_list[wave * 16 + __popcll(bal & ((1ull << wl) - 1ull))] = (uint32_t)grp;
+        if (wl == 0) s_wcnt[wave] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+
+    // ---- phase B: the workgroup's open queries, eight lanes each, 32 per trip
+    const uint32_t c0 = s_wcnt[0], c1 = s_wcnt[1], c2 = s_wcnt[2], c3 = s_wcnt[3];
+    const uint32_t n_open = (c0 + c1) + (c2 + c3);  // workgroup-uniform
+#ifndef NO_PHASE_B
+    if (n_open) {
+        for (uint32_t k0 = 0; k0 < n_open; k0 += 32) {
+            // (normally one trip: the lane-dependent set-up is kept inside it instead of being hoisted into registers that
+            // would have to live across the whole loop)
+            int tid_b = tid;
+            asm volatile("" : "+v"(tid_b));
+            const int grp = tid_b >> 3, lane = tid_b & 7;
+            const bool live = k0 + grp < n_open;
+            uint32_t idx = live ? k0 + grp : 0u, w = 0;
+            if (idx >= c0) { idx -= c0; w = 1; if (idx >= c1) { idx -= c1; w = 2; if (idx >= c2) { idx -= c2; w = 3; } } }
+            const uint32_t slot = s_list[w * 16 + idx];
+            float* pk = park + slot * kParkStride;
+            const float qx = pk[kParkWorld], qy = pk[kParkWorld + 1], qz = pk[kParkWorld + 2];
+            const float ub = pk[kParkUb];
+            float ub_next;
+            const bool done = ring_query<8, 2, true, 11, true, false, true, FLH_UNR_B>(g, rs, segs + grp * kSegB, lane, q0 + (int)slot, N, live, qx, qy, qz,
+                                                                      ub, max_sqdist, 2, nn_pts, nn_cnt, selected, cand_counter, pk, ub_next);
+            (void)done;  // always settled: the block covers the gate radius (see the head of this file); a status left open is not fitted
+            wave_sync();  // the segment tables are rewritten by the next trip
+        }
+        __syncthreads();
+    }
+#endif
+
+    // ---- fit: one wave, lane = query.  Which wave: spread over the SIMDs (a workgroup's waves land on the four SIMDs of a CU
+    // in order, so a fixed choice would load one SIMD of every CU with all the fits)
+    // (lane and wave are derived again rather than kept in registers across phase B)
+    int tid_f = threadIdx.x;
+    asm volatile("" : "+v"(tid_f));
+    if ((tid_f >> 6) != (int)((blockIdx.x >> 3) & 3u)) return;
+    const int wl = tid_f & 63;
+    const int qf = q0 + wl;
+    double v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = 0.0;
+    {
+        const float* pk = park + wl * kParkStride;
+        const uint32_t st = __float_as_uint(pk[kParkStatus]);
+        if (qf < N) {
+            bool sel = false;
+            if (st == kStFit) {  // laserMapping.cpp:674
+                float P[5][3];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) { P[j][0] = pk[3 * j]; P[j][1] = pk[3 * j + 1]; P[j][2] = pk[3 * j + 2]; }
+                float pabcd[4], pd2;
+                bool ok;
+                const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
+                sel = fit_point<ORD, false, 1>(s, pk[kParkBody], pk[kParkBody + 1], pk[kParkBody + 2], pk[kParkWorld], pk[kParkWorld + 1],
+                                               pk[kParkWorld + 2], P, none, ext, thr, pabcd, ok, pd2, v);
+                if (ok && plane_cache) plane_cache[qf] = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
+            }
+            selected[qf] = sel ? 1 : 0;
+        }
+    }
+    double* T = reinterpret_cast<double*>(segs);
+    wave_sync();
+    tile_store(T, wl, v);
+    wave_sync();
+    const v4f64 acc = tile_gram(T, wl);
+
+    // ---- this workgroup's share of the normal equations -> HBM (write-through, agent scope), then the group's ticket
+    typedef __attribute__((address_space(1))) double gdouble;
+    const int nsl = gran_section_slots(ncol);  // the last one: the number of queries that needed phase B (a statistic the host reports)
+    gdouble* gpart = (gdouble*)partials;
+    {
+        const int col = wl & 15, kq = wl >> 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int slot = gram_slot(kq + 4 * r, col, ncol);
+            if (slot >= 0) __hip_atomic_store(gpart + (size_t)blockIdx.x * nsl + slot, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (wl == 0) {  // (read again from LDS rather than kept in a register across phase B and the fit)
+            const uint32_t n_b = (s_wcnt[0] + s_wcnt[1]) + (s_wcnt[2] + s_wcnt[3]);
+            __hip_atomic_store(gpart + (size_t)blockIdx.x * nsl + (nsl - 1), (double)n_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const int nblk = gridDim.x;
+    const int group = blockIdx.x / red;
+    const int gsize = min(red, nblk - group * red);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t tk = 0;
+    if (wl == 0) tk = __hip_atomic_fetch_add(&tickets[1 + group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+    if (tk != (uint32_t)(gsize - 1)) return;
+    // ---- last workgroup of its group: sum the group's partials in workgroup order (two halves of the wave take the two halves of
+    // the group; lower half + upper half, the same order whoever arrives last) and publish the granules
+    {
+        const int b0 = group * red;
+        const int half = (gsize + 1) >> 1;
+        const int hi = wl >> 5, sl = wl & 31;
+        const int jlo = hi ? half : 0, jhi = hi ? gsize : half;
+        for (int slot = sl; slot < ((nsl + 31) & ~31); slot += 32) {
+            const int sc = slot < nsl ? slot : nsl - 1;
+            double s0 = 0.0;
+            for (int j0 = jlo; j0 < jhi; j0 += 16) {
+                double pv[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    pv[j] = (j0 + j < jhi) ? __hip_atomic_load(gpart + (size_t)(b0 + j0 + j) * nsl + sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) s0 += pv[j];
+            }
+            const double other = __shfl_xor(s0, 32, 64);
+            const double total = hi ? other + s0 : s0 + other;  // lower half + upper half on both sides
+            if (hi == 0 && slot < nsl) publish_granule(gout, 1 + (size_t)group * nsl + slot, total, seq);
+        }
+        if (wl == 0) {
+            tickets[1 + group] = 0;  // re-arm this group's ticket for the next launch
+            if (group == 0) publish_granule(gout, 0, (double)(((nblk + red - 1) / red) * nsl), seq);  // the section's header
+        }
+    }
+}
+
+int pass_blocks(int N) { return ((N > 0 ? N : 1) + kPassQueries - 1) / kPassQueries; }
+// workgroups per reduction group: 64, more when that would make more than max_groups groups
+int pass_group_size(int N, int max_groups) {
+    const int nblk = pass_blocks(N);
+    int red = 64;
+    while ((nblk + red - 1) / red > max_groups) red *= 2;
+    return red;
+}
+
+hipError_t launch_pass(int order, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points, float max_sqdist,
+                       float thr, int ext, float4* nn_pts, uint8_t* nn_cnt, uint8_t* selected, float4* plane_cache, double* partials,
+                       uint32_t* tickets, const GranOut& out, double seq, int red, unsigned long long* cand_counter,
+                       int own_axis, float own_lo, float own_hi, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (N <= 0 || out.n_dst < 1 || out.n_dst > kPeersMax) return hipErrorInvalidValue;
+    const int ncol = ext ? 12 : 6;
+    const dim3 grid(pass_blocks(N)), blk(256);
+#define FLH_PASS(O)                                                                                                                   \
+    do {                                                                                                                              \
+        if (ev_start != nullptr || ev_stop != nullptr)                                                                                \
+            hipExtLaunchKernelGGL((k_pass<O>), grid, blk, 0, st, ev_start, ev_stop, 0, g, s, body, N, map_points, max_sqdist, thr, ext, \
+                                  ncol, nn_pts, nn_cnt, selected, plane_cache, partials, tickets, out, seq, red, cand_counter, own_axis, \
+                                  own_lo, own_hi);                                                                                     \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((k_pass<O>), grid, blk, 0, st, g, s, body, N, map_points, max_sqdist, thr, ext, ncol, nn_pts, nn_cnt,   \
+                               selected, plane_cache, partials, tickets, out, seq, red, cand_counter, own_axis, own_lo, own_hi);       \
+    } while (0)
+    switch (order) {
+        case 0: FLH_PASS(0); break;
+        case 2: FLH_PASS(2); break;
+        case 3: FLH_PASS(3); break;
+        default: FLH_PASS(1); break;
+    }
+#undef FLH_PASS
+    return hipGetLastError();
+}
+
+}  // namespace flh

@@ -49,12 +49,14 @@ typedef struct flh_config {
     float plane_threshold;  /* esti_plane inlier threshold; <=0 -> 0.1f (src/laserMapping.cpp:678) */
     float max_sqdist;       /* kNN gate on the 5th neighbour; <=0 -> 5.0f (src/laserMapping.cpp:671) */
     void* stream;           /* hipStream_t to run on; NULL -> the handle creates its own */
-    int lanes_per_query;    /* fast search kernel: lanes cooperating on one query, 2/4/8/16 (default 4);
-                               0 = run the general exact kernel for every query */
+    int lanes_per_query;    /* 4 (default, also for any other non-zero value): the ring search, four lanes per query in its first
+                               stage; 0 = run the general exact kernel for every query (the tests' cross-check) */
     int sort_queries;       /* 1: Morton-sort scan points at upload for cache locality (default 1 if <0) */
-    int first_stage;        /* block of cells the first search stage scans: 1 (and 0 = default) = the 3x3x3 block around the
-                               query's cell, 2 = the 2x2x2 block nearest to the query (8 cells instead of 27; more queries go on
-                               to the second stage).  Performance only: either setting returns the same exact 5-NN */
+    int pass_kernel;        /* 1 (default, also for < 0): a SEARCHING pass is ONE launch -- 5-NN, plane fit, residual gate, Jacobian
+                               rows, H^T H / H^T h and their group sums in one kernel (k_pass); 0: the three-launch pass (two search
+                               stages, then the fit).  Same results bit for bit.  The one-launch pass needs cells of at least
+                               sqrt(max_sqdist) / 1.49 (1.5 m for the default gate) and lanes_per_query = 4; otherwise, with
+                               plane_fit_dtype = 1, and with an RCCL communicator attached the three-launch pass runs */
     int eigen_order;        /* fp32 summation order of esti_plane's reductions (include/common_lib.h:241 runs Eigen's
                                ColPivHouseholderQR, whose reduction order depends on how Eigen was vectorised):
                                FLH_ORDER_SEQ / _SSE / _PAIRWISE / _NOVEC; <0 -> FLH_ORDER_SSE (Eigen 3.3.x, x86-64 + SSE2:
@@ -67,9 +69,6 @@ typedef struct flh_config {
     int plane_cache;        /* 1 (default, also for < 0): a pass that does not search takes each point's plane from the fit of the last
                                searching pass instead of re-reading five neighbours and repeating the QR (a plane depends on the
                                neighbours only, not on the state: same bits); 0: re-fit on every pass */
-    int second_stage_lanes; /* lanes cooperating on one query of the second search stage (the queries the first stage could not
-                               settle: 5x5x5 cells inside the first stage's bound): 8 (default, also for any other value), 16
-                               or 32.  Performance only */
     int fused_small_changes; /* 1 (default, also for < 0): a map change of at most 8192 points (flh_map_add, flh_map_incremental:
                                every scan of a running odometry) gives the surviving points their ids and sorts them by brick in
                                one workgroup instead of the general path's scan + device-wide sort (one launch instead of eight,
@@ -88,6 +87,12 @@ int flh_device_available(void);
  * its spatial index (radix-sorted cell grid) from M world-frame points.  Map indices reported by
  * flh_fetch_neighbors refer to positions in this array. */
 int flh_map_build(flh_handle* h, const void* xyz, size_t stride_bytes, size_t M);
+/* Map changes (flh_map_add, flh_map_delete_boxes, flh_map_incremental with apply) are ENQUEUED and return; their counters -- and
+ * an error a change ran into on the device: a re-indexing that failed, a fault -- are collected by whichever call needs them
+ * next.  flh_map_sync collects them now and returns the change's status (0 / -1 with flh_last_error); flh_map_size and
+ * flh_map_stats collect them too (they may wait for the device and re-index; not to be called concurrently with other calls on
+ * the handle) and report the state before the change if collecting failed. */
+int flh_map_sync(flh_handle* h);
 size_t flh_map_size(const flh_handle* h);
 
 /* ---- the incremental map around the hot path --------------------------------------
@@ -220,11 +225,25 @@ int flh_eval_device(flh_handle* h, const double state[FLH_NSTATE], int do_search
 void flh_unpack_gram(const double gram256[256], double HTH[144], double HTh[12], int64_t* n_eff,
                      double* total_residual);
 
-/* ---- multi-GPU: RCCL all-reduce of the normal equations over xGMI ---------------------------------------
+/* ---- multi-GPU -------------------------------------------------------------------------------------------
  * The scan's points are sharded over the GPUs (map replicated), or the map is partitioned (flh_set_owned_interval); either
- * way a pass's only exchange is the sum of the ranks' 16x16 Gram blocks.  Once a handle has a communicator, flh_eval (and
- * with it the mirrored h_share_model / esekf) all-reduces before it returns: every rank gets the same normal equations
- * and runs the same 23x23 solve.  RCCL is loaded on first use.
+ * way a pass's only exchange is the sum of the ranks' normal equations (esekfom.hpp:1784,1804), and every rank runs the same
+ * 23x23 solve on the same bits.  Two exchanges:
+ *
+ * PEER GRANULES (flh_peer_*, the default of bench.py --gpus N): no collective and no extra launch.  The last workgroup of every
+ *   reduction group of a pass writes its {value, sequence} granules straight into EVERY rank's pinned granule buffer -- one
+ *   POSIX shared-memory segment that each process maps and registers with its device -- and every host adds ranks x groups
+ *   in (rank, group) order while it polls.  A pass on G GPUs then costs what it costs on one GPU with N/G points plus one
+ *   PCIe write latency.  Every rank must call flh_eval the same number of times (they do: same normal equations, same
+ *   decisions); a scan shard must not be empty.
+ *     one process per GPU: every rank calls flh_peer_open(h, name, nranks, rank) with the same name ("/something", see
+ *       shm_open(3)); rank 0 creates the segment, the others wait for it (30 s).  flh_peer_close (or flh_destroy) detaches;
+ *       rank 0 unlinks the name.
+ *     one process, several handles: flh_peer_init_all, then flh_eval_group.
+ *
+ * RCCL (flh_rccl_*): the ranks' 16x16 Gram blocks all-reduced on the device (ncclAllReduce of 256 doubles on the handle's stream)
+ *   and published by one small kernel.  Once a handle has a communicator, flh_eval all-reduces before it returns.  RCCL is
+ *   loaded on first use.  A handle has at most one of the two.
  *   one process per GPU: rank 0 calls flh_rccl_unique_id, hands the 128 bytes to the others by any means (MPI, a file,
  *     torch.distributed), every rank calls flh_rccl_init_rank.
  *   one process, several GPUs: flh_rccl_init_all over one handle per device, then flh_eval_group (enqueues on every device
@@ -238,6 +257,15 @@ int flh_rccl_size(const flh_handle* h);
 int flh_rccl_rank(const flh_handle* h);
 int flh_eval_group(flh_handle* const* handles, int n, const double state[FLH_NSTATE], int do_search, int extrinsic_est_en,
                    double HTH[144], double HTh[12], int64_t* n_eff, double* total_residual);
+#define FLH_MAX_PEERS 8
+int flh_peer_open(flh_handle* h, const char* shm_name, int nranks, int rank);
+int flh_peer_init_all(flh_handle* const* handles, int n);
+void flh_peer_close(flh_handle* h);
+int flh_peer_size(const flh_handle* h);
+int flh_peer_rank(const flh_handle* h);
+/* Counters of the handle's evaluations since creation: {searching passes, of them as ONE launch (flh_config.pass_kernel),
+ * queries that needed the second search (summed over those passes and, with peers, over the ranks), no-search passes}. */
+int flh_get_pass_stats(const flh_handle* h, uint64_t out[4]);
 /* Map partitioned over the ranks (BASELINE configs[4]): this handle's map is one slab of the world plus a halo of at least
  * sqrt(max_sqdist) on either side; every rank holds the whole scan; a query is searched (and then fitted) only by the
  * rank whose half-open interval [lo, hi) of world coordinate `axis` (0/1/2) contains it.  The ranks' intervals must tile
@@ -267,9 +295,10 @@ int flh_last_timing(flh_handle* h, flh_timing* t);
  * out[0] = sum of search-kernel ms, out[1] = number of search launches, out[2] = sum of fit(+reduce) ms,
  * out[3] = number of fit launches, out[4] = sum of first-launch-to-host-visible ms, out[5] = evaluations. */
 int flh_get_counters(flh_handle* h, double out[6], int reset);
-/* The search part of the same, split by kind: out[0], out[1] = ms and launches of a scan's FIRST search (every query over its
- * whole 3x3x3 block), out[2], out[3] = of its LATER searches (bounded by the neighbours the previous search cached).  Reset
- * together with flh_get_counters(reset != 0). */
+/* The search part of the same, split by kind: out[0], out[1] = ms and launches of a scan's FIRST search (at the prior: the most
+ * queries for the second stage), out[2], out[3] = of its LATER searches.  The same kernels run either way; the split is a
+ * measurement label.  With the one-launch pass (flh_config.pass_kernel) the figures are the pass kernel's.  Reset together with
+ * flh_get_counters(reset != 0). */
 int flh_get_search_counters(flh_handle* h, double out[4]);
 /* The HIP events behind flh_last_timing / flh_get_counters: recorded on every n-th flh_eval (1 = always, the default;
  * 0 = never).  With every_n == 1 the evaluation waits for its last event and reads the three times at once (tens of

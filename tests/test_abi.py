@@ -54,9 +54,8 @@ def test_config_mirror_matches_the_c_struct():
     cfg = capi.FlhConfig()
     C.memset(C.byref(cfg), 0x5A, C.sizeof(cfg))
     capi.lib().flh_default_config(C.byref(cfg))
-    assert cfg.device == -1 and cfg.lanes_per_query == 4 and cfg.first_stage == 0 and cfg.plane_fit_dtype == 0
+    assert cfg.device == -1 and cfg.lanes_per_query == 4 and cfg.plane_fit_dtype == 0
     assert cfg.cell_size == 1.5 and cfg.max_sqdist == 5.0 and abs(cfg.plane_threshold - 0.1) < 1e-7
     assert not cfg.stream
     # "default" markers the library resolves in flh_create
-    assert (cfg.sort_queries, cfg.eigen_order, cfg.undistort_first_point, cfg.plane_cache, cfg.fused_small_changes) == (-1,) * 5
-    assert cfg.second_stage_lanes == 0
+    assert (cfg.sort_queries, cfg.pass_kernel, cfg.eigen_order, cfg.undistort_first_point, cfg.plane_cache, cfg.fused_small_changes) == (-1,) * 6

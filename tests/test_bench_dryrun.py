@@ -55,8 +55,10 @@ def test_two_ranks_over_gloo():
     # N > 1: the headline is the north_star split (ONE scan sharded over the ranks + all-reduce inside every pass), strong
     # scaling; the N independent replicas are a labelled sub-field and never `value`
     assert d["n_gpus"] == 2 and d["ranks_seen_by_collective"] == 2 and d["scaling"] == "strong"
-    assert "sharded" in d["config"]["parallelism"] and d["ranks_in_rccl_communicator"] is not None
-    assert d["sharded_path"]["collective"].startswith("ncclAllReduce") and "shard_mode" not in d
+    assert "sharded" in d["config"]["parallelism"] and d["ranks_exchanging_normal_equations"] is not None
+    # the default exchange: peer-written granules (no collective); the RCCL all-reduce is timed beside it
+    assert d["sharded_path"]["collective"].startswith("peer granules") and "shard_mode" not in d
+    assert d["other_exchange"]["collective"].startswith("rccl") and "error" not in d["other_exchange"]
     assert d["replicas_no_collective"]["scaling"] == "weak" and "NO collective" in d["replicas_no_collective"]["note"]
     assert abs(d["value"] * d["ms_per_step"] / 1000.0 - 1.0) < 0.01  # value = scans of the ONE sharded stream per second (not x ranks)
 

@@ -80,11 +80,12 @@ def test_eval_search_and_nosearch_passes(prob, ext):
     check_neighbors(h, sc)
 
 
-@pytest.mark.parametrize("lpq,sort,stage", [(0, 1, 0), (2, 1, 0), (4, 0, 0), (8, 1, 0), (16, 0, 0), (1, 1, 1), (1, 1, 2), (2, 1, 2),
-                                            (4, 1, 2)])
-def test_search_kernel_variants(prob, lpq, sort, stage):
+@pytest.mark.parametrize("lpq,sort,one_launch", [(0, 1, 0), (4, 0, 0), (4, 1, 0), (4, 0, 1), (4, 1, 1)])
+def test_search_kernel_variants(prob, lpq, sort, one_launch):
+    """The general exact kernel for every query, and the ring search as three launches / as ONE launch (flh_config.pass_kernel),
+    with and without the Morton order of the scan: the same neighbours, flags, planes and normal equations as the oracle."""
     pr, m, xp, P, _ = prob
-    h = capi.Handle(lanes_per_query=lpq, sort_queries=sort, first_stage=stage)
+    h = capi.Handle(lanes_per_query=lpq, sort_queries=sort, pass_kernel=one_launch)
     h.map_build(pr.map_xyz)
     h.scan_upload(pr.body[:5000])
     sc = po.Scan(pr.body[:5000], nthreads=8)
@@ -390,7 +391,7 @@ def test_rccl_allreduce_path_single_rank(prob):
     must be the plain path's, bit for bit, through eval, the full update and flh_eval_group."""
     pr, m, xp, P, _ = prob
     body = pr.body[:6000]
-    ref_h = capi.Handle()
+    ref_h = capi.Handle(pass_kernel=0)  # with a communicator the three-launch pass runs: compare like with like, bit for bit
     ref_h.map_build(pr.map_xyz)
     ref_h.scan_upload(body)
     ref = ref_h.eval(xp, True, False)
@@ -424,6 +425,48 @@ def test_rccl_allreduce_path_single_rank(prob):
         np.testing.assert_array_equal(a, b)
     g.close()
     ref_h.close()
+
+
+def test_peer_granules_one_and_two_handles(prob):
+    """The exchange without a collective (flh_peer_*): every handle's group reducers write their granules into every handle's
+    pinned buffer, the host adds (rank, group) in order.  One handle attached to itself: the plain path's bits.  One scan
+    split over two handles (Morton-first shards, map replicated) through flh_eval_group: flags of every point as in the
+    single-handle evaluation, normal equations equal up to the order of the fp64 sums, at a searching and a no-search pass,
+    with and without the extrinsic columns."""
+    from fast_lio_amd import dist as fdist
+
+    pr, m, xp, P, _ = prob
+    body = pr.body
+    one = capi.Handle()
+    one.map_build(pr.map_xyz)
+    one.scan_upload(body)
+    solo = capi.Handle()
+    capi.peer_init_all([solo])
+    assert solo.peer_size() == 1
+    solo.map_build(pr.map_xyz)
+    solo.scan_upload(body)
+    shards = [fdist.morton_shard(body, r, 2) for r in range(2)]
+    hs = [capi.Handle(), capi.Handle()]
+    capi.peer_init_all(hs)
+    assert hs[1].peer_size() == 2
+    for hh, idx in zip(hs, shards):
+        hh.map_build(pr.map_xyz)
+        hh.scan_upload(np.ascontiguousarray(body[idx]))
+    for ext in (False, True):
+        for x, search in ((xp, True), (pr.x_true, False), (pr.x_true, True), (xp, False)):
+            ref = one.eval(x, search, ext)
+            got1 = capi.eval_group([solo], x, search, ext)
+            for a, b in zip(got1, ref):
+                np.testing.assert_array_equal(a, b)
+            got = capi.eval_group(hs, x, search, ext)
+            np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=1e-12 * np.abs(ref[0]).max())
+            np.testing.assert_allclose(got[1], ref[1], rtol=0, atol=1e-12 * np.abs(ref[1]).max())
+            assert got[2] == ref[2] and abs(got[3] - ref[3]) <= 1e-12 * max(abs(ref[3]), 1.0)
+            sel = one.fetch_selected()
+            for hh, idx in zip(hs, shards):
+                np.testing.assert_array_equal(hh.fetch_selected(), sel[idx])
+    for hh in hs + [solo, one]:
+        hh.close()
 
 
 def test_map_partitioned_over_two_handles_equals_the_whole_map(prob):

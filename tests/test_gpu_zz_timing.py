@@ -13,10 +13,42 @@ pytestmark = pytest.mark.gpu
 def setup():
     pr = synth.make_problem(200000, 20000, "avia", cfg=1)
     xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
-    h = capi.Handle()
+    h = capi.Handle(pass_kernel=0)  # the three-launch pass: search and fit are kernels of their own, each with its time stamps
     h.map_build(pr.map_xyz)
     h.scan_upload(pr.body)
     return pr, xp, h
+
+
+def test_one_launch_pass_is_timed_as_one_kernel():
+    """flh_config.pass_kernel (default): a searching evaluation is ONE kernel; its time is reported as the evaluation's and the
+    search's, no fit sample is counted; no-search evaluations are timed as before."""
+    pr = synth.make_problem(200000, 20000, "avia", cfg=1)
+    xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    h.scan_upload(pr.body)
+    ref_s = h.eval(xp, True, False)
+    ref_n = h.eval(xp, False, False)
+    t = h.timing()
+    assert t["fit_ms"] > 0.0
+    h.set_timing_stride(2)
+    h.counters(reset=True)
+    for k in range(12):  # sampled: k = 0, 2, ... (all searching)
+        o = h.eval(xp, k % 2 == 0, False)
+        r = ref_s if k % 2 == 0 else ref_n
+        np.testing.assert_array_equal(o[0], r[0])
+        assert o[2] == r[2]
+    c = h.counters(reset=True)
+    assert c["n_search"] == 6 and c["n_fit"] == 0 and c["n_eval"] == 6
+    assert 0.0 < c["search_ms"] / c["n_search"] < 20.0 and c["eval_ms"] == c["search_ms"]
+    h.set_timing_stride(2)
+    for k in range(1, 13):  # sampled: k = 1, 3, ... -> wait: the count restarts at the stride change, so the 1st, 3rd, ... call
+        h.eval(xp, k % 2 == 0, False)
+    c = h.counters()
+    assert c["n_search"] == 0 and c["n_fit"] == 6
+    st = h.pass_stats()
+    assert st["search_passes"] == st["one_launch_passes"] and st["search_passes"] >= 13
+    h.close()
 
 
 def test_deferred_event_reading_counts_and_leaves_results_alone(setup):
@@ -128,48 +160,59 @@ def test_search_only_sampling_counts_searching_evaluations(setup):
     h.set_timing_stride(1)
 
 
-@pytest.mark.parametrize("lanes", [16, 32])
-def test_second_stage_lanes_change_no_result(lanes):
-    """flh_config.second_stage_lanes: the second search stage with 16 / 32 lanes per query examines the same cells as with 8 (the default), so
-    flags, neighbour ids in rank order, planes and the whole update must be identical -- on a dense scan, on a thinned-out scan
-    (many queries reach the second stage) and with a prior so far off that most queries do."""
+def test_one_launch_pass_equals_three_launch_pass():
+    """flh_config.pass_kernel: the searching pass as ONE launch (k_pass: both search stages, fit, rows, Gram, group sums) against
+    the three-launch pass -- flags, neighbour ids in rank order, distances, planes must be identical bit for bit; the normal
+    equations agree to the last bits (the one-launch pass adds 64-point workgroups, the other 256-point blocks: a different
+    association of the same fp64 terms) and the whole update with them -- on a dense scan, on a thinned-out scan (many queries
+    reach the second stage), on a ragged size, and with a prior so far off that most queries do."""
     pr = synth.make_problem(200000, 20000, "avia", cfg=1)
     xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
     x_far = np.array(xp, dtype=np.float64)
     x_far[:3] += [0.9, -0.7, 0.8]          # metres off: 5th neighbours beyond the first stage's guaranteed radius
-    scans = {"dense": pr.body, "sparse": np.ascontiguousarray(pr.body[::37]), "ragged": np.ascontiguousarray(pr.body[:5003])}
+    scans = {"dense": pr.body, "sparse": np.ascontiguousarray(pr.body[::37]), "ragged": np.ascontiguousarray(pr.body[:5003]),
+             "tiny": np.ascontiguousarray(pr.body[:7])}
     for name, body in scans.items():
         out = []
-        for ln in (8, lanes):
-            h = capi.Handle(second_stage_lanes=ln)
+        for one in (0, 1):
+            h = capi.Handle(pass_kernel=one)
             h.map_build(pr.map_xyz)
             h.scan_upload(body)
             res = []
-            for x, search in ((xp, True), (x_far, True), (pr.x_true, False), (pr.x_true, True)):
-                HTH, HTh, n_eff, tres = h.eval(x, search, False)
-                idx, d2, cnt = h.fetch_neighbors()
-                res.append((HTH.copy(), HTh.copy(), n_eff, tres, h.fetch_selected().copy(), idx.copy(), cnt.copy(), d2.copy()))
+            for ext in (False, True):
+                for x, search in ((xp, True), (x_far, True), (pr.x_true, False), (pr.x_true, True), (xp, False)):
+                    HTH, HTh, n_eff, tres = h.eval(x, search, ext)
+                    idx, d2, cnt = h.fetch_neighbors()
+                    res.append((HTH.copy(), HTh.copy(), n_eff, tres, h.fetch_selected().copy(), idx.copy(), cnt.copy(), d2.copy(),
+                                h.fetch_normvec().copy()))
+            st = h.pass_stats()
+            assert st["one_launch_passes"] == (st["search_passes"] if one else 0), name
+            if one and name == "dense":
+                assert st["second_stage_queries"] > 0
             h.scan_upload(body)
             kf = capi.Esekf(h, max_iter=3)
             kf.change_x(xp)
             kf.change_P(P)
-            st = kf.update(0.001)
-            out.append((res, kf.get_x().copy(), kf.get_P().copy(), list(st.n_eff)[: st.passes]))
+            us = kf.update(0.001)
+            out.append((res, kf.get_x().copy(), kf.get_P().copy(), list(us.n_eff)[: us.passes]))
             kf.close()
             h.close()
         (r0, x0, P0, n0), (r1, x1, P1, n1) = out
         assert n0 == n1, name
-        np.testing.assert_array_equal(x0, x1, err_msg=name)
-        np.testing.assert_array_equal(P0, P1, err_msg=name)
+        np.testing.assert_allclose(x0, x1, rtol=0, atol=1e-11, err_msg=name)
+        np.testing.assert_allclose(P0, P1, rtol=0, atol=1e-12 * np.abs(P0).max(), err_msg=name)
         for a, b in zip(r0, r1):
             np.testing.assert_array_equal(a[4], b[4], err_msg=name + ": flags")
             np.testing.assert_array_equal(a[6], b[6], err_msg=name + ": neighbour counts")
             inside = a[7] <= 5.0                     # inside the gate the two must agree entry for entry
             np.testing.assert_array_equal(a[5][inside], b[5][inside], err_msg=name + ": neighbour ids")
             np.testing.assert_array_equal(a[7][inside].view(np.uint32), b[7][inside].view(np.uint32), err_msg=name + ": distances")
-            np.testing.assert_array_equal(a[0], b[0], err_msg=name)
-            np.testing.assert_array_equal(a[1], b[1], err_msg=name)
-            assert a[2] == b[2] and a[3] == b[3], name
+            sel = a[4].astype(bool)
+            np.testing.assert_array_equal(a[8][sel].view(np.uint32), b[8][sel].view(np.uint32), err_msg=name + ": planes")
+            np.testing.assert_allclose(a[0], b[0], rtol=0, atol=1e-12 * max(np.abs(a[0]).max(), 1e-300), err_msg=name)
+            np.testing.assert_allclose(a[1], b[1], rtol=0, atol=1e-12 * max(np.abs(a[1]).max(), 1e-300), err_msg=name)
+            assert a[2] == b[2], name
+            assert abs(a[3] - b[3]) <= 1e-12 * max(abs(a[3]), 1.0), name
 
 
 def test_synchronous_and_asynchronous_staging_do_not_share_scratch_unguarded():

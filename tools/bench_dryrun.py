@@ -34,6 +34,9 @@ class FakeHandle:
     def close(self): pass
     def rccl_init_rank(self, n, uid, r): assert len(uid) == 128
     def rccl_size(self): return 1
+    def peer_open(self, name, n, r): assert name.startswith("/")
+    def peer_size(self): return 1
+    def pass_stats(self): return {"search_passes": 40, "one_launch_passes": 40, "second_stage_queries": 4000, "nosearch_passes": 40}
     def set_owned_interval(self, a, lo, hi): pass
     def map_incremental(self, x, fsm, inited, apply=True): self.M += 10 if apply else 0; return (5, 5)
     def scan_stage_undistorted(self, slot, pts, poses, x_end, leaf, want_undistorted=True): return 1234, None

@@ -42,15 +42,15 @@ for CFG in $CFGS; do
   if [ $ok = 1 ]; then
     fa=$(find /tmp/pm${CFG}_FETCH_SIZE -name '*counter_collection.csv' | head -1); fb=$(find /tmp/pm${CFG}_WRITE_SIZE -name '*counter_collection.csv' | head -1)
     if [ -n "$fa" ] && [ -n "$fb" ]; then
-      python $R/tools/pmc_summary.py $O/r${RND}_pmc_summary_config${CFG}.csv $fa $fb | grep "k_search\|k_fit"
-      echo "{\"commit\": \"$COMMIT\", \"src_hash\": \"$SRC\", \"first_stage\": 0, \"command\": \"bench.py --config $CFG $ARGS --steps 40 --warmup 5 --cpu-scans 0 --no-extra-legs --in-process\"}" > $O/r${RND}_pmc_summary_config${CFG}.meta.json
+      python $R/tools/pmc_summary.py $O/r${RND}_pmc_summary_config${CFG}.csv $fa $fb | grep "k_pass\|k_search\|k_fit"
+      echo "{\"commit\": \"$COMMIT\", \"src_hash\": \"$SRC\", \"pass_kernel\": -1, \"command\": \"bench.py --config $CFG $ARGS --steps 40 --warmup 5 --cpu-scans 0 --no-extra-legs --in-process\"}" > $O/r${RND}_pmc_summary_config${CFG}.meta.json
     fi
   fi
   if [ $CFG = 2 ]; then  # what bounds the kernels: issue counters and L1 line accesses (one pass each; config 2 only)
     rm -rf /tmp/sq2; timeout $T rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d /tmp/sq2 -o c -- python $R/bench.py --config 2 --steps 40 --warmup 5 --cpu-scans 0 --no-extra-legs --in-process > /dev/null 2>$O/sq2.err
-    f=$(find /tmp/sq2 -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python $R/tools/pmc_summary.py $O/r${RND}_pmc_sq_config2.csv $f | grep "k_search\|k_fit"
+    f=$(find /tmp/sq2 -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python $R/tools/pmc_summary.py $O/r${RND}_pmc_sq_config2.csv $f | grep "k_pass\|k_search\|k_fit"
     rm -rf /tmp/tcp2; timeout $T rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d /tmp/tcp2 -o c -- python $R/bench.py --config 2 --steps 40 --warmup 5 --cpu-scans 0 --no-extra-legs --in-process > /dev/null 2>$O/tcp2.err
-    f=$(find /tmp/tcp2 -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python $R/tools/pmc_summary.py $O/r${RND}_pmc_tcp_config2.csv $f | grep "k_search\|k_fit"
+    f=$(find /tmp/tcp2 -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python $R/tools/pmc_summary.py $O/r${RND}_pmc_tcp_config2.csv $f | grep "k_pass\|k_search\|k_fit"
   fi
   el "config $CFG done"
 done

@@ -14,7 +14,7 @@ ap.add_argument("--N", type=int, default=100_000)
 ap.add_argument("--sensor", default="avia")
 ap.add_argument("--cfg", type=int, default=2)
 ap.add_argument("--lpq", type=int, default=4)
-ap.add_argument("--stage", type=int, default=0)
+ap.add_argument("--pass-kernel", type=int, default=-1)
 ap.add_argument("--cell", type=float, default=1.5)
 ap.add_argument("--reps", type=int, default=6)
 ap.add_argument("--state", default="both", choices=["prior", "truth", "both"])
@@ -22,7 +22,7 @@ args = ap.parse_args()
 
 pr = synth.make_problem(args.M, args.N, args.sensor, cfg=args.cfg)
 xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
-h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, first_stage=args.stage)
+h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, pass_kernel=args.pass_kernel)
 h.map_build(pr.map_xyz)
 h.scan_upload(pr.body)
 h.set_timing_stride(0)

@@ -21,7 +21,7 @@ ap.add_argument("--N", type=int, default=100_000)
 ap.add_argument("--cfg", type=int, default=2)
 ap.add_argument("--sensor", default="avia")
 ap.add_argument("--reps", type=int, default=10)
-ap.add_argument("--first-stage", type=int, default=0)
+ap.add_argument("--pass-kernel", type=int, default=-1)
 ap.add_argument("--lpq", type=int, default=4)
 args = ap.parse_args()
 if args.name:
@@ -38,7 +38,7 @@ from fast_lio_amd import capi, synth  # noqa: E402
 
 pr = synth.make_problem(args.M, args.N, args.sensor, cfg=args.cfg)
 xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
-h = capi.Handle(lanes_per_query=args.lpq, first_stage=args.first_stage)
+h = capi.Handle(lanes_per_query=args.lpq, pass_kernel=args.pass_kernel)
 h.map_build(pr.map_xyz)
 h.scan_upload(pr.body)
 h.set_timing_stride(0)
