@@ -170,6 +170,9 @@ def main():
     ap.add_argument("--two-streams", action="store_true", help="side legs: also time two scan streams on one GPU")
     ap.add_argument("--cache-dir", default=os.path.join(ROOT, ".bench_cache"),
                     help="where generated scans + priors are kept between runs ('' = do not cache)")
+    ap.add_argument("--fresh-scans", action="store_true",
+                    help="generate the scans in this process even when --cache-dir holds them (the condition of the two device faults "
+                         "of rounds 2 and 3: 16 host threads allocating right before the GPU work; tools/fault_hunt.sh)")
     ap.add_argument("--in-process", action="store_true",
                     help="one GPU: do the GPU work in this process (default: in a child that is started once more if it dies, "
                          "so that a transient device fault costs a retry and not the line); profilers want this flag")
@@ -231,7 +234,7 @@ def main():
         from concurrent.futures import ThreadPoolExecutor
 
         cache = None
-        if args.cache_dir:
+        if args.cache_dir and not args.fresh_scans:
             os.makedirs(args.cache_dir, exist_ok=True)
             cache = os.path.join(args.cache_dir, f"scans_cfg{args.config}_n{count}_b{seed_base}.npz")
             if os.path.exists(cache):
@@ -516,6 +519,9 @@ def main():
     cand_per_query = h.timing()["candidates"] / max(N, 1)
     h.enable_stats(False)
     h.set_timing_stride(0)
+    instrumented, words = h.debug_bounds()
+    if instrumented:  # a -DFLH_BOUNDS developer build (tools/fault_hunt.sh): violations per translation unit {count, site, index, cap, block}
+        out["debug_bounds"] = {"kernels": words[0:5], "pass": words[5:10], "mapinc": words[10:15], "scanprep": words[15:20]}
     ps = h.pass_stats()
     out["second_stage_queries_per_search_pass"] = round(ps["second_stage_queries"] / max(ps["search_passes"], 1), 1)
     if roof is not None:

@@ -538,6 +538,9 @@ static int rebuild_index_impl(flh_handle* h, DevBuf<float4>& pts, size_t M, bool
     g.hash = h->hash.p;
     g.starts = h->starts.p;
     g.pts = h->map_sorted.p;
+#ifdef FLH_BOUNDS
+    g.pts_cap = pts_cap; g.rows_cap = rows_cap; g.ids_cap = std::min(h->map_orig.cap, h->dead_id.cap);
+#endif
     h->grid = g;
     h->nbricks = nbricks;
     h->M = M;
@@ -696,6 +699,9 @@ static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size
         if (h->dead_id.cap != before) HIPC(hipMemsetAsync(h->dead_id.p + h->n_ids, 0, h->dead_id.cap - h->n_ids, st));
     }
     HIPC(h->ins.reserve(n));
+#ifdef FLH_BOUNDS
+    h->grid.ids_cap = std::min(h->map_orig.cap, h->dead_id.cap);
+#endif
     // the points inserted with down-sampling are grouped by voxel in a hash table (no sort): per voxel the best new point, which
     // then meets the points the map already holds there
     const uint32_t vcap = flh::vox_table_slots((uint32_t)n1);
@@ -904,13 +910,19 @@ static int ensure_pinned(unsigned char*& p, size_t& cap, size_t bytes) {
     cap = want;
     return 0;
 }
-static bool is_pinned_host(const void* p) {
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-        (void)hipGetLastError();  // plain malloc'd memory: not an error
-        return false;
-    }
-    return a.type == hipMemoryTypeHost;
+// Page-locked buffers the DMA engine may read where they lie: ONLY the ones flh_host_alloc handed out (a registry of [base, end)
+// ranges).  The runtime's pointer query is not asked about arbitrary caller memory any more: after a page-locked region has been
+// freed, malloc may hand the same addresses out again, and a stale "this is pinned" answer would let the copy engine read
+// pageable memory -- a device-side memory access fault at a host address, rarely and only after much host allocation churn
+// (the shape of the two faults of rounds 2 and 3).  Everything else takes the slot's own page-locked bounce buffer.
+static std::mutex g_pin_mu;
+static std::vector<std::pair<uintptr_t, uintptr_t>> g_pin_ranges;
+static bool is_pinned_host(const void* p, size_t bytes) {
+    const uintptr_t a = (uintptr_t)p;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (const auto& r : g_pin_ranges)
+        if (a >= r.first && a + bytes <= r.second) return true;
+    return false;
 }
 
 static int stage_prepare(flh_handle* h, flh_handle::Slot& sl) {
@@ -960,7 +972,7 @@ static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size
     HIPC(h->st_bytes.reserve(bytes ? bytes : 4));
     bool direct = false;
     if (N > 0) {
-        direct = is_pinned_host(pts);
+        direct = is_pinned_host(pts, bytes);
         const void* src = pts;
         if (!direct) {  // pageable memory cannot be DMA'd: through the slot's pinned buffer (the caller's is free at once)
             if (ensure_pinned(sl.pin, sl.pin_cap, bytes) != 0) return -1;
@@ -1031,7 +1043,7 @@ static int stage_raw(flh_handle* h, flh_handle::Slot& sl, const char* who, const
         const size_t bytes = n * stride_bytes;
         HIPC(h->st_bytes.reserve(bytes));
         const void* src = pts;
-        const bool direct = is_pinned_host(pts);
+        const bool direct = is_pinned_host(pts, bytes);
         if (!direct) {
             if (ensure_pinned(sl.pin, sl.pin_cap, bytes) != 0) return -1;
             std::memcpy(sl.pin, pts, bytes);
@@ -1246,14 +1258,24 @@ int flh_scan_wait(flh_handle* h, int slot) {
 
 void* flh_host_alloc(size_t bytes) {
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    const size_t n = bytes ? bytes : 1;
+    if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) {
         (void)fail("flh_host_alloc: hipHostMalloc failed");
         return nullptr;
     }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pin_ranges.emplace_back((uintptr_t)p, (uintptr_t)p + n);
     return p;
 }
 void flh_host_free(void* p) {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (size_t i = 0; i < g_pin_ranges.size(); ++i)
+            if (g_pin_ranges[i].first == (uintptr_t)p) { g_pin_ranges.erase(g_pin_ranges.begin() + (long)i); break; }
+    }
+    (void)hipDeviceSynchronize();  // a staging that reads the buffer where it lies may still be under way (flh_scan_stage_async)
+    (void)hipHostFree(p);
 }
 
 // downSizeFilterSurf.setInputCloud(feats_undistort); downSizeFilterSurf.filter(*feats_down_body) -- :904-905
@@ -1347,7 +1369,7 @@ int flh_points_body_to_world(flh_handle* h, const double x[FLH_NSTATE], const vo
     const size_t bytes = n * stride_bytes;
     HIPC(h->fw_bytes.reserve(bytes)); HIPC(h->fw_in.reserve(n)); HIPC(h->fw_out.reserve(n));
     const void* src = pts;
-    if (!is_pinned_host(pts)) {
+    if (!is_pinned_host(pts, bytes)) {
         if (ensure_pinned(h->pin_in, h->pin_in_cap, bytes) != 0) return -1;
         std::memcpy(h->pin_in, pts, bytes);
         src = h->pin_in;
@@ -1379,13 +1401,11 @@ static StateDev make_state(const double rot[4], const double pos[3], const doubl
     return s;
 }
 
-// Group size of k_fit's first-level reduction when the group sums go to the host as granules: 16 blocks, more when that
-// would make more than kGranGroups groups; 0 = too many points for the granule path.
+// Units (64 scan points each: a workgroup of k_pass, a wave of k_fit) per reduction group when the group sums go to the host as
+// granules: 64, more when that would make more than kGranGroups groups; 0 = too many points for the granule path.
 static int gran_group_size(size_t N) {
-    const int nblk = flh::fit_blocks((int)N);
-    int red = 16;
-    while ((nblk + red - 1) / red > kGranGroups) red *= 2;
-    return red <= 128 ? red : 0;
+    const int red = flh::pass_group_size((int)N, kGranGroups);
+    return red <= 1024 ? red : 0;
 }
 
 // Deferred event timing (see flh_handle::evp).
@@ -1445,7 +1465,7 @@ static flh::GranOut gran_out(const flh_handle* h, double seq) {
 }
 // does a searching evaluation of the active scan run as ONE launch?
 static bool use_pass_kernel(const flh_handle* h, bool host_granules) {
-    return h->pass_ok && host_granules && h->N > 0 && flh::pass_group_size((int)h->N, kGranGroups) <= 1024;
+    return h->pass_ok && host_granules && h->N > 0;
 }
 
 static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext, double* d_out, double seq, hipEvent_t* ev3,
@@ -1464,7 +1484,7 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
         // the whole searching pass in one launch (flh_pass.hip); timed: the kernel's own start and end stamps in ev3[0] / ev3[3]
         HIPC(flh::launch_pass(h->cfg.eigen_order, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap, h->cfg.max_sqdist,
                               h->cfg.plane_threshold, ext, h->nn_pts.p, h->nn_cnt.p, h->selected.p, h->plane_cache ? h->plane.p : nullptr,
-                              h->partials.p, h->tickets.p, gout, seq, flh::pass_group_size((int)h->N, kGranGroups),
+                              h->partials.p, h->tickets.p, gout, seq, gran_group_size(h->N),
                               h->stats ? h->counter.p : nullptr, h->own_axis, h->own_lo, h->own_hi, st, timed ? ev3[0] : nullptr,
                               timed ? ev3[3] : nullptr));
     } else {
@@ -1602,7 +1622,7 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
     hipStream_t st = h->stream;
     // group sums as granules in pinned memory (this rank's and, with peers, every rank's): not with an RCCL communicator (the
     // block is all-reduced on the device), not for an empty scan
-    const bool granules = !h->comm && h->N > 0 && (h->peer_n > 1 || gran_group_size(h->N) > 0);
+    const bool granules = !h->comm && h->N > 0 && gran_group_size(h->N) > 0;
     const bool one_launch = do_search && use_pass_kernel(h, granules);
     if (h->peer_n > 1 && !granules) return fail("flh_eval: a scan shard may not be empty when the ranks exchange granules (flh_peer_*)");
     if (h->comm) {
@@ -2321,6 +2341,32 @@ void flh_peer_close(flh_handle* h) {
 }
 int flh_peer_size(const flh_handle* h) { return h ? h->peer_n : 0; }
 int flh_peer_rank(const flh_handle* h) { return h ? h->peer_rank : -1; }
+// Developer builds (-DFLH_BOUNDS, tools/variant.py): the bounds records of the four kernel translation units, 5 words each
+// {violations, site of the first one, its index, the capacity, its workgroup}; all zero in the product (nothing is checked there).
+#ifdef FLH_BOUNDS
+namespace flh {
+void bounds_read_kernels(unsigned long long out[5]);
+void bounds_read_pass(unsigned long long out[5]);
+void bounds_read_mapinc(unsigned long long out[5]);
+void bounds_read_scanprep(unsigned long long out[5]);
+}
+#endif
+int flh_debug_bounds(flh_handle* h, uint64_t out[20]) {
+    if (!h || !out) return fail("flh_debug_bounds: null argument");
+    for (int i = 0; i < 20; ++i) out[i] = 0;
+#ifdef FLH_BOUNDS
+    HIPC(hipSetDevice(h->device));
+    HIPC(hipDeviceSynchronize());
+    unsigned long long r[5];
+    flh::bounds_read_kernels(r); for (int i = 0; i < 5; ++i) out[i] = r[i];
+    flh::bounds_read_pass(r); for (int i = 0; i < 5; ++i) out[5 + i] = r[i];
+    flh::bounds_read_mapinc(r); for (int i = 0; i < 5; ++i) out[10 + i] = r[i];
+    flh::bounds_read_scanprep(r); for (int i = 0; i < 5; ++i) out[15 + i] = r[i];
+    return 1;
+#else
+    return 0;
+#endif
+}
 int flh_get_pass_stats(const flh_handle* h, uint64_t out[4]) {
     if (!h || !out) return fail("flh_get_pass_stats: null argument");
     out[0] = h->n_search_pass; out[1] = h->n_one_launch; out[2] = h->n_second_stage; out[3] = h->n_nosearch_pass;

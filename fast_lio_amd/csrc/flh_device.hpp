@@ -18,7 +18,29 @@ struct StateDev {  // the four members of state_ikfom h_share_model reads (src/l
     double offT[3];
 };
 
+// ---------------------------------------------------------------------------------------------
+// Developer instrumentation, compiled out of the product (tools/variant.py --define FLH_BOUNDS; profiles/r04_fault_hunt/):
+// every computed index into a device buffer goes through FLH_IDX(site, index, capacity).  A violation is counted, the first one
+// recorded (site, index, capacity, workgroup) in a per-translation-unit device record that flh_debug_bounds() reads back, and the
+// index is clamped so that the run goes on (a faulting run would tell less than a named site does).
+// ---------------------------------------------------------------------------------------------
+#ifdef FLH_BOUNDS
+struct BoundsRec { unsigned long long count, site, index, cap, block; };
+static __device__ BoundsRec g_bounds;  // one per translation unit
+__device__ __forceinline__ unsigned long long flh_idx_(unsigned site, unsigned long long idx, unsigned long long cap) {
+    if (idx < cap) return idx;
+    if (atomicAdd(&g_bounds.count, 1ull) == 0ull) { g_bounds.site = site; g_bounds.index = idx; g_bounds.cap = cap; g_bounds.block = blockIdx.x; }
+    return cap ? cap - 1 : 0;
+}
+#define FLH_IDX(site, idx, cap) flh_idx_((site), (unsigned long long)(idx), (unsigned long long)(cap))
+#else
+#define FLH_IDX(site, idx, cap) (idx)
+#endif
+
 struct GridParams {
+#ifdef FLH_BOUNDS
+    unsigned long long pts_cap, rows_cap, ids_cap;  // capacities of pts (map_sorted), of the brick tables / cap_end / live, of map_orig / dead_id
+#endif
     float ox, oy, oz;  // world coordinate of the corner of cell (0,0,0)
     float c, inv_c;    // cell edge, 1/edge
     int nx, ny, nz;    // grid extent in cells (each <= 4096)
@@ -398,8 +420,15 @@ __device__ __forceinline__ uint2 lookup_cell(const GridParams& g, int cx, int cy
         return make_uint2(0u, 0u);
     const uint32_t rank = lookup_brick(g, brick_key(cx, cy, cz));
     if (rank == kEmptyKey) return make_uint2(0u, 0u);
+#ifdef FLH_BOUNDS
+    (void)FLH_IDX(101, rank, g.rows_cap);
+#endif
     const uint32_t* st = g.starts + (size_t)rank * kBrickStride + cell_local(cx, cy, cz);
     const uint32_t a = st[0], b = st[1];
+#ifdef FLH_BOUNDS
+    (void)FLH_IDX(102, (unsigned long long)b, g.pts_cap + 1);
+    (void)FLH_IDX(103, (unsigned long long)a, (unsigned long long)b + 1);
+#endif
     return make_uint2(a, b - a);
 }
 

@@ -125,4 +125,50 @@ __device__ __forceinline__ void publish_granule(const GranOut& o, size_t idx, do
         if (d < o.n_dst) store_granule(o.dst[d] + ((size_t)o.sect_off + idx) * 2, value, seq);
 }
 
+
+// ---- the cross-workgroup sum both pass kernels share (k_pass: one 64-point workgroup = one unit; k_fit on the granule path: one
+// 64-point WAVE = one unit, so that a no-search pass adds the same terms in the same order as a searching one -- identical bits).
+// Units are grouped `red` at a time; every unit stores the entries of its 16x16 block that the filter reads (+ one statistic)
+// write-through at agent scope, drains, and takes a ticket of its group; the last arriver sums the group's units in unit
+// order -- two halves of the wave take the two halves of the group, lower half + upper half -- and publishes the granules.
+// No release/acquire fences (hence no L2 write-back sweep): write-through stores + vmcnt(0) before the ticket, agent-scope
+// (L1-bypassing) loads after it.
+typedef __attribute__((address_space(1))) double gdouble;
+__device__ __forceinline__ void unit_partial_store(double* partials, int unit, int nsl, int ncol, const v4f64& acc, int wl, double stat) {
+    gdouble* gp = (gdouble*)partials + (size_t)unit * nsl;
+    const int col = wl & 15, kq = wl >> 4;  // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int slot = gram_slot(kq + 4 * r, col, ncol);
+        if (slot >= 0) __hip_atomic_store(gp + FLH_IDX(601, slot, nsl - 1), acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wl == 0) __hip_atomic_store(gp + (nsl - 1), stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one wave; units [group * red, group * red + gsize)
+__device__ __forceinline__ void group_sum_publish(const double* partials, int group, int gsize, int red, int nsl, int ngroups,
+                                                  const GranOut& gout, double seq, int wl) {
+    const gdouble* gpart = (const gdouble*)partials;
+    const int u0 = group * red;
+    const int half = (gsize + 1) >> 1;
+    const int hi = wl >> 5, sl = wl & 31;
+    const int jlo = hi ? half : 0, jhi = hi ? gsize : half;
+    for (int slot = sl; slot < ((nsl + 31) & ~31); slot += 32) {
+        const int sc = slot < nsl ? slot : nsl - 1;
+        double s0 = 0.0;
+        for (int j0 = jlo; j0 < jhi; j0 += 16) {
+            double pv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                pv[j] = (j0 + j < jhi) ? __hip_atomic_load(gpart + (size_t)(u0 + j0 + j) * nsl + sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s0 += pv[j];
+        }
+        const double other = __shfl_xor(s0, 32, 64);
+        const double total = hi ? other + s0 : s0 + other;  // lower half + upper half on both sides
+        if (hi == 0 && slot < nsl) publish_granule(gout, 1 + (size_t)group * nsl + slot, total, seq);
+    }
+    if (wl == 0 && group == 0) publish_granule(gout, 0, (double)(ngroups * nsl), seq);  // the section's header
+}
+
 }  // namespace flh

@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) k_map_place(const float4* __restrict__ pt
     float4 p = pts[src];
     p.w = __uint_as_float(src);  // identity of the point = its position in the index-ordered array
     const uint32_t r = brick_rank_incl[j] - 1;
-    out[(cap_incl[r] - cap[r]) + (j - brick_start[r])] = p;
+    out[(cap_incl[r] - cap[r]) + (j - brick_start[r])] = p;  // (capacity: the host sized the storage from the same prefix sums)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -301,7 +301,7 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
         for (int j = 0; j < 5; ++j) nn[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) nn[j] = nn_pts[(size_t)j * N + ic];
+        for (int j = 0; j < 5; ++j) nn[j] = nn_pts[FLH_IDX(301, (size_t)j * N + ic, (size_t)5 * (N > 0 ? N : 1))];
     }
     if (i < N) {  // feats_down_world is rewritten for every point on every pass (laserMapping.cpp:656-661)
         body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
@@ -322,78 +322,64 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
     __syncthreads();
     const v4f64 acc = tile_gram(lds + wave * 64 * kTileStride, lane);
     const int col = lane & 15, kq = lane >> 4;
+    const int t = threadIdx.x;
+    const int nblk = gridDim.x;
+    if (gout.n_dst > 0) {
+        // ---- flh_eval's path: every WAVE is a unit of the cross-workgroup sum k_pass uses (64 points each, the same points in
+        // the same lanes), grouped and added in the same order: a no-search pass produces the bits a searching pass would at
+        // the same state.  red1 = units per group (a multiple of 4).  The statistic slot carries, through unit 0, the number of
+        // queries the first search stage listed for the second in this pass (three-launch searching pass; the second stage has
+        // retired), after which the work-list counters are re-armed.
+        const int nsl = gran_section_slots(ncol);
+        const int nunits = (N + 63) / 64 > 0 ? (N + 63) / 64 : 1;
+        const int unit = blockIdx.x * 4 + wave;
+        double stat = 0.0;
+        if (unit == 0) {
+            uint32_t c = slow_count[lane];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+            stat = (double)c;
+            slow_count[lane] = 0;
+            slow_count[kStripes + lane] = 0;
+        }
+        if (unit < nunits) unit_partial_store(partials, unit, nsl, ncol, acc, lane, stat);
+        const int bpg = red1 / 4;  // blocks per group
+        const int group = blockIdx.x / bpg;
+        const int gblocks = min(bpg, nblk - group * bpg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) s_ticket = __hip_atomic_fetch_add(&tickets[1 + group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_ticket != (uint32_t)(gblocks - 1)) return;  // block-uniform
+        if (wave == 0) {
+            group_sum_publish(partials, group, min(red1, nunits - group * red1), red1, nsl, (nunits + red1 - 1) / red1, gout, seq, lane);
+            if (lane == 0) tickets[1 + group] = 0;  // re-arm this group's ticket for the next launch
+        }
+        return;
+    }
     __syncthreads();
     // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
     double* Rb = lds;
 #pragma unroll
     for (int r = 0; r < 4; ++r) Rb[wave * 256 + (kq + 4 * r) * 16 + col] = acc[r];
     __syncthreads();
-    const int t = threadIdx.x;
-    // ---- R: deterministic two-level cross-block sum inside this launch (no reduce kernels, no extra
-    // boundaries).  Blocks are grouped kRed1 at a time; the LAST block of a group to finish sums the group's
-    // partials in block order, the LAST group to finish sums the group sums in group order and writes the
-    // result (out256 is pinned host memory on the flh_eval path).  Fixed summation order -> run-to-run
-    // identical bits regardless of which block happens to arrive last.
-    // Hand-off: partials are stored write-through (8-byte agent-scope stores = sc1), every storing wave
-    // drains, one lane takes a relaxed agent-scope ticket; the reducer reads them back with agent-scope
-    // (L1-bypassing) loads.  No release/acquire fence, hence no L2 write-back sweep per block.
-    typedef __attribute__((address_space(1))) double gdouble;
+    // ---- R (evaluations whose block stays on the device: the RCCL path, flh_eval_device, the fetches): deterministic two-level
+    // cross-block sum inside this launch (no reduce kernels, no extra boundaries).  Blocks are grouped kRed1 at a time; the LAST
+    // block of a group to finish sums the group's partials in block order, the LAST group to finish sums the group sums in group
+    // order and writes the result.  Fixed summation order -> run-to-run identical bits regardless of which block happens to
+    // arrive last.  Hand-off as in flh_fit_dev.hpp: write-through stores, vmcnt(0), a relaxed agent-scope ticket, agent-scope loads.
     gdouble* gpart = (gdouble*)partials;
     gdouble* gpart2 = (gdouble*)part2;
     __hip_atomic_store(gpart + (size_t)blockIdx.x * 256 + t, (Rb[t] + Rb[256 + t]) + (Rb[512 + t] + Rb[768 + t]),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int nblk = gridDim.x;
-    const bool gran = gout.n_dst > 0;
-    const int red = gran ? red1 : kRed1;
-    const int ngroups_gran = gran ? (nblk + red1 - 1) / red1 : 0;
-    const int group = blockIdx.x / red;
+    const int group = blockIdx.x / kRed1;
     const int ngroups = (nblk + kRed1 - 1) / kRed1;
-    const int gsize = min(red, nblk - group * red);
+    const int gsize = min(kRed1, nblk - group * kRed1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) s_ticket = __hip_atomic_fetch_add(&tickets[1 + group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_ticket != (uint32_t)(gsize - 1)) return;  // block-uniform
-    if (gran) {
-        // ---- flh_eval's path: ONE level on the device.  The last block of a group sums the group's partials in block
-        // order and hands the entries the host needs (upper triangle of the leading ncol x ncol block, the Hth column,
-        // n_eff, total_residual -- 29 values without extrinsic estimation, 92 with) straight to pinned host memory as
-        // 16-byte {value, sequence} granules: no drain, no flag, no second ticket, no final block.  The host checks every
-        // granule's tag and adds the groups up in group order (gram_slot() is shared with it).
-        const int b0 = group * red;
-        const int nsl = gran_section_slots(ncol);
-        double s0 = 0.0;
-        for (int j0 = 0; j0 < gsize; j0 += 16) {
-            double v[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                v[j] = (j0 + j < gsize) ? __hip_atomic_load(gpart + (size_t)(b0 + j0 + j) * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                        : 0.0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) s0 += v[j];
-        }
-        const int slot = gram_slot(t >> 4, t & 15, ncol);
-        if (slot >= 0) publish_granule(gout, 1 + (size_t)group * nsl + slot, s0, seq);
-        if (t == 0) tickets[1 + group] = 0;                         // re-arm this group's ticket for the next launch
-        // the statistic slot: the number of queries the first search stage listed for the second in this pass (its work-list
-        // counters, summed by group 0 -- the second stage has retired -- which then re-arms them), 0 from the other groups
-        if (group == 0) {
-            if (t >= 192) {
-                uint32_t c = slow_count[t - 192];
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
-                if (t == 255) {
-                    publish_granule(gout, 1 + (size_t)nsl - 1, (double)c, seq);
-                    publish_granule(gout, 0, (double)(ngroups_gran * nsl), seq);  // the section's header
-                }
-            }
-            __syncthreads();
-            if (t < 2 * kStripes) slow_count[t] = 0;
-        } else if (t == 255) {
-            publish_granule(gout, 1 + (size_t)group * nsl + (nsl - 1), 0.0, seq);
-        }
-        return;
-    }
     {
         const int b0 = group * kRed1;
         double v[kRed1];
@@ -496,7 +482,7 @@ __global__ void __launch_bounds__(256) k_scan_gather(const float4* __restrict__ 
                                                      uint32_t N, float4* __restrict__ body) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    const uint32_t src = perm ? perm[i] : i;
+    const uint32_t src = (uint32_t)FLH_IDX(302, perm ? perm[i] : i, N);
     float4 p = raw[src];
     p.w = __uint_as_float(src);
     body[i] = p;
@@ -698,5 +684,9 @@ hipError_t launch_fit(int order, int half_fit, const StateDev& s, const float4* 
 #undef FLH_FIT
     return hipGetLastError();
 }
+
+#ifdef FLH_BOUNDS
+void bounds_read_kernels(unsigned long long out[5]) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bounds), sizeof(BoundsRec)); }
+#endif
 
 }  // namespace flh

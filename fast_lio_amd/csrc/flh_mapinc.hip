@@ -74,10 +74,10 @@ k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, 
     float4 best_p = make_float4(0.f, 0.f, 0.f, 0.f);
     float best_ub = INFINITY;  // >= the squared distance of the nearest point, with a rounding margin
     auto scan_brick = [&](uint32_t rank) {
-        const uint32_t* stt = g.starts + (size_t)rank * kBrickStride;
+        const uint32_t* stt = g.starts + (size_t)FLH_IDX(201, rank, g.rows_cap) * kBrickStride;
         const uint32_t i0 = stt[0], i1 = stt[64];
         for (uint32_t i = i0; i < i1; ++i) {
-            const float4 p = g.pts[i];
+            const float4 p = g.pts[FLH_IDX(202, i, g.pts_cap)];
             if (is_tombstone(p)) continue;
             const float d = dist2(p.x, p.y, p.z, wx, wy, wz);
             const u64 k = ((u64)__float_as_uint(d) << 32) | (u64)__float_as_uint(p.w);
@@ -120,7 +120,7 @@ k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, 
             if ((unsigned)x >= (unsigned)nb[0] || (unsigned)y >= (unsigned)nb[1] || (unsigned)z >= (unsigned)nb[2]) continue;
             const uint32_t key = ((uint32_t)z << 20) | ((uint32_t)y << 10) | (uint32_t)x;
             const uint32_t rank = lookup_brick(g, key);
-            if (rank == kEmptyKey || live[rank] == 0u) continue;
+            if (rank == kEmptyKey || live[FLH_IDX(203, rank, g.rows_cap)] == 0u) continue;
             float lb2, ub2;
             box(key, lb2, ub2);
             if (lb2 * 0.9999f > best_ub) continue;
@@ -144,7 +144,7 @@ k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, 
         // pass 1: a brick with a live point holds one within its far corner, so the min over such bricks bounds the answer
         for (uint32_t slot = lane; slot < hash_size; slot += 64) {
             const unsigned long long e = hash64[slot];
-            if ((uint32_t)e == kEmptyKey || live[(uint32_t)(e >> 32)] == 0u) continue;
+            if ((uint32_t)e == kEmptyKey || live[FLH_IDX(204, (uint32_t)(e >> 32), g.rows_cap)] == 0u) continue;
             float lb2, ub2;
             box((uint32_t)e, lb2, ub2);
             best_ub = fminf(best_ub, ub2 * 1.0001f);
@@ -181,7 +181,7 @@ k_mi_classify(StateDev s, const float4* __restrict__ body, const float4* __restr
     const uint32_t o = __float_as_uint(b.w);
     float wx, wy, wz;
     body_to_world(s, b.x, b.y, b.z, wx, wy, wz);  // pointBodyToWorld with the POSTERIOR state (:436)
-    world_out[o] = make_float4(wx, wy, wz, 0.f);
+    world_out[FLH_IDX(205, o, N)] = make_float4(wx, wy, wz, 0.f);
     const int cnt = nn_cnt[i];                              // found inside the bound, ascending
     const int true_cnt = map_points < 5u ? (int)map_points : 5;  // what the unbounded search returns
     uint8_t c = 1;  // Nearest_Points[i].empty() || !flg_EKF_inited -> PointToAdd (:463-466)
@@ -207,7 +207,7 @@ k_mi_classify(StateDev s, const float4* __restrict__ body, const float4* __restr
             c = need_add ? 1 : 0;
         }
     }
-    cls[o] = c;
+    cls[FLH_IDX(206, o, N)] = c;
 }
 
 // class 1 (down-sampled insert) then class 2 (plain insert), each in original scan order
@@ -234,8 +234,8 @@ __global__ void __launch_bounds__(256) k_cls_compact(const float4* __restrict__ 
     if (i == 0 && host_counts) publish_granule(host_counts, incl[N - 1], incl[2 * N - 1], 0u, seq);
     if (i >= N) return;
     const uint8_t c = cls[i];
-    if (c == 1) out[incl[i] - 1] = world[i];
-    else if (c == 2) out[incl[N + i] - 1] = world[i];
+    if (c == 1) out[FLH_IDX(207, incl[i] - 1, N)] = world[i];
+    else if (c == 2) out[FLH_IDX(208, incl[N + i] - 1, N)] = world[i];
 }
 
 // exact AABB of a point array: ordered-uint encoding of floats + atomics
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256) k_add_insert(const float4* __restrict__ a
     const u64 val = ((u64)__float_as_uint(dist_to_center(p.x, p.y, p.z, kx, ky, kz, ds)) << 32) | (u64)(~i);
     uint32_t slot = vox_slot(key, shift);
     for (;;) {
-        const u64 prev = atomicCAS(tab + 2 * (size_t)slot, ~0ull, key);
+        const u64 prev = atomicCAS(tab + 2 * (size_t)FLH_IDX(209, slot, (u64)mask + 1), ~0ull, key);
         if (prev == ~0ull || prev == key) break;
         slot = (slot + 1) & mask;
     }
@@ -378,7 +378,7 @@ k_add_resolve(GridParams g, float4* pts_rw /* = g.pts */, const float4* __restri
         const int z = c0z + c / (sx * sy), y = c0y + (c / sx) % sy, x = c0x + c % sx;
         const uint2 ce = lookup_cell(g, x, y, z);
         for (uint32_t i = ce.x; i < ce.x + ce.y; ++i) {
-            const float4 q = pts_rw[i];
+            const float4 q = pts_rw[FLH_IDX(210, i, g.pts_cap)];
             if (is_tombstone(q)) continue;
             long long qx, qy, qz;
             vox_of(q.x, q.y, q.z, ds, qx, qy, qz);
@@ -412,15 +412,15 @@ k_add_resolve(GridParams g, float4* pts_rw /* = g.pts */, const float4* __restri
                 if (qx != kx || qy != ky || qz != kz) continue;
                 const uint32_t id = __float_as_uint(q.w);
                 if (new_wins || id != best_e) {
-                    dead_id[id] = 1;
-                    pts_rw[i] = tombstone();
-                    atomicSub(live + rank, 1u);
+                    dead_id[FLH_IDX(211, id, g.ids_cap)] = 1;
+                    pts_rw[FLH_IDX(212, i, g.pts_cap)] = tombstone();
+                    atomicSub(live + FLH_IDX(213, rank, g.rows_cap), 1u);
                     atomicAdd(ctr + 3, 1u);
                 }
             }
         }
     }
-    if (new_wins && lane == 0) alive_new[best_new] = 1;
+    if (new_wins && lane == 0) alive_new[FLH_IDX(214, best_new, n)] = 1;
 }
 
 // Delete_Point_Boxes over the storage: every live slot inside a box becomes a tombstone
@@ -442,9 +442,9 @@ __global__ void __launch_bounds__(256) k_delete_boxes(GridParams g, float4* pts_
     cell_of(g, p.x, p.y, p.z, cx, cy, cz, fx, fy, fz);
     cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);  // as k_map_keys
     const uint32_t rank = lookup_brick(g, brick_key(cx, cy, cz));
-    dead_id[__float_as_uint(p.w)] = 1;
+    dead_id[FLH_IDX(215, __float_as_uint(p.w), g.ids_cap)] = 1;
     pts_rw[i] = tombstone();
-    if (rank != kEmptyKey) atomicSub(live + rank, 1u);
+    if (rank != kEmptyKey) atomicSub(live + FLH_IDX(216, rank, g.rows_cap), 1u);
     atomicAdd(ctr + 3, 1u);
 }
 
@@ -466,7 +466,7 @@ k_ins_prepare(GridParams g, const float4* __restrict__ add, const uint8_t* __res
               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ ctr) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n || !alive_new[i]) return;
-    const uint32_t r = incl[i] - 1, id = n_ids + r;
+    const uint32_t r = (uint32_t)FLH_IDX(217, incl[i] - 1, n), id = (uint32_t)FLH_IDX(218, n_ids + r, g.ids_cap);
     float4 p = add[i];
     p.w = 0.f;
     map_orig[id] = p;
@@ -504,9 +504,14 @@ k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g
     const uint32_t rank = lookup_brick(g, key);
     uint32_t old_base = 0, old_end = 0, old_cap_end = 0;
     if (rank != kEmptyKey) {
-        old_base = starts[(size_t)rank * kBrickStride];
+        old_base = starts[(size_t)FLH_IDX(219, rank, rows_cap) * kBrickStride];
         old_end = starts[(size_t)rank * kBrickStride + 64];
         old_cap_end = cap_end[rank];
+#ifdef FLH_BOUNDS
+        (void)FLH_IDX(220, old_end, (u64)old_cap_end + 1);
+        (void)FLH_IDX(221, old_cap_end, (u64)pts_cap + 1);
+        (void)FLH_IDX(222, old_base, (u64)old_end + 1);
+#endif
     }
     if (tid == 0) { s_cnt = 0; s_ok = 1; }
     if (tid < 64) hist[tid] = 0;
@@ -524,7 +529,7 @@ k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g
         if (tid == 0) atomicOr(ctr + 2, 2u);
         return;
     }
-    for (uint32_t i = tid; i < run; i += 128) buf[nold + i] = ins[perm[j + i]];
+    for (uint32_t i = tid; i < run; i += 128) buf[nold + i] = ins[FLH_IDX(223, perm[j + i], n)];
     if (tid == 0) {
         if (rank != kEmptyKey && old_base + total <= old_cap_end) {
             s_base = old_base; s_rank = rank; s_cap_end = old_cap_end;
@@ -575,7 +580,7 @@ k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g
         uint32_t acc = 0;
         for (int c = 0; c < 64; ++c) {
             offs[c] = acc;
-            starts[(size_t)r * kBrickStride + c] = base + acc;
+            starts[(size_t)FLH_IDX(226, r, rows_cap) * kBrickStride + c] = base + acc;
             acc += hist[c];
         }
         starts[(size_t)r * kBrickStride + 64] = base + acc;
@@ -586,13 +591,13 @@ k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g
 #pragma unroll
     for (int u = 0; u < kTile / 128; ++u) {
         const uint32_t i = tid + u * 128;
-        if (i < total) pts[base + atomicAdd(&offs[cl[u]], 1u)] = buf[i];
+        if (i < total) pts[FLH_IDX(224, base + atomicAdd(&offs[cl[u]], 1u), pts_cap)] = buf[i];
     }
     // what the brick no longer uses becomes tombstones: the tail of the old range (in place), or all of it (relocated)
     if (rank != kEmptyKey) {
         const uint32_t a = (base == old_base) ? old_base + total : old_base;
         const uint32_t b = (base == old_base) ? old_end : old_cap_end;
-        for (uint32_t i = a + tid; i < b; i += 128) pts[i] = tombstone();
+        for (uint32_t i = a + tid; i < b; i += 128) pts[FLH_IDX(225, i, pts_cap)] = tombstone();
     }
 }
 
@@ -610,7 +615,7 @@ __global__ void __launch_bounds__(256) k_live_compact(const float4* __restrict__
     if (i >= n_ids || !flags[i]) return;
     float4 p = map_orig[i];
     p.w = 0.f;
-    out[incl[i] - 1] = p;
+    out[FLH_IDX(227, incl[i] - 1, n_ids)] = p;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -662,7 +667,7 @@ k_ins_sort_small(GridParams g, const float4* __restrict__ add, const uint8_t* __
         key[u] = 0u;
         val[u] = 0u;
         if (valid[u]) {
-            const uint32_t id = n_ids + r;
+            const uint32_t id = (uint32_t)FLH_IDX(228, n_ids + r, g.ids_cap);
             float4 p = add[i];
             p.w = 0.f;
             map_orig[id] = p;
@@ -675,7 +680,7 @@ k_ins_sort_small(GridParams g, const float4* __restrict__ add, const uint8_t* __
                 cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
             }
             p.w = __uint_as_float(id);
-            ins[r] = p;
+            ins[FLH_IDX(229, r, n)] = p;
             key[u] = brick_key(cx, cy, cz);
             keys_tmp[r] = key[u];
             val[u] = r;
@@ -723,7 +728,7 @@ k_ins_sort_small(GridParams g, const float4* __restrict__ add, const uint8_t* __
         if (j < n) {
             const bool has = j < total;
             perm[j] = has ? val[u] : 0u;
-            ks[j] = has ? keys_tmp[val[u]] : kEmptyKey;
+            ks[j] = has ? keys_tmp[FLH_IDX(230, val[u], n)] : kEmptyKey;
         }
     }
     if (tid == 0) *n_alive_out = total;
@@ -840,5 +845,9 @@ hipError_t launch_live_compact(const float4* map_orig, const uint32_t* flags, co
     hipLaunchKernelGGL(k_live_compact, dim3(cdiv2(n_ids, 256)), dim3(256), 0, st, map_orig, flags, incl, n_ids, out);
     return hipGetLastError();
 }
+
+#ifdef FLH_BOUNDS
+void bounds_read_mapinc(unsigned long long out[5]) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bounds), sizeof(BoundsRec)); }
+#endif
 
 }  // namespace flh

@@ -94,7 +94,7 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
             pk[kParkUb] = ub_next;
         }
         const u64 bal = __ballot(open && lane == 0);
-        if (open && lane == 0) s_list[wave * 16 + __popcll(bal & ((1ull << wl) - 1ull))] = (uint32_t)grp;
+        if (open && lane == 0) s_list[FLH_IDX(401, wave * 16 + __popcll(bal & ((1ull << wl) - 1ull)), 64)] = (uint32_t)grp;
         if (wl == 0) s_wcnt[wave] = (uint32_t)__popcll(bal);
     }
     __syncthreads();
@@ -113,7 +113,7 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
             const bool live = k0 + grp < n_open;
             uint32_t idx = live ? k0 + grp : 0u, w = 0;
             if (idx >= c0) { idx -= c0; w = 1; if (idx >= c1) { idx -= c1; w = 2; if (idx >= c2) { idx -= c2; w = 3; } } }
-            const uint32_t slot = s_list[w * 16 + idx];
+            const uint32_t slot = s_list[FLH_IDX(402, w * 16 + idx, 64)] & 63u;
             float* pk = park + slot * kParkStride;
             const float qx = pk[kParkWorld], qy = pk[kParkWorld + 1], qz = pk[kParkWorld + 2];
             const float ub = pk[kParkUb];
@@ -163,22 +163,10 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     wave_sync();
     const v4f64 acc = tile_gram(T, wl);
 
-    // ---- this workgroup's share of the normal equations -> HBM (write-through, agent scope), then the group's ticket
-    typedef __attribute__((address_space(1))) double gdouble;
+    // ---- this workgroup's share of the normal equations -> HBM, the group's ticket, and for the last arriver the group's sum
     const int nsl = gran_section_slots(ncol);  // the last one: the number of queries that needed phase B (a statistic the host reports)
-    gdouble* gpart = (gdouble*)partials;
-    {
-        const int col = wl & 15, kq = wl >> 4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int slot = gram_slot(kq + 4 * r, col, ncol);
-            if (slot >= 0) __hip_atomic_store(gpart + (size_t)blockIdx.x * nsl + slot, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (wl == 0) {  // (read again from LDS rather than kept in a register across phase B and the fit)
-            const uint32_t n_b = (s_wcnt[0] + s_wcnt[1]) + (s_wcnt[2] + s_wcnt[3]);
-            __hip_atomic_store(gpart + (size_t)blockIdx.x * nsl + (nsl - 1), (double)n_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    const uint32_t n_b = (s_wcnt[0] + s_wcnt[1]) + (s_wcnt[2] + s_wcnt[3]);  // (read again from LDS rather than kept in a register)
+    unit_partial_store(partials, (int)blockIdx.x, nsl, ncol, acc, wl, (double)n_b);
     const int nblk = gridDim.x;
     const int group = blockIdx.x / red;
     const int gsize = min(red, nblk - group * red);
@@ -187,34 +175,8 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     if (wl == 0) tk = __hip_atomic_fetch_add(&tickets[1 + group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
     if (tk != (uint32_t)(gsize - 1)) return;
-    // ---- last workgroup of its group: sum the group's partials in workgroup order (two halves of the wave take the two halves of
-    // the group; lower half + upper half, the same order whoever arrives last) and publish the granules
-    {
-        const int b0 = group * red;
-        const int half = (gsize + 1) >> 1;
-        const int hi = wl >> 5, sl = wl & 31;
-        const int jlo = hi ? half : 0, jhi = hi ? gsize : half;
-        for (int slot = sl; slot < ((nsl + 31) & ~31); slot += 32) {
-            const int sc = slot < nsl ? slot : nsl - 1;
-            double s0 = 0.0;
-            for (int j0 = jlo; j0 < jhi; j0 += 16) {
-                double pv[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    pv[j] = (j0 + j < jhi) ? __hip_atomic_load(gpart + (size_t)(b0 + j0 + j) * nsl + sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                           : 0.0;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) s0 += pv[j];
-            }
-            const double other = __shfl_xor(s0, 32, 64);
-            const double total = hi ? other + s0 : s0 + other;  // lower half + upper half on both sides
-            if (hi == 0 && slot < nsl) publish_granule(gout, 1 + (size_t)group * nsl + slot, total, seq);
-        }
-        if (wl == 0) {
-            tickets[1 + group] = 0;  // re-arm this group's ticket for the next launch
-            if (group == 0) publish_granule(gout, 0, (double)(((nblk + red - 1) / red) * nsl), seq);  // the section's header
-        }
-    }
+    group_sum_publish(partials, group, gsize, red, nsl, (nblk + red - 1) / red, gout, seq, wl);
+    if (wl == 0) tickets[1 + group] = 0;  // re-arm this group's ticket for the next launch
 }
 
 int pass_blocks(int N) { return ((N > 0 ? N : 1) + kPassQueries - 1) / kPassQueries; }
@@ -252,5 +214,9 @@ hipError_t launch_pass(int order, const GridParams& g, const StateDev& s, const 
 #undef FLH_PASS
     return hipGetLastError();
 }
+
+#ifdef FLH_BOUNDS
+void bounds_read_pass(unsigned long long out[5]) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bounds), sizeof(BoundsRec)); }
+#endif
 
 }  // namespace flh

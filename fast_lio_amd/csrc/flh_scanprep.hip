@@ -43,11 +43,11 @@ __global__ void __launch_bounds__(256) k_vg_reduce(const float4* __restrict__ ra
     float sx = 0.f, sy = 0.f, sz = 0.f;
     uint32_t e = j;
     for (; e < n && keys_sorted[e] == key; ++e) {
-        const float4 p = raw[vals_sorted[e]];
+        const float4 p = raw[FLH_IDX(501, vals_sorted[e], n)];
         sx = sx + p.x; sy = sy + p.y; sz = sz + p.z;
     }
     const float cnt = (float)(e - j);
-    const uint32_t o = incl[j] - 1;
+    const uint32_t o = (uint32_t)FLH_IDX(502, incl[j] - 1, n);
     out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, 0.f);
 }
 
@@ -241,5 +241,9 @@ hipError_t launch_vg_reduce(const float4* raw, const u64* keys_sorted, const uin
     hipLaunchKernelGGL(k_vg_reduce, dim3(cdiv3(n, 256)), dim3(256), 0, st, raw, keys_sorted, vals_sorted, flags, incl, n, out);
     return hipGetLastError();
 }
+
+#ifdef FLH_BOUNDS
+void bounds_read_scanprep(unsigned long long out[5]) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bounds), sizeof(BoundsRec)); }
+#endif
 
 }  // namespace flh

@@ -231,8 +231,8 @@ __device__ __forceinline__ void top5_finish(Top5& L, const GridParams& g, int q,
                 if (jr == j) pp = rp[j];
             const bool has = jr < cnt;
             float4 v = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-            if (has) v = g.pts[pp];
-            nn_pts[(size_t)jr * N + q] = v;
+            if (has) v = g.pts[FLH_IDX(10, pp, g.pts_cap)];
+            nn_pts[FLH_IDX(11, (size_t)jr * N + q, (size_t)5 * N)] = v;
             if (park) { park[3 * jr] = v.x; park[3 * jr + 1] = v.y; park[3 * jr + 2] = v.z; }
         }
     }
@@ -276,7 +276,7 @@ __device__ __forceinline__ uint32_t exact_query(const GridParams& g, int q, int 
         const uint2 e = lookup_cell(g, cx + dx, cy + dy, cz + dz);
         ncand += e.y;
         for (uint32_t i = e.x; i < e.x + e.y; ++i) {
-            const float4 pv = g.pts[i];
+            const float4 pv = g.pts[FLH_IDX(14, i, g.pts_cap)];
             L.insert(make_key(dist2(qx, qy, qz, pv.x, pv.y, pv.z), pv.w), i);
         }
     }
@@ -389,6 +389,10 @@ __device__ __forceinline__ bool ring_query(const GridParams& g, const RingRsrc& 
         for (int u = 0; u < SPL; ++u) {
             const bool hit = (uint32_t)he[u] == key[u];
             const uint32_t row = hit ? (uint32_t)(he[u] >> 32) : 0u;
+#ifdef FLH_BOUNDS
+            (void)FLH_IDX(6, row, g.rows_cap);
+            (void)FLH_IDX(7, i0[u] + 3u, (unsigned)kBrickStride);
+#endif
             tb[u] = __builtin_amdgcn_raw_buffer_load_b128(rs.tab, (int)((row * (uint32_t)kBrickStride + i0[u]) * 4u), 0, 0);
         }
 #pragma unroll
@@ -407,6 +411,10 @@ __device__ __forceinline__ bool ring_query(const GridParams& g, const RingRsrc& 
         for (int u = 0; u < SPL; ++u) {
             const bool hit = (uint32_t)he[u] == key[u];
             const uint32_t row = hit ? (uint32_t)(he[u] >> 32) : 0u;
+#ifdef FLH_BOUNDS
+            (void)FLH_IDX(8, row, g.rows_cap);
+            (void)FLH_IDX(9, i1[u], 65u);
+#endif
             la[u] = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (int)((row * (uint32_t)kBrickStride + i0[u]) * 4u), 0, 0);
             lb[u] = __builtin_amdgcn_raw_buffer_load_b32(rs.tab, (int)((row * (uint32_t)kBrickStride + i1[u]) * 4u), 0, 0);
         }
@@ -452,10 +460,10 @@ __device__ __forceinline__ bool ring_query(const GridParams& g, const RingRsrc& 
         for (int u = 0; u < SPL; ++u) {
             const uint32_t ex = base_ + loc[u];
             const uint32_t exT = ex & 0xFFFFFFu;
-            if (nseg[u]) seg[ex >> 24] = make_uint2(la[u] - exT, exT + nseg[u]);
+            if (nseg[u]) seg[FLH_IDX(15, ex >> 24, NSEG + 1)] = make_uint2(la[u] - exT, exT + nseg[u]);
         }
         T = tot & 0xFFFFFFu;
-        if (lane == 0) seg[tot >> 24] = make_uint2(0u, 0xFFFFFFFFu);  // sentinel: the walk never runs off the end
+        if (lane == 0) seg[FLH_IDX(16, tot >> 24, NSEG + 1)] = make_uint2(0u, 0xFFFFFFFFu);  // sentinel: the walk never runs off the end
     }
     wave_sync();
     // ---- one pass over the candidates: the group's T candidates are dealt round-robin to its lanes
@@ -476,6 +484,10 @@ __device__ __forceinline__ bool ring_query(const GridParams& g, const RingRsrc& 
                     sg = nx; ++cur; nx = seg[cur + 1];
                     while (t >= sg.y) { sg = nx; ++cur; nx = seg[cur + 1]; }
                 }
+#ifdef FLH_BOUNDS
+                (void)FLH_IDX(1, cur + 1, NSEG + 2);
+                if (t < T) (void)FLH_IDX(2, sg.x + t, g.pts_cap);
+#endif
                 v[w] = load_xyz(rs.pts, (t < T) ? sg.x + t : 0xFFFFFFFu);  // past the end: out-of-range -> zeros, masked below
             }
 #pragma unroll
@@ -528,6 +540,10 @@ __device__ __forceinline__ bool ring_query(const GridParams& g, const RingRsrc& 
                 int c2 = 0;
                 uint2 s2 = seg[0];
                 while (t >= s2.y) s2 = seg[++c2];
+#ifdef FLH_BOUNDS
+                (void)FLH_IDX(3, c2, NSEG + 1);
+                (void)FLH_IDX(4, s2.x + t, g.pts_cap);
+#endif
                 pv[r] = load_pt(rs.pts, s2.x + t);
             }
         }
@@ -555,7 +571,7 @@ __device__ __forceinline__ bool ring_query(const GridParams& g, const RingRsrc& 
                         e += (i < m && (da[i] < dv[r] || (da[i] == dv[r] && ia[i] < myid))) ? 1 : 0;
                 }
                 if (e < 5) {
-                    nn_pts[(size_t)e * N + q] = pv[r];  // the squared distances are not stored: k_fill_d2 recomputes them on demand
+                    nn_pts[FLH_IDX(5, (size_t)e * N + q, (size_t)5 * N)] = pv[r];  // the squared distances are not stored: k_fill_d2 recomputes them on demand
                     if (park) { park[3 * e] = pv[r].x; park[3 * e + 1] = pv[r].y; park[3 * e + 2] = pv[r].z; }
                     if (e == 4) {
                         const bool gate = j < m && !(dv[r] > max_sqdist);  // laserMapping.cpp:671
@@ -586,6 +602,10 @@ __device__ __forceinline__ bool ring_query(const GridParams& g, const RingRsrc& 
                 for (int w = 0; w < RU; ++w) {
                     const uint32_t t = t0 + (uint32_t)(w * LPQ);
                     while (t >= s2.y) s2 = seg[++c2];
+#ifdef FLH_BOUNDS
+                    (void)FLH_IDX(12, c2, NSEG + 1);
+                    if (t < T) (void)FLH_IDX(13, s2.x + t, g.pts_cap);
+#endif
                     pos[w] = (t < T) ? s2.x + t : 0xFFFFFFFu;
                     pv[w] = load_pt(rs.pts, pos[w]);
                 }

@@ -160,7 +160,10 @@ int flh_scan_activate(flh_handle* h, int slot);
  * flh_host_alloc is DMA'd from where it lies. */
 int flh_scan_stage_async(flh_handle* h, int slot, const void* pts, size_t stride_bytes, size_t N);
 int flh_scan_wait(flh_handle* h, int slot);
-/* Page-locked host memory for scan / cloud buffers handed to this library (saves the copy through the staging buffer). */
+/* Page-locked host memory for scan / cloud buffers handed to this library (saves the copy through the staging buffer).  ONLY
+ * buffers from flh_host_alloc are read where they lie; any other memory -- pageable or page-locked by somebody else -- is copied
+ * through the slot's own page-locked buffer (the library does not ask the runtime what a foreign pointer is).  flh_host_free
+ * waits for the device first. */
 void* flh_host_alloc(size_t bytes);
 void flh_host_free(void* p);
 
@@ -266,6 +269,10 @@ int flh_peer_rank(const flh_handle* h);
 /* Counters of the handle's evaluations since creation: {searching passes, of them as ONE launch (flh_config.pass_kernel),
  * queries that needed the second search (summed over those passes and, with peers, over the ranks), no-search passes}. */
 int flh_get_pass_stats(const flh_handle* h, uint64_t out[4]);
+/* Developer builds only (-DFLH_BOUNDS: every computed device index checked against its buffer's capacity): returns 1 and the
+ * violation records of the four kernel translation units, 5 words each {count, site, index, capacity, workgroup}; the product
+ * library checks nothing, returns 0 and zeros. */
+int flh_debug_bounds(flh_handle* h, uint64_t out[20]);
 /* Map partitioned over the ranks (BASELINE configs[4]): this handle's map is one slab of the world plus a halo of at least
  * sqrt(max_sqdist) on either side; every rank holds the whole scan; a query is searched (and then fitted) only by the
  * rank whose half-open interval [lo, hi) of world coordinate `axis` (0/1/2) contains it.  The ranks' intervals must tile

@@ -388,10 +388,11 @@ def test_frame_world_and_points_body_to_world(prob):
 def test_rccl_allreduce_path_single_rank(prob):
     """The native multi-GPU path (flh_rccl_*): with a communicator attached, flh_eval leaves its Gram block on the device,
     RCCL sums it over the ranks and a publish kernel hands it to the host.  One rank here (the box has one GPU): the result
-    must be the plain path's, bit for bit, through eval, the full update and flh_eval_group."""
+    must be the plain path's up to the order of the fp64 sums (the device-resident block is summed block-wise, the granules
+    unit-wise), through eval, the full update and flh_eval_group."""
     pr, m, xp, P, _ = prob
     body = pr.body[:6000]
-    ref_h = capi.Handle(pass_kernel=0)  # with a communicator the three-launch pass runs: compare like with like, bit for bit
+    ref_h = capi.Handle()
     ref_h.map_build(pr.map_xyz)
     ref_h.scan_upload(body)
     ref = ref_h.eval(xp, True, False)
@@ -403,17 +404,21 @@ def test_rccl_allreduce_path_single_rank(prob):
     assert h.rccl_size() == 1
     h.map_build(pr.map_xyz)
     h.scan_upload(body)
+    def close(a, b):
+        np.testing.assert_allclose(a[0], b[0], rtol=0, atol=1e-12 * np.abs(b[0]).max())
+        np.testing.assert_allclose(a[1], b[1], rtol=0, atol=1e-12 * np.abs(b[1]).max())
+        assert a[2] == b[2] and abs(a[3] - b[3]) <= 1e-12 * max(abs(b[3]), 1.0)
+
     got = h.eval(xp, True, False)
-    for a, b in zip(got, ref):
-        np.testing.assert_array_equal(a, b)
+    close(got, ref)
     got2 = h.eval(xp, False, False)
-    np.testing.assert_array_equal(got2[0], ref[0])
+    np.testing.assert_array_equal(got2[0], got[0])  # search / no-search at one state: the same bits
     kf = capi.Esekf(h, max_iter=3)
     kf.change_x(xp); kf.change_P(P)
     st = kf.update(0.001)
     assert st.passes == st0.passes and list(st.n_eff) == list(st0.n_eff)
-    np.testing.assert_array_equal(kf.get_x(), kf0.get_x())
-    np.testing.assert_array_equal(kf.get_P(), kf0.get_P())
+    np.testing.assert_allclose(kf.get_x(), kf0.get_x(), rtol=0, atol=1e-11)
+    np.testing.assert_allclose(kf.get_P(), kf0.get_P(), rtol=0, atol=1e-12 * np.abs(kf0.get_P()).max())
     h.close()
     # one process, one handle per device
     g = capi.Handle()
@@ -421,7 +426,7 @@ def test_rccl_allreduce_path_single_rank(prob):
     g.map_build(pr.map_xyz)
     g.scan_upload(body)
     grp = capi.eval_group([g], xp, True, False)
-    for a, b in zip(grp, ref):
+    for a, b in zip(grp, got):
         np.testing.assert_array_equal(a, b)
     g.close()
     ref_h.close()

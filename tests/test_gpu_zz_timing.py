@@ -162,10 +162,10 @@ def test_search_only_sampling_counts_searching_evaluations(setup):
 
 def test_one_launch_pass_equals_three_launch_pass():
     """flh_config.pass_kernel: the searching pass as ONE launch (k_pass: both search stages, fit, rows, Gram, group sums) against
-    the three-launch pass -- flags, neighbour ids in rank order, distances, planes must be identical bit for bit; the normal
-    equations agree to the last bits (the one-launch pass adds 64-point workgroups, the other 256-point blocks: a different
-    association of the same fp64 terms) and the whole update with them -- on a dense scan, on a thinned-out scan (many queries
-    reach the second stage), on a ragged size, and with a prior so far off that most queries do."""
+    the three-launch pass -- flags, neighbour ids in rank order, distances, planes, the normal equations (both add the same
+    64-point units in the same order: flh_fit_dev.hpp) and with them the whole update must be identical bit for bit -- on a dense
+    scan, on a thinned-out scan (many queries reach the second stage), on a ragged size, on seven points, and with a prior so
+    far off that most queries reach the second stage."""
     pr = synth.make_problem(200000, 20000, "avia", cfg=1)
     xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
     x_far = np.array(xp, dtype=np.float64)
@@ -199,8 +199,8 @@ def test_one_launch_pass_equals_three_launch_pass():
             h.close()
         (r0, x0, P0, n0), (r1, x1, P1, n1) = out
         assert n0 == n1, name
-        np.testing.assert_allclose(x0, x1, rtol=0, atol=1e-11, err_msg=name)
-        np.testing.assert_allclose(P0, P1, rtol=0, atol=1e-12 * np.abs(P0).max(), err_msg=name)
+        np.testing.assert_array_equal(x0, x1, err_msg=name)
+        np.testing.assert_array_equal(P0, P1, err_msg=name)
         for a, b in zip(r0, r1):
             np.testing.assert_array_equal(a[4], b[4], err_msg=name + ": flags")
             np.testing.assert_array_equal(a[6], b[6], err_msg=name + ": neighbour counts")
@@ -209,10 +209,9 @@ def test_one_launch_pass_equals_three_launch_pass():
             np.testing.assert_array_equal(a[7][inside].view(np.uint32), b[7][inside].view(np.uint32), err_msg=name + ": distances")
             sel = a[4].astype(bool)
             np.testing.assert_array_equal(a[8][sel].view(np.uint32), b[8][sel].view(np.uint32), err_msg=name + ": planes")
-            np.testing.assert_allclose(a[0], b[0], rtol=0, atol=1e-12 * max(np.abs(a[0]).max(), 1e-300), err_msg=name)
-            np.testing.assert_allclose(a[1], b[1], rtol=0, atol=1e-12 * max(np.abs(a[1]).max(), 1e-300), err_msg=name)
-            assert a[2] == b[2], name
-            assert abs(a[3] - b[3]) <= 1e-12 * max(abs(a[3]), 1.0), name
+            np.testing.assert_array_equal(a[0], b[0], err_msg=name)
+            np.testing.assert_array_equal(a[1], b[1], err_msg=name)
+            assert a[2] == b[2] and a[3] == b[3], name
 
 
 def test_synchronous_and_asynchronous_staging_do_not_share_scratch_unguarded():

@@ -36,6 +36,7 @@ class FakeHandle:
     def rccl_size(self): return 1
     def peer_open(self, name, n, r): assert name.startswith("/")
     def peer_size(self): return 1
+    def debug_bounds(self): return False, [0] * 20
     def pass_stats(self): return {"search_passes": 40, "one_launch_passes": 40, "second_stage_queries": 4000, "nosearch_passes": 40}
     def set_owned_interval(self, a, lo, hi): pass
     def map_incremental(self, x, fsm, inited, apply=True): self.M += 10 if apply else 0; return (5, 5)
