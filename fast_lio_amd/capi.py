@@ -95,7 +95,7 @@ EXPORTS = [
     "flh_scan_stage_async", "flh_scan_wait", "flh_host_alloc", "flh_host_free", "flh_frame_world", "flh_points_body_to_world",
     "flh_esekf_last_error", "flh_rccl_unique_id", "flh_rccl_init_rank", "flh_rccl_init_all", "flh_rccl_destroy", "flh_rccl_size",
     "flh_rccl_rank", "flh_eval_group", "flh_set_owned_interval", "flh_esekf_run_scans", "flh_get_search_counters", "flh_set_timing_sampling",
-    "flh_map_sync", "flh_debug_bounds", "flh_peer_open", "flh_peer_init_all", "flh_peer_close", "flh_peer_size", "flh_peer_rank", "flh_get_pass_stats",
+    "flh_map_sync", "flh_eval_begin", "flh_eval_end", "flh_debug_bounds", "flh_debug_pass_stamps", "flh_peer_open", "flh_peer_init_all", "flh_peer_close", "flh_peer_size", "flh_peer_rank", "flh_get_pass_stats",
 ]
 
 _lib = None
@@ -201,6 +201,7 @@ def lib():
     L.flh_rccl_destroy.restype = None
     L.flh_map_sync.argtypes = [C.c_void_p]
     L.flh_debug_bounds.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.flh_debug_pass_stamps.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS"), C.c_size_t]
     L.flh_peer_open.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
     L.flh_peer_init_all.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     L.flh_peer_close.argtypes = [C.c_void_p]
@@ -385,6 +386,14 @@ class Handle:
         if rc < 0:
             raise FlhError(lib().flh_last_error().decode())
         return bool(rc), [int(v) for v in out]
+
+    def debug_pass_stamps(self, n_waves: int):
+        """(instrumented?, n_waves x 8 array of 100 MHz ticks) -- see flh_debug_pass_stamps (tools/pass_stamps.py)."""
+        out = np.zeros((n_waves, 8), np.uint64)
+        rc = lib().flh_debug_pass_stamps(self._h, out, out.size)
+        if rc < 0:
+            raise FlhError(lib().flh_last_error().decode())
+        return bool(rc), out
 
     def pass_stats(self) -> dict:
         out = (C.c_uint64 * 4)()

@@ -32,6 +32,18 @@
 
 using flh::GridParams;
 using flh::StateDev;
+// developer builds only (tools/variant.py): readers of the instrumentation records, one per kernel translation unit
+#ifdef FLH_BOUNDS
+namespace flh {
+void bounds_read_kernels(unsigned long long out[5]);
+void bounds_read_pass(unsigned long long out[5]);
+void bounds_read_mapinc(unsigned long long out[5]);
+void bounds_read_scanprep(unsigned long long out[5]);
+}
+#endif
+#ifdef FLH_PASS_STAMPS
+namespace flh { void pass_stamps_read(unsigned long long* out, size_t words); }
+#endif
 typedef unsigned long long u64;
 #define FLH_COUNTER_WORDS 1
 
@@ -184,6 +196,11 @@ struct flh_handle {
     bool pass_ok = false;          // the one-launch searching pass may run (flh_config.pass_kernel and its requirements)
     uint64_t n_second_stage = 0;   // queries that needed the second search, summed over the searching passes since creation
     uint64_t n_search_pass = 0, n_one_launch = 0, n_nosearch_pass = 0;
+    struct PendingEval {           // between flh_eval_begin and flh_eval_end
+        bool active = false, do_search = false, granules = false, one_launch = false, timed = false, deferred = false;
+        int ext = 0;
+        double seq = 0;
+    } pend;
     double* h_gran_own = nullptr;  // the handle's own pinned buffer (h_gran points into the peers' segment while attached)
     struct PeerSeg* peer_seg = nullptr;
     double* h_gram = nullptr;  // pinned 256 doubles
@@ -1602,41 +1619,60 @@ void flh_unpack_gram(const double G[256], double HTH[144], double HTh[12], int64
     if (total_residual) *total_residual = G[14 * 16 + 13];
 }
 
-int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const double offR[4], const double offT[3],
-             int do_search, int ext, double HTH[144], double HTh[12], int64_t* n_eff, double* total_residual) {
+// One h_share_model evaluation in two halves: flh_eval_begin enqueues the pass and returns; flh_eval_end waits for its normal
+// equations.  Between the two the caller's thread is free for host work that does not depend on them (the mirror esekf projects
+// the covariance and inverts P / R there: a third of the 23x23 algebra of a pass leaves the critical path).
+int flh_eval_begin(flh_handle* h, const double rot[4], const double pos[3], const double offR[4], const double offT[3], int do_search,
+                   int ext) {
     if (!h) return fail("flh_eval: null handle");
-    if (!rot || !pos || !offR || !offT || !HTH || !HTh) return fail("flh_eval: null argument");
+    if (!rot || !pos || !offR || !offT) return fail("flh_eval: null argument");
+    if (h->pend.active) return fail("flh_eval_begin: the previous evaluation has not been collected (flh_eval_end)");
     HIPC(hipSetDevice(h->device));
     const StateDev s = make_state(rot, pos, offR, offT);
-    // the final reduce kernel writes the 16x16 block straight into pinned, device-mapped host memory:
-    // no copy kernel, no extra boundary -- the stream sync below is the only wait
-    const bool timed = h->timing_stride > 0 && (!h->timing_search_only || do_search) && (h->eval_no++ % (uint64_t)h->timing_stride) == 0;
-    bool deferred = false;
+    flh_handle::PendingEval& pe = h->pend;
+    pe = flh_handle::PendingEval();
+    pe.do_search = do_search != 0;
+    pe.ext = ext;
+    pe.timed = h->timing_stride > 0 && (!h->timing_search_only || do_search) && (h->eval_no++ % (uint64_t)h->timing_stride) == 0;
     hipEvent_t* ev3 = nullptr;
-    if (timed) {
-        deferred = h->timing_stride >= 2 && ensure_event_pool(h);
-        if (deferred && h->evp_n == flh_handle::kEvPool) drain_events(h);
-        ev3 = deferred ? h->evp[h->evp_n] : h->ev;
+    if (pe.timed) {
+        pe.deferred = h->timing_stride >= 2 && ensure_event_pool(h);
+        if (pe.deferred && h->evp_n == flh_handle::kEvPool) drain_events(h);
+        ev3 = pe.deferred ? h->evp[h->evp_n] : h->ev;
     }
-    const double seq = (double)(++h->seq);
+    pe.seq = (double)(++h->seq);
     hipStream_t st = h->stream;
     // group sums as granules in pinned memory (this rank's and, with peers, every rank's): not with an RCCL communicator (the
     // block is all-reduced on the device), not for an empty scan
-    const bool granules = !h->comm && h->N > 0 && gran_group_size(h->N) > 0;
-    const bool one_launch = do_search && use_pass_kernel(h, granules);
-    if (h->peer_n > 1 && !granules) return fail("flh_eval: a scan shard may not be empty when the ranks exchange granules (flh_peer_*)");
+    pe.granules = !h->comm && h->N > 0 && gran_group_size(h->N) > 0;
+    pe.one_launch = pe.do_search && use_pass_kernel(h, pe.granules);
+    if (h->peer_n > 1 && !pe.granules) return fail("flh_eval: a scan shard may not be empty when the ranks exchange granules (flh_peer_*)");
     if (h->comm) {
         // this rank's partial block stays in device memory, RCCL sums the ranks' blocks in place (256 doubles: latency-bound,
         // xGMI bandwidth is irrelevant), then one small kernel publishes the sum + sequence word to pinned host memory
         if (enqueue_eval(h, s, do_search, ext, h->gram.p, 0.0, ev3) != 0) return -1;
-        if (rccl_allreduce_publish(h, seq) != 0) return -1;
-    } else if (enqueue_eval(h, s, do_search, ext, h->h_gram, seq, ev3, granules) != 0) {
+        if (rccl_allreduce_publish(h, pe.seq) != 0) return -1;
+    } else if (enqueue_eval(h, s, do_search, ext, h->h_gram, pe.seq, ev3, pe.granules) != 0) {
         return -1;
     }
     if (h->stats && do_search) HIPC(hipMemcpyAsync(h->h_counter, h->counter.p, sizeof(u64), hipMemcpyDeviceToHost, st));
-    if (do_search) { h->n_search_pass++; if (one_launch) h->n_one_launch++; } else h->n_nosearch_pass++;
-    if (granules) {
-        if (collect_granules(h, seq, do_search, ext) != 0) return -1;
+    if (do_search) { h->n_search_pass++; if (pe.one_launch) h->n_one_launch++; } else h->n_nosearch_pass++;
+    pe.active = true;
+    return 0;
+}
+
+int flh_eval_end(flh_handle* h, double HTH[144], double HTh[12], int64_t* n_eff, double* total_residual) {
+    if (!h) return fail("flh_eval: null handle");
+    if (!HTH || !HTh) return fail("flh_eval: null argument");
+    if (!h->pend.active) return fail("flh_eval_end: no evaluation under way (flh_eval_begin)");
+    const flh_handle::PendingEval pe = h->pend;
+    h->pend.active = false;
+    HIPC(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const double seq = pe.seq;
+    const bool do_search = pe.do_search, one_launch = pe.one_launch, timed = pe.timed, deferred = pe.deferred;
+    if (pe.granules) {
+        if (collect_granules(h, seq, do_search, pe.ext) != 0) return -1;
         if (h->stats) HIPC(hipStreamSynchronize(st));  // the candidate counter's copy
     } else if (h->stats) {
         HIPC(hipStreamSynchronize(st));
@@ -1688,6 +1724,13 @@ int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const doub
         h->acc[4] += c; h->acc[5] += 1;
     }
     return 0;
+}
+
+int flh_eval(flh_handle* h, const double rot[4], const double pos[3], const double offR[4], const double offT[3],
+             int do_search, int ext, double HTH[144], double HTh[12], int64_t* n_eff, double* total_residual) {
+    if (!HTH || !HTh) return fail("flh_eval: null argument");
+    if (flh_eval_begin(h, rot, pos, offR, offT, do_search, ext) != 0) return -1;
+    return flh_eval_end(h, HTH, HTh, n_eff, total_residual);
 }
 
 int flh_get_counters(flh_handle* h, double out[6], int reset) {
@@ -2343,14 +2386,6 @@ int flh_peer_size(const flh_handle* h) { return h ? h->peer_n : 0; }
 int flh_peer_rank(const flh_handle* h) { return h ? h->peer_rank : -1; }
 // Developer builds (-DFLH_BOUNDS, tools/variant.py): the bounds records of the four kernel translation units, 5 words each
 // {violations, site of the first one, its index, the capacity, its workgroup}; all zero in the product (nothing is checked there).
-#ifdef FLH_BOUNDS
-namespace flh {
-void bounds_read_kernels(unsigned long long out[5]);
-void bounds_read_pass(unsigned long long out[5]);
-void bounds_read_mapinc(unsigned long long out[5]);
-void bounds_read_scanprep(unsigned long long out[5]);
-}
-#endif
 int flh_debug_bounds(flh_handle* h, uint64_t out[20]) {
     if (!h || !out) return fail("flh_debug_bounds: null argument");
     for (int i = 0; i < 20; ++i) out[i] = 0;
@@ -2364,6 +2399,19 @@ int flh_debug_bounds(flh_handle* h, uint64_t out[20]) {
     flh::bounds_read_scanprep(r); for (int i = 0; i < 5; ++i) out[15 + i] = r[i];
     return 1;
 #else
+    return 0;
+#endif
+}
+// Developer builds (-DFLH_PASS_STAMPS): the per-wave phase stamps of the last k_pass launch, 8 words per wave (100 MHz ticks).
+int flh_debug_pass_stamps(flh_handle* h, uint64_t* out, size_t words) {
+    if (!h || !out) return fail("flh_debug_pass_stamps: null argument");
+#ifdef FLH_PASS_STAMPS
+    HIPC(hipSetDevice(h->device));
+    HIPC(hipDeviceSynchronize());
+    flh::pass_stamps_read(reinterpret_cast<unsigned long long*>(out), words);
+    return 1;
+#else
+    (void)words;
     return 0;
 #endif
 }

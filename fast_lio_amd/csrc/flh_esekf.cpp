@@ -55,6 +55,10 @@ static void gpu_model_adapter(state_ikfom& s, esekfom::dyn_share_datastruct<doub
     flh_esekf* e = static_cast<flh_esekf*>(ctx);
     fastlio_amd::h_share_model(s, d, &e->gpu_ctx);
 }
+static void gpu_begin_adapter(state_ikfom& s, esekfom::dyn_share_datastruct<double>& d, void* ctx) {
+    flh_esekf* e = static_cast<flh_esekf*>(ctx);
+    fastlio_amd::h_share_model_begin(s, d, &e->gpu_ctx);
+}
 
 extern "C" {
 
@@ -65,6 +69,7 @@ flh_esekf* flh_esekf_create(flh_handle* handle, int maximum_iter, const double l
     double lim[FLH_NDOF];
     for (int i = 0; i < FLH_NDOF; ++i) lim[i] = limit ? limit[i] : 0.001;  // epsi, laserMapping.cpp:826-827
     e->kf.init_dyn_share(get_f, df_dx, df_dw, static_cast<kf_t::measurementModel_dyn_share_ctx*>(gpu_model_adapter), maximum_iter, lim, e);
+    if (handle) e->kf.set_meas_begin(gpu_begin_adapter);  // the pass runs on the device while the filter projects the covariance
     return e;
 }
 void flh_esekf_destroy(flh_esekf* e) { delete e; }
@@ -73,6 +78,7 @@ void flh_esekf_set_meas_model(flh_esekf* e, flh_meas_fn h, void* ctx) {
     e->user_h = h;
     e->user_ctx = ctx;
     e->kf.set_meas_model(static_cast<kf_t::measurementModel_dyn_share_ctx*>(h ? user_model_adapter : gpu_model_adapter), e);
+    if (!h && e->gpu_ctx.handle) e->kf.set_meas_begin(gpu_begin_adapter);
 }
 void flh_esekf_change_x(flh_esekf* e, const double x[FLH_NSTATE]) {
     state_ikfom s = e->kf.get_x();

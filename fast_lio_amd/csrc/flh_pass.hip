@@ -51,6 +51,23 @@ constexpr int kSegA = ring_seg_slots<1>();             // 20 LDS table entries p
 constexpr int kSegB = 2 * 16 + 2;                      // 34 per phase-B group (32 groups, 4x4 window)
 constexpr int kSegWords = (64 * kSegA > 32 * kSegB) ? 64 * kSegA : 32 * kSegB;
 static_assert(kSegWords * 8 >= 64 * kTileStride * 8, "the fit's transpose tile reuses the segment tables");
+// Developer instrumentation (tools/variant.py --define FLH_PASS_STAMPS, tools/pass_stamps.py): per-wave 100 MHz time stamps of the
+// phases of k_pass, read back with flh_debug_pass_stamps.  Compiled out of the product.
+#ifdef FLH_PASS_STAMPS
+constexpr int kStampWaves = 16384;
+__device__ unsigned long long g_pass_stamps[kStampWaves * 8];
+#define STAMP(i)                                                                                                         \
+    do {                                                                                                                 \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < kStampWaves)                                \
+            g_pass_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();           \
+    } while (0)
+void pass_stamps_read(unsigned long long* out, size_t words) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pass_stamps), sizeof(unsigned long long) * (words < (size_t)kStampWaves * 8 ? words : (size_t)kStampWaves * 8));
+}
+#else
+#define STAMP(i)
+#endif
+
 template <int ORD>
 __global__ void __launch_bounds__(256) PASS_ATTR
 k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist, float thr, int ext,
@@ -64,6 +81,7 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     const int tid = threadIdx.x;
     const int q0 = blockIdx.x * kPassQueries;
     const RingRsrc rs(g, map_points);
+    STAMP(0);  // start
 
     // ---- phase A: every query of the workgroup, four lanes each
     {
@@ -97,7 +115,9 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
         if (open && lane == 0) s_list[FLH_IDX(401, wave * 16 + __popcll(bal & ((1ull << wl) - 1ull)), 64)] = (uint32_t)grp;
         if (wl == 0) s_wcnt[wave] = (uint32_t)__popcll(bal);
     }
+    STAMP(1);  // this wave's phase A done
     __syncthreads();
+    STAMP(2);  // the workgroup's phase A done
 
     // ---- phase B: the workgroup's open queries, eight lanes each, 32 per trip
     const uint32_t c0 = s_wcnt[0], c1 = s_wcnt[1], c2 = s_wcnt[2], c3 = s_wcnt[3];
@@ -126,6 +146,7 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
         __syncthreads();
     }
 #endif
+    STAMP(3);  // phase B done (= stamp 2 without open queries)
 
     // ---- fit: one wave, lane = query.  Which wave: spread over the SIMDs (a workgroup's waves land on the four SIMDs of a CU
     // in order, so a fixed choice would load one SIMD of every CU with all the fits)
@@ -162,6 +183,7 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     tile_store(T, wl, v);
     wave_sync();
     const v4f64 acc = tile_gram(T, wl);
+    STAMP(4);  // fit + Gram done
 
     // ---- this workgroup's share of the normal equations -> HBM, the group's ticket, and for the last arriver the group's sum
     const int nsl = gran_section_slots(ncol);  // the last one: the number of queries that needed phase B (a statistic the host reports)
@@ -171,11 +193,15 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     const int group = blockIdx.x / red;
     const int gsize = min(red, nblk - group * red);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(5);  // partial stored and drained
     uint32_t tk = 0;
     if (wl == 0) tk = __hip_atomic_fetch_add(&tickets[1 + group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+    STAMP(6);  // ticket taken
     if (tk != (uint32_t)(gsize - 1)) return;
     group_sum_publish(partials, group, gsize, red, nsl, (nblk + red - 1) / red, gout, seq, wl);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(7);  // (the group's last arriver) group sum published
     if (wl == 0) tickets[1 + group] = 0;  // re-arm this group's ticket for the next launch
 }
 

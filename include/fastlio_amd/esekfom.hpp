@@ -38,6 +38,26 @@ struct dyn_share_datastruct {
     T total_residual = 0;
 };
 
+// Measurement models of the reference's plain signature (esekfom.hpp:129) that come in two halves register their first half
+// here, keyed by the address of the model; init_dyn_share / set_meas_model look it up.  fastlio_amd::h_share_model does
+// (h_share_model.hpp), so the node's lines laserMapping.cpp:826-828 get the overlap without a change.
+struct split_model_entry { void* model; void* begin; };
+inline std::vector<split_model_entry>& split_models() {
+    static std::vector<split_model_entry> v;
+    return v;
+}
+inline bool register_split_model(void* model, void* begin) {
+    for (auto& e : split_models())
+        if (e.model == model) { e.begin = begin; return true; }
+    split_models().push_back({model, begin});
+    return true;
+}
+inline void* find_split_begin(void* model) {
+    for (const auto& e : split_models())
+        if (e.model == model) return e.begin;
+    return nullptr;
+}
+
 template <typename state, int process_noise_dof, typename input = state>
 class esekf {
    public:
@@ -55,6 +75,13 @@ class esekf {
     // process); either can be registered.
     typedef void measurementModel_dyn_share(state&, dyn_share_datastruct<scalar_type>&);
     typedef void measurementModel_dyn_share_ctx(state&, dyn_share_datastruct<scalar_type>&, void* ctx);
+    // Optional FIRST HALF of a measurement model that can be started before it is waited for (a GPU pass: flh_eval_begin).  When
+    // one is known for the registered model -- set_meas_begin, or register_split_model below for the reference's plain signature --
+    // the update starts the model, does the part of the pass's 23x23 algebra that does not depend on the measurement (covariance
+    // projection, (P / R)^-1: about a third of it) while the device works, and only then calls the model proper, which waits.
+    // Same arithmetic on the same operands: same bits.
+    typedef void measurementModel_begin(state&, dyn_share_datastruct<scalar_type>&);
+    typedef void measurementModel_begin_ctx(state&, dyn_share_datastruct<scalar_type>&, void* ctx);
 
     esekf(const state& x = state(), const cov& P = cov::Identity()) : x_(x), P_(P) {}
 
@@ -65,6 +92,8 @@ class esekf {
         h_dyn_share = h_dyn_share_in;
         h_dyn_share_ctx = nullptr;
         h_ctx_ = nullptr;
+        h_begin = reinterpret_cast<measurementModel_begin*>(find_split_begin(reinterpret_cast<void*>(h_dyn_share_in)));
+        h_begin_ctx = nullptr;
     }
     // the same with a context pointer handed to the measurement model
     void init_dyn_share(processModel f_in, processMatrix1 f_x_in, processMatrix2 f_w_in,
@@ -74,9 +103,17 @@ class esekf {
         h_dyn_share = nullptr;
         h_dyn_share_ctx = h_dyn_share_in;
         h_ctx_ = h_ctx;
+        h_begin = nullptr;
+        h_begin_ctx = nullptr;
     }
-    void set_meas_model(measurementModel_dyn_share_ctx h, void* ctx) { h_dyn_share = nullptr; h_dyn_share_ctx = h; h_ctx_ = ctx; }
-    void set_meas_model(measurementModel_dyn_share h) { h_dyn_share = h; h_dyn_share_ctx = nullptr; h_ctx_ = nullptr; }
+    void set_meas_model(measurementModel_dyn_share_ctx h, void* ctx) { h_dyn_share = nullptr; h_dyn_share_ctx = h; h_ctx_ = ctx; h_begin = nullptr; h_begin_ctx = nullptr; }
+    void set_meas_model(measurementModel_dyn_share h) {
+        h_dyn_share = h; h_dyn_share_ctx = nullptr; h_ctx_ = nullptr;
+        h_begin = reinterpret_cast<measurementModel_begin*>(find_split_begin(reinterpret_cast<void*>(h)));
+        h_begin_ctx = nullptr;
+    }
+    // first half of the _ctx model registered last (same context pointer); nullptr: the model is called in one piece
+    void set_meas_begin(measurementModel_begin_ctx b) { h_begin_ctx = b; h_begin = nullptr; }
 
     // esekfom.hpp:279-383 (dense path)
     void predict(double& dt, processnoisecovariance& Q, const input& i_in) {
@@ -151,11 +188,26 @@ class esekf {
         Vec<n> K_h;
         cov K_x;
         vectorized_state dx_new = vectorized_state::Zero();
+        vectorized_state dx_early, dx_new_early;
+        cov P_early, P_temp_early;
         for (int i = -1; i < maximum_iter; i++) {
             dyn_share.valid = true;
             dyn_share.has_normal_eq = false;
             const auto t_h0 = clk::now();
             const bool searched = dyn_share.converge;
+            bool early = false;
+            if ((h_dyn_share_ctx && h_begin_ctx) || (!h_dyn_share_ctx && h_begin)) {
+                // the measurement model is under way on the device: what :1655-1699 and the first inverse of :1782 compute from the
+                // state alone is computed now, into temporaries (an invalid measurement must leave P_ as the reference does)
+                if (h_dyn_share_ctx) h_begin_ctx(x_, dyn_share, h_ctx_);
+                else h_begin(x_, dyn_share);
+                x_.boxminus(dx_early, x_propagated);
+                dx_new_early = dx_early;
+                P_early = P_propagated;
+                project_cov(P_early, dx_new_early, dx_early, x_, x_propagated);
+                P_temp_early = fastlio_amd::inverse(P_early / R);
+                early = true;
+            }
             if (h_dyn_share_ctx) h_dyn_share_ctx(x_, dyn_share, h_ctx_);
             else h_dyn_share(x_, dyn_share);
             stats_.h_ms += std::chrono::duration<double, std::milli>(clk::now() - t_h0).count();
@@ -174,17 +226,23 @@ class esekf {
             const auto solve_start = clk::now();
             dof_Measurement = (int)meas_rows(dyn_share);
             vectorized_state dx;
-            x_.boxminus(dx, x_propagated);
-            dx_new = dx;
-            P_ = P_propagated;
-            project_cov(P_, dx_new, dx, x_, x_propagated);  // :1659-1699
+            if (early) {
+                dx = dx_early;
+                dx_new = dx_new_early;
+                P_ = P_early;
+            } else {
+                x_.boxminus(dx, x_propagated);
+                dx_new = dx;
+                P_ = P_propagated;
+                project_cov(P_, dx_new, dx, x_, x_propagated);  // :1659-1699
+            }
 
             if (n > dof_Measurement) {  // :1715-1744 gain form on explicit rows
                 gain_small(dyn_share, dof_Measurement, R, K_h, K_x);
             } else {  // :1782-1809 information form
                 double HTH[144], HTh[12];
                 normal_equations(dyn_share, dof_Measurement, HTH, HTh);
-                cov P_temp = fastlio_amd::inverse(P_ / R);
+                cov P_temp = early ? P_temp_early : fastlio_amd::inverse(P_ / R);
                 for (int a = 0; a < 12; ++a)
                     for (int b = 0; b < 12; ++b) P_temp(a, b) += HTH[a * 12 + b];
                 // only P_inv.block<n,12>(0,0) is read below (:1803-1806): the first 12 columns of the inverse, bit for bit
@@ -386,6 +444,8 @@ class esekf {
     measurementModel_dyn_share* h_dyn_share = nullptr;
     measurementModel_dyn_share_ctx* h_dyn_share_ctx = nullptr;
     void* h_ctx_ = nullptr;
+    measurementModel_begin* h_begin = nullptr;
+    measurementModel_begin_ctx* h_begin_ctx = nullptr;
     int maximum_iter = 0;
     scalar_type limit[n];
     dyn_share_datastruct<scalar_type> dyn_share_;

@@ -24,6 +24,7 @@ struct HShareContext {
     double total_residual = 0.0;    // :86
     double res_mean_last = 0.05;    // :86
     double match_ms = 0.0;          // wall time inside flh_eval (match_time + solve_time buckets, :640,716-717,753)
+    bool begun = false;             // h_share_model_begin has enqueued this pass: h_share_model only waits for it
 };
 
 inline HShareContext g_hshare;  // the globals of laserMapping.cpp:69-114 that the two-argument form reads
@@ -33,17 +34,36 @@ inline void h_share_model(state_ikfom& s, esekfom::dyn_share_datastruct<double>&
     h_share_model(s, ekfom_data, &g_hshare);
 }
 
-inline void h_share_model(state_ikfom& s, esekfom::dyn_share_datastruct<double>& ekfom_data, void* ctx_) {
+// First half: the pass is enqueued on the device and the call returns (flh_eval_begin); the filter does the part of its algebra
+// that needs no measurement, then calls h_share_model, which waits.  Registered for both forms (below; esekf::set_meas_begin).
+inline void h_share_model_begin(state_ikfom& s, esekfom::dyn_share_datastruct<double>& ekfom_data, void* ctx_) {
     HShareContext* ctx = static_cast<HShareContext*>(ctx_);
     if (!ctx || !ctx->handle) throw std::runtime_error("fastlio_amd::h_share_model: no flh_handle bound");
     const double rot[4] = {s.rot.x, s.rot.y, s.rot.z, s.rot.w};
     const double offR[4] = {s.offset_R_L_I.x, s.offset_R_L_I.y, s.offset_R_L_I.z, s.offset_R_L_I.w};
     const double pos[3] = {s.pos[0], s.pos[1], s.pos[2]};
     const double offT[3] = {s.offset_T_L_I[0], s.offset_T_L_I[1], s.offset_T_L_I[2]};
+    if (flh_eval_begin(ctx->handle, rot, pos, offR, offT, ekfom_data.converge ? 1 : 0, ctx->extrinsic_est_en ? 1 : 0) != 0)
+        throw std::runtime_error(std::string("flh_eval failed: ") + flh_last_error());
+    ctx->begun = true;
+}
+inline void h_share_model_begin(state_ikfom& s, esekfom::dyn_share_datastruct<double>& ekfom_data) {
+    h_share_model_begin(s, ekfom_data, &g_hshare);
+}
+namespace detail {
+inline const bool h_share_model_split_registered = esekfom::register_split_model(
+    reinterpret_cast<void*>(static_cast<void (*)(state_ikfom&, esekfom::dyn_share_datastruct<double>&)>(&h_share_model)),
+    reinterpret_cast<void*>(static_cast<void (*)(state_ikfom&, esekfom::dyn_share_datastruct<double>&)>(&h_share_model_begin)));
+}
+
+inline void h_share_model(state_ikfom& s, esekfom::dyn_share_datastruct<double>& ekfom_data, void* ctx_) {
+    HShareContext* ctx = static_cast<HShareContext*>(ctx_);
+    if (!ctx || !ctx->handle) throw std::runtime_error("fastlio_amd::h_share_model: no flh_handle bound");
     int64_t n_eff = 0;
     double total_res = 0;
-    if (flh_eval(ctx->handle, rot, pos, offR, offT, ekfom_data.converge ? 1 : 0, ctx->extrinsic_est_en ? 1 : 0,
-                 ekfom_data.HTH, ekfom_data.HTh, &n_eff, &total_res) != 0)
+    if (!ctx->begun) h_share_model_begin(s, ekfom_data, ctx_);  // called in one piece
+    ctx->begun = false;
+    if (flh_eval_end(ctx->handle, ekfom_data.HTH, ekfom_data.HTh, &n_eff, &total_res) != 0)
         throw std::runtime_error(std::string("flh_eval failed: ") + flh_last_error());
     ctx->effct_feat_num = (int)n_eff;
     ctx->total_residual = total_res;

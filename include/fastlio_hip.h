@@ -219,6 +219,14 @@ int flh_eval(flh_handle* h, const double rot_xyzw[4], const double pos[3], const
              const double offT[3], int do_search, int extrinsic_est_en, double HTH[144], double HTh[12],
              int64_t* n_eff, double* total_residual);
 
+/* The same evaluation in two halves: flh_eval_begin enqueues the pass and returns, flh_eval_end waits for its normal equations.
+ * Between the two the caller's thread may do host work that does not depend on them (the mirror esekf projects the covariance and
+ * inverts P / R there -- include/fastlio_amd/esekfom.hpp).  One evaluation under way per handle; an error in flh_eval_begin
+ * leaves none under way. */
+int flh_eval_begin(flh_handle* h, const double rot_xyzw[4], const double pos[3], const double offR_xyzw[4], const double offT[3],
+                   int do_search, int extrinsic_est_en);
+int flh_eval_end(flh_handle* h, double HTH[144], double HTh[12], int64_t* n_eff, double* total_residual);
+
 /* Same evaluation, but the reduced 16x16 Gram block is left in DEVICE memory at d_gram256 (256
  * doubles, row-major G = sum_k v_k v_k^T with v = [row(12) | h | 1 | |pd2| | 0]) and the call
  * returns after enqueueing on the handle's stream.  This is the hook for the multi-GPU path: the
@@ -273,6 +281,8 @@ int flh_get_pass_stats(const flh_handle* h, uint64_t out[4]);
  * violation records of the four kernel translation units, 5 words each {count, site, index, capacity, workgroup}; the product
  * library checks nothing, returns 0 and zeros. */
 int flh_debug_bounds(flh_handle* h, uint64_t out[20]);
+/* Developer builds only (-DFLH_PASS_STAMPS): 8 time stamps (100 MHz) per wave of the last one-launch pass; returns 1, else 0. */
+int flh_debug_pass_stamps(flh_handle* h, uint64_t* out, size_t words);
 /* Map partitioned over the ranks (BASELINE configs[4]): this handle's map is one slab of the world plus a halo of at least
  * sqrt(max_sqdist) on either side; every rank holds the whole scan; a query is searched (and then fitted) only by the
  * rank whose half-open interval [lo, hi) of world coordinate `axis` (0/1/2) contains it.  The ranks' intervals must tile

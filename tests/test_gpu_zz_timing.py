@@ -169,7 +169,7 @@ def test_one_launch_pass_equals_three_launch_pass():
     pr = synth.make_problem(200000, 20000, "avia", cfg=1)
     xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
     x_far = np.array(xp, dtype=np.float64)
-    x_far[:3] += [0.9, -0.7, 0.8]          # metres off: 5th neighbours beyond the first stage's guaranteed radius
+    x_far[:3] += [1.6, -1.3, 1.7]          # metres off: 5th neighbours beyond the first stage's guaranteed radius
     scans = {"dense": pr.body, "sparse": np.ascontiguousarray(pr.body[::37]), "ragged": np.ascontiguousarray(pr.body[:5003]),
              "tiny": np.ascontiguousarray(pr.body[:7])}
     for name, body in scans.items():

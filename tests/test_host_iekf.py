@@ -143,3 +143,18 @@ def test_update_scan_is_change_x_change_P_update(small):
     kf = capi.Esekf(None, max_iter=3)
     with pytest.raises(capi.FlhError):
         kf.update_scan(0, np.ascontiguousarray(xp, np.float64), np.ascontiguousarray(P, np.float64), 0.001)
+
+
+def test_two_halves_measurement_model_changes_no_bit(tmp_path):
+    """esekf with a measurement model whose first half is registered (the GPU pass: flh_eval_begin) does the covariance projection
+    and (P / R)^-1 between the two halves; tests/cpp/split_model_check.cpp compares it with the one-piece flow bit for bit,
+    including passes whose measurement is invalid."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "split_model_check"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "split_model_check.cpp"), "-o", str(exe)])
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode == 0 and "identical bits" in r.stdout.decode(), r.stdout.decode()

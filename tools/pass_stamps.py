@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Developer tool (GPU box): where the time of the one-launch pass goes.  Needs the library built with -DFLH_PASS_STAMPS
+(python tools/variant.py --name stamps --define FLH_PASS_STAMPS --build-only; FLH_LIB=.../libfastlio_hip_stamps.so).
+Prints, for a search at the prior and one at the true state of BASELINE configs[1], the distribution over waves / workgroups of
+the phase end times of k_pass relative to the kernel's first wave start (microseconds)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fast_lio_amd import capi, synth  # noqa: E402
+
+M, N = 5_000_000, 100_000
+pr = synth.make_problem(M, N, "avia", cfg=2)
+xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
+h = capi.Handle()
+h.map_build(pr.map_xyz)
+h.scan_upload(pr.body)
+h.set_timing_stride(0)
+nw = (N + 63) // 64 * 4
+
+
+def pc(v, name):
+    if len(v) == 0:
+        print(f"  {name:34s} (none)")
+        return
+    q = np.percentile(v, [0, 25, 50, 75, 95, 99, 100])
+    print(f"  {name:34s} n={len(v):5d}  p0 {q[0]:6.2f}  p25 {q[1]:6.2f}  p50 {q[2]:6.2f}  p75 {q[3]:6.2f}  p95 {q[4]:6.2f}  p99 {q[5]:6.2f}  max {q[6]:6.2f}")
+
+
+for name, x in (("prior (first search of a scan)", xp), ("true state (a later search)", pr.x_true)):
+    for rep in range(3):
+        h.eval(x, True, False)
+    ok, st = h.debug_pass_stamps(nw)
+    if not ok:
+        sys.exit("library not built with -DFLH_PASS_STAMPS")
+    t = st.astype(np.float64) / 100.0  # us
+    t0 = t[:, 0][t[:, 0] > 0].min()
+    rel = np.where(t > 0, t - t0, np.nan)
+    fit = ~np.isnan(rel[:, 4]) & (st[:, 4] > st[:, 0])  # the fit waves (stamps of this launch: later than the wave's own start)
+    red = fit & (st[:, 7] > st[:, 6])
+    print(name)
+    pc(rel[:, 0], "wave start")
+    pc(rel[:, 1], "wave: phase A done")
+    pc(rel[:, 1] - rel[:, 0], "wave: phase A duration")
+    pc(rel[fit, 2], "workgroup: phase A done (barrier)")
+    pc(rel[fit, 3] - rel[fit, 2], "workgroup: phase B duration")
+    pc(rel[fit, 4] - rel[fit, 3], "fit wave: fit + Gram duration")
+    pc(rel[fit, 5] - rel[fit, 4], "fit wave: partial store + drain")
+    pc(rel[fit, 6] - rel[fit, 5], "fit wave: ticket round trip")
+    pc(rel[fit, 6], "fit wave: done (ticket taken)")
+    pc(rel[red, 7] - rel[red, 6], "reducer: group sum + publish")
+    pc(rel[red, 7], "reducer: published")
+    last = np.nanmax(rel[:, :8])
+    print(f"  last stamp of the launch: {last:.2f} us after the first wave's start")
+h.close()
