@@ -410,23 +410,53 @@ def main():
     other_exchange = None
     if run_shard_leg:
         headline = mode in ("shard", "partition")
+        def all_ranks_ok(ok):
+            """did the leg succeed on EVERY rank?  (a rank that failed makes the others time out in their granule wait or in
+            the collective, so every rank gets here)"""
+            if dist is None:
+                return ok
+            t_ = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t_, op=dist.ReduceOp.MIN)
+            return bool(int(t_.item()))
+
+        oth = "rccl" if args.exchange == "peer" else "peer"
+        k2 = args.steps if headline else max(10, min(60, args.steps // 4))  # (a side leg only with --force-shard-leg)
+        w2 = args.warmup if headline else max(3, args.warmup // 4)
+        used, err = args.exchange, None
+        res = None
         try:
-            k2 = args.steps if headline else max(10, min(60, args.steps // 4))  # (a side leg only with --force-shard-leg)
-            w2 = args.warmup if headline else max(3, args.warmup // 4)
-            shard_out, (dt2, acc2, ctr2), pts_here = shard_leg(args.exchange, w2, k2)
+            res = shard_leg(args.exchange, w2, k2)
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)[:400]
+        if not all_ranks_ok(res is not None):
+            # the chosen exchange did not come up on this node (say, the shared segment could not be page-locked): the headline
+            # is then measured with the other one, and the line says so
+            first_err = err or "another rank failed"
+            res, used = None, oth
+            try:
+                res = shard_leg(oth, w2, k2)
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)[:400]
+            if not all_ranks_ok(res is not None):
+                if headline:
+                    raise RuntimeError(f"sharded leg failed with both exchanges: {first_err} / {err}")
+                res = None
+                shard_out = {"error": f"{first_err} / {err}"}
+            elif res is not None:
+                res[0]["exchange_fallback"] = f"--exchange {args.exchange} failed ({first_err}); measured with {oth}"
+        if res is not None:
+            shard_out, (dt2, acc2, ctr2), pts_here = res
             if headline:
                 dt, acc, ctr = dt2, acc2, ctr2
                 units = args.steps
                 n_pts = pts_here
-        except Exception as e:  # the side leg must not cost the headline line (streams mode); in shard / partition mode it IS the headline
-            if headline:
-                raise
-            shard_out = {"error": repr(e)[:400]}
-        try:  # the other exchange, shorter, for comparison
-            oth = "rccl" if args.exchange == "peer" else "peer"
-            other_exchange, _r, _p = shard_leg(oth, max(3, args.warmup // 4), max(10, min(60, args.steps // 2)))
-        except Exception as e:  # noqa: BLE001
-            other_exchange = {"error": repr(e)[:400]}
+        if used == args.exchange:
+            try:  # the other exchange, shorter, for comparison
+                other_exchange, _r, _p = shard_leg(oth, max(3, args.warmup // 4), max(10, min(60, args.steps // 2)))
+            except Exception as e:  # noqa: BLE001
+                other_exchange = {"error": repr(e)[:400]}
+            if not all_ranks_ok(isinstance(other_exchange, dict) and "error" not in other_exchange) and "error" not in other_exchange:
+                other_exchange = {"error": "another rank failed"}
     value = units / dt
     ms_per_step = dt / args.steps * 1e3
 
