@@ -388,8 +388,9 @@ class Handle:
         return bool(rc), [int(v) for v in out]
 
     def debug_pass_stamps(self, n_waves: int):
-        """(instrumented?, n_waves x 8 array of 100 MHz ticks) -- see flh_debug_pass_stamps (tools/pass_stamps.py)."""
-        out = np.zeros((n_waves, 8), np.uint64)
+        """(instrumented?, n_waves x 12 array: 8 stamps in 100 MHz ticks, HW_ID, XCC_ID, longest candidate list, open queries)
+        -- see flh_debug_pass_stamps (tools/pass_stamps.py)."""
+        out = np.zeros((n_waves, 12), np.uint64)
         rc = lib().flh_debug_pass_stamps(self._h, out, out.size)
         if rc < 0:
             raise FlhError(lib().flh_last_error().decode())

@@ -2402,7 +2402,8 @@ int flh_debug_bounds(flh_handle* h, uint64_t out[20]) {
     return 0;
 #endif
 }
-// Developer builds (-DFLH_PASS_STAMPS): the per-wave phase stamps of the last k_pass launch, 8 words per wave (100 MHz ticks).
+// Developer builds (-DFLH_PASS_STAMPS): the per-wave phase stamps of the last k_pass launch, 12 words per wave (8 stamps in 100 MHz ticks,
+// HW_ID, XCC_ID, longest candidate list, open queries).
 int flh_debug_pass_stamps(flh_handle* h, uint64_t* out, size_t words) {
     if (!h || !out) return fail("flh_debug_pass_stamps: null argument");
 #ifdef FLH_PASS_STAMPS

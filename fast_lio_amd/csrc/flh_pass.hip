@@ -55,14 +55,16 @@ static_assert(kSegWords * 8 >= 64 * kTileStride * 8, "the fit's transpose tile r
 // phases of k_pass, read back with flh_debug_pass_stamps.  Compiled out of the product.
 #ifdef FLH_PASS_STAMPS
 constexpr int kStampWaves = 16384;
-__device__ unsigned long long g_pass_stamps[kStampWaves * 8];
-#define STAMP(i)                                                                                                         \
+constexpr int kStampWords = 12;  // 0..7 time stamps; 8 HW_ID, 9 XCC_ID, 10 the longest candidate list of the wave's queries, 11 its open queries
+__device__ unsigned long long g_pass_stamps[kStampWaves * kStampWords];
+#define STAMP_VAL(i, val)                                                                                                \
     do {                                                                                                                 \
         if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < kStampWaves)                                \
-            g_pass_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();           \
+            g_pass_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * kStampWords + (i)] = (val);                            \
     } while (0)
+#define STAMP(i) STAMP_VAL(i, __builtin_amdgcn_s_memrealtime())
 void pass_stamps_read(unsigned long long* out, size_t words) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pass_stamps), sizeof(unsigned long long) * (words < (size_t)kStampWaves * 8 ? words : (size_t)kStampWaves * 8));
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pass_stamps), sizeof(unsigned long long) * (words < (size_t)kStampWaves * kStampWords ? words : (size_t)kStampWaves * kStampWords));
 }
 #else
 #define STAMP(i)
@@ -114,6 +116,16 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
         const u64 bal = __ballot(open && lane == 0);
         if (open && lane == 0) s_list[FLH_IDX(401, wave * 16 + __popcll(bal & ((1ull << wl) - 1ull)), 64)] = (uint32_t)grp;
         if (wl == 0) s_wcnt[wave] = (uint32_t)__popcll(bal);
+#ifdef FLH_PASS_STAMPS
+        {
+            float tm = lane == 0 ? pk[23] : 0.f;  // ring_query left the length of the query's candidate list there
+            for (int off = 32; off >= 1; off >>= 1) tm = fmaxf(tm, __shfl_xor(tm, off, 64));
+            STAMP_VAL(8, (unsigned long long)__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11)));
+            STAMP_VAL(9, (unsigned long long)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11)));
+            STAMP_VAL(10, (unsigned long long)tm);
+            STAMP_VAL(11, (unsigned long long)__popcll(bal));
+        }
+#endif
     }
     STAMP(1);  // this wave's phase A done
     __syncthreads();

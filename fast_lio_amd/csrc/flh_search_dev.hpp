@@ -519,6 +519,9 @@ __device__ __forceinline__ bool ring_query(const GridParams& g, const RingRsrc& 
     const bool covered = (cnt == 5 && d5hi <= gr2) || gr2 >= max_sqdist;
     const bool done = !amb && covered;
     if (cand_counter && live && lane == 0) atomicAdd(cand_counter, (u64)T);
+#ifdef FLH_PASS_STAMPS
+    if (park && lane == 0 && RING == 1) park[23] = (float)T;  // developer build: the length of the candidate list (tools/pass_stamps.py)
+#endif
     // ---- results: lane l loads ranks l, l + LPQ, ... (< m): flat index -> map position (table walk) -> one point load
     // each, all issued before the first is consumed; the exact squared distance is recomputed from the point (same
     // formula, same bits as the scan saw before packing).  The group then exchanges the (d2, map index) pairs and every

@@ -281,7 +281,8 @@ int flh_get_pass_stats(const flh_handle* h, uint64_t out[4]);
  * violation records of the four kernel translation units, 5 words each {count, site, index, capacity, workgroup}; the product
  * library checks nothing, returns 0 and zeros. */
 int flh_debug_bounds(flh_handle* h, uint64_t out[20]);
-/* Developer builds only (-DFLH_PASS_STAMPS): 8 time stamps (100 MHz) per wave of the last one-launch pass; returns 1, else 0. */
+/* Developer builds only (-DFLH_PASS_STAMPS): 12 words per wave of the last one-launch pass (8 time stamps
+ * at 100 MHz, HW_ID, XCC_ID, the longest candidate list among the wave's queries, its open queries); returns 1, else 0. */
 int flh_debug_pass_stamps(flh_handle* h, uint64_t* out, size_t words);
 /* Map partitioned over the ranks (BASELINE configs[4]): this handle's map is one slab of the world plus a halo of at least
  * sqrt(max_sqdist) on either side; every rank holds the whole scan; a query is searched (and then fitted) only by the

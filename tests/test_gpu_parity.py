@@ -417,8 +417,9 @@ def test_rccl_allreduce_path_single_rank(prob):
     kf.change_x(xp); kf.change_P(P)
     st = kf.update(0.001)
     assert st.passes == st0.passes and list(st.n_eff) == list(st0.n_eff)
-    np.testing.assert_allclose(kf.get_x(), kf0.get_x(), rtol=0, atol=1e-11)
-    np.testing.assert_allclose(kf.get_P(), kf0.get_P(), rtol=0, atol=1e-12 * np.abs(kf0.get_P()).max())
+    # (block-wise against unit-wise fp64 sums: rounding of the normal equations times the conditioning of the update)
+    np.testing.assert_allclose(kf.get_x(), kf0.get_x(), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(kf.get_P(), kf0.get_P(), rtol=0, atol=1e-8 * np.abs(kf0.get_P()).max())
     h.close()
     # one process, one handle per device
     g = capi.Handle()

@@ -46,7 +46,9 @@ def test_two_processes_exchange_granules(tmp_path):
         st = kf.update(0.001)
         assert list(st.n_eff)[: st.passes] == list(res[0][tag + "_neff"]), tag
         np.testing.assert_allclose(kf.get_x(), res[0][tag + "_x"], rtol=0, atol=1e-10, err_msg=tag)
-        np.testing.assert_allclose(kf.get_P(), res[0][tag + "_P"], rtol=0, atol=1e-10 * np.abs(kf.get_P()).max(), err_msg=tag)
+        # (the sums of the shards are added in another order than the single process adds its units: the posterior covariance
+        # moves by that rounding times the conditioning of the information matrix; the contract is 1e-4 of max|P|)
+        np.testing.assert_allclose(kf.get_P(), res[0][tag + "_P"], rtol=0, atol=1e-8 * np.abs(kf.get_P()).max(), err_msg=tag)
         sel = h.fetch_selected()
         for r in range(world):
             np.testing.assert_array_equal(res[r][tag + "_sel"], sel[res[r][tag + "_idx"]], err_msg=f"{tag}: flags of rank {r}")

@@ -54,4 +54,27 @@ for name, x in (("prior (first search of a scan)", xp), ("true state (a later se
     pc(rel[red, 7], "reducer: published")
     last = np.nanmax(rel[:, :8])
     print(f"  last stamp of the launch: {last:.2f} us after the first wave's start")
+    # which waves are the slow ones?  by length of the longest candidate list (trips of 32 candidates per query), by place
+    durA = rel[:, 1] - rel[:, 0]
+    tmax, nopen = st[:, 10].astype(np.int64), st[:, 11].astype(np.int64)
+    hw, xcc = st[:, 8].astype(np.int64), st[:, 9].astype(np.int64) & 0xF
+    simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
+    trips = (tmax + 31) // 32
+    print("  phase A duration by trips of the wave's longest query:")
+    for k in range(0, int(trips.max()) + 1):
+        m = trips == k
+        if m.any():
+            print(f"    trips {k}: n={int(m.sum()):5d}  mean {np.nanmean(durA[m]):6.2f}  p95 {np.nanpercentile(durA[m], 95):6.2f}  max {np.nanmax(durA[m]):6.2f}")
+    print("  phase A duration by XCC:", "  ".join(f"{x}: {np.nanmean(durA[xcc == x]):.2f}/{np.nanmax(durA[xcc == x]):.2f}" for x in sorted(set(xcc.tolist()))))
+    order = np.argsort(-np.nan_to_num(durA))[:16]
+    print("  slowest waves (phase A): wave block dur start tmax open xcc se sh cu simd")
+    for w in order:
+        print(f"    {w:5d} {w // 4:5d} {durA[w]:6.2f} {rel[w, 0]:5.2f} {tmax[w]:4d} {nopen[w]:3d}  {xcc[w]} {se[w]} {sh[w]} {cu[w]:2d} {simd[w]}")
+    # waves per (xcc, se, sh, cu): is a CU that got more workgroups slower?
+    cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    cnt = np.bincount(cuid)
+    per = cnt[cuid]
+    for k in sorted(set(per.tolist())):
+        m = per == k
+        print(f"    waves on CUs holding {k:2d} waves: n={int(m.sum()):5d}  mean phase A {np.nanmean(durA[m]):6.2f}  max {np.nanmax(durA[m]):6.2f}")
 h.close()
