@@ -95,7 +95,7 @@ EXPORTS = [
     "flh_scan_stage_async", "flh_scan_wait", "flh_host_alloc", "flh_host_free", "flh_frame_world", "flh_points_body_to_world",
     "flh_esekf_last_error", "flh_rccl_unique_id", "flh_rccl_init_rank", "flh_rccl_init_all", "flh_rccl_destroy", "flh_rccl_size",
     "flh_rccl_rank", "flh_eval_group", "flh_set_owned_interval", "flh_esekf_run_scans", "flh_get_search_counters", "flh_set_timing_sampling",
-    "flh_map_sync", "flh_eval_begin", "flh_eval_end", "flh_debug_bounds", "flh_debug_pass_stamps", "flh_peer_open", "flh_peer_init_all", "flh_peer_close", "flh_peer_size", "flh_peer_rank", "flh_get_pass_stats",
+    "flh_map_sync", "flh_eval_begin", "flh_eval_end", "flh_debug_bounds", "flh_debug_pass_stamps", "flh_peer_open", "flh_peer_init_all", "flh_peer_close", "flh_peer_size", "flh_peer_rank", "flh_get_pass_stats", "flh_map_change_stats",
 ]
 
 _lib = None
@@ -178,6 +178,7 @@ def lib():
     L.flh_map_delete_boxes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.flh_map_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.flh_map_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.flh_map_change_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.flh_map_incremental.argtypes = [C.c_void_p, _f64p, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32)]
     L.flh_fetch_map_incremental.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -328,13 +329,23 @@ class Handle:
         return {"reindex": int(out[0]), "brickwise": int(out[1]), "slots_used": int(out[2]), "slots": int(out[3]),
                 "ids": int(out[4]), "bricks": int(out[5])}
 
+    def map_change_stats(self) -> dict:
+        out = (C.c_uint64 * 2)()
+        _chk(lib().flh_map_change_stats(self._h, out), "flh_map_change_stats")
+        return {"enqueued_without_wait": int(out[0]), "replayed": int(out[1])}
+
     def map_download(self) -> np.ndarray:
         out = np.zeros((self.M, 3), np.float32)
         _chk(lib().flh_map_download(self._h, out.ctypes.data, out.shape[0]), "flh_map_download")
         return out
 
-    def map_incremental(self, x, filter_size_map: float = 0.5, flg_EKF_inited: bool = True, apply: bool = True):
-        """map_incremental() -- src/laserMapping.cpp:427-474.  Returns (n_add, n_no_downsample)."""
+    def map_incremental(self, x, filter_size_map: float = 0.5, flg_EKF_inited: bool = True, apply: bool = True, counts: bool = True):
+        """map_incremental() -- src/laserMapping.cpp:427-474.  Returns (n_add, n_no_downsample); counts=False: nobody asks for the
+        two list lengths (as the node's loop does not), which lets the library enqueue Add_Points without waiting for them -- None."""
+        if not counts:
+            _chk(lib().flh_map_incremental(self._h, np.ascontiguousarray(x, dtype=np.float64), float(filter_size_map),
+                                           int(flg_EKF_inited), int(apply), None, None), "flh_map_incremental")
+            return None
         n1, n2 = C.c_uint32(0), C.c_uint32(0)
         _chk(lib().flh_map_incremental(self._h, np.ascontiguousarray(x, dtype=np.float64), float(filter_size_map),
                                        int(flg_EKF_inited), int(apply), C.byref(n1), C.byref(n2)), "flh_map_incremental")

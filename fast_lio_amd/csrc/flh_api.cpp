@@ -139,6 +139,15 @@ struct flh_handle {
     // then the device has long finished, so nothing waits.
     uint32_t* h_mi = nullptr;
     uint32_t mi_seq = 0;
+    // map_incremental without the wait in the middle (a change of a scan's usual size): the two list lengths stay on the device
+    // (mi_cnt: [0] n1, [1] n, [2] survivors), Add_Points is enqueued with launches sized for small_change_max() points; a change
+    // that turns out larger is not applied by those launches and replayed by map_settle()
+    DevBuf<uint32_t> mi_cnt;
+    uint32_t mi_pred_n = 0xFFFFFFFFu;  // points of the previous change (the prediction for the next one); unknown at first
+    bool mi_deferred = false;          // the pending change was enqueued that way
+    uint32_t mi_cls_seq = 0;           // sequence word of the list-length granule of that change (h_mi[0..3])
+    double mi_pending_ds = 0.0;        // its down-sampling length
+    uint64_t n_mi_deferred = 0, n_mi_replayed = 0;
     bool map_pending = false;
     uint32_t map_pending_seq = 0;
     size_t pts_cap = 0, rows_cap = 0, alloc_top = 0;
@@ -283,6 +292,20 @@ static StateDev make_state(const double rot[4], const double pos[3], const doubl
 
 const char* flh_last_error(void) { return g_err.c_str(); }
 
+// a non-blocking stream at the highest (urgent) or the lowest priority the device offers
+static hipError_t create_stream(hipStream_t* st, bool urgent) {
+#ifndef FLH_NO_STREAM_PRIORITY  // (developer A/B builds only, tools/variant.py)
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+        if (hipStreamCreateWithPriority(st, hipStreamNonBlocking, urgent ? greatest : least) == hipSuccess) return hipSuccess;
+    }
+    (void)hipGetLastError();
+#else
+    (void)urgent;
+#endif
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+
 int flh_device_available(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -338,7 +361,10 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.stream) {
         h->stream = (hipStream_t)cfg.stream;
     } else {
-        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        // the update's kernels are the latency chain of a scan: its stream gets the device's highest priority, the copy stream
+        // (staging of the NEXT scan, beside this one's update) the lowest, so that staging kernels take the wave slots the update
+        // leaves and not the other way round
+        hipError_t e = create_stream(&h->stream, true);
         if (e != hipSuccess) {
             delete h;
             return fail(std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -391,7 +417,7 @@ void flh_destroy(flh_handle* h) {
     h->ins.release();
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     if (h->h_mi) (void)hipHostFree(h->h_mi);
-    h->map_orig.release(); h->map_next.release(); h->mb_aabb.release(); h->mu_add.release(); h->mi_world.release();
+    h->map_orig.release(); h->map_next.release(); h->mb_aabb.release(); h->mu_add.release(); h->mi_world.release(); h->mi_cnt.release();
     h->mu_alive.release(); h->mi_cls.release(); h->mu_flags.release(); h->mu_incl.release(); h->mu_boxes.release();
     h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_list2.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
     h->world.release(); h->nn_pts.release(); h->normvec.release(); h->plane.release();
@@ -425,6 +451,7 @@ void flh_destroy(flh_handle* h) {
 }
 
 static int map_settle(flh_handle* h);
+static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size_t n2, double ds, const uint32_t* d_cnt = nullptr);
 int flh_map_sync(flh_handle* h) {
     if (!h) return fail("flh_map_sync: null handle");
     return map_settle(h);
@@ -674,6 +701,19 @@ static int map_settle(flh_handle* h) {
     if (wait_granule(h, 4, h->map_pending_seq, "map change") != 0 || wait_granule(h, 8, h->map_pending_seq, "map change") != 0) return -1;
     h->map_pending = false;
     const uint32_t top = h->h_mi[4], bricks = h->h_mi[5], flags = h->h_mi[6], removed = h->h_mi[8], n_alive = h->h_mi[9];
+    if (h->h_mi[10] != 0xFFFFFFFFu) h->mi_pred_n = h->h_mi[10];  // the size of this change predicts the next one's
+    if (h->mi_deferred) {
+        h->mi_deferred = false;
+        if (flags & flh::kMapChangeNotApplied) {
+            // larger than the launches it was enqueued with: none of its kernels did anything.  The lists are still where
+            // k_cls_compact put them (mu_add), their lengths arrived long ago: Add_Points again, with launches that fit.
+            if (wait_granule(h, 0, h->mi_cls_seq, "map change (replay)") != 0) return -1;
+            const uint32_t c1 = h->h_mi[0], c2 = h->h_mi[1] - h->h_mi[0];
+            ++h->n_mi_replayed;
+            if (apply_map_changes(h, h->mu_add.p, c1, c2, h->mi_pending_ds) != 0) return -1;
+            return map_settle(h);
+        }
+    }
     h->n_ids += n_alive;
     h->M = h->M + n_alive - removed;
     h->id_pos_valid = false;
@@ -689,10 +729,12 @@ static int map_settle(flh_handle* h) {
 // d_add holds n1 points to insert WITH down-sampling followed by n2 points to insert as they are.  Everything is enqueued on
 // the handle's stream with launch sizes the host knows (n1, n2; the number of points that survive the down-sampling stays on the
 // device: n bounds it, and entries beyond it carry a sentinel key); the change's counters are collected by map_settle().
-static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size_t n2, double ds) {
+static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size_t n2, double ds, const uint32_t* d_cnt) {
     hipStream_t st = h->stream;
     if (map_settle(h) != 0) return -1;
-    const size_t n = n1 + n2;
+    // d_cnt: the true {n1, n} live on the device (mi_cnt); n1 = n2's sum is then only the bound the launches are sized for
+    const size_t n = d_cnt ? n1 : n1 + n2;
+    if (!d_cnt) h->mi_pred_n = (uint32_t)std::min<size_t>(n, 0xFFFFFFFEu);
     if (h->n_ids + n >= (1ull << 31)) return fail("map update: too many points");
     if (!h->grid.hash) {  // no map yet: index an empty one so there are tables to insert into
         if (rebuild_index(h, h->map_orig, 0) != 0) return -1;
@@ -726,14 +768,17 @@ static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size
         HIPC(h->vox_tab.reserve(2 * (size_t)vcap));
         HIPC(hipMemsetAsync(h->vox_tab.p, 0xFF, 2 * (size_t)vcap * sizeof(unsigned long long), st));
     }
-    HIPC(flh::launch_add_insert(d_add, (uint32_t)n1, nu, ds, h->vox_tab.p, vcap, h->mu_alive.p, h->ctr.p, st));
+    uint32_t* const d_alive_out = d_cnt ? h->mi_cnt.p + 2 : h->mu_incl.p + (n - 1);  // where the number of surviving points goes
+    HIPC(flh::launch_add_insert(d_add, (uint32_t)n1, nu, ds, h->vox_tab.p, vcap, h->mu_alive.p, h->ctr.p, st, d_cnt));
     if (n1 > 0)
         HIPC(flh::launch_add_resolve(h->grid, h->map_sorted.p, d_add, h->vox_tab.p, vcap, (uint32_t)n1, ds, h->dead_id.p, h->live.p,
-                                     h->ctr.p, h->mu_alive.p, st));
+                                     h->ctr.p, h->mu_alive.p, st, d_cnt));
+    if (d_cnt && !(h->cfg.fused_small_changes != 0 && nu <= flh::small_change_max()))
+        return fail("map update: device-side list lengths need the one-workgroup path");
     if (h->cfg.fused_small_changes != 0 && nu <= flh::small_change_max()) {
         // a scan's worth of points: ids, brick keys and their sort in one workgroup (one launch instead of eight)
         HIPC(flh::launch_ins_sort_small(h->grid, d_add, h->mu_alive.p, nu, (uint32_t)h->n_ids, h->map_orig.p, h->dead_id.p, h->ins.p, bk0,
-                                        bk1, h->mb_v1.p, h->ctr.p, h->mu_incl.p + (n - 1), st));
+                                        bk1, h->mb_v1.p, h->ctr.p, d_alive_out, st, d_cnt));
     } else {
         // ids of the survivors, in input order; the brick keys start as sentinels
         HIPC(flh::launch_byte_flags(h->mu_alive.p, nu, 0, h->mu_flags.p, st, bk0));
@@ -749,9 +794,11 @@ static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size
         }
     }
     HIPC(flh::launch_brick_rewrite(h->grid, h->map_sorted.p, h->starts.p, h->hash.p, h->cap_end.p, h->live.p, h->ctr.p, h->ins.p,
-                                   bk1, h->mb_v1.p, nu, (uint32_t)h->pts_cap, (uint32_t)h->rows_cap, st));
+                                   bk1, h->mb_v1.p, nu, (uint32_t)h->pts_cap, (uint32_t)h->rows_cap, st, d_cnt));
     const uint32_t seq = ++h->mi_seq;
-    HIPC(flh::launch_map_publish(h->ctr.p, h->mu_incl.p + (n - 1), h->h_mi + 4, seq, st));
+    HIPC(flh::launch_map_publish(h->ctr.p, d_alive_out, h->h_mi + 4, seq, st, d_cnt, nu));
+    h->mi_deferred = d_cnt != nullptr;
+    h->mi_pending_ds = ds;
     h->map_pending = true;
     h->map_pending_seq = seq;
     h->id_pos_valid = false;
@@ -831,6 +878,12 @@ int flh_map_stats(const flh_handle* h, uint64_t out[6]) {
     if (!h || !out) return fail("flh_map_stats: null argument");
     if (map_settle(const_cast<flh_handle*>(h)) != 0) return -1;
     out[0] = h->n_reindex; out[1] = h->n_inplace; out[2] = h->alloc_top; out[3] = h->pts_cap; out[4] = h->n_ids; out[5] = h->nbricks;
+    return 0;
+}
+
+int flh_map_change_stats(const flh_handle* h, uint64_t out[2]) {
+    if (!h || !out) return fail("flh_map_change_stats: null argument");
+    out[0] = h->n_mi_deferred; out[1] = h->n_mi_replayed;
     return 0;
 }
 
@@ -944,7 +997,7 @@ static bool is_pinned_host(const void* p, size_t bytes) {
 
 static int stage_prepare(flh_handle* h, flh_handle::Slot& sl) {
     HIPC(hipSetDevice(h->device));
-    if (!h->copy_stream) HIPC(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (!h->copy_stream) HIPC(create_stream(&h->copy_stream, false));
     if (!sl.ready) HIPC(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
     if (!sl.h2d_done) HIPC(hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
     sl.host_valid = false;
@@ -1772,15 +1825,15 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
     hipStream_t st = h->stream;
     const size_t N = h->N;
     const StateDev s_post = make_state(x + 3, x + 0, x + 7, x + 11);
-    if (ensure_d2(h) != 0) return -1;
     HIPC(h->mi_world.reserve(N ? N : 1)); HIPC(h->mi_cls.reserve(N ? N : 1));
+    if (N > 0) { HIPC(h->mu_flags.reserve(2 * N)); HIPC(h->mu_incl.reserve(2 * N)); }
+    // (pointSearchSqDis is recomputed inside the kernels from the neighbour cache -- the search's own expression -- instead of
+    // being materialised by k_fill_d2 first; the classification also writes the two lists' membership flags)
     HIPC(flh::launch_mi_classify(h->grid, h->grid.hash_mask + 1, (uint32_t)h->M, h->search_state, s_post, h->cur_body,
-                                 h->nn_pts.p, h->nn_cnt.p, h->nn_d2.p, h->cfg.max_sqdist, (int)N, filter_size_map, flg_EKF_inited,
-                                 h->live.p, h->mi_world.p, h->mi_cls.p, st));
+                                 h->nn_pts.p, h->nn_cnt.p, h->cfg.max_sqdist, (int)N, filter_size_map, flg_EKF_inited,
+                                 h->live.p, h->mi_world.p, h->mi_cls.p, N > 0 ? h->mu_flags.p : nullptr, st));
     uint32_t c1 = 0, c2 = 0;
     if (N > 0) {
-        HIPC(h->mu_flags.reserve(2 * N)); HIPC(h->mu_incl.reserve(2 * N));
-        HIPC(flh::launch_cls_flags(h->mi_cls.p, (int)N, h->mu_flags.p, st));
         size_t tb = 0;
         HIPC(flh::inclusive_sum(nullptr, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)(2 * N), st));
         HIPC(h->mb_tmp.reserve(tb));
@@ -1789,8 +1842,20 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
         // the two lists hold at most N points together: compacted without knowing their lengths; the kernel hands the lengths to
         // the host as a granule in pinned memory (no copy, no stream synchronisation)
         HIPC(h->mu_add.reserve(N + 1));
+        HIPC(h->mi_cnt.reserve(4));
         const uint32_t seq = ++h->mi_seq;
-        HIPC(flh::launch_cls_compact(h->mi_world.p, h->mi_cls.p, h->mu_incl.p, (int)N, h->mu_add.p, h->h_mi, seq, st));
+        HIPC(flh::launch_cls_compact(h->mi_world.p, h->mi_cls.p, h->mu_incl.p, (int)N, h->mu_add.p, h->h_mi, seq, st, h->mi_cnt.p));
+        // A running odometry inserts about as many points with every scan.  When the previous change was comfortably within the
+        // one-workgroup path and nobody asked for the list lengths, Add_Points is enqueued right behind this kernel with the
+        // lengths read on the device: the host does not stand in the middle of the call (a wait for the granule, then five
+        // launches, while the device idles).  A change that outgrows the launches is replayed by map_settle().
+        const uint32_t cap = flh::small_change_max();
+        if (apply && !n_add && !n_no_downsample && h->cfg.fused_small_changes != 0 && h->mi_pred_n <= cap - cap / 4) {
+            h->mi_valid_N = N;
+            h->mi_cls_seq = seq;
+            ++h->n_mi_deferred;
+            return apply_map_changes(h, h->mu_add.p, std::min<size_t>(cap, N), 0, filter_size_map, h->mi_cnt.p);
+        }
         if (wait_granule(h, 0, seq, "flh_map_incremental") != 0) return -1;
         c1 = h->h_mi[0];
         c2 = h->h_mi[1] - h->h_mi[0];

@@ -126,13 +126,18 @@ __device__ __forceinline__ void publish_granule(const GranOut& o, size_t idx, do
 }
 
 
-// ---- the cross-workgroup sum both pass kernels share (k_pass: one 64-point workgroup = one unit; k_fit on the granule path: one
-// 64-point WAVE = one unit, so that a no-search pass adds the same terms in the same order as a searching one -- identical bits).
-// Units are grouped `red` at a time; every unit stores the entries of its 16x16 block that the filter reads (+ one statistic)
-// write-through at agent scope, drains, and takes a ticket of its group; the last arriver sums the group's units in unit
-// order -- two halves of the wave take the two halves of the group, lower half + upper half -- and publishes the granules.
-// No release/acquire fences (hence no L2 write-back sweep): write-through stores + vmcnt(0) before the ticket, agent-scope
-// (L1-bypassing) loads after it.
+// ---- the cross-workgroup sum both pass kernels share.  A UNIT is 64 consecutive scan points (a workgroup of k_pass, a wave of
+// k_fit: the same points in the same lanes), a QUAD four consecutive units, a GROUP `red` consecutive units (a multiple of four).
+// The one summation tree of a pass, whichever kernel runs it (so a no-search pass produces the bits a searching pass would at the
+// same state, and the one-launch pass the bits of the three-launch pass):
+//     quad  = ((u0 + u1) + u2) + u3                     missing units of the scan's last quad count as +0.0
+//     half  = q_a + q_(a+1) + ...  in quad order        lower half = the first ceil(quads / 2) quads of the group
+//     group = lower half + upper half                   -> one {value, sequence} granule per entry; the host adds the groups in order
+// k_pass stores one partial per unit and its group's last arriver forms the quads; a block of k_fit IS a quad: it adds its four
+// waves in LDS, stores one partial, and its group's last arriver reads a quarter of the partials.
+// Hand-off: the entries of the 16x16 block that the filter reads (+ one statistic) are stored write-through at agent scope, the
+// stores drained (vmcnt(0)), then a ticket of the group is taken; the last arriver reads with agent-scope (L1-bypassing) loads.
+// No release/acquire fences, hence no L2 write-back sweep.
 typedef __attribute__((address_space(1))) double gdouble;
 __device__ __forceinline__ void unit_partial_store(double* partials, int unit, int nsl, int ncol, const v4f64& acc, int wl, double stat) {
     gdouble* gp = (gdouble*)partials + (size_t)unit * nsl;
@@ -144,25 +149,42 @@ __device__ __forceinline__ void unit_partial_store(double* partials, int unit, i
     }
     if (wl == 0) __hip_atomic_store(gp + (nsl - 1), stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// one wave; units [group * red, group * red + gsize)
+// One wave; the group's units are [group * red, group * red + gsize).  QUADS: partials holds one record per QUAD (k_fit), indexed by
+// quad number = unit / 4; else one per unit (k_pass).
+template <bool QUADS>
 __device__ __forceinline__ void group_sum_publish(const double* partials, int group, int gsize, int red, int nsl, int ngroups,
                                                   const GranOut& gout, double seq, int wl) {
     const gdouble* gpart = (const gdouble*)partials;
     const int u0 = group * red;
-    const int half = (gsize + 1) >> 1;
+    const int nq = (gsize + 3) >> 2;   // quads of the group
+    const int halfq = (nq + 1) >> 1;   // quads of its lower half
     const int hi = wl >> 5, sl = wl & 31;
-    const int jlo = hi ? half : 0, jhi = hi ? gsize : half;
+    const int qlo = hi ? halfq : 0, qhi = hi ? nq : halfq;
     for (int slot = sl; slot < ((nsl + 31) & ~31); slot += 32) {
         const int sc = slot < nsl ? slot : nsl - 1;
         double s0 = 0.0;
-        for (int j0 = jlo; j0 < jhi; j0 += 16) {
-            double pv[16];
+        for (int q0 = qlo; q0 < qhi; q0 += 4) {  // sixteen loads in flight (four quads of units, or four quad records)
+            double qv[4];
+            if (QUADS) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                pv[j] = (j0 + j < jhi) ? __hip_atomic_load(gpart + (size_t)(u0 + j0 + j) * nsl + sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                       : 0.0;
+                for (int j = 0; j < 4; ++j)
+                    qv[j] = (q0 + j < qhi) ? __hip_atomic_load(gpart + (size_t)((u0 >> 2) + q0 + j) * nsl + sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : 0.0;
+            } else {
+                double pv[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) s0 += pv[j];
+                for (int j = 0; j < 16; ++j) {
+                    const int u = 4 * q0 + j;  // unit inside the group
+                    pv[j] = (q0 + (j >> 2) < qhi && u < gsize)
+                                ? __hip_atomic_load(gpart + (size_t)(u0 + u) * nsl + sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qv[j] = ((pv[4 * j] + pv[4 * j + 1]) + pv[4 * j + 2]) + pv[4 * j + 3];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (q0 + j < qhi) s0 += qv[j];  // (uniform over the wave's half: qhi is)
         }
         const double other = __shfl_xor(s0, 32, 64);
         const double total = hi ? other + s0 : s0 + other;  // lower half + upper half on both sides

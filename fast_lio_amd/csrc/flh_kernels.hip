@@ -326,24 +326,37 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
     const int nblk = gridDim.x;
     if (gout.n_dst > 0) {
         // ---- flh_eval's path: every WAVE is a unit of the cross-workgroup sum k_pass uses (64 points each, the same points in
-        // the same lanes), grouped and added in the same order: a no-search pass produces the bits a searching pass would at
+        // the same lanes) and this block is a QUAD of that sum's tree (flh_fit_dev.hpp): its four waves are added in LDS,
+        // ((w0 + w1) + w2) + w3, and ONE record goes to memory -- a no-search pass produces the bits a searching pass would at
         // the same state.  red1 = units per group (a multiple of 4).  The statistic slot carries, through unit 0, the number of
         // queries the first search stage listed for the second in this pass (three-launch searching pass; the second stage has
         // retired), after which the work-list counters are re-armed.
         const int nsl = gran_section_slots(ncol);
         const int nunits = (N + 63) / 64 > 0 ? (N + 63) / 64 : 1;
-        const int unit = blockIdx.x * 4 + wave;
-        double stat = 0.0;
-        if (unit == 0) {
-            uint32_t c = slow_count[lane];
+        __syncthreads();  // every wave has read its tile: the same LDS now holds the waves' blocks
+        double* Rq = lds;
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
-            stat = (double)c;
-            slow_count[lane] = 0;
-            slow_count[kStripes + lane] = 0;
+        for (int r = 0; r < 4; ++r) Rq[wave * 256 + (kq + 4 * r) * 16 + col] = acc[r];
+        __syncthreads();
+        {
+            const int slot = gram_slot(t >> 4, t & 15, ncol);  // t = row * 16 + col of the 16x16 block
+            if (slot >= 0)
+                __hip_atomic_store((gdouble*)partials + (size_t)blockIdx.x * nsl + slot, ((Rq[t] + Rq[256 + t]) + Rq[512 + t]) + Rq[768 + t],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (unit < nunits) unit_partial_store(partials, unit, nsl, ncol, acc, lane, stat);
-        const int bpg = red1 / 4;  // blocks per group
+        if (wave == 0) {  // the statistic (block 0 only; the other quads carry +0.0)
+            double stat = 0.0;
+            if (blockIdx.x == 0) {
+                uint32_t c = slow_count[lane];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+                stat = (double)c;
+                slow_count[lane] = 0;
+                slow_count[kStripes + lane] = 0;
+            }
+            if (lane == 0) __hip_atomic_store((gdouble*)partials + (size_t)blockIdx.x * nsl + (nsl - 1), stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const int bpg = red1 / 4;  // blocks (quads) per group
         const int group = blockIdx.x / bpg;
         const int gblocks = min(bpg, nblk - group * bpg);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -352,7 +365,7 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
         __syncthreads();
         if (s_ticket != (uint32_t)(gblocks - 1)) return;  // block-uniform
         if (wave == 0) {
-            group_sum_publish(partials, group, min(red1, nunits - group * red1), red1, nsl, (nunits + red1 - 1) / red1, gout, seq, lane);
+            group_sum_publish<true>(partials, group, min(red1, nunits - group * red1), red1, nsl, (nunits + red1 - 1) / red1, gout, seq, lane);
             if (lane == 0) tickets[1 + group] = 0;  // re-arm this group's ticket for the next launch
         }
         return;

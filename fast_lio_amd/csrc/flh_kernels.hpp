@@ -64,25 +64,30 @@ int gram_slot_host(int r, int c, int ncol);
 // ---- flh_mapinc.hip: map_incremental and the incremental map ----
 hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t map_points, const StateDev& s_search,
                               const StateDev& s_post, const float4* body, float4* nn_pts, const uint8_t* nn_cnt,
-                              const float* nn_d2, float max_sqdist, int N, double fsm, int ekf_inited, const uint32_t* live,
-                              float4* world_out, uint8_t* cls, hipStream_t st);
+                              float max_sqdist, int N, double fsm, int ekf_inited, const uint32_t* live,
+                              float4* world_out, uint8_t* cls, uint32_t* flags /* 2 N words, may be null */, hipStream_t st);
 hipError_t launch_cls_flags(const uint8_t* cls, int N, uint32_t* flags, hipStream_t st);
 hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* incl, int N, float4* out,
-                              uint32_t* host_counts, uint32_t seq, hipStream_t st);
-hipError_t launch_map_publish(const uint32_t* ctr, const uint32_t* n_alive, uint32_t* host_out, uint32_t seq, hipStream_t st);
+                              uint32_t* host_counts, uint32_t seq, hipStream_t st, uint32_t* dev_counts = nullptr);
+// dev_counts (the launches of a map change below): {n1, n} in device memory, read by the kernels instead of the host's values, which
+// then only size the launches; a change larger than that does nothing and k_map_publish raises kMapChangeNotApplied
+constexpr uint32_t kMapChangeNotApplied = 0x80000000u;
+hipError_t launch_map_publish(const uint32_t* ctr, const uint32_t* n_alive, uint32_t* host_out, uint32_t seq, hipStream_t st,
+                              const uint32_t* dev_counts = nullptr, uint32_t cap = 0);
 hipError_t launch_aabb(const float4* pts, uint32_t M, uint32_t* out6, hipStream_t st);
 uint32_t vox_table_slots(uint32_t n1);
 hipError_t launch_add_insert(const float4* add, uint32_t n1, uint32_t n, double ds, unsigned long long* tab, uint32_t cap,
-                             uint8_t* alive_new, uint32_t* ctr, hipStream_t st);
+                             uint8_t* alive_new, uint32_t* ctr, hipStream_t st, const uint32_t* dev_counts = nullptr);
 // map changes of at most small_change_max() points: ids, brick keys and their sort in one workgroup (flh_mapinc.hip)
 uint32_t small_change_max();
 hipError_t launch_ins_sort_small(const GridParams& g, const float4* add, const uint8_t* alive_new, uint32_t n, uint32_t n_ids,
                                  float4* map_orig, uint8_t* dead_id, float4* ins, uint32_t* keys_tmp, uint32_t* ks, uint32_t* perm,
-                                 uint32_t* ctr, uint32_t* n_alive_out, hipStream_t st);
+                                 uint32_t* ctr, uint32_t* n_alive_out, hipStream_t st, const uint32_t* dev_counts = nullptr);
 hipError_t sort_brick_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
                             uint32_t n, hipStream_t st);
 hipError_t launch_add_resolve(const GridParams& g, float4* pts_rw, const float4* add, const unsigned long long* tab, uint32_t cap,
-                              uint32_t n, double ds, uint8_t* dead_id, uint32_t* live, uint32_t* ctr, uint8_t* alive_new, hipStream_t st);
+                              uint32_t n, double ds, uint8_t* dead_id, uint32_t* live, uint32_t* ctr, uint8_t* alive_new, hipStream_t st,
+                              const uint32_t* dev_counts = nullptr);
 hipError_t launch_delete_boxes(const GridParams& g, float4* pts_rw, uint32_t n_slots, const float* boxes, int nb, uint8_t* dead_id,
                                uint32_t* live, uint32_t* ctr, hipStream_t st);
 hipError_t launch_ins_prepare(const GridParams& g, const float4* add, const uint8_t* alive_new, const uint32_t* incl, uint32_t n,
@@ -90,7 +95,7 @@ hipError_t launch_ins_prepare(const GridParams& g, const float4* add, const uint
                               uint32_t* vals, uint32_t* ctr, hipStream_t st);
 hipError_t launch_brick_rewrite(const GridParams& g, float4* pts, uint32_t* starts, uint2* hash, uint32_t* cap_end, uint32_t* live,
                                 uint32_t* ctr, const float4* ins, const uint32_t* ks, const uint32_t* perm, uint32_t n,
-                                uint32_t pts_cap, uint32_t rows_cap, hipStream_t st);
+                                uint32_t pts_cap, uint32_t rows_cap, hipStream_t st, const uint32_t* dev_counts = nullptr);
 hipError_t launch_byte_flags(const uint8_t* in, uint32_t n, int invert, uint32_t* flags, hipStream_t st,
                              uint32_t* keys_sentinel = nullptr);
 hipError_t launch_live_compact(const float4* map_orig, const uint32_t* flags, const uint32_t* incl, uint32_t n_ids, float4* out,

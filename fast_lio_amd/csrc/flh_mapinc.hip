@@ -39,17 +39,9 @@ static inline int cdiv2(long long a, long long b) { return (int)((a + b - 1) / b
 // found is smaller than the distance from the query to that cube's faces -- a few hundred directory probes when the nearest
 // point is some tens of metres away.  Only when the shells grow past the directory itself (a query very far from everything)
 // the remaining work is done by scanning the whole directory twice (bound, then exact).
-__global__ void __launch_bounds__(256)
-k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, const uint8_t* __restrict__ nn_cnt,
-              const float* __restrict__ nn_d2, float max_sqdist, int N, uint32_t hash_size, const uint32_t* __restrict__ live,
-              float4* __restrict__ nn_pts) {
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (q >= N) return;
-    if (nn_cnt[q] != 0 && nn_d2[q] <= max_sqdist) return;  // wave-uniform: the cached nearest is the true one
-    const float4 b = body[q];
-    float wx, wy, wz;
-    body_to_world(s_search, b.x, b.y, b.z, wx, wy, wz);  // the world position the last search used
+// the shell search of ONE query by one wave (see above); wx, wy, wz = the world position the last search used
+__device__ __forceinline__ void far_search(const GridParams& g, int q, int lane, float wx, float wy, float wz, uint32_t hash_size,
+                                           const uint32_t* __restrict__ live, float4* __restrict__ nn_pts) {
     const unsigned long long* __restrict__ hash64 = reinterpret_cast<const unsigned long long*>(g.hash);
     const float bw = 4.0f * g.c;
     const float w[3] = {wx, wy, wz};
@@ -170,17 +162,47 @@ k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, 
     if (gbest != ~0ull && best == gbest) nn_pts[q] = best_p;  // unique: the key carries the index
 }
 
+// One THREAD per query decides whether its cached nearest neighbour is the true one (it is when it lies inside the search bound:
+// pointSearchSqDis[0], recomputed here with the search's own expression) -- all but a handful of a scan's points; the wave then
+// takes its few remaining queries one after the other through the shell search.
+__global__ void __launch_bounds__(256)
+k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, const uint8_t* __restrict__ nn_cnt,
+              float max_sqdist, int N, uint32_t hash_size, const uint32_t* __restrict__ live, float4* __restrict__ nn_pts) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    float wx = 0.f, wy = 0.f, wz = 0.f;
+    bool need = false;
+    if (q < N) {
+        const float4 b = body[q];
+        body_to_world(s_search, b.x, b.y, b.z, wx, wy, wz);  // the world position the last search used
+        need = true;
+        if (nn_cnt[q] != 0) {
+            const float4 p0 = nn_pts[q];
+            if (__float_as_uint(p0.w) != 0xFFFFFFFFu && dist2(wx, wy, wz, p0.x, p0.y, p0.z) <= max_sqdist) need = false;
+        }
+    }
+    unsigned long long todo = __ballot(need);
+    while (todo) {  // wave-uniform
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const float qx = __shfl(wx, src, 64), qy = __shfl(wy, src, 64), qz = __shfl(wz, src, 64);
+        far_search(g, (q & ~63) + src, lane, qx, qy, qz, hash_size, live, nn_pts);
+    }
+}
+
 // Outputs are in ORIGINAL scan order (the body buffer is Morton-ordered; .w carries the original index).
 __global__ void __launch_bounds__(256)
-k_mi_classify(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn_pts,
-              const uint8_t* __restrict__ nn_cnt, const float* __restrict__ nn_d2, float max_sqdist, int N, uint32_t map_points,
-              double fsm, int ekf_inited, float4* __restrict__ world_out, uint8_t* __restrict__ cls) {
+k_mi_classify(StateDev s, StateDev s_search, const float4* __restrict__ body, const float4* __restrict__ nn_pts,
+              const uint8_t* __restrict__ nn_cnt, float max_sqdist, int N, uint32_t map_points,
+              double fsm, int ekf_inited, float4* __restrict__ world_out, uint8_t* __restrict__ cls, uint32_t* __restrict__ flags) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const float4 b = body[i];
     const uint32_t o = __float_as_uint(b.w);
     float wx, wy, wz;
     body_to_world(s, b.x, b.y, b.z, wx, wy, wz);  // pointBodyToWorld with the POSTERIOR state (:436)
+    float sx, sy, sz;
+    body_to_world(s_search, b.x, b.y, b.z, sx, sy, sz);  // where the last search saw the point: pointSearchSqDis is measured from there
     world_out[FLH_IDX(205, o, N)] = make_float4(wx, wy, wz, 0.f);
     const int cnt = nn_cnt[i];                              // found inside the bound, ascending
     const int true_cnt = map_points < 5u ? (int)map_points : 5;  // what the unbounded search returns
@@ -199,8 +221,10 @@ k_mi_classify(StateDev s, const float4* __restrict__ body, const float4* __restr
             bool need_add = true;
             if (true_cnt >= 5) {  // points_near.size() < NUM_MATCH_POINTS -> break (:454)
                 for (int r = 0; r < cnt; ++r) {
-                    if (!(nn_d2[(size_t)r * N + i] <= max_sqdist)) break;  // beyond the bound: not a vetted neighbour, and too far to veto
                     const float4 pn = nn_pts[(size_t)r * N + i];
+                    // pointSearchSqDis[r], the expression (and bits) the search compared (k_fill_d2 writes the same on demand)
+                    const float d2r = (__float_as_uint(pn.w) == 0xFFFFFFFFu) ? INFINITY : dist2(sx, sy, sz, pn.x, pn.y, pn.z);
+                    if (!(d2r <= max_sqdist)) break;  // beyond the bound: not a vetted neighbour, and too far to veto
                     if (dist2(pn.x, pn.y, pn.z, mx, my, mz) < dist) need_add = false;  // :455-459
                 }
             }
@@ -208,6 +232,10 @@ k_mi_classify(StateDev s, const float4* __restrict__ body, const float4* __restr
         }
     }
     cls[FLH_IDX(206, o, N)] = c;
+    if (flags) {  // the two lists' membership flags, in ORIGINAL scan order: class 1 (down-sampled insert), then class 2 (plain insert)
+        flags[o] = c == 1 ? 1u : 0u;
+        flags[(size_t)N + o] = c == 2 ? 1u : 0u;
+    }
 }
 
 // class 1 (down-sampled insert) then class 2 (plain insert), each in original scan order
@@ -225,13 +253,15 @@ __device__ __forceinline__ void publish_granule(uint32_t* dst, uint32_t a, uint3
     const u32x4g v = {a, b, c, seq};
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
 }
-// Also hands the two list lengths to the host (granule {PointToAdd, PointToAdd + PointNoNeedDownsample, 0, seq}): the host needs
-// them to size the launches of Add_Points, and a copy + stream synchronisation would cost more than this whole kernel.
+// Also hands the two list lengths on: to the host as a granule {PointToAdd, PointToAdd + PointNoNeedDownsample, 0, seq} (it sizes
+// the launches of Add_Points with them; a copy + stream synchronisation would cost more than this whole kernel), and to dev_counts
+// in device memory, where the kernels of an Add_Points enqueued WITHOUT waiting for the granule read them (MiCounts below).
 __global__ void __launch_bounds__(256) k_cls_compact(const float4* __restrict__ world, const uint8_t* __restrict__ cls,
                                                      const uint32_t* __restrict__ incl, int N, float4* __restrict__ out,
-                                                     uint32_t* __restrict__ host_counts, uint32_t seq) {
+                                                     uint32_t* __restrict__ host_counts, uint32_t seq, uint32_t* __restrict__ dev_counts) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0 && host_counts) publish_granule(host_counts, incl[N - 1], incl[2 * N - 1], 0u, seq);
+    if (i == 0 && dev_counts) { dev_counts[0] = incl[N - 1]; dev_counts[1] = incl[2 * N - 1]; }
     if (i >= N) return;
     const uint8_t c = cls[i];
     if (c == 1) out[FLH_IDX(207, incl[i] - 1, N)] = world[i];
@@ -277,6 +307,20 @@ __global__ void __launch_bounds__(256) k_aabb(const float4* __restrict__ pts, ui
 // ------------------------------------------------------------------------------------------------
 // Add_Points with down-sampling
 // ------------------------------------------------------------------------------------------------
+// A map change enqueued before the host knows how many points it holds (flh_map_incremental without the wait in the middle):
+// the launches are sized for `cap` points, the kernels read the true lengths {n1, n} from device memory (k_cls_compact left them
+// there) and -- when the change turns out larger than the launches allow -- do NOTHING at all; k_map_publish then tells the host,
+// which replays the change with launch sizes that fit (flh_api.cpp: map_settle).  p == nullptr: the host's n1 / n hold.
+struct MiCounts {
+    const uint32_t* p;
+    uint32_t cap;
+};
+__device__ __forceinline__ bool mi_counts(const MiCounts& mc, uint32_t& n1, uint32_t& n) {
+    if (!mc.p) return true;
+    n1 = mc.p[0];
+    n = mc.p[1];
+    return n <= mc.cap;
+}
 __device__ __forceinline__ void vox_of(float x, float y, float z, double ds, long long& kx, long long& ky, long long& kz) {
     kx = (long long)floor((double)x / ds);
     ky = (long long)floor((double)y / ds);
@@ -301,9 +345,10 @@ __device__ __forceinline__ u64 pack_vox(long long kx, long long ky, long long kz
 __device__ __forceinline__ uint32_t vox_slot(u64 key, int shift) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> shift); }
 __global__ void __launch_bounds__(256) k_add_insert(const float4* __restrict__ add, uint32_t n1, uint32_t n, double ds,
                                                     u64* __restrict__ tab, uint32_t mask, int shift, uint8_t* __restrict__ alive_new,
-                                                    uint32_t* __restrict__ ctr) {
+                                                    uint32_t* __restrict__ ctr, MiCounts mc) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) { ctr[2] = 0u; ctr[3] = 0u; }
+    if (!mi_counts(mc, n1, n)) return;
     if (i >= n) return;
     alive_new[i] = i < n1 ? 0 : 1;
     if (i >= n1) return;
@@ -342,7 +387,11 @@ __device__ __forceinline__ uint2 lookup_cell_rank(const GridParams& g, int cx, i
 __global__ void __launch_bounds__(256)
 k_add_resolve(GridParams g, float4* pts_rw /* = g.pts */, const float4* __restrict__ add, const u64* __restrict__ tab, uint32_t mask,
               int shift, uint32_t n, double ds, uint8_t* __restrict__ dead_id, uint32_t* __restrict__ live, uint32_t* __restrict__ ctr,
-              uint8_t* __restrict__ alive_new) {
+              uint8_t* __restrict__ alive_new, MiCounts mc) {
+    {
+        uint32_t n_all = n;
+        if (!mi_counts(mc, n, n_all)) return;  // n = the points inserted with down-sampling
+    }
     // eight lanes per point: the cells the voxel box overlaps are dealt to the lanes, so the directory probe -> prefix table
     // -> points chain of each cell runs side by side instead of one after the other (it was 106 us with one thread per voxel)
     constexpr int L = 8;
@@ -488,12 +537,16 @@ __global__ void __launch_bounds__(128)
 k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g.starts */, uint2* hash /* = g.hash */,
                 uint32_t* __restrict__ cap_end, uint32_t* __restrict__ live, uint32_t* __restrict__ ctr,
                 const float4* __restrict__ ins, const uint32_t* __restrict__ ks, const uint32_t* __restrict__ perm, uint32_t n,
-                uint32_t pts_cap, uint32_t rows_cap) {
+                uint32_t pts_cap, uint32_t rows_cap, MiCounts mc) {
     __shared__ float4 buf[kTile];
     __shared__ uint32_t hist[64], offs[64];
     __shared__ uint32_t s_cnt, s_base, s_rank, s_cap_end, s_ok;
     const uint32_t j = blockIdx.x;
     const int tid = threadIdx.x;
+    {
+        uint32_t n1_unused = 0;
+        if (!mi_counts(mc, n1_unused, n)) return;
+    }
     if (j >= n) return;
     const uint32_t key = ks[j];
     if (key == kEmptyKey) return;           // beyond the surviving points (n is the host's upper bound of their number)
@@ -644,9 +697,17 @@ uint32_t small_change_max() { return kSmallMax; }
 __global__ void __launch_bounds__(kSmallThreads)
 k_ins_sort_small(GridParams g, const float4* __restrict__ add, const uint8_t* __restrict__ alive_new, uint32_t n, uint32_t n_ids,
                  float4* __restrict__ map_orig, uint8_t* __restrict__ dead_id, float4* __restrict__ ins, uint32_t* __restrict__ keys_tmp,
-                 uint32_t* __restrict__ ks, uint32_t* __restrict__ perm, uint32_t* __restrict__ ctr, uint32_t* __restrict__ n_alive_out) {
+                 uint32_t* __restrict__ ks, uint32_t* __restrict__ perm, uint32_t* __restrict__ ctr, uint32_t* __restrict__ n_alive_out,
+                 MiCounts mc) {
     __shared__ SmallShared sh;
     const uint32_t tid = threadIdx.x;
+    {
+        uint32_t n1_unused = 0;
+        if (!mi_counts(mc, n1_unused, n)) {  // block-uniform: a change larger than this launch was sized for -- nothing is done
+            if (tid == 0) *n_alive_out = 0u;
+            return;
+        }
+    }
     // items in blocked arrangement: thread t holds points 8t .. 8t+7, so ranks follow the input order
     bool valid[kSmallItems];
     uint32_t cnt = 0;
@@ -735,24 +796,24 @@ k_ins_sort_small(GridParams g, const float4* __restrict__ add, const uint8_t* __
 }
 hipError_t launch_ins_sort_small(const GridParams& g, const float4* add, const uint8_t* alive_new, uint32_t n, uint32_t n_ids,
                                  float4* map_orig, uint8_t* dead_id, float4* ins, uint32_t* keys_tmp, uint32_t* ks, uint32_t* perm,
-                                 uint32_t* ctr, uint32_t* n_alive_out, hipStream_t st) {
+                                 uint32_t* ctr, uint32_t* n_alive_out, hipStream_t st, const uint32_t* dev_counts) {
     if (n == 0 || n > kSmallMax) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_ins_sort_small, dim3(1), dim3(kSmallThreads), 0, st, g, add, alive_new, n, n_ids, map_orig, dead_id, ins, keys_tmp,
-                       ks, perm, ctr, n_alive_out);
+                       ks, perm, ctr, n_alive_out, MiCounts{dev_counts, n});
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t map_points, const StateDev& s_search,
                               const StateDev& s_post, const float4* body, float4* nn_pts, const uint8_t* nn_cnt,
-                              const float* nn_d2, float max_sqdist, int N, double fsm, int ekf_inited, const uint32_t* live,
-                              float4* world_out, uint8_t* cls, hipStream_t st) {
+                              float max_sqdist, int N, double fsm, int ekf_inited, const uint32_t* live,
+                              float4* world_out, uint8_t* cls, uint32_t* flags, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     if (map_points > 0 && ekf_inited)
-        hipLaunchKernelGGL(k_far_nearest, dim3(cdiv2(N, 4)), dim3(256), 0, st, g, s_search, body, nn_cnt, nn_d2, max_sqdist, N,
+        hipLaunchKernelGGL(k_far_nearest, dim3(cdiv2(N, 256)), dim3(256), 0, st, g, s_search, body, nn_cnt, max_sqdist, N,
                            hash_size, live, nn_pts);
-    hipLaunchKernelGGL(k_mi_classify, dim3(cdiv2(N, 256)), dim3(256), 0, st, s_post, body, nn_pts, nn_cnt, nn_d2, max_sqdist, N,
-                       map_points, fsm, ekf_inited, world_out, cls);
+    hipLaunchKernelGGL(k_mi_classify, dim3(cdiv2(N, 256)), dim3(256), 0, st, s_post, s_search, body, nn_pts, nn_cnt, max_sqdist, N,
+                       map_points, fsm, ekf_inited, world_out, cls, flags);
     return hipGetLastError();
 }
 hipError_t launch_cls_flags(const uint8_t* cls, int N, uint32_t* flags, hipStream_t st) {
@@ -761,23 +822,28 @@ hipError_t launch_cls_flags(const uint8_t* cls, int N, uint32_t* flags, hipStrea
     return hipGetLastError();
 }
 hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* incl, int N, float4* out,
-                              uint32_t* host_counts, uint32_t seq, hipStream_t st) {
+                              uint32_t* host_counts, uint32_t seq, hipStream_t st, uint32_t* dev_counts) {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_cls_compact, dim3(cdiv2(N, 256)), dim3(256), 0, st, world, cls, incl, N, out, host_counts, seq);
+    hipLaunchKernelGGL(k_cls_compact, dim3(cdiv2(N, 256)), dim3(256), 0, st, world, cls, incl, N, out, host_counts, seq, dev_counts);
     return hipGetLastError();
 }
 // the counters of a map change and the number of points it inserted, as two granules, each carrying the sequence word (system-scope
-// stores need not reach the host in order): {storage top, bricks, re-index flags, seq} {removed, inserted, 0, seq}
+// stores need not reach the host in order): {storage top, bricks, re-index flags, seq} {removed, inserted, points of the change, seq}.
+// A change whose kernels found it larger than their launches (MiCounts) did nothing: flag kMapChangeNotApplied tells the host so.
 __global__ void k_map_publish(const uint32_t* __restrict__ ctr, const uint32_t* __restrict__ n_alive, uint32_t* __restrict__ host_out,
-                              uint32_t seq) {
+                              uint32_t seq, MiCounts mc) {
     if (threadIdx.x != 0) return;
-    const uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
-    const uint32_t na = n_alive ? *n_alive : 0u;
+    const uint32_t c0 = ctr[0], c1 = ctr[1], c3 = ctr[3];
+    uint32_t c2 = ctr[2];
+    uint32_t na = n_alive ? *n_alive : 0u;
+    uint32_t n1 = 0, n = 0xFFFFFFFFu;  // the size of the change is not this kernel's to know unless the lengths live on the device
+    if (!mi_counts(mc, n1, n)) { c2 |= kMapChangeNotApplied; na = 0u; }
     publish_granule(host_out, c0, c1, c2, seq);
-    publish_granule(host_out + 4, c3, na, 0u, seq);
+    publish_granule(host_out + 4, c3, na, n, seq);
 }
-hipError_t launch_map_publish(const uint32_t* ctr, const uint32_t* n_alive, uint32_t* host_out, uint32_t seq, hipStream_t st) {
-    hipLaunchKernelGGL(k_map_publish, dim3(1), dim3(64), 0, st, ctr, n_alive, host_out, seq);
+hipError_t launch_map_publish(const uint32_t* ctr, const uint32_t* n_alive, uint32_t* host_out, uint32_t seq, hipStream_t st,
+                              const uint32_t* dev_counts, uint32_t cap) {
+    hipLaunchKernelGGL(k_map_publish, dim3(1), dim3(64), 0, st, ctr, n_alive, host_out, seq, MiCounts{dev_counts, cap});
     return hipGetLastError();
 }
 hipError_t launch_aabb(const float4* pts, uint32_t M, uint32_t* out6, hipStream_t st) {
@@ -795,9 +861,10 @@ uint32_t vox_table_slots(uint32_t n1) {
 }
 static int vox_shift(uint32_t cap) { return 64 - (31 - __builtin_clz(cap)); }
 hipError_t launch_add_insert(const float4* add, uint32_t n1, uint32_t n, double ds, u64* tab, uint32_t cap, uint8_t* alive_new,
-                             uint32_t* ctr, hipStream_t st) {
+                             uint32_t* ctr, hipStream_t st, const uint32_t* dev_counts) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_add_insert, dim3(cdiv2(n, 256)), dim3(256), 0, st, add, n1, n, ds, tab, cap - 1u, vox_shift(cap), alive_new, ctr);
+    hipLaunchKernelGGL(k_add_insert, dim3(cdiv2(n, 256)), dim3(256), 0, st, add, n1, n, ds, tab, cap - 1u, vox_shift(cap), alive_new, ctr,
+                       MiCounts{dev_counts, n});
     return hipGetLastError();
 }
 // the surviving points by brick: 30-bit brick keys (sentinel 0xFFFFFFFF behind them), stable
@@ -806,10 +873,11 @@ hipError_t sort_brick_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* kin, u
     return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kin, kout, vin, vout, (int)n, 0, 32, st);
 }
 hipError_t launch_add_resolve(const GridParams& g, float4* pts_rw, const float4* add, const u64* tab, uint32_t cap, uint32_t n,
-                              double ds, uint8_t* dead_id, uint32_t* live, uint32_t* ctr, uint8_t* alive_new, hipStream_t st) {
+                              double ds, uint8_t* dead_id, uint32_t* live, uint32_t* ctr, uint8_t* alive_new, hipStream_t st,
+                              const uint32_t* dev_counts) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_add_resolve, dim3(cdiv2((long long)n * 8, 256)), dim3(256), 0, st, g, pts_rw, add, tab, cap - 1u, vox_shift(cap),
-                       n, ds, dead_id, live, ctr, alive_new);
+                       n, ds, dead_id, live, ctr, alive_new, MiCounts{dev_counts, n});
     return hipGetLastError();
 }
 hipError_t launch_delete_boxes(const GridParams& g, float4* pts_rw, uint32_t n_slots, const float* boxes, int nb, uint8_t* dead_id,
@@ -828,10 +896,10 @@ hipError_t launch_ins_prepare(const GridParams& g, const float4* add, const uint
 }
 hipError_t launch_brick_rewrite(const GridParams& g, float4* pts, uint32_t* starts, uint2* hash, uint32_t* cap_end, uint32_t* live,
                                 uint32_t* ctr, const float4* ins, const uint32_t* ks, const uint32_t* perm, uint32_t n, uint32_t pts_cap,
-                                uint32_t rows_cap, hipStream_t st) {
+                                uint32_t rows_cap, hipStream_t st, const uint32_t* dev_counts) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_brick_rewrite, dim3(n), dim3(128), 0, st, g, pts, starts, hash, cap_end, live, ctr, ins, ks, perm, n, pts_cap,
-                       rows_cap);
+                       rows_cap, MiCounts{dev_counts, n});
     return hipGetLastError();
 }
 hipError_t launch_byte_flags(const uint8_t* in, uint32_t n, int invert, uint32_t* flags, hipStream_t st, uint32_t* keys_sentinel) {

@@ -81,7 +81,15 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     __shared__ uint32_t s_list[64];  // per wave: the slots (0..63) of its queries that go to phase B
     __shared__ uint32_t s_wcnt[4];
     const int tid = threadIdx.x;
-    const int q0 = blockIdx.x * kPassQueries;
+    // which 64 scan points (unit of the summation tree) this workgroup takes.  Workgroups are dispatched in blockIdx order over ~2 us;
+    // FLH_PASS_REVERSED (developer A/B builds) hands the END of the Morton order -- the scan's far field, whose waves are the slowest
+    // of the launch -- to the workgroups dispatched first
+#ifdef FLH_PASS_REVERSED
+    const int unit = (int)gridDim.x - 1 - (int)blockIdx.x;
+#else
+    const int unit = (int)blockIdx.x;
+#endif
+    const int q0 = unit * kPassQueries;
     const RingRsrc rs(g, map_points);
     STAMP(0);  // start
 
@@ -165,7 +173,7 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     // (lane and wave are derived again rather than kept in registers across phase B)
     int tid_f = threadIdx.x;
     asm volatile("" : "+v"(tid_f));
-    if ((tid_f >> 6) != (int)((blockIdx.x >> 3) & 3u)) return;
+    if ((tid_f >> 6) != (int)(((unsigned)unit >> 3) & 3u)) return;
     const int wl = tid_f & 63;
     const int qf = q0 + wl;
     double v[16];
@@ -200,9 +208,9 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     // ---- this workgroup's share of the normal equations -> HBM, the group's ticket, and for the last arriver the group's sum
     const int nsl = gran_section_slots(ncol);  // the last one: the number of queries that needed phase B (a statistic the host reports)
     const uint32_t n_b = (s_wcnt[0] + s_wcnt[1]) + (s_wcnt[2] + s_wcnt[3]);  // (read again from LDS rather than kept in a register)
-    unit_partial_store(partials, (int)blockIdx.x, nsl, ncol, acc, wl, (double)n_b);
+    unit_partial_store(partials, unit, nsl, ncol, acc, wl, (double)n_b);
     const int nblk = gridDim.x;
-    const int group = blockIdx.x / red;
+    const int group = unit / red;
     const int gsize = min(red, nblk - group * red);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(5);  // partial stored and drained
@@ -211,7 +219,7 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
     STAMP(6);  // ticket taken
     if (tk != (uint32_t)(gsize - 1)) return;
-    group_sum_publish(partials, group, gsize, red, nsl, (nblk + red - 1) / red, gout, seq, wl);
+    group_sum_publish<false>(partials, group, gsize, red, nsl, (nblk + red - 1) / red, gout, seq, wl);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(7);  // (the group's last arriver) group sum published
     if (wl == 0) tickets[1 + group] = 0;  // re-arm this group's ticket for the next launch

@@ -115,6 +115,11 @@ int flh_map_delete_boxes(flh_handle* h, const float* boxes, size_t nb);
  * per-brick storage ranges with slack; an insert rewrites only the bricks it touches and a removal tombstones its slot;
  * the whole index is rebuilt only when something no longer fits (a point outside the grid, storage or tables full). */
 int flh_map_stats(const flh_handle* h, uint64_t out[6]);
+/* flh_map_incremental with apply and without the two count outputs: out = {calls whose Add_Points was enqueued right behind the
+ * classification, the list lengths read on the device (no wait of the host in the middle of the call: taken when the previous
+ * change was at most 6144 points), of those the ones that turned out larger than their launches (8192 points) and were
+ * replayed when their counters were collected}. */
+int flh_map_change_stats(const flh_handle* h, uint64_t out[2]);
 /* The map in index order, 3 floats per point (what ikdtree.flatten / PCL_Storage hands back, :406-411). */
 int flh_map_download(flh_handle* h, float* xyz, size_t capacity_points);
 /* map_incremental() -- src/laserMapping.cpp:427-474, evaluated on the device from the neighbour cache the active

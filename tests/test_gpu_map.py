@@ -473,6 +473,41 @@ def test_velodyne_stream_with_incremental_map():
     assert grown > 0
 
 
+def test_map_incremental_enqueued_without_the_hosts_wait():
+    """The node's loop never asks map_incremental for its two list lengths; from the second small change on, Add_Points is then
+    enqueued right behind the classification with the lengths read on the device (flh_map_change_stats counts them).  Same map
+    as the oracle's after every scan -- and also after a change that outgrows its launches (a scan of 12 000 points over new
+    ground after a small one: more than 8 192 to insert), which the library replays when it collects the change's counters."""
+    M, N = 250000, 9000
+    pr0 = synth.make_problem(M, N, "velodyne", cfg=3)
+    scene = pr0.scene
+    h = capi.Handle()
+    h.map_build(pr0.map_xyz)
+    cur = pr0.map_xyz.astype(np.float32)
+    rng = np.random.default_rng(5)
+    for k in range(5):
+        pr = synth.make_problem(M, N, "velodyne", cfg=3, scan_seed=10 + k, scene=scene)
+        body = np.ascontiguousarray(pr.body[:4000])  # at most 4 000 points to insert: a change of a scan's usual size
+        if k == 3:  # new ground: points in the empty space above the scene, all of them inserted
+            far = rng.uniform(-60, 60, (12000, 3)).astype(np.float32)
+            far[:, 2] = rng.uniform(200, 260, 12000).astype(np.float32)
+            body = np.ascontiguousarray(far)
+        m = po.Map(cur)
+        h.scan_upload(body)
+        h.eval(pr.x_true, True, False)
+        sc = po.Scan(body, nthreads=8)
+        sc.h_share_model(m, pr.x_true, True, False)
+        w_ref, c_ref = sc.map_incremental_classify(m, pr.x_true, DS, True)
+        assert h.map_incremental(pr.x_true, DS, True, apply=True, counts=(k == 0)) is None or k == 0
+        assert int((c_ref != 0).sum()) > (8192 if k == 3 else 0)
+        cur = po.map_add(po.map_add(cur, w_ref[c_ref == 1], True, DS), w_ref[c_ref == 2], False, DS)
+        same_points(h.map_download(), cur, f"map after scan {k}")
+        assert search_matches(h, cur, pr.body[:3000], pr.x_true) > 500
+    st = h.map_change_stats()
+    assert st["enqueued_without_wait"] >= 3 and st["replayed"] == 1, st
+    h.close()
+
+
 # ---------------------------------------------------------------------------------------------- brick storage paths
 def test_brickwise_updates_and_every_fallback(prob):
     """The map index is changed brick by brick; whatever does not fit falls back to a full re-indexing from the id-ordered
