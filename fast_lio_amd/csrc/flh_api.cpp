@@ -143,6 +143,7 @@ struct flh_handle {
     // (mi_cnt: [0] n1, [1] n, [2] survivors), Add_Points is enqueued with launches sized for small_change_max() points; a change
     // that turns out larger is not applied by those launches and replayed by map_settle()
     DevBuf<uint32_t> mi_cnt;
+    DevBuf<uint32_t> mi_far;           // [0] the number of scan points whose nearest map point lies outside the search bound, then the points
     uint32_t mi_pred_n = 0xFFFFFFFFu;  // points of the previous change (the prediction for the next one); unknown at first
     bool mi_deferred = false;          // the pending change was enqueued that way
     uint32_t mi_cls_seq = 0;           // sequence word of the list-length granule of that change (h_mi[0..3])
@@ -417,7 +418,7 @@ void flh_destroy(flh_handle* h) {
     h->ins.release();
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     if (h->h_mi) (void)hipHostFree(h->h_mi);
-    h->map_orig.release(); h->map_next.release(); h->mb_aabb.release(); h->mu_add.release(); h->mi_world.release(); h->mi_cnt.release();
+    h->map_orig.release(); h->map_next.release(); h->mb_aabb.release(); h->mu_add.release(); h->mi_world.release(); h->mi_cnt.release(); h->mi_far.release();
     h->mu_alive.release(); h->mi_cls.release(); h->mu_flags.release(); h->mu_incl.release(); h->mu_boxes.release();
     h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_list2.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
     h->world.release(); h->nn_pts.release(); h->normvec.release(); h->plane.release();
@@ -1827,11 +1828,15 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
     const StateDev s_post = make_state(x + 3, x + 0, x + 7, x + 11);
     HIPC(h->mi_world.reserve(N ? N : 1)); HIPC(h->mi_cls.reserve(N ? N : 1));
     if (N > 0) { HIPC(h->mu_flags.reserve(2 * N)); HIPC(h->mu_incl.reserve(2 * N)); }
+    if (h->mi_far.cap < N + 1) {  // (re)allocated: the list's counter starts at zero; every call leaves it there
+        HIPC(h->mi_far.reserve(N + 1));
+        HIPC(hipMemsetAsync(h->mi_far.p, 0, sizeof(uint32_t), st));
+    }
     // (pointSearchSqDis is recomputed inside the kernels from the neighbour cache -- the search's own expression -- instead of
     // being materialised by k_fill_d2 first; the classification also writes the two lists' membership flags)
     HIPC(flh::launch_mi_classify(h->grid, h->grid.hash_mask + 1, (uint32_t)h->M, h->search_state, s_post, h->cur_body,
                                  h->nn_pts.p, h->nn_cnt.p, h->cfg.max_sqdist, (int)N, filter_size_map, flg_EKF_inited,
-                                 h->live.p, h->mi_world.p, h->mi_cls.p, N > 0 ? h->mu_flags.p : nullptr, st));
+                                 h->live.p, h->mi_world.p, h->mi_cls.p, N > 0 ? h->mu_flags.p : nullptr, h->mi_far.p, st));
     uint32_t c1 = 0, c2 = 0;
     if (N > 0) {
         size_t tb = 0;

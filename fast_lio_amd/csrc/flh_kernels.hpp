@@ -65,8 +65,8 @@ int gram_slot_host(int r, int c, int ncol);
 hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t map_points, const StateDev& s_search,
                               const StateDev& s_post, const float4* body, float4* nn_pts, const uint8_t* nn_cnt,
                               float max_sqdist, int N, double fsm, int ekf_inited, const uint32_t* live,
-                              float4* world_out, uint8_t* cls, uint32_t* flags /* 2 N words, may be null */, hipStream_t st);
-hipError_t launch_cls_flags(const uint8_t* cls, int N, uint32_t* flags, hipStream_t st);
+                              float4* world_out, uint8_t* cls, uint32_t* flags /* 2 N words, may be null */,
+                              uint32_t* far /* N + 1 words, far[0] == 0 on entry and on exit */, hipStream_t st);
 hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* incl, int N, float4* out,
                               uint32_t* host_counts, uint32_t seq, hipStream_t st, uint32_t* dev_counts = nullptr);
 // dev_counts (the launches of a map change below): {n1, n} in device memory, read by the kernels instead of the host's values, which

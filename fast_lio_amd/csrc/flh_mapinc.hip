@@ -162,18 +162,20 @@ __device__ __forceinline__ void far_search(const GridParams& g, int q, int lane,
     if (gbest != ~0ull && best == gbest) nn_pts[q] = best_p;  // unique: the key carries the index
 }
 
-// One THREAD per query decides whether its cached nearest neighbour is the true one (it is when it lies inside the search bound:
-// pointSearchSqDis[0], recomputed here with the search's own expression) -- all but a handful of a scan's points; the wave then
-// takes its few remaining queries one after the other through the shell search.
+// k_far_nearest: one THREAD per query decides whether its cached nearest neighbour is the true one (it is when it lies inside the
+// search bound: pointSearchSqDis[0], recomputed here with the search's own expression) -- all but a handful of a scan's points; the
+// others are listed (far[0] = their number, far[1..] = the queries; one atomic per wave).  k_far_search: one WAVE per listed query
+// (grid-stride), so that a cluster of far points -- Morton neighbours, the first scans over new ground -- is searched side by side
+// and not one after the other by the wave that found them.  k_mi_classify re-arms the counter.
 __global__ void __launch_bounds__(256)
-k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, const uint8_t* __restrict__ nn_cnt,
-              float max_sqdist, int N, uint32_t hash_size, const uint32_t* __restrict__ live, float4* __restrict__ nn_pts) {
+k_far_nearest(StateDev s_search, const float4* __restrict__ body, const uint8_t* __restrict__ nn_cnt, float max_sqdist, int N,
+              const float4* __restrict__ nn_pts, uint32_t* __restrict__ far) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    float wx = 0.f, wy = 0.f, wz = 0.f;
     bool need = false;
     if (q < N) {
         const float4 b = body[q];
+        float wx, wy, wz;
         body_to_world(s_search, b.x, b.y, b.z, wx, wy, wz);  // the world position the last search used
         need = true;
         if (nn_cnt[q] != 0) {
@@ -181,12 +183,24 @@ k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, 
             if (__float_as_uint(p0.w) != 0xFFFFFFFFu && dist2(wx, wy, wz, p0.x, p0.y, p0.z) <= max_sqdist) need = false;
         }
     }
-    unsigned long long todo = __ballot(need);
-    while (todo) {  // wave-uniform
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1ull;
-        const float qx = __shfl(wx, src, 64), qy = __shfl(wy, src, 64), qz = __shfl(wz, src, 64);
-        far_search(g, (q & ~63) + src, lane, qx, qy, qz, hash_size, live, nn_pts);
+    const unsigned long long bal = __ballot(need);
+    if (bal == 0ull) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(far, (uint32_t)__popcll(bal));
+    base = (uint32_t)__shfl((int)base, 0, 64);
+    if (need) far[1 + FLH_IDX(231, base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull)), N)] = (uint32_t)q;
+}
+__global__ void __launch_bounds__(256)
+k_far_search(GridParams g, StateDev s_search, const float4* __restrict__ body, uint32_t hash_size, const uint32_t* __restrict__ live,
+             float4* __restrict__ nn_pts, const uint32_t* __restrict__ far, int N) {
+    const uint32_t n = min(far[0], (uint32_t)N);
+    const int lane = threadIdx.x & 63;
+    for (uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n; k += gridDim.x * 4) {  // wave-uniform
+        const int q = (int)far[1 + k];
+        const float4 b = body[q];
+        float wx, wy, wz;
+        body_to_world(s_search, b.x, b.y, b.z, wx, wy, wz);
+        far_search(g, q, lane, wx, wy, wz, hash_size, live, nn_pts);
     }
 }
 
@@ -194,8 +208,10 @@ k_far_nearest(GridParams g, StateDev s_search, const float4* __restrict__ body, 
 __global__ void __launch_bounds__(256)
 k_mi_classify(StateDev s, StateDev s_search, const float4* __restrict__ body, const float4* __restrict__ nn_pts,
               const uint8_t* __restrict__ nn_cnt, float max_sqdist, int N, uint32_t map_points,
-              double fsm, int ekf_inited, float4* __restrict__ world_out, uint8_t* __restrict__ cls, uint32_t* __restrict__ flags) {
+              double fsm, int ekf_inited, float4* __restrict__ world_out, uint8_t* __restrict__ cls, uint32_t* __restrict__ flags,
+              uint32_t* __restrict__ far) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && far) far[0] = 0u;  // k_far_search (before this kernel on the stream) has read the list: empty for the next call
     if (i >= N) return;
     const float4 b = body[i];
     const uint32_t o = __float_as_uint(b.w);
@@ -238,14 +254,6 @@ k_mi_classify(StateDev s, StateDev s_search, const float4* __restrict__ body, co
     }
 }
 
-// class 1 (down-sampled insert) then class 2 (plain insert), each in original scan order
-__global__ void __launch_bounds__(256) k_cls_flags(const uint8_t* __restrict__ cls, int N, uint32_t* __restrict__ flags) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const uint8_t c = cls[i];
-    flags[i] = c == 1 ? 1u : 0u;
-    flags[N + i] = c == 2 ? 1u : 0u;
-}
 // One 16-byte system-scope store: {a, b, c, sequence} lands in pinned host memory as one granule (the host polls the sequence word
 // and then trusts the other three -- the hand-off k_fit's group reducers use, MI355X_MICROARCH.md "granule").
 typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
@@ -807,18 +815,14 @@ hipError_t launch_ins_sort_small(const GridParams& g, const float4* add, const u
 hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t map_points, const StateDev& s_search,
                               const StateDev& s_post, const float4* body, float4* nn_pts, const uint8_t* nn_cnt,
                               float max_sqdist, int N, double fsm, int ekf_inited, const uint32_t* live,
-                              float4* world_out, uint8_t* cls, uint32_t* flags, hipStream_t st) {
+                              float4* world_out, uint8_t* cls, uint32_t* flags, uint32_t* far, hipStream_t st) {
     if (N <= 0) return hipSuccess;
-    if (map_points > 0 && ekf_inited)
-        hipLaunchKernelGGL(k_far_nearest, dim3(cdiv2(N, 256)), dim3(256), 0, st, g, s_search, body, nn_cnt, max_sqdist, N,
-                           hash_size, live, nn_pts);
+    if (map_points > 0 && ekf_inited) {
+        hipLaunchKernelGGL(k_far_nearest, dim3(cdiv2(N, 256)), dim3(256), 0, st, s_search, body, nn_cnt, max_sqdist, N, nn_pts, far);
+        hipLaunchKernelGGL(k_far_search, dim3(min(cdiv2(N, 4), 512)), dim3(256), 0, st, g, s_search, body, hash_size, live, nn_pts, far, N);
+    }
     hipLaunchKernelGGL(k_mi_classify, dim3(cdiv2(N, 256)), dim3(256), 0, st, s_post, s_search, body, nn_pts, nn_cnt, max_sqdist, N,
-                       map_points, fsm, ekf_inited, world_out, cls, flags);
-    return hipGetLastError();
-}
-hipError_t launch_cls_flags(const uint8_t* cls, int N, uint32_t* flags, hipStream_t st) {
-    if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_cls_flags, dim3(cdiv2(N, 256)), dim3(256), 0, st, cls, N, flags);
+                       map_points, fsm, ekf_inited, world_out, cls, flags, far);
     return hipGetLastError();
 }
 hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* incl, int N, float4* out,

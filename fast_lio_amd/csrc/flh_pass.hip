@@ -81,13 +81,14 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     __shared__ uint32_t s_list[64];  // per wave: the slots (0..63) of its queries that go to phase B
     __shared__ uint32_t s_wcnt[4];
     const int tid = threadIdx.x;
-    // which 64 scan points (unit of the summation tree) this workgroup takes.  Workgroups are dispatched in blockIdx order over ~2 us;
-    // FLH_PASS_REVERSED (developer A/B builds) hands the END of the Morton order -- the scan's far field, whose waves are the slowest
-    // of the launch -- to the workgroups dispatched first
-#ifdef FLH_PASS_REVERSED
-    const int unit = (int)gridDim.x - 1 - (int)blockIdx.x;
-#else
+    // which 64 scan points (a unit of the summation tree) this workgroup takes: the LAST ones first.  Workgroups are dispatched in
+    // blockIdx order over ~2 us, and the end of the scan's Morton order is its far field, whose waves are the slowest of the launch
+    // (sparse queries: every dependent load of the search misses) -- they decide when the kernel ends, so they start first.
+    // Measured on BASELINE configs[1], same box, two pairs: 41.9 -> 38.8 us per launch (profiles/r04_call8/).
+#ifdef FLH_PASS_FORWARD  // (developer A/B builds)
     const int unit = (int)blockIdx.x;
+#else
+    const int unit = (int)gridDim.x - 1 - (int)blockIdx.x;
 #endif
     const int q0 = unit * kPassQueries;
     const RingRsrc rs(g, map_points);
