@@ -50,6 +50,28 @@ HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured c
 RING = 4                 # staging slots cycled by the pipelined loop
 
 
+_JSON_FD = None  # the process's original stdout once keep_stdout_for_the_line() has run
+
+
+def keep_stdout_for_the_line():
+    """The contract is ONE JSON line on stdout.  Libraries write there too -- RCCL prints its version banner through C stdio, which
+    is flushed at exit, i.e. BEHIND the line -- so the measuring process points fd 1 at stderr and keeps the original for emit()."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(d):
+    data = (json.dumps(d) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -186,6 +208,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and not args.in_process and args.leg != "main":
         return run_main_in_child()
+    keep_stdout_for_the_line()
     local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         log(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
@@ -626,7 +649,7 @@ def main():
         out.update(run_extra_legs_in_child(args))
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if kf is not None:
         kf.close()
         h.close()
