@@ -53,32 +53,9 @@ def _props(h, body, x, ext=False):
 
 
 def test_config2_full_update_against_oracle():
-    from oracle import pyoracle as po
-
-    pr = synth.make_problem(5_000_000, 100_000, "avia", cfg=2)
-    xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
-    h = capi.Handle()
-    h.map_build(pr.map_xyz)
-    h.scan_upload(pr.body)
-    kf = capi.Esekf(h, max_iter=3)
-    kf.change_x(xp)
-    kf.change_P(P)
-    st = kf.update(0.001)
-    m = po.Map(pr.map_xyz)
-    sc = po.Scan(pr.body, nthreads=16)
-    x_ref, P_ref, st_ref = sc.update_iterated(m, xp, P)
-    assert st.passes == st_ref.passes and st.searches == st_ref.searches
-    assert list(st.n_eff)[: st.passes] == list(st_ref.n_eff)[: st_ref.passes]
-    np.testing.assert_array_equal(h.fetch_selected(), sc.selected)          # bit-exact point_selected_surf
-    x = kf.get_x()
-    assert np.linalg.norm(x[:3] - x_ref[:3]) <= 1e-4                          # pose within 1e-4 m
-    np.testing.assert_allclose(x, x_ref, rtol=1e-4, atol=1e-7)
-    np.testing.assert_allclose(kf.get_P(), P_ref, rtol=0, atol=1e-4 * np.abs(P_ref).max())
-    idx, d2, cnt = h.fetch_neighbors()
-    gate = (sc.nn_cnt == 5) & (sc.nn_d2[:, 4] <= 5.0)
-    np.testing.assert_array_equal(idx[gate], sc.nn_idx[gate])
-    assert _props(h, pr.body, xp) > 50_000
-    h.close()
+    """BASELINE configs[1], the headline: the same helper as configs 4 and 5 -- flags, planes + pd2 (normvec), neighbour indices
+    AND their squared distances bit for bit, posterior within the bars -- plus the size-independent properties."""
+    assert _full_update_against_oracle(5_000_000, 100_000, "avia", 2, nthreads=16, props=True) > 50_000
 
 
 def test_config4_properties_20M_map_130k_ouster():
