@@ -15,8 +15,10 @@ stream with incremental map inserts) a step also runs map_incremental (src/laser
 Prints ONE JSON line on rank 0: the contract fields, `roofline` (HIP events on the handle's stream inside the timed
 region; `traffic` from the committed PMC summary of the same command), `cpu_baseline` (the oracle's restated
 reference path on a bounded sample, at the reference's 3 OpenMP threads and at all host cores), and -- measured after
-the timed region, never part of `value` -- `two_streams_per_gpu`, `map_incremental`, `scan_front_end`; with N > 1 also
-`shard_mode` (one scan's points split over the ranks, all-reduce of the 16x16 Gram block per pass).
+the timed region, never part of `value` -- `two_streams_per_gpu`, `map_incremental`, `scan_front_end`.  With N > 1 `value` is the
+sharded path (one scan's points split over the ranks -- config 5: the map partitioned -- the ranks' normal equations meeting per
+pass as peer-written granules, --exchange peer, or through an RCCL all-reduce, --exchange rccl; the other one timed beside it as
+`other_exchange`), the N independent replicas a labelled sub-field.
 """
 from __future__ import annotations
 
