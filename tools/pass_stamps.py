@@ -57,7 +57,9 @@ for name, x in (("prior (first search of a scan)", xp), ("true state (a later se
     # which waves are the slow ones?  by length of the longest candidate list (trips of 32 candidates per query), by place
     durA = rel[:, 1] - rel[:, 0]
     tmax, nopen = st[:, 10].astype(np.int64), st[:, 11].astype(np.int64)
-    hw, xcc = st[:, 8].astype(np.int64), st[:, 9].astype(np.int64) & 0xF
+    hw, xcc, unit = st[:, 8].astype(np.int64), st[:, 9].astype(np.int64) & 0xF, (st[:, 9] >> np.uint64(32)).astype(np.int64)
+    if not unit.any():  # a build that does not stamp the unit: the product's mapping, the END of the Morton order first
+        unit = (nw // 4 - 1) - np.arange(len(unit)) // 4
     simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
     trips = (tmax + 31) // 32
     print("  phase A duration by trips of the wave's longest query:")
@@ -67,9 +69,24 @@ for name, x in (("prior (first search of a scan)", xp), ("true state (a later se
             print(f"    trips {k}: n={int(m.sum()):5d}  mean {np.nanmean(durA[m]):6.2f}  p95 {np.nanpercentile(durA[m], 95):6.2f}  max {np.nanmax(durA[m]):6.2f}")
     print("  phase A duration by XCC:", "  ".join(f"{x}: {np.nanmean(durA[xcc == x]):.2f}/{np.nanmax(durA[xcc == x]):.2f}" for x in sorted(set(xcc.tolist()))))
     order = np.argsort(-np.nan_to_num(durA))[:16]
-    print("  slowest waves (phase A): wave block dur start tmax open xcc se sh cu simd")
+    print("  slowest waves (phase A): wave block unit dur start tmax open xcc se sh cu simd")
     for w in order:
-        print(f"    {w:5d} {w // 4:5d} {durA[w]:6.2f} {rel[w, 0]:5.2f} {tmax[w]:4d} {nopen[w]:3d}  {xcc[w]} {se[w]} {sh[w]} {cu[w]:2d} {simd[w]}")
+        print(f"    {w:5d} {w // 4:5d} {unit[w]:5d} {durA[w]:6.2f} {rel[w, 0]:5.2f} {tmax[w]:4d} {nopen[w]:3d}  {xcc[w]} {se[w]} {sh[w]} {cu[w]:2d} {simd[w]}")
+    # by dispatch position (blockIdx) and by unit (position in the scan's Morton order): where the slow workgroups are, and when they start
+    nb = (len(durA) + 3) // 4
+    wgA = np.nanmax(rel[: nb * 4, 2].reshape(nb, 4), axis=1)          # the workgroup's phase A done
+    wgF = np.nanmax(np.nan_to_num(rel[: nb * 4, 6], nan=-1.0).reshape(nb, 4), axis=1)  # its fit wave done
+    wgS = np.nanmin(rel[: nb * 4, 0].reshape(nb, 4), axis=1)
+    wgU = unit[: nb * 4].reshape(nb, 4)[:, 0]
+    print("  deciles of the DISPATCH order (blockIdx): start / phase A done / fit done (means), max fit done")
+    for d in range(10):
+        m = slice(d * nb // 10, (d + 1) * nb // 10)
+        print(f"    {d}: {np.nanmean(wgS[m]):5.2f} / {np.nanmean(wgA[m]):6.2f} / {np.nanmean(wgF[m]):6.2f}   max {np.nanmax(wgF[m]):6.2f}")
+    print("  deciles of the UNIT index (Morton order of the scan): phase A duration of the workgroup (mean / max), mean dispatch position")
+    o = np.argsort(wgU)
+    for d in range(10):
+        m = o[d * nb // 10:(d + 1) * nb // 10]
+        print(f"    {d}: {np.nanmean(wgA[m] - wgS[m]):6.2f} / {np.nanmax(wgA[m] - wgS[m]):6.2f}   {np.mean(m):7.1f}")
     # waves per (xcc, se, sh, cu): is a CU that got more workgroups slower?
     cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
     cnt = np.bincount(cuid)
