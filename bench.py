@@ -547,8 +547,9 @@ def main():
         "map_build_s": round(t_build, 3),
     }
     if with_map_inserts:
-        # host time inside flh_map_incremental per scan: classification (waits for its two list lengths) + enqueueing the
-        # Add_Points work; the device finishes it while the host stages / activates the next scan -- all inside ms_per_step
+        # host time inside flh_map_incremental per scan: enqueueing the classification and the Add_Points work (nobody asks for the
+        # two list lengths, so the host does not wait for them when the previous change was of a scan's usual size); the device
+        # finishes the change while the host stages / activates the next scan -- all inside ms_per_step
         out["ms_map_incremental_call_per_scan"] = round(acc_mi, 4)
     if G > 1 and dist is not None:
         out["ranks_seen_by_collective"] = int(dist.get_world_size())
@@ -791,7 +792,7 @@ def extra_legs(args):
         h.map_incremental(xpost, 0.5, True, apply=False)
         t2 = time.perf_counter()
         m0 = h.M
-        h.map_incremental(xpost, 0.5, True, apply=True)
+        h.map_incremental(xpost, 0.5, True, apply=True, counts=False)  # as the node's loop calls it: the two counts are not asked for
         t3a = time.perf_counter()
         m1 = h.M  # the change is enqueued; reading the map's size waits for its counters (= the device has finished it)
         t3 = time.perf_counter()
@@ -801,7 +802,7 @@ def extra_legs(args):
         added += m1 - m0
     out["map_incremental"] = {"ms_per_scan": round(t_all / S * 1e3, 3), "classify_only_ms": round(t_cls / S * 1e3, 3),
                               "host_time_of_the_call_ms": round(t_enq / S * 1e3, 3),
-                              "net_points_added_per_scan": round(added / S, 1), "scans": S,
+                              "net_points_added_per_scan": round(added / S, 1), "scans": S, "changes": h.map_change_stats(),
                               "note": "filter_size_map 0.5; only the touched bricks are rewritten (slack-carrying brick storage); ms_per_scan = "
                                       "call + wait until the device has finished the change; the call itself only enqueues it"}
 

@@ -39,7 +39,8 @@ class FakeHandle:
     def debug_bounds(self): return False, [0] * 20
     def pass_stats(self): return {"search_passes": 40, "one_launch_passes": 40, "second_stage_queries": 4000, "nosearch_passes": 40}
     def set_owned_interval(self, a, lo, hi): pass
-    def map_incremental(self, x, fsm, inited, apply=True): self.M += 10 if apply else 0; return (5, 5)
+    def map_incremental(self, x, fsm, inited, apply=True, counts=True): self.M += 10 if apply else 0; return (5, 5) if counts else None
+    def map_change_stats(self): return {"enqueued_without_wait": 2, "replayed": 0}
     def scan_stage_undistorted(self, slot, pts, poses, x_end, leaf, want_undistorted=True): return 1234, None
     def scan_wait(self, slot): pass
     def frame_world(self, x, slot=-1, dense=True): return np.zeros((10, 3), np.float32)
