@@ -380,21 +380,58 @@ def main():
     # --mode partition / config 5, the map cut into slabs with a halo and every rank holding the whole scan); per pass each
     # rank reduces its part to the 16x16 Gram block in device memory and RCCL sums the blocks INSIDE flh_eval (native
     # call site, no Python and no D2H in the pass); every rank then runs the identical 23x23 solve.
+    class ExchangeUnavailable(RuntimeError):
+        """the named exchange did not come up on every rank (raised on ALL ranks, after they have agreed on it)"""
+
+    def all_ranks_ok(ok):
+        """did this step succeed on EVERY rank?  One all-reduce that every rank reaches: the steps it guards catch their own errors."""
+        if dist is None:
+            return ok
+        t_ = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t_, op=dist.ReduceOp.MIN)
+        return bool(int(t_.item()))
+
+    def why(err):
+        """the first rank's error text, known to every rank (called by all ranks after they agreed that something failed)"""
+        if dist is None:
+            return err or "failed"
+        errs = [None] * G
+        dist.all_gather_object(errs, err)
+        return next((f"rank {r_}: {e_}" for r_, e_ in enumerate(errs) if e_), "failed")
+
     def shard_leg(exchange, n_warm, n_steps):
-        """ONE scan over the ranks with the named exchange; returns (dict for the line, (dt, acc, ctr), points on this rank)."""
+        """ONE scan over the ranks with the named exchange; returns (dict for the line, (dt, acc, ctr), points on this rank).
+        Setting the exchange up is fallible (a shared segment that cannot be page-locked, an RCCL that is not there) and must not
+        leave the ranks in different collectives: every fallible step catches its own error, the ranks then agree, and a failure
+        anywhere raises ExchangeUnavailable everywhere."""
         partition = args.mode == "partition" or (args.mode == "auto" and args.config == 5)
-        hs = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
-                         pass_kernel=args.pass_kernel)
-        if exchange == "rccl":
-            uid = [capi.rccl_unique_id() if rank == 0 else None]
-            if dist is not None:
-                dist.broadcast_object_list(uid, src=0)
-            hs.rccl_init_rank(G, uid[0], rank)
-        else:
-            nm = [f"/flh_bench_{os.getpid()}" if rank == 0 else None]
-            if dist is not None:
-                dist.broadcast_object_list(nm, src=0)
-            hs.peer_open(nm[0], G, rank)
+        hs, err = None, None
+        tok = [None]
+        try:
+            hs = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
+                             pass_kernel=args.pass_kernel)
+            if rank == 0:  # the token every rank needs: RCCL's unique id / the name of the shared segment
+                tok = [capi.rccl_unique_id() if exchange == "rccl" else f"/flh_bench_{os.getpid()}"]
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)[:300]
+        if dist is not None:
+            dist.broadcast_object_list(tok, src=0)
+        if err is None and tok[0] is None:
+            err = "rank 0 could not make the exchange's token"
+        if not all_ranks_ok(err is None):  # before the set-up proper: ncclCommInitRank blocks until every rank has joined
+            if hs is not None:
+                hs.close()
+            raise ExchangeUnavailable(why(err))
+        try:
+            if exchange == "rccl":
+                hs.rccl_init_rank(G, tok[0], rank)
+            else:
+                hs.peer_open(tok[0], G, rank)
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)[:300]
+        if not all_ranks_ok(err is None):
+            hs.close()
+            raise ExchangeUnavailable(why(err))
         if partition:
             axis, edges = fdist.partition_bounds(scene.map_xyz, G)
             keep = fdist.partition_slab(scene.map_xyz, axis, edges, rank, fdist.HALO_DEFAULT)
@@ -435,40 +472,22 @@ def main():
     other_exchange = None
     if run_shard_leg:
         headline = mode in ("shard", "partition")
-        def all_ranks_ok(ok):
-            """did the leg succeed on EVERY rank?  (a rank that failed makes the others time out in their granule wait or in
-            the collective, so every rank gets here)"""
-            if dist is None:
-                return ok
-            t_ = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
-            dist.all_reduce(t_, op=dist.ReduceOp.MIN)
-            return bool(int(t_.item()))
-
         oth = "rccl" if args.exchange == "peer" else "peer"
         k2 = args.steps if headline else max(10, min(60, args.steps // 4))  # (a side leg only with --force-shard-leg)
         w2 = args.warmup if headline else max(3, args.warmup // 4)
-        used, err = args.exchange, None
-        res = None
+        used, res = args.exchange, None
         try:
             res = shard_leg(args.exchange, w2, k2)
-        except Exception as e:  # noqa: BLE001
-            err = repr(e)[:400]
-        if not all_ranks_ok(res is not None):
-            # the chosen exchange did not come up on this node (say, the shared segment could not be page-locked): the headline
-            # is then measured with the other one, and the line says so
-            first_err = err or "another rank failed"
-            res, used = None, oth
+        except ExchangeUnavailable as e1:
+            # the chosen exchange did not come up on this node: the sharded path is then measured with the other one, and the line says so
+            used = oth
             try:
                 res = shard_leg(oth, w2, k2)
-            except Exception as e:  # noqa: BLE001
-                err = repr(e)[:400]
-            if not all_ranks_ok(res is not None):
+                res[0]["exchange_fallback"] = f"--exchange {args.exchange} failed ({e1}); measured with {oth}"
+            except ExchangeUnavailable as e2:
                 if headline:
-                    raise RuntimeError(f"sharded leg failed with both exchanges: {first_err} / {err}")
-                res = None
-                shard_out = {"error": f"{first_err} / {err}"}
-            elif res is not None:
-                res[0]["exchange_fallback"] = f"--exchange {args.exchange} failed ({first_err}); measured with {oth}"
+                    raise RuntimeError(f"sharded leg: neither exchange came up: {e1} / {e2}")
+                shard_out = {"error": f"{e1} / {e2}"}
         if res is not None:
             shard_out, (dt2, acc2, ctr2), pts_here = res
             if headline:
@@ -478,10 +497,8 @@ def main():
         if used == args.exchange:
             try:  # the other exchange, shorter, for comparison
                 other_exchange, _r, _p = shard_leg(oth, max(3, args.warmup // 4), max(10, min(60, args.steps // 2)))
-            except Exception as e:  # noqa: BLE001
-                other_exchange = {"error": repr(e)[:400]}
-            if not all_ranks_ok(isinstance(other_exchange, dict) and "error" not in other_exchange) and "error" not in other_exchange:
-                other_exchange = {"error": "another rank failed"}
+            except ExchangeUnavailable as e:
+                other_exchange = {"error": str(e)[:400]}
     value = units / dt
     ms_per_step = dt / args.steps * 1e3
 
@@ -599,6 +616,8 @@ def main():
         out["sharded_path"] = {k: shard_out[k] for k in ("layout", "points_per_rank", "map_points_this_rank", "collective",
                                                           "ranks_in_communicator", "max_abs_state_disagreement_across_ranks",
                                                           "ms_search_pass", "ms_nosearch_pass")}
+        if "exchange_fallback" in shard_out:
+            out["sharded_path"]["exchange_fallback"] = shard_out["exchange_fallback"]
     if other_exchange is not None:
         out["other_exchange"] = other_exchange
     if replicas_out is not None:

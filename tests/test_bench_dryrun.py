@@ -63,6 +63,21 @@ def test_two_ranks_over_gloo():
     assert abs(d["value"] * d["ms_per_step"] / 1000.0 - 1.0) < 0.01  # value = scans of the ONE sharded stream per second (not x ranks)
 
 
+def test_two_ranks_fall_back_to_the_other_exchange_when_one_rank_cannot_open_the_peers():
+    """The sharded leg is the headline for N > 1: when the chosen exchange does not come up on EVERY rank (here: rank 1 cannot
+    page-lock the shared segment), all ranks agree to measure with the other one and the line says so."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", DRYRUN_PEER_FAILS_ON_RANK="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29543", DRY, "--gpus", "2", "--config", "1", "--steps", "6", "--warmup", "2", "--scans", "3",
+                        "--cpu-scans", "0", "--backend", "gloo", "--single-device", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900, env=env)
+    d = _line(r.stdout.decode())
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["sharded_path"]["collective"].startswith("rccl") and "flh_peer_open" in d["sharded_path"]["exchange_fallback"]
+    assert "other_exchange" not in d  # the other exchange IS the headline now; nothing is timed beside it
+    assert abs(d["value"] * d["ms_per_step"] / 1000.0 - 1.0) < 0.01
+
+
 def test_without_a_device_the_real_bench_says_so_and_does_not_retry():
     from fast_lio_amd import capi
 

@@ -34,7 +34,10 @@ class FakeHandle:
     def close(self): pass
     def rccl_init_rank(self, n, uid, r): assert len(uid) == 128
     def rccl_size(self): return 1
-    def peer_open(self, name, n, r): assert name.startswith("/")
+    def peer_open(self, name, n, r):
+        assert name.startswith("/")
+        if os.environ.get("DRYRUN_PEER_FAILS_ON_RANK") == str(r):  # tests/test_bench_dryrun.py: the fallback to the other exchange
+            raise RuntimeError("flh_peer_open: hipHostRegister: out of memory (dry-run fault injection)")
     def peer_size(self): return 1
     def debug_bounds(self): return False, [0] * 20
     def pass_stats(self): return {"search_passes": 40, "one_launch_passes": 40, "second_stage_queries": 4000, "nosearch_passes": 40}
