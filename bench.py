@@ -549,7 +549,9 @@ def main():
                                     "copy stream while the previous scan updates, then the full iterated update"
                                     if mode not in ("shard", "partition") else "scan shards resident in HBM, full iterated update"),
                    "parallelism": ("1 GPU" if G == 1 else
-                                   (f"scan points sharded over {G} ranks, normal equations summed per pass ({args.exchange})"
+                                   ((f"map partitioned over {G} ranks (slabs + halo), whole scan on every rank, queries owned by position"
+                                     if mode == "partition" else f"scan points sharded over {G} ranks") +
+                                    f", normal equations summed per pass ({used if run_shard_leg else args.exchange})"
                                     if mode in ("shard", "partition") else
                                     f"{G} independent scan streams (one per rank), replicated map, no collective in the data path")),
                    "distinct_scans": S, "cell_size_m": args.cell, "lanes_per_query": args.lpq,
