@@ -29,6 +29,9 @@
 #include "../../include/fastlio_hip.h"
 #include "../../include/fastlio_amd/local_map.hpp"
 #include "flh_kernels.hpp"
+#ifdef FLH_EXP_PRELAUNCH
+#include "exp/flh_mail_dev.hpp"
+#endif
 
 using flh::GridParams;
 using flh::StateDev;
@@ -282,6 +285,20 @@ struct flh_handle {
     DevBuf<uint32_t> st_m0, st_m1;          // Morton keys of the staging sort
     DevBuf<uint32_t> st_v0, st_v1;
     DevBuf<unsigned char> st_tmp;
+#ifdef FLH_EXP_PRELAUNCH  // (developer builds: the pre-launched no-search pass, exp/flh_prelaunch_host.inc)
+    struct PreLaunch {
+        bool enabled = false, off = false, armed = false, via_mail = false;
+        uint32_t mseq = 0;
+        double eval_seq = 0;
+        int ext = 0;
+        size_t N = 0;
+        const float4* body = nullptr;
+        double* host_box = nullptr;
+        unsigned long long* status = nullptr;
+        double* dev_box = nullptr;
+        uint64_t n_armed = 0, n_go = 0, n_abort = 0, n_gone = 0;
+    } pre;
+#endif
 };
 
 extern "C" {
@@ -289,6 +306,10 @@ extern "C" {
 static void release_build_scratch(flh_handle* h);
 static void stop_stager(flh_handle* h);
 static int rccl_allreduce_publish(flh_handle* h, double seq);
+#ifdef FLH_EXP_PRELAUNCH
+int flh_exp_prelaunch(flh_handle* h, int enable);
+static void pre_release(flh_handle* h);
+#endif
 static StateDev make_state(const double rot[4], const double pos[3], const double offR[4], const double offT[3]);
 
 const char* flh_last_error(void) { return g_err.c_str(); }
@@ -410,6 +431,9 @@ void flh_destroy(flh_handle* h) {
     if (!h) return;
     stop_stager(h);
     (void)hipSetDevice(h->device);
+#ifdef FLH_EXP_PRELAUNCH
+    (void)flh_exp_prelaunch(h, 0);
+#endif
     flh_rccl_destroy(h);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -448,6 +472,9 @@ void flh_destroy(flh_handle* h) {
         for (auto& e : t3)
             if (e) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+#ifdef FLH_EXP_PRELAUNCH
+    pre_release(h);
+#endif
     delete h;
 }
 
@@ -1603,6 +1630,9 @@ static int ensure_d2(flh_handle* h) {
     return 0;
 }
 
+#ifdef FLH_EXP_PRELAUNCH
+static int pre_gone_relaunch(flh_handle* h, double seq, int ext);
+#endif
 // The group reducers of every rank write {value, sequence} granules straight into this rank's pinned buffer: per rank a
 // header (how many granules follow), then [group][slot].  Waits until every granule carries this evaluation's sequence
 // number, adding the groups up in (rank, group) order as they are seen complete (fixed order -> identical bits run to
@@ -1623,6 +1653,9 @@ static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
             if (_mm_cvtsd_f64(_mm_unpackhi_pd(x, x)) == seq) { *value = _mm_cvtsd_f64(x); return 0; }
             cpu_relax();
             if ((++spins & 0xFFFFFu) == 0) {
+#ifdef FLH_EXP_PRELAUNCH
+                if (pre_gone_relaunch(h, seq, ext) != 0) return -1;
+#endif
                 if (hipStreamQuery(st) != hipErrorNotReady) {  // this rank's kernel finished or failed
                     HIPC(hipStreamSynchronize(st));
                     const __m128d y = _mm_load_pd(gp);
@@ -1673,6 +1706,9 @@ void flh_unpack_gram(const double G[256], double HTH[144], double HTh[12], int64
     if (total_residual) *total_residual = G[14 * 16 + 13];
 }
 
+#ifdef FLH_EXP_PRELAUNCH
+#include "exp/flh_prelaunch_host.inc"
+#endif
 // One h_share_model evaluation in two halves: flh_eval_begin enqueues the pass and returns; flh_eval_end waits for its normal
 // equations.  Between the two the caller's thread is free for host work that does not depend on them (the mirror esekf projects
 // the covariance and inverts P / R there: a third of the 23x23 algebra of a pass leaves the critical path).
@@ -1701,6 +1737,11 @@ int flh_eval_begin(flh_handle* h, const double rot[4], const double pos[3], cons
     pe.granules = !h->comm && h->N > 0 && gran_group_size(h->N) > 0;
     pe.one_launch = pe.do_search && use_pass_kernel(h, pe.granules);
     if (h->peer_n > 1 && !pe.granules) return fail("flh_eval: a scan shard may not be empty when the ranks exchange granules (flh_peer_*)");
+#ifdef FLH_EXP_PRELAUNCH
+    if (pre_try_go(h, s, pe)) {
+        // the kernel of this evaluation was enqueued beside the previous pass: the state went to its mailbox
+    } else
+#endif
     if (h->comm) {
         // this rank's partial block stays in device memory, RCCL sums the ranks' blocks in place (256 doubles: latency-bound,
         // xGMI bandwidth is irrelevant), then one small kernel publishes the sum + sequence word to pinned host memory
@@ -1711,6 +1752,9 @@ int flh_eval_begin(flh_handle* h, const double rot[4], const double pos[3], cons
     }
     if (h->stats && do_search) HIPC(hipMemcpyAsync(h->h_counter, h->counter.p, sizeof(u64), hipMemcpyDeviceToHost, st));
     if (do_search) { h->n_search_pass++; if (pe.one_launch) h->n_one_launch++; } else h->n_nosearch_pass++;
+#ifdef FLH_EXP_PRELAUNCH
+    if (pre_arm(h, pe) != 0) return -1;
+#endif
     pe.active = true;
     return 0;
 }
@@ -2073,6 +2117,9 @@ static int fetch_rows_peers(flh_handle* h, double* hx, double* hv, int64_t cap, 
 int flh_fetch_rows(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* n_rows) {
     if (!h || !n_rows) return fail("flh_fetch_rows: null argument");
     if (!h->have_eval) return fail("flh_fetch_rows: no evaluation yet");
+#ifdef FLH_EXP_PRELAUNCH
+    pre_cancel(h);  // (the gain-form branch fetches rows between two passes of an update)
+#endif
     if (h->comm && h->comm_size > 1) return fetch_rows_gathered(h, hx, hv, cap, n_rows);
     if (h->peer_seg && h->peer_n > 1) return fetch_rows_peers(h, hx, hv, cap, n_rows);
     return fetch_rows_local(h, hx, hv, cap, n_rows);

@@ -14,6 +14,9 @@
 #include "../../include/fastlio_hip.h"
 
 typedef esekfom::esekf<state_ikfom, 12, input_ikfom> kf_t;
+#ifdef FLH_EXP_PRELAUNCH
+extern "C" int flh_exp_prelaunch(flh_handle* h, int enable);  // exp/flh_prelaunch_host.inc
+#endif
 
 struct flh_esekf {
     kf_t kf;
@@ -103,12 +106,21 @@ int flh_esekf_update(flh_esekf* e, double R, flh_update_stats* st) {
     if (!e) return -1;
     e->err.clear();
     double solve_time = 0;
+#ifdef FLH_EXP_PRELAUNCH  // (developer builds: the no-search passes of this update are enqueued ahead of their states)
+    if (e->gpu_ctx.handle && !e->user_h) (void)flh_exp_prelaunch(e->gpu_ctx.handle, 1);
+#endif
     try {
         e->kf.update_iterated_dyn_share_modified(R, solve_time);
     } catch (const std::exception& ex) {
+#ifdef FLH_EXP_PRELAUNCH
+        if (e->gpu_ctx.handle) (void)flh_exp_prelaunch(e->gpu_ctx.handle, 0);
+#endif
         e->err = ex.what();
         return -1;
     }
+#ifdef FLH_EXP_PRELAUNCH
+    if (e->gpu_ctx.handle) (void)flh_exp_prelaunch(e->gpu_ctx.handle, 0);
+#endif
     if (st) {
         const kf_t::update_stats& s = e->kf.last_stats();
         st->passes = s.passes;

@@ -703,3 +703,7 @@ void bounds_read_kernels(unsigned long long out[5]) { (void)hipMemcpyFromSymbol(
 #endif
 
 }  // namespace flh
+
+#ifdef FLH_EXP_PRELAUNCH  // (developer builds: the pre-launched no-search pass)
+#include "exp/flh_fit_mb.inc"
+#endif

@@ -60,6 +60,12 @@ hipError_t launch_fit(int order, int half_fit, const StateDev& s, const float4* 
 hipError_t launch_fill_d2(const StateDev& s_search, const float4* body, const float4* nn_pts, int N, float* nn_d2, hipStream_t st);
 int gram_slots_host(int ncol);
 int gram_slot_host(int r, int c, int ncol);
+#ifdef FLH_EXP_PRELAUNCH  // (developer builds: exp/flh_fit_mb.inc)
+struct MailArgs;
+hipError_t launch_fit_mb(const MailArgs& mail, const float4* body, int N, int ext, float thr, uint8_t* selected, double* partials,
+                         double seq, uint32_t* tickets, uint32_t* slow_count, const GranOut& gran, int red1, const float4* plane_cache,
+                         hipStream_t st);
+#endif
 
 // ---- flh_mapinc.hip: map_incremental and the incremental map ----
 hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t map_points, const StateDev& s_search,

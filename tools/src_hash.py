@@ -7,10 +7,10 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def src_hash() -> str:
+def src_hash(root: str = ROOT) -> str:
     h = hashlib.sha256()
     for d in ("fast_lio_amd/csrc", "include", "include/fastlio_amd"):
-        p = os.path.join(ROOT, d)
+        p = os.path.join(root, d)
         for f in sorted(os.listdir(p)):
             fp = os.path.join(p, f)
             if os.path.isfile(fp) and f.rsplit(".", 1)[-1] in ("hip", "inc", "hpp", "cpp", "h"):
