@@ -160,30 +160,37 @@ __device__ __forceinline__ void group_sum_publish(const double* partials, int gr
     const int halfq = (nq + 1) >> 1;   // quads of its lower half
     const int hi = wl >> 5, sl = wl & 31;
     const int qlo = hi ? halfq : 0, qhi = hi ? nq : halfq;
+#ifdef FLH_EXP_RED8  // (developer builds: k_fit's reducer reads the eight quad records of a half group in ONE load round trip
+                     // instead of two; the same tree, the same order of additions, hence the same bits.  k_pass's reducer keeps
+                     // sixteen loads per trip: thirty-two do not fit its 72 registers)
+    constexpr int QB = QUADS ? 8 : 4;
+#else
+    constexpr int QB = 4;
+#endif
     for (int slot = sl; slot < ((nsl + 31) & ~31); slot += 32) {
         const int sc = slot < nsl ? slot : nsl - 1;
         double s0 = 0.0;
-        for (int q0 = qlo; q0 < qhi; q0 += 4) {  // sixteen loads in flight (four quads of units, or four quad records)
-            double qv[4];
+        for (int q0 = qlo; q0 < qhi; q0 += QB) {  // sixteen loads in flight (four quads of units, or four quad records)
+            double qv[QB];
             if (QUADS) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < QB; ++j)
                     qv[j] = (q0 + j < qhi) ? __hip_atomic_load(gpart + (size_t)((u0 >> 2) + q0 + j) * nsl + sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                            : 0.0;
             } else {
-                double pv[16];
+                double pv[4 * QB];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
+                for (int j = 0; j < 4 * QB; ++j) {
                     const int u = 4 * q0 + j;  // unit inside the group
                     pv[j] = (q0 + (j >> 2) < qhi && u < gsize)
                                 ? __hip_atomic_load(gpart + (size_t)(u0 + u) * nsl + sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                 : 0.0;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) qv[j] = ((pv[4 * j] + pv[4 * j + 1]) + pv[4 * j + 2]) + pv[4 * j + 3];
+                for (int j = 0; j < QB; ++j) qv[j] = ((pv[4 * j] + pv[4 * j + 1]) + pv[4 * j + 2]) + pv[4 * j + 3];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < QB; ++j)
                 if (q0 + j < qhi) s0 += qv[j];  // (uniform over the wave's half: qhi is)
         }
         const double other = __shfl_xor(s0, 32, 64);
