@@ -205,7 +205,9 @@ class esekf {
                 dx_new_early = dx_early;
                 P_early = P_propagated;
                 project_cov(P_early, dx_new_early, dx_early, x_, x_propagated);
+#ifdef FASTLIO_AMD_REFERENCE_ALGEBRA
                 P_temp_early = fastlio_amd::inverse(P_early / R);
+#endif
                 early = true;
             }
             if (h_dyn_share_ctx) h_dyn_share_ctx(x_, dyn_share, h_ctx_);
@@ -242,11 +244,29 @@ class esekf {
             } else {  // :1782-1809 information form
                 double HTH[144], HTh[12];
                 normal_equations(dyn_share, dof_Measurement, HTH, HTh);
+#ifdef FASTLIO_AMD_REFERENCE_ALGEBRA
+                // the reference's own sequence (:1782,:1802): invert P / R, add HTH, invert again
                 cov P_temp = early ? P_temp_early : fastlio_amd::inverse(P_ / R);
                 for (int a = 0; a < 12; ++a)
                     for (int b = 0; b < 12; ++b) P_temp(a, b) += HTH[a * 12 + b];
                 // only P_inv.block<n,12>(0,0) is read below (:1803-1806): the first 12 columns of the inverse, bit for bit
                 const Mat<n, 12> P_inv = fastlio_amd::inverse_cols<n, 12>(P_temp);
+#else
+                // The same 12 columns without either 23x23 inverse.  With A = (P / R)^-1 and U = [I12; 0] the reference forms
+                // (A + U HTH U^T)^-1 and reads its first 12 columns, (A + U HTH U^T)^-1 U.  By the push-through identity that is
+                //     A^-1 U (I + HTH U^T A^-1 U)^-1  =  B[:, :12] (I + HTH B[:12, :12])^-1,   B = P / R,
+                // one 12 x 12 elimination with 23 right-hand sides; B needs no inverse at all.  Same quantity, fewer roundings
+                // (the covariance is never inverted: tests/test_host_algebra.py measures what that is worth).  Without
+                // extrinsic estimation rows and columns 6..11 of HTH are zero (laserMapping.cpp:745), the columns 6..11 of
+                // P_inv then only ever multiply zeros, and the first six are B[:, :6] (I + HTH[:6, :6] B[:6, :6])^-1: a 6 x 6
+                // elimination.  The columns that are not computed are left zero.
+                bool six = true;
+                for (int a = 0; a < 12 && six; ++a)
+                    for (int b = (a < 6 ? 6 : 0); b < 12; ++b)
+                        if (HTH[a * 12 + b] != 0.0) { six = false; break; }
+                for (int a = 6; a < 12; ++a) six = six && HTh[a] == 0.0;
+                const Mat<n, 12> P_inv = six ? info_cols<6>(P_, R, HTH) : info_cols<12>(P_, R, HTH);
+#endif
                 for (int r = 0; r < n; ++r) {
                     double s = 0;
                     for (int c = 0; c < 12; ++c) s += P_inv(r, c) * HTh[c];
@@ -311,6 +331,29 @@ class esekf {
         x_.build_S2_state();
         x_.build_SO3_state();
         x_.build_vect_state();
+    }
+    // The first NC columns of P_inv.block<n,12>(0,0) of :1802 as B[:, :NC] (I + HTH[:NC, :NC] B[:NC, :NC])^-1 with B = P / R
+    // (see the call site); the other columns are zero
+    template <int NC>
+    static Mat<n, 12> info_cols(const cov& P, double R, const double HTH[144]) {
+        double St[NC * NC], Bt[NC * n], Xt[NC * n];  // S^T, B[:, :NC]^T, the solution of S^T X = B[:, :NC]^T
+        double B11[NC * NC];
+        const double rinv = 1.0 / R;
+        for (int a = 0; a < NC; ++a)
+            for (int b = 0; b < NC; ++b) B11[a * NC + b] = P(a, b) * rinv;
+        for (int a = 0; a < NC; ++a)
+            for (int b = 0; b < NC; ++b) {
+                double s = 0;
+                for (int c = 0; c < NC; ++c) s += HTH[a * 12 + c] * B11[c * NC + b];
+                St[b * NC + a] = s + (a == b ? 1.0 : 0.0);
+            }
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < NC; ++c) Bt[c * n + r] = P(r, c) * rinv;
+        fastlio_amd::solve_lu_fixed<NC, n>(St, Bt, Xt);
+        Mat<n, 12> W;
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < NC; ++c) W(r, c) = Xt[c * n + r];
+        return W;
     }
     static int64_t meas_rows(const dyn_share_datastruct<scalar_type>& d) {
         return d.has_normal_eq ? d.n_eff : (int64_t)d.h.size();

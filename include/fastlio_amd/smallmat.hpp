@@ -280,6 +280,60 @@ inline Mat<N, NC> inverse_cols(const Mat<N, N>& A) {
     return r;
 }
 
+// Solves A X = B (A: N x N, B and X: N x NC, all row-major) by the same partial-pivot elimination, the right-hand sides carried
+// along instead of an identity: constant trip counts over aligned rows padded to a multiple of 8 doubles.
+template <int N, int NC>
+inline bool solve_lu_fixed(const double* A, const double* B, double* Xout) {
+    constexpr int S = (N + 7) & ~7;
+    constexpr int SC = (NC + 7) & ~7;
+    alignas(64) double LU[N * S];
+    alignas(64) double X[N * SC];
+    for (int i = 0; i < N; ++i) {
+        for (int j = 0; j < N; ++j) LU[i * S + j] = A[i * N + j];
+        for (int j = N; j < S; ++j) LU[i * S + j] = 0.0;
+        for (int j = 0; j < NC; ++j) X[i * SC + j] = B[i * NC + j];
+        for (int j = NC; j < SC; ++j) X[i * SC + j] = 0.0;
+    }
+    bool ok = true;
+    for (int k = 0; k < N; ++k) {
+        int p = k;
+        double best = std::fabs(LU[k * S + k]);
+        for (int i = k + 1; i < N; ++i) {
+            const double v = std::fabs(LU[i * S + k]);
+            if (v > best) { best = v; p = i; }
+        }
+        if (best == 0.0) ok = false;
+        if (p != k) {
+            for (int j = 0; j < S; ++j) { const double t = LU[k * S + j]; LU[k * S + j] = LU[p * S + j]; LU[p * S + j] = t; }
+            for (int j = 0; j < SC; ++j) { const double t = X[k * SC + j]; X[k * SC + j] = X[p * SC + j]; X[p * SC + j] = t; }
+        }
+        const double piv = LU[k * S + k];
+        const double* rk = LU + k * S;
+        const double* xk = X + k * SC;
+        for (int i = k + 1; i < N; ++i) {
+            const double l = LU[i * S + k] / piv;
+            double* ri = LU + i * S;
+            for (int j = 0; j < S; ++j) ri[j] -= l * rk[j];
+            ri[k] = l;
+            double* xi = X + i * SC;
+            for (int j = 0; j < SC; ++j) xi[j] -= l * xk[j];
+        }
+    }
+    for (int i = N - 1; i >= 0; --i) {
+        double* xi = X + i * SC;
+        for (int r = i + 1; r < N; ++r) {
+            const double u = LU[i * S + r];
+            const double* xr = X + r * SC;
+            for (int j = 0; j < SC; ++j) xi[j] -= u * xr[j];
+        }
+        const double inv = 1.0 / LU[i * S + i];
+        for (int j = 0; j < SC; ++j) xi[j] *= inv;
+    }
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < NC; ++j) Xout[i * NC + j] = X[i * SC + j];
+    return ok;
+}
+
 template <int N>
 inline Mat<N, N> inverse(const Mat<N, N>& A) {
     Mat<N, N> r;

@@ -83,9 +83,12 @@ def test_sharded_update_matches_single_process(tmp_path, n_scan, ext):
     x_ref, P_ref, st_ref = sc.update_iterated(m, xp, P, extrinsic_est_en=ext)
     assert int(got["passes"]) == st_ref.passes and int(got["searches"]) == st_ref.searches
     assert list(got["n_eff"])[: st_ref.passes] == list(st_ref.n_eff)[: st_ref.passes]
-    # the shards' fp64 partial sums add up in a different order than the single-process sum; with extrinsic estimation on,
-    # the 12-column system is poorly conditioned and that last-bit difference shows at ~1e-10 absolute in the state
-    np.testing.assert_allclose(got["x"], x_ref, rtol=1e-9, atol=1e-9)
+    # With extrinsic estimation on, the 12-column system is poorly conditioned and the ORACLE's answer (the reference's sequence:
+    # invert P / R, add HTH, invert again) is itself only good to ~1e-8 m on this problem: it moves by 1.1e-8 when its normal
+    # equations are perturbed in the last bit.  The product's filter forms the same 12 columns without inverting the covariance
+    # (esekfom.hpp: info_cols) and moves by 8.5e-14 under the same perturbation (tests/test_host_algebra.py); it sits 8.3e-9 from
+    # the oracle here, as the reference-sequence build of the same filter does (8.6e-9).
+    np.testing.assert_allclose(got["x"], x_ref, rtol=1e-9, atol=1e-7)
     np.testing.assert_allclose(got["P"], P_ref, rtol=0, atol=1e-6 * np.abs(P_ref).max())
 
 
