@@ -285,6 +285,9 @@ struct flh_handle {
     DevBuf<uint32_t> st_m0, st_m1;          // Morton keys of the staging sort
     DevBuf<uint32_t> st_v0, st_v1;
     DevBuf<unsigned char> st_tmp;
+#ifdef FLH_EXP_SPINSTAGER
+    std::atomic<uint64_t> st_posted{0};  // jobs ever handed to the staging thread
+#endif
 #ifdef FLH_EXP_PRELAUNCH  // (developer builds: the pre-launched no-search pass, exp/flh_prelaunch_host.inc)
     struct PreLaunch {
         bool enabled = false, off = false, armed = false, via_mail = false;
@@ -1255,6 +1258,19 @@ static void stager_main(flh_handle* h) {
     (void)hipSetDevice(h->device);
     std::unique_lock<std::mutex> lk(h->st_mu);
     for (;;) {
+#ifdef FLH_EXP_SPINSTAGER  // (developer builds) in a running stream the next job arrives within a scan's time: poll for it for a
+                            // while before sleeping, so that flh_scan_stage_async's notify finds nobody to wake (no futex call on
+                            // the thread that is about to launch a scan's first pass)
+        if (h->st_queue.empty() && !h->st_quit) {
+            const uint64_t seen = h->st_posted.load(std::memory_order_acquire);
+            lk.unlock();
+            const auto t0 = std::chrono::steady_clock::now();
+            while (h->st_posted.load(std::memory_order_acquire) == seen &&
+                   std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(400))
+                cpu_relax();
+            lk.lock();
+        }
+#endif
         h->st_cv.wait(lk, [&] { return h->st_quit || !h->st_queue.empty(); });
         if (h->st_queue.empty()) return;  // quit
         flh_handle::StageJob job = h->st_queue.front();
@@ -1344,6 +1360,9 @@ int flh_scan_stage_async(flh_handle* h, int slot, const void* pts, size_t stride
     if (!h->stager.joinable()) h->stager = std::thread(stager_main, h);
     h->slots[slot].pending = true;
     h->st_queue.push_back({slot, pts, stride_bytes, N});
+#ifdef FLH_EXP_SPINSTAGER
+    h->st_posted.fetch_add(1, std::memory_order_release);
+#endif
     h->st_cv.notify_one();
     return 0;
 }
