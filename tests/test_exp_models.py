@@ -1,0 +1,26 @@
+"""CPU models of experiments that only a GPU can run (fast_lio_amd/csrc/exp/, compiled out of the product)."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_mailbox_protocol_model(tmp_path):
+    """FLH_EXP_PRELAUNCH: the decisions of the forwarder wave, of every workgroup's wait and of the host's post -- go, abort,
+    a launch that was passed over, a host that comes too late -- restated with threads and atomics (tests/cpp/mailbox_model.cpp)."""
+    exe = tmp_path / "mailbox_model"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "cpp", "mailbox_model.cpp"), "-o", str(exe)])
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0 and "all cases as specified" in r.stdout.decode(), r.stdout.decode()
+
+
+def test_product_library_exports_no_experiment():
+    """The experiments' entry points exist in developer builds only."""
+    from fast_lio_amd import _build
+
+    if not os.path.exists(_build.LIB):
+        import pytest
+
+        pytest.skip("library not built")
+    out = subprocess.run(["nm", "-D", "--defined-only", _build.LIB], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert "flh_exp_" not in out and "k_fit_mb" not in out

@@ -147,7 +147,7 @@ def test_update_scan_is_change_x_change_P_update(small):
 
 def test_two_halves_measurement_model_changes_no_bit(tmp_path):
     """esekf with a measurement model whose first half is registered (the GPU pass: flh_eval_begin) does the covariance projection
-    and (P / R)^-1 between the two halves; tests/cpp/split_model_check.cpp compares it with the one-piece flow bit for bit,
+    between the two halves; tests/cpp/split_model_check.cpp compares it with the one-piece flow bit for bit,
     including passes whose measurement is invalid."""
     import os
     import subprocess
