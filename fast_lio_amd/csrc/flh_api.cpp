@@ -1657,6 +1657,29 @@ static int pre_gone_relaunch(flh_handle* h, double seq, int ext);
 // number, adding the groups up in (rank, group) order as they are seen complete (fixed order -> identical bits run to
 // run, and on every rank), and leaves the 16x16 block in h_gram (G[15][15] = seq).  No device-side final sum, no
 // collective, no flag.
+// slot of the compact Gram layout -> its place(s) in the 16 x 16 block, tabulated once per column count from gram_slot (the walk
+// over all 256 cells with a call each used to be repeated on every pass)
+struct GramMap {
+    int n = 0;
+    short pos[kGranSlots], mir[kGranSlots];
+};
+static GramMap build_gram_map(int ncol) {
+    GramMap m;
+    for (int k = 0; k < kGranSlots; ++k) { m.pos[k] = 0; m.mir[k] = -1; }
+    for (int r = 0; r < 16; ++r)
+        for (int c = 0; c < 16; ++c) {
+            const int sl = flh::gram_slot_host(r, c, ncol);
+            if (sl < 0 || sl >= kGranSlots) continue;
+            m.pos[sl] = (short)(r * 16 + c);
+            m.mir[sl] = (c < 12 && r < c) ? (short)(c * 16 + r) : (short)-1;
+            if (sl + 1 > m.n) m.n = sl + 1;
+        }
+    return m;
+}
+static const GramMap& gram_map(int ncol) {
+    static const GramMap m6 = build_gram_map(6), m12 = build_gram_map(12);
+    return ncol == 12 ? m12 : m6;
+}
 static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
     hipStream_t st = h->stream;
     const int ncol = ext ? 12 : 6;
@@ -1705,13 +1728,11 @@ static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
     if (do_search) h->n_second_stage += (uint64_t)sum[nslots];
     double* G = h->h_gram;
     std::memset(G, 0, 256 * sizeof(double));
-    for (int r = 0; r < 16; ++r)
-        for (int c = 0; c < 16; ++c) {
-            const int sl = flh::gram_slot_host(r, c, ncol);
-            if (sl < 0) continue;
-            G[r * 16 + c] = sum[sl];
-            if (c < 12 && r < c) G[c * 16 + r] = sum[sl];  // the block is symmetric bit for bit (same products, same order)
-        }
+    const GramMap& gm = gram_map(ncol);
+    for (int sl = 0; sl < gm.n; ++sl) {
+        G[gm.pos[sl]] = sum[sl];
+        if (gm.mir[sl] >= 0) G[gm.mir[sl]] = sum[sl];  // the block is symmetric bit for bit (same products, same order)
+    }
     G[255] = seq;
     return 0;
 }
