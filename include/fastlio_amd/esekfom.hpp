@@ -77,8 +77,8 @@ class esekf {
     typedef void measurementModel_dyn_share_ctx(state&, dyn_share_datastruct<scalar_type>&, void* ctx);
     // Optional FIRST HALF of a measurement model that can be started before it is waited for (a GPU pass: flh_eval_begin).  When
     // one is known for the registered model -- set_meas_begin, or register_split_model below for the reference's plain signature --
-    // the update starts the model, does the part of the pass's 23x23 algebra that does not depend on the measurement (covariance
-    // projection, (P / R)^-1: about a third of it) while the device works, and only then calls the model proper, which waits.
+    // the update starts the model, does the part of the pass's 23x23 algebra that does not depend on the measurement (x [-] x_prop, the
+    // covariance projection) while the device works, and only then calls the model proper, which waits.
     // Same arithmetic on the same operands: same bits.
     typedef void measurementModel_begin(state&, dyn_share_datastruct<scalar_type>&);
     typedef void measurementModel_begin_ctx(state&, dyn_share_datastruct<scalar_type>&, void* ctx);

@@ -225,8 +225,8 @@ int flh_eval(flh_handle* h, const double rot_xyzw[4], const double pos[3], const
              int64_t* n_eff, double* total_residual);
 
 /* The same evaluation in two halves: flh_eval_begin enqueues the pass and returns, flh_eval_end waits for its normal equations.
- * Between the two the caller's thread may do host work that does not depend on them (the mirror esekf projects the covariance and
- * inverts P / R there -- include/fastlio_amd/esekfom.hpp).  One evaluation under way per handle; an error in flh_eval_begin
+ * Between the two the caller's thread may do host work that does not depend on them (the mirror esekf projects the covariance
+ * there -- include/fastlio_amd/esekfom.hpp).  One evaluation under way per handle; an error in flh_eval_begin
  * leaves none under way. */
 int flh_eval_begin(flh_handle* h, const double rot_xyzw[4], const double pos[3], const double offR_xyzw[4], const double offT[3],
                    int do_search, int extrinsic_est_en);

@@ -1,6 +1,6 @@
 // CPU check of the two-halves measurement model in the mirrored esekf (include/fastlio_amd/esekfom.hpp): a model whose first half
 // is registered (esekfom::register_split_model / set_meas_begin) must give the very bits of the same model called in one piece --
-// the filter only moves the covariance projection and (P / R)^-1 in front of the wait -- and an INVALID measurement on a pass
+// the filter only moves the covariance projection in front of the wait -- and an INVALID measurement on a pass
 // must leave the covariance exactly as the one-piece flow leaves it.
 #include <cstdio>
 #include <cstring>
