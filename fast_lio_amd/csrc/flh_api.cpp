@@ -1709,6 +1709,30 @@ static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
             }
         }
     };
+    // A one-launch searching pass hands the END of the scan's order to the workgroups dispatched first, and workgroups finish in
+    // dispatch order: its groups arrive LAST GROUP FIRST, and the section's header -- group 0's reducer
+    // publishes it behind its sums -- is the very last granule of the pass.  Waiting for the header and only then reading 25 x 30
+    // granules would put the whole pick-up behind the last arrival.  So the granules of such a pass are taken in the order they
+    // come, into a local buffer, and added up in group order afterwards: the same additions in the same order, hence the same
+    // bits.  (One rank only: a peer's section cannot be sized before its header is there.)
+    const bool last_group_first = do_search && h->peer_n == 1 && h->peer_rank == 0 && use_pass_kernel(h, true);
+    if (last_group_first) {
+        const int red = gran_group_size(h->N);
+        const int ng = red > 0 ? (flh::pass_blocks((int)h->N) + red - 1) / red : 0;  // the groups launch_pass's kernel publishes
+        if (ng < 1 || ng > kGranGroups) return fail("flh_eval: granule groups out of range");
+        double val[kGranGroups * kGranSlots];
+        const double* sect = base;
+        for (int gi = ng - 1; gi >= 0; --gi) {
+            const double* gg = sect + 2 * (1 + (size_t)gi * nsl);
+            for (int k = 0; k < nsl; ++k)
+                if (wait_for(gg + 2 * k, &val[(size_t)gi * nsl + k]) != 0) return -1;
+        }
+        double cnt_d = 0;
+        if (wait_for(sect, &cnt_d) != 0) return -1;
+        if ((int)cnt_d != ng * nsl) return fail("flh_eval: malformed granule section");
+        for (int gi = 0; gi < ng; ++gi)
+            for (int k = 0; k < nsl; ++k) sum[k] += val[(size_t)gi * nsl + k];
+    } else
     for (int r = 0; r < h->peer_n; ++r) {
         const double* sect = base + (size_t)r * kGranSect * 2;
         double cnt_d = 0;
