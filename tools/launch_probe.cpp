@@ -40,6 +40,36 @@ int main() {
             if (i >= 200) { t_launch += us(t0, t1); t_all += us(t0, t2); }
         }
         std::printf("floor: empty kernel -> pinned flag: launch call %.2f us, launch -> host sees the flag %.2f us\n", t_launch / R, t_all / R);
+        // the same through hipModuleLaunchKernel on the kernel's hipFunction_t (no host-function lookup): with a kernelParams array,
+        // and with the arguments as one prepared buffer (HIP_LAUNCH_PARAM_BUFFER_POINTER) -- round-5 question: is the 2.8 us the
+        // runtime's bookkeeping or the packet's way to the device?
+        hipFunction_t fn = nullptr;
+        if (hipGetFuncBySymbol(&fn, reinterpret_cast<const void*>(&k_flag)) == hipSuccess && fn) {
+            for (int mode = 0; mode < 2; ++mode) {
+                t_launch = 0; t_all = 0;
+                for (int i = 0; i < R + 200; ++i) {
+                    seq += 1;
+                    double* fp = flag;
+                    void* params[2] = {&fp, &seq};
+                    struct { double* f; double s; } buf = {flag, seq};
+                    size_t bytes = sizeof(buf);
+                    void* extra[5] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &buf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+                    const auto t0 = clk::now();
+                    const hipError_t e = mode == 0 ? hipModuleLaunchKernel(fn, 1, 1, 1, 64, 1, 1, 0, st, params, nullptr)
+                                                   : hipModuleLaunchKernel(fn, 1, 1, 1, 64, 1, 1, 0, st, nullptr, extra);
+                    const auto t1 = clk::now();
+                    if (e != hipSuccess) { std::printf("hipModuleLaunchKernel (%s): %s\n", mode ? "buffer" : "params", hipGetErrorString(e)); break; }
+                    while (*(volatile double*)flag != seq) __builtin_ia32_pause();
+                    const auto t2 = clk::now();
+                    if (i >= 200) { t_launch += us(t0, t1); t_all += us(t0, t2); }
+                }
+                std::printf("floor: hipModuleLaunchKernel (%s): launch call %.2f us, launch -> host sees the flag %.2f us\n",
+                            mode ? "one argument buffer" : "kernelParams", t_launch / R, t_all / R);
+            }
+        } else {
+            std::printf("hipGetFuncBySymbol not available: hipModuleLaunchKernel variants skipped\n");
+            (void)hipGetLastError();
+        }
         hipStreamDestroy(st);
         hipHostFree(flag);
     }

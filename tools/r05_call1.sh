@@ -9,6 +9,7 @@
 #   python tools/variant.py --name prelaunch_red8 --define FLH_EXP_PRELAUNCH --define FLH_EXP_RED8 --build-only
 #   python tools/variant.py --name prelaunch_red8_spin --define FLH_EXP_PRELAUNCH --define FLH_EXP_RED8 --define FLH_EXP_SPINSTAGER --build-only
 #   hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/mailbox_probe.cpp -o tools/mailbox_probe
+#   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude tools/launch_probe.cpp -Lfast_lio_amd/lib -lfastlio_hip -Wl,-rpath,'$ORIGIN/../fast_lio_amd/lib' -o tools/launch_probe
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/r05_call1; mkdir -p $O
 export TMPDIR=/tmp
@@ -17,6 +18,8 @@ cd $R
 V=$R/fast_lio_amd/lib/libfastlio_hip_prelaunch.so
 timeout 900 python -m pytest -q -m gpu -x tests 2>&1 | tail -15 > $O/gpu_tests.txt; tail -4 $O/gpu_tests.txt | cut -c1-200
 el "product GPU suite"
+if [ -x tools/launch_probe ]; then HIP_FORCE_DEV_KERNARG=0 timeout 120 tools/launch_probe 2>&1 | head -4 > $O/launch_probe_kernarg0.txt; HIP_FORCE_DEV_KERNARG=1 timeout 120 tools/launch_probe > $O/launch_probe.txt 2>&1; echo "launch probe (first lines: kernel arguments in host memory; then in device memory)"; cat $O/launch_probe_kernarg0.txt $O/launch_probe.txt; fi
+el "launch probe"
 if [ -x tools/mailbox_probe ]; then timeout 120 tools/mailbox_probe > $O/mailbox_probe.txt 2>&1; echo "mailbox probe rc=$?"; cat $O/mailbox_probe.txt; fi
 el "mailbox probe"
 if [ -f $V ]; then
