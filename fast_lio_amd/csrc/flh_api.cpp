@@ -50,6 +50,7 @@ namespace flh { void pass_stamps_read(unsigned long long* out, size_t words); }
 typedef unsigned long long u64;
 #define FLH_COUNTER_WORDS 1
 
+constexpr int kStagerPollUs = 400;  // how long the staging thread polls for its next job before it sleeps (stager_main)
 constexpr int kGranGroups = 64;   // at most this many first-level groups go the granule way (else the in-kernel two-level sum)
 constexpr int kGranSlots = 93;    // gran_section_slots(12): the Gram entries the filter reads + one statistic
 constexpr size_t kGranSect = 1 + (size_t)kGranGroups * kGranSlots;  // granules of one rank's section: header + [group][slot]
@@ -285,9 +286,7 @@ struct flh_handle {
     DevBuf<uint32_t> st_m0, st_m1;          // Morton keys of the staging sort
     DevBuf<uint32_t> st_v0, st_v1;
     DevBuf<unsigned char> st_tmp;
-#ifdef FLH_EXP_SPINSTAGER
-    std::atomic<uint64_t> st_posted{0};  // jobs ever handed to the staging thread
-#endif
+    std::atomic<uint64_t> st_posted{0};  // jobs ever handed to the staging thread (what it polls before it sleeps)
 #ifdef FLH_EXP_PRELAUNCH  // (developer builds: the pre-launched no-search pass, exp/flh_prelaunch_host.inc)
     struct PreLaunch {
         bool enabled = false, off = false, armed = false, via_mail = false;
@@ -1258,19 +1257,19 @@ static void stager_main(flh_handle* h) {
     (void)hipSetDevice(h->device);
     std::unique_lock<std::mutex> lk(h->st_mu);
     for (;;) {
-#ifdef FLH_EXP_SPINSTAGER  // (developer builds) in a running stream the next job arrives within a scan's time: poll for it for a
-                            // while before sleeping, so that flh_scan_stage_async's notify finds nobody to wake (no futex call on
-                            // the thread that is about to launch a scan's first pass)
+        // In a running stream the next job arrives within a scan's time: poll for it for a while before sleeping, so that
+        // flh_scan_stage_async's notify finds nobody to wake -- no futex call on the thread that is about to launch a scan's
+        // first pass (measured without a device, tests/cpp/stager_check.cpp: the hand-over costs its caller 0.5 us instead
+        // of 4-6).  A stream slower than the window pays the wake-up as before.
         if (h->st_queue.empty() && !h->st_quit) {
             const uint64_t seen = h->st_posted.load(std::memory_order_acquire);
             lk.unlock();
             const auto t0 = std::chrono::steady_clock::now();
             while (h->st_posted.load(std::memory_order_acquire) == seen &&
-                   std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(400))
+                   std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(kStagerPollUs))
                 cpu_relax();
             lk.lock();
         }
-#endif
         h->st_cv.wait(lk, [&] { return h->st_quit || !h->st_queue.empty(); });
         if (h->st_queue.empty()) return;  // quit
         flh_handle::StageJob job = h->st_queue.front();
@@ -1360,9 +1359,7 @@ int flh_scan_stage_async(flh_handle* h, int slot, const void* pts, size_t stride
     if (!h->stager.joinable()) h->stager = std::thread(stager_main, h);
     h->slots[slot].pending = true;
     h->st_queue.push_back({slot, pts, stride_bytes, N});
-#ifdef FLH_EXP_SPINSTAGER
     h->st_posted.fetch_add(1, std::memory_order_release);
-#endif
     h->st_cv.notify_one();
     return 0;
 }

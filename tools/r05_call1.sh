@@ -7,7 +7,6 @@
 #   python tools/variant.py --name prelaunch --define FLH_EXP_PRELAUNCH --build-only
 #   python tools/variant.py --name red8 --define FLH_EXP_RED8 --build-only
 #   python tools/variant.py --name prelaunch_red8 --define FLH_EXP_PRELAUNCH --define FLH_EXP_RED8 --build-only
-#   python tools/variant.py --name prelaunch_red8_spin --define FLH_EXP_PRELAUNCH --define FLH_EXP_RED8 --define FLH_EXP_SPINSTAGER --build-only
 #   hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/mailbox_probe.cpp -o tools/mailbox_probe
 #   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude tools/launch_probe.cpp -Lfast_lio_amd/lib -lfastlio_hip -Wl,-rpath,'$ORIGIN/../fast_lio_amd/lib' -o tools/launch_probe
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -27,9 +26,9 @@ if [ -f $V ]; then
   FLH_LIB=$V timeout 600 python tools/prelaunch_check.py > $O/prelaunch_check_config2.txt 2>&1; echo "prelaunch check (config 2) rc=$?"; tail -16 $O/prelaunch_check_config2.txt
   el "prelaunch check"
   # A/B on one box, alternating: the product, the pre-launched no-search pass, k_fit's reducer with eight loads per trip
-  # (-DFLH_EXP_RED8), both, both + a staging thread that polls before it sleeps (-DFLH_EXP_SPINSTAGER)
+  # (-DFLH_EXP_RED8), both
   for rep in 1 2; do
-    for v in base prelaunch red8 prelaunch_red8 prelaunch_red8_spin; do
+    for v in base prelaunch red8 prelaunch_red8; do
       L=$R/fast_lio_amd/lib/libfastlio_hip.so; [ $v != base ] && L=$R/fast_lio_amd/lib/libfastlio_hip_$v.so
       [ -f $L ] || continue
       FLH_LIB=$L timeout 300 python bench.py --steps 300 --warmup 30 --cpu-scans 0 --no-extra-legs > $O/bench_${v}_$rep.json 2> $O/bench_${v}_$rep.err; echo "$v $rep rc=$?"; python tools/bench_line.py $O/bench_${v}_$rep.json
