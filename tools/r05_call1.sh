@@ -7,6 +7,7 @@
 #   python tools/variant.py --name prelaunch --define FLH_EXP_PRELAUNCH --build-only
 #   python tools/variant.py --name red8 --define FLH_EXP_RED8 --build-only
 #   python tools/variant.py --name prelaunch_red8 --define FLH_EXP_PRELAUNCH --define FLH_EXP_RED8 --build-only
+#   python tools/variant.py --name skipwait --define FLH_EXP_SKIPWAIT --build-only
 #   hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/mailbox_probe.cpp -o tools/mailbox_probe
 #   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude tools/launch_probe.cpp -Lfast_lio_amd/lib -lfastlio_hip -Wl,-rpath,'$ORIGIN/../fast_lio_amd/lib' -o tools/launch_probe
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -26,9 +27,9 @@ if [ -f $V ]; then
   FLH_LIB=$V timeout 600 python tools/prelaunch_check.py > $O/prelaunch_check_config2.txt 2>&1; echo "prelaunch check (config 2) rc=$?"; tail -16 $O/prelaunch_check_config2.txt
   el "prelaunch check"
   # A/B on one box, alternating: the product, the pre-launched no-search pass, k_fit's reducer with eight loads per trip
-  # (-DFLH_EXP_RED8), both
+  # (-DFLH_EXP_RED8), both; no barrier packet in front of a scan's first pass when its staging has finished (-DFLH_EXP_SKIPWAIT)
   for rep in 1 2; do
-    for v in base prelaunch red8 prelaunch_red8; do
+    for v in base prelaunch red8 prelaunch_red8 skipwait; do
       L=$R/fast_lio_amd/lib/libfastlio_hip.so; [ $v != base ] && L=$R/fast_lio_amd/lib/libfastlio_hip_$v.so
       [ -f $L ] || continue
       FLH_LIB=$L timeout 300 python bench.py --steps 300 --warmup 30 --cpu-scans 0 --no-extra-legs > $O/bench_${v}_$rep.json 2> $O/bench_${v}_$rep.err; echo "$v $rep rc=$?"; python tools/bench_line.py $O/bench_${v}_$rep.json
