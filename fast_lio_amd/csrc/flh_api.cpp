@@ -204,6 +204,9 @@ struct flh_handle {
     bool gran_owned = true;        // h_gran came from hipHostMalloc (else: a window of the peers' shared segment)
     double* gran_dst[flh::kPeersMax] = {};
     int peer_n = 1, peer_rank = 0;
+    int sect_ng[flh::kPeersMax] = {};   // groups in rank r's granule section for the ACTIVE scan (0 = not seen yet): learnt from a
+                                        // section's header, the same for every pass of a scan (collect_granules)
+    std::vector<double> gran_val;       // collect_granules' buffer when it takes a pass's granules in the order they arrive
     void* peer_map = nullptr;      // the mapped (and registered) shared segment
     size_t peer_map_bytes = 0;
     std::string peer_name;
@@ -983,6 +986,7 @@ static int prepare_scan_buffers(flh_handle* h, size_t N, bool full_clear) {
         HIPC(hipMemsetAsync(h->world.p, 0, n1 * sizeof(float4), st));
     }
     h->N = N;
+    for (int& g : h->sect_ng) g = 0;  // the peers' shards change with the scan
     h->have_eval = false;
     h->searched_once = false;
     h->d2_valid = false;
@@ -1715,35 +1719,89 @@ static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
         }
     };
     // A one-launch searching pass hands the END of the scan's order to the workgroups dispatched first, and workgroups finish in
-    // dispatch order: its groups arrive LAST GROUP FIRST, and the section's header -- group 0's reducer
+    // dispatch order: its groups arrive LAST GROUP FIRST, and a section's header -- group 0's reducer
     // publishes it behind its sums -- is the very last granule of the pass.  Waiting for the header and only then reading 25 x 30
     // granules would put the whole pick-up behind the last arrival.  So the granules of such a pass are taken in the order they
-    // come, into a local buffer, and added up in group order afterwards: the same additions in the same order, hence the same
-    // bits.  (One rank only: a peer's section cannot be sized before its header is there.)
-    const bool last_group_first = do_search && h->peer_n == 1 && h->peer_rank == 0 && use_pass_kernel(h, true);
-    if (last_group_first) {
-        const int red = gran_group_size(h->N);
-        const int ng = red > 0 ? (flh::pass_blocks((int)h->N) + red - 1) / red : 0;  // the groups launch_pass's kernel publishes
-        if (ng < 1 || ng > kGranGroups) return fail("flh_eval: granule groups out of range");
-        double val[kGranGroups * kGranSlots];
-        const double* sect = base;
-        for (int gi = ng - 1; gi >= 0; --gi) {
-            const double* gg = sect + 2 * (1 + (size_t)gi * nsl);
-            for (int k = 0; k < nsl; ++k)
-                if (wait_for(gg + 2 * k, &val[(size_t)gi * nsl + k]) != 0) return -1;
-        }
-        double cnt_d = 0;
-        if (wait_for(sect, &cnt_d) != 0) return -1;
-        if ((int)cnt_d != ng * nsl) return fail("flh_eval: malformed granule section");
-        for (int gi = 0; gi < ng; ++gi)
-            for (int k = 0; k < nsl; ++k) sum[k] += val[(size_t)gi * nsl + k];
-    } else
+    // come -- every rank's last group, then every rank's last but one, ... -- into a buffer, and added up in (rank, group) order
+    // afterwards: the same additions in the same order, hence the same bits.  That needs the number of groups of every section
+    // before its header is there: this rank's follows from its scan; a peer's is learnt from the header of an earlier pass of the
+    // same scan (it depends on the shard's size only), until then the section is read header first, as a no-search pass's is
+    // (k_fit's groups arrive in ascending order).
+    const int own_red = gran_group_size(h->N);
+    const int own_ng = own_red > 0 ? (flh::pass_blocks((int)h->N) + own_red - 1) / own_red : 0;  // what this rank's kernels publish
+    bool arrival_order = do_search && use_pass_kernel(h, true);
+    int ng_of[flh::kPeersMax] = {};
     for (int r = 0; r < h->peer_n; ++r) {
+        ng_of[r] = (r == h->peer_rank) ? own_ng : h->sect_ng[r];
+        if (ng_of[r] < 1 || ng_of[r] > kGranGroups) arrival_order = false;
+    }
+    bool taken[flh::kPeersMax] = {};  // sections whose sums are in val already (arrival order); the others are read header first
+    size_t off[flh::kPeersMax + 1] = {};
+    if (arrival_order) {
+        int max_ng = 0;
+        for (int r = 0; r < h->peer_n; ++r) {
+            off[r + 1] = off[r] + (size_t)ng_of[r] * nsl;
+            if (ng_of[r] > max_ng) max_ng = ng_of[r];
+            taken[r] = true;
+        }
+        if (h->gran_val.size() < off[h->peer_n]) h->gran_val.resize(off[h->peer_n]);
+        double* val = h->gran_val.data();
+        // a peer's group count is a hint (its shard may have changed since the header it was learnt from): while waiting for a
+        // hinted group the section's header is watched too -- it is the last granule a rank publishes, so a header without the
+        // awaited group means the hint was wrong, and the section is read header first below
+        auto wait_hinted = [&](const double* gp, double* value, const double* hdr) -> int {
+            for (uint32_t n = 0;; ++n) {
+                const __m128d x = _mm_load_pd(gp);
+                if (_mm_cvtsd_f64(_mm_unpackhi_pd(x, x)) == seq) { *value = _mm_cvtsd_f64(x); return 0; }
+                if ((n & 63u) == 63u) {
+                    const __m128d hx = _mm_load_pd(hdr);
+                    if (_mm_cvtsd_f64(_mm_unpackhi_pd(hx, hx)) == seq) {
+                        const __m128d y = _mm_load_pd(gp);  // (the group may have landed between the two looks)
+                        if (_mm_cvtsd_f64(_mm_unpackhi_pd(y, y)) == seq) { *value = _mm_cvtsd_f64(y); return 0; }
+                        return 1;
+                    }
+                    double dummy;
+                    if ((n & 0xFFFFu) == 0xFFFFu && wait_for(hdr, &dummy) != 0) return -1;  // the slow path's checks (it returns once the header is there)
+                }
+                cpu_relax();
+            }
+        };
+        for (int step = 0; step < max_ng; ++step)
+            for (int r = 0; r < h->peer_n; ++r) {
+                const int gi = ng_of[r] - 1 - step;
+                if (gi < 0 || !taken[r]) continue;
+                const double* sect = base + (size_t)r * kGranSect * 2;
+                const double* gg = sect + 2 * (1 + (size_t)gi * nsl);
+                for (int k = 0; k < nsl; ++k) {
+                    const int rc = (r == h->peer_rank) ? wait_for(gg + 2 * k, &val[off[r] + (size_t)gi * nsl + k])
+                                                       : wait_hinted(gg + 2 * k, &val[off[r] + (size_t)gi * nsl + k], sect);
+                    if (rc < 0) return -1;
+                    if (rc > 0) { taken[r] = false; break; }
+                }
+            }
+        for (int r = 0; r < h->peer_n; ++r) {
+            if (!taken[r]) continue;
+            double cnt_d = 0;
+            if (wait_for(base + (size_t)r * kGranSect * 2, &cnt_d) != 0) return -1;
+            if ((int)cnt_d != ng_of[r] * nsl) {
+                if (r == h->peer_rank) return fail("flh_eval: malformed granule section");
+                taken[r] = false;  // a peer with more groups than the hint said
+            }
+        }
+    }
+    for (int r = 0; r < h->peer_n; ++r) {  // the sums, in (rank, group) order
+        if (taken[r]) {
+            const double* val = h->gran_val.data();
+            for (int gi = 0; gi < ng_of[r]; ++gi)
+                for (int k = 0; k < nsl; ++k) sum[k] += val[off[r] + (size_t)gi * nsl + k];
+            continue;
+        }
         const double* sect = base + (size_t)r * kGranSect * 2;
         double cnt_d = 0;
         if (wait_for(sect, &cnt_d) != 0) return -1;
         const int cnt = (int)cnt_d;
         if (cnt <= 0 || cnt % nsl != 0 || cnt / nsl > kGranGroups) return fail("flh_eval: malformed granule section");
+        h->sect_ng[r] = cnt / nsl;
         for (int gi = 0; gi < cnt / nsl; ++gi) {
             const double* gg = sect + 2 * (1 + (size_t)gi * nsl);
             for (int k = 0; k < nsl; ++k) {
@@ -2472,6 +2530,7 @@ static void peer_attach(flh_handle* h, PeerSeg* sg, int nranks, int rank) {
     sg->refs++;
     h->peer_n = nranks;
     h->peer_rank = rank;
+    for (int& g : h->sect_ng) g = 0;
     h->h_gran_own = h->h_gran;
     h->h_gran = reinterpret_cast<double*>(sg->host) + (size_t)rank * window;
     h->gran_owned = false;
@@ -2557,6 +2616,7 @@ void flh_peer_close(flh_handle* h) {
     h->gran_dst[0] = h->h_gran;
     h->peer_n = 1;
     h->peer_rank = 0;
+    for (int& g : h->sect_ng) g = 0;
     if (--sg->refs == 0) {
         if (sg->shm) {
             (void)hipHostUnregister(sg->host);
