@@ -1269,9 +1269,12 @@ static void stager_main(flh_handle* h) {
             const uint64_t seen = h->st_posted.load(std::memory_order_acquire);
             lk.unlock();
             const auto t0 = std::chrono::steady_clock::now();
-            while (h->st_posted.load(std::memory_order_acquire) == seen &&
-                   std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(kStagerPollUs))
-                cpu_relax();
+            while (h->st_posted.load(std::memory_order_acquire) == seen) {
+                const auto waited = std::chrono::steady_clock::now() - t0;
+                if (waited >= std::chrono::microseconds(kStagerPollUs)) break;
+                if (waited < std::chrono::microseconds(50)) cpu_relax();
+                else std::this_thread::yield();  // (gives the core away when somebody else wants it, returns at once when nobody does)
+            }
             lk.lock();
         }
         h->st_cv.wait(lk, [&] { return h->st_quit || !h->st_queue.empty(); });
