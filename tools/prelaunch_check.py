@@ -5,6 +5,7 @@ through a mailbox, fast_lio_amd/csrc/exp/): is the result the same, bit for bit,
     python tools/variant.py --name prelaunch --define FLH_EXP_PRELAUNCH --build-only          # here (cross-compile)
     FLH_LIB=fast_lio_amd/lib/libfastlio_hip_prelaunch.so python tools/prelaunch_check.py      # on the GPU box
 
+0. kernel    one no-search evaluation through the mailbox against the same evaluation launched the usual way: same bits.
 1. parity   the same scans updated with the switch off (plain launches) and on: posterior state and covariance, pass schedule,
             n_eff of every pass, point_selected_surf must be IDENTICAL (the mailbox kernel runs k_fit<1,false,2>'s statements on
             the same units in the same tree); the counters must show that the mailbox was really used.
@@ -71,6 +72,25 @@ def update_all(on):
                     [st.pass_search[i] for i in range(st.passes)], h.fetch_selected().copy()))
     return res
 
+
+# ---- 0. one evaluation, kernel against kernel: k_fit<1,false,2> and k_fit_mb at the same state after the same search
+switch(h, 1)
+h.scan_upload(probs[0].body)
+xa, xb = priors[0][0], probs[0].x_true
+ref_s = h.eval(xa, True, False)
+ref_n = h.eval(xb, False, False)
+ca = switch(h, -1)
+L.flh_exp_prelaunch(h.ptr, 1)
+got_s = h.eval(xa, True, False)     # arms the next pass's kernel
+got_n = h.eval(xb, False, False)    # handed over through the mailbox
+L.flh_exp_prelaunch(h.ptr, 0)
+cb = switch(h, -1)
+one_ok = (np.array_equal(got_s[0], ref_s[0]) and np.array_equal(got_n[0], ref_n[0]) and np.array_equal(got_n[1], ref_n[1])
+          and got_n[2] == ref_n[2] and got_n[3] == ref_n[3])
+print("one evaluation: go", cb["go"] - ca["go"], "abort", cb["abort"] - ca["abort"], "->", "identical" if one_ok else
+      f"DIFFERENT (max |dHTH| {np.abs(got_n[0] - ref_n[0]).max():.3e} of {np.abs(ref_n[0]).max():.3e}, n_eff {got_n[2]} vs {ref_n[2]})")
+if not one_ok or cb["go"] == ca["go"]:
+    bad += 1
 
 # ---- 1. parity
 c0 = switch(h, -1)
