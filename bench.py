@@ -188,6 +188,8 @@ def main():
                     help="developer: sample every n-th searching evaluation with events, ALSO under a profiler (0 = the default "
                          "sampling, none under a profiler)")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the headline + roofline (profiling runs)")
+    ap.add_argument("--repeats", type=int, default=4,
+                    help="after the contract's timed region, repeat it this many times on the same stream -> value_repeats (median/min/max)")
     ap.add_argument("--cpu-scans", type=int, default=96,
                     help="upper bound of the scans timed on the CPU oracle at --cpu-threads (it stops after ~12 s; 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=3, help="OpenMP threads (reference MP_PROC_NUM = 3)")
@@ -369,10 +371,23 @@ def main():
     if mode in ("shard", "partition") and G == 1 and not args.force_shard_leg:
         mode = "streams"  # one rank: nothing to shard
     replicas_out = None
+    repeats = None
     if mode == "streams":
         dt, acc, ctr = run(kf, h, jobs_pipe, args.warmup, args.steps)
         units = args.steps * G
         n_pts = N
+        # the contract's fields are THIS region's.  One region of the driver's command is 3 ms on boxes that differ by 20 %: the
+        # same region is repeated on the same stream (the scans keep cycling, no new warm-up beyond two scans) so that the line
+        # carries a spread beside its one number
+        if args.repeats > 0 and not PROFILED:
+            vals = [units / dt]
+            for _ in range(args.repeats):
+                dt_r, _a, _c = run(kf, h, jobs_pipe, 2, args.steps)
+                vals.append(units / dt_r)
+            sv = sorted(vals)
+            repeats = {"regions": len(vals), "median": round(sv[len(sv) // 2], 3), "min": round(sv[0], 3), "max": round(sv[-1], 3),
+                       "all": [round(v, 1) for v in vals],
+                       "note": "the first entry of `all` is the contract's region (= value); the others repeat it on the same stream"}
     elif run_replica_leg:
         k1 = max(10, min(60, args.steps // 2))
         dt1, _a1, _c1 = run(kf, h, jobs_pipe, max(3, args.warmup // 2), k1)
@@ -568,6 +583,8 @@ def main():
         "searches_per_scan": round(acc.searches / args.steps, 3),
         "map_build_s": round(t_build, 3),
     }
+    if repeats is not None:
+        out["value_repeats"] = repeats
     if with_map_inserts:
         # host time inside flh_map_incremental per scan: enqueueing the classification and the Add_Points work (nobody asks for the
         # two list lengths, so the host does not wait for them when the previous change was of a scan's usual size); the device

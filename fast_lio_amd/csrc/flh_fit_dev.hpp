@@ -160,13 +160,11 @@ __device__ __forceinline__ void group_sum_publish(const double* partials, int gr
     const int halfq = (nq + 1) >> 1;   // quads of its lower half
     const int hi = wl >> 5, sl = wl & 31;
     const int qlo = hi ? halfq : 0, qhi = hi ? nq : halfq;
-#ifdef FLH_EXP_RED8  // (developer builds: k_fit's reducer reads the eight quad records of a half group in ONE load round trip
-                     // instead of two; the same tree, the same order of additions, hence the same bits.  k_pass's reducer keeps
-                     // sixteen loads per trip: thirty-two do not fit its 72 registers)
+    // k_fit's reducer reads the eight quad records of a half group in ONE load round trip (the same tree, the same order of
+    // additions as with two trips of four; same box, two alternating pairs, profiles/r05_call1/: no-search pass 18.3 / 18.4 ->
+    // 17.8 / 18.0 us, 7 431 / 7 399 -> 7 512 / 7 484 scans/s).  k_pass's reducer keeps sixteen loads per trip: thirty-two do
+    // not fit its 72 registers
     constexpr int QB = QUADS ? 8 : 4;
-#else
-    constexpr int QB = 4;
-#endif
     for (int slot = sl; slot < ((nsl + 31) & ~31); slot += 32) {
         const int sc = slot < nsl ? slot : nsl - 1;
         double s0 = 0.0;
