@@ -34,6 +34,9 @@ class FlhConfig(C.Structure):
         ("undistort_first_point", C.c_int),
         ("plane_cache", C.c_int),
         ("fused_small_changes", C.c_int),
+        ("prelaunch", C.c_int),
+        ("index_cache", C.c_int),
+        ("pass_lanes", C.c_int),
     ]
 
 
@@ -96,6 +99,7 @@ EXPORTS = [
     "flh_esekf_last_error", "flh_rccl_unique_id", "flh_rccl_init_rank", "flh_rccl_init_all", "flh_rccl_destroy", "flh_rccl_size",
     "flh_rccl_rank", "flh_eval_group", "flh_set_owned_interval", "flh_esekf_run_scans", "flh_get_search_counters", "flh_set_timing_sampling",
     "flh_map_sync", "flh_eval_begin", "flh_eval_end", "flh_debug_bounds", "flh_debug_pass_stamps", "flh_peer_open", "flh_peer_init_all", "flh_peer_close", "flh_peer_size", "flh_peer_rank", "flh_get_pass_stats", "flh_map_change_stats",
+    "flh_eval_expect_next", "flh_set_prelaunch", "flh_get_prelaunch_stats",
 ]
 
 _lib = None
@@ -209,6 +213,9 @@ def lib():
     L.flh_peer_close.restype = None
     L.flh_peer_size.argtypes = [C.c_void_p]
     L.flh_peer_rank.argtypes = [C.c_void_p]
+    L.flh_eval_expect_next.argtypes = [C.c_void_p, C.c_int]
+    L.flh_set_prelaunch.argtypes = [C.c_void_p, C.c_int]
+    L.flh_get_prelaunch_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.flh_get_pass_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.flh_rccl_size.argtypes = [C.c_void_p]
     L.flh_rccl_rank.argtypes = [C.c_void_p]
@@ -270,7 +277,7 @@ class Handle:
     def __init__(self, cell_size: float = 1.5, lanes_per_query: int = 4, device: int = -1, stream: int | None = None,
                  plane_threshold: float = 0.1, max_sqdist: float = 5.0, sort_queries: int = -1, pass_kernel: int = -1,
                  eigen_order: int = -1, plane_fit_dtype: int = 0, undistort_first_point: int = -1, plane_cache: int = -1,
-                 fused_small_changes: int = -1):
+                 fused_small_changes: int = -1, prelaunch: int = -1, index_cache: int = -1, pass_lanes: int = 0):
         L = lib()
         cfg = FlhConfig()
         L.flh_default_config(C.byref(cfg))
@@ -287,6 +294,9 @@ class Handle:
         cfg.undistort_first_point = undistort_first_point
         cfg.plane_cache = plane_cache
         cfg.fused_small_changes = fused_small_changes
+        cfg.prelaunch = prelaunch
+        cfg.index_cache = index_cache
+        cfg.pass_lanes = pass_lanes
         self._h = C.c_void_p()
         _chk(L.flh_create(C.byref(cfg), C.byref(self._h)), "flh_create")
         self._keep = []
@@ -412,6 +422,18 @@ class Handle:
         _chk(lib().flh_get_pass_stats(self._h, out), "flh_get_pass_stats")
         return {"search_passes": int(out[0]), "one_launch_passes": int(out[1]), "second_stage_queries": int(out[2]),
                 "nosearch_passes": int(out[3])}
+
+    def expect_next(self, kind: int) -> None:
+        """flh_eval_expect_next: 0 unknown, 1 a no-search evaluation probably follows the next one, 2 nothing follows."""
+        _chk(lib().flh_eval_expect_next(self._h, kind), "flh_eval_expect_next")
+
+    def set_prelaunch(self, on: bool) -> None:
+        _chk(lib().flh_set_prelaunch(self._h, 1 if on else 0), "flh_set_prelaunch")
+
+    def prelaunch_stats(self) -> dict:
+        out = (C.c_uint64 * 4)()
+        _chk(lib().flh_get_prelaunch_stats(self._h, out), "flh_get_prelaunch_stats")
+        return {"armed": int(out[0]), "go": int(out[1]), "abort": int(out[2]), "gone": int(out[3])}
 
     def rccl_size(self) -> int:
         return int(lib().flh_rccl_size(self._h))

@@ -27,11 +27,10 @@
 #include <vector>
 
 #include "../../include/fastlio_hip.h"
+#include "../../include/fastlio_hip_dev.h"
 #include "../../include/fastlio_amd/local_map.hpp"
 #include "flh_kernels.hpp"
-#ifdef FLH_EXP_PRELAUNCH
-#include "exp/flh_mail_dev.hpp"
-#endif
+#include "flh_mail_dev.hpp"
 
 using flh::GridParams;
 using flh::StateDev;
@@ -177,6 +176,7 @@ struct flh_handle {
     // scan
     size_t N = 0;
     DevBuf<float4> world, nn_pts, normvec;
+    DevBuf<uint32_t> nn_idx;               // the neighbour cache as map indices (flh_config.index_cache): what a one-launch pass writes
     DevBuf<float4> plane;     // flh_config.plane_cache: (a, b, c, d) of the last searching pass's fits, reused by no-search passes
     bool plane_cache = false;
     bool planes_valid = false;  // `plane` holds the fits of the CURRENT neighbour cache (written by the fit that followed the last search)
@@ -231,6 +231,7 @@ struct flh_handle {
     bool searched_once = false;
     bool d2_valid = false;    // nn_d2 holds the distances of the current neighbour cache (filled on demand, ensure_d2)
     bool aux_valid = false;   // world / normvec hold the last evaluation's (filled on demand, ensure_aux)
+    bool nn_pts_valid = true; // nn_pts holds the coordinates of the current neighbour cache (false: only nn_idx does; ensure_nn_pts gathers)
     int timing_stride = 1;   // record HIP events on every n-th evaluation (0 = never)
     bool timing_search_only = false;  // count (and time) SEARCHING evaluations only
     uint64_t eval_no = 0;
@@ -290,9 +291,14 @@ struct flh_handle {
     DevBuf<uint32_t> st_v0, st_v1;
     DevBuf<unsigned char> st_tmp;
     std::atomic<uint64_t> st_posted{0};  // jobs ever handed to the staging thread (what it polls before it sleeps)
-#ifdef FLH_EXP_PRELAUNCH  // (developer builds: the pre-launched no-search pass, exp/flh_prelaunch_host.inc)
+    // The pre-launched no-search pass (flh_eval_expect_next; device side: flh_mail_dev.hpp, k_fit_mb in flh_kernels.hip).
+    //   expect     what the caller said the evaluation AFTER the next flh_eval_begin will be (consumed by that begin)
+    //   armed      a k_fit_mb sits in the stream waiting for mailbox sequence `mseq`; it will publish with granule sequence `eval_seq`
+    //   via_mail   the evaluation under way was started through the mailbox (collect_granules: if the kernel had already given up --
+    //              the host came more than 20 ms late -- the pass is launched the usual way, pre_gone_relaunch)
     struct PreLaunch {
-        bool enabled = false, off = false, armed = false, via_mail = false;
+        bool off = false, armed = false, via_mail = false;
+        int expect = 0;
         uint32_t mseq = 0;
         double eval_seq = 0;
         int ext = 0;
@@ -303,7 +309,6 @@ struct flh_handle {
         double* dev_box = nullptr;
         uint64_t n_armed = 0, n_go = 0, n_abort = 0, n_gone = 0;
     } pre;
-#endif
 };
 
 extern "C" {
@@ -311,10 +316,8 @@ extern "C" {
 static void release_build_scratch(flh_handle* h);
 static void stop_stager(flh_handle* h);
 static int rccl_allreduce_publish(flh_handle* h, double seq);
-#ifdef FLH_EXP_PRELAUNCH
-int flh_exp_prelaunch(flh_handle* h, int enable);
 static void pre_release(flh_handle* h);
-#endif
+static void pre_cancel(flh_handle* h);
 static StateDev make_state(const double rot[4], const double pos[3], const double offR[4], const double offT[3]);
 
 const char* flh_last_error(void) { return g_err.c_str(); }
@@ -354,6 +357,9 @@ void flh_default_config(flh_config* c) {
     c->undistort_first_point = -1;
     c->plane_cache = -1;
     c->fused_small_changes = -1;
+    c->prelaunch = -1;
+    c->index_cache = -1;
+    c->pass_lanes = 0;
 }
 
 int flh_create(const flh_config* cfg_in, flh_handle** out) {
@@ -374,6 +380,9 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.undistort_first_point != 0) cfg.undistort_first_point = 1;
     if (cfg.plane_cache != 0) cfg.plane_cache = 1;
     if (cfg.fused_small_changes != 0) cfg.fused_small_changes = 1;
+    if (cfg.prelaunch != 0) cfg.prelaunch = 1;
+    if (cfg.index_cache != 0) cfg.index_cache = 1;
+    if (cfg.pass_lanes != 4 && cfg.pass_lanes != 8 && cfg.pass_lanes != 16) cfg.pass_lanes = 0;
     if (cfg.lanes_per_query != 0) cfg.lanes_per_query = 4;  // 0 = exact kernel for every query
     flh_handle* h = new flh_handle();
     h->cfg = cfg;
@@ -418,6 +427,7 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
         return fail("hipMalloc failed");
     }
     h->plane_cache = cfg.plane_cache != 0;
+    h->pre.off = cfg.prelaunch == 0;
     h->rmax = (int)std::ceil((std::sqrt((double)cfg.max_sqdist) + 2e-3 * cfg.cell_size) / cfg.cell_size);
     if (h->rmax < 1) h->rmax = 1;
     {
@@ -436,9 +446,7 @@ void flh_destroy(flh_handle* h) {
     if (!h) return;
     stop_stager(h);
     (void)hipSetDevice(h->device);
-#ifdef FLH_EXP_PRELAUNCH
-    (void)flh_exp_prelaunch(h, 0);
-#endif
+    pre_cancel(h);
     flh_rccl_destroy(h);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -450,7 +458,7 @@ void flh_destroy(flh_handle* h) {
     h->map_orig.release(); h->map_next.release(); h->mb_aabb.release(); h->mu_add.release(); h->mi_world.release(); h->mi_cnt.release(); h->mi_far.release();
     h->mu_alive.release(); h->mi_cls.release(); h->mu_flags.release(); h->mu_incl.release(); h->mu_boxes.release();
     h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_list2.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
-    h->world.release(); h->nn_pts.release(); h->normvec.release(); h->plane.release();
+    h->world.release(); h->nn_pts.release(); h->normvec.release(); h->plane.release(); h->nn_idx.release();
     h->nn_d2.release(); h->nn_cnt.release(); h->selected.release(); h->vox_tab.release();
     h->partials.release(); h->part2.release(); h->gram.release(); h->gather_buf.release(); h->counter.release();
     for (auto& sl : h->slots) {
@@ -477,9 +485,7 @@ void flh_destroy(flh_handle* h) {
         for (auto& e : t3)
             if (e) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
-#ifdef FLH_EXP_PRELAUNCH
     pre_release(h);
-#endif
     delete h;
 }
 
@@ -503,8 +509,10 @@ size_t flh_scan_size(const flh_handle* h) { return h ? h->N : 0; }
 static int rebuild_index_impl(flh_handle* h, DevBuf<float4>& pts, size_t M, bool& touched);
 // Map index (re)build.  The new index is written over the old one's buffers, so a failure after that point leaves no
 // usable map: the handle is then marked map-less (flh_eval refuses) instead of pointing at half-written tables.
+static int ensure_nn_pts(flh_handle* h);
 static int rebuild_index(flh_handle* h, DevBuf<float4>& pts, size_t M) {
     bool touched = false;
+    if (ensure_nn_pts(h) != 0) return -1;  // a re-indexing renumbers the ids an index-only neighbour cache refers to: coordinates first
     const int rc = rebuild_index_impl(h, pts, M, touched);
     if (rc != 0 && touched) {
         h->M = 0;
@@ -957,6 +965,7 @@ static int prepare_scan_buffers(flh_handle* h, size_t N, bool full_clear) {
     const size_t n1 = N ? N : 1;
     HIPC(h->world.reserve(n1)); HIPC(h->nn_pts.reserve(5 * n1)); HIPC(h->normvec.reserve(n1));
     if (h->plane_cache) HIPC(h->plane.reserve(n1));
+    if (h->plane_cache && h->cfg.index_cache) HIPC(h->nn_idx.reserve(5 * n1));
     HIPC(h->nn_d2.reserve(5 * n1)); HIPC(h->nn_cnt.reserve(n1)); HIPC(h->selected.reserve(n1));
     {
         const size_t ln = (size_t)flh::list_stripes() * flh::list_stripe_cap((int)N);
@@ -981,6 +990,7 @@ static int prepare_scan_buffers(flh_handle* h, size_t N, bool full_clear) {
         HIPC(hipMemsetAsync(h->selected.p, 1, n1, st));  // memset(point_selected_surf, true, ...) :812
         HIPC(hipMemsetAsync(h->nn_cnt.p, 0, n1, st));
         HIPC(hipMemsetAsync(h->nn_pts.p, 0xFF, 5 * n1 * sizeof(float4), st));  // idx = -1
+        if (h->nn_idx.p) HIPC(hipMemsetAsync(h->nn_idx.p, 0xFF, 5 * n1 * sizeof(uint32_t), st));
         HIPC(hipMemsetAsync(h->nn_d2.p, 0x7F, 5 * n1 * sizeof(float), st));    // large finite; rewritten by search
         HIPC(hipMemsetAsync(h->normvec.p, 0, n1 * sizeof(float4), st));
         HIPC(hipMemsetAsync(h->world.p, 0, n1 * sizeof(float4), st));
@@ -992,6 +1002,7 @@ static int prepare_scan_buffers(flh_handle* h, size_t N, bool full_clear) {
     h->d2_valid = false;
     h->aux_valid = false;
     h->planes_valid = false;
+    h->nn_pts_valid = true;  // (no search on this scan yet: nothing to gather)
     h->mi_valid_N = (size_t)-1;
     return 0;
 }
@@ -1595,6 +1606,16 @@ static bool use_pass_kernel(const flh_handle* h, bool host_granules) {
     return h->pass_ok && host_granules && h->N > 0;
 }
 
+// The coordinates of the current neighbour cache, for whoever reads nn_pts: gathered from the indices a one-launch pass left
+// (flh_config.index_cache), once, on the handle's stream.  Ids are stable between re-indexings; rebuild_index calls this first.
+static int ensure_nn_pts(flh_handle* h) {
+    if (h->nn_pts_valid || h->N == 0 || !h->nn_idx.p) { h->nn_pts_valid = true; return 0; }
+    HIPC(hipSetDevice(h->device));
+    HIPC(flh::launch_nn_gather(h->map_orig.p, (uint32_t)h->n_ids, h->nn_idx.p, (int)h->N, h->nn_pts.p, h->stream));
+    h->nn_pts_valid = true;
+    return 0;
+}
+
 static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext, double* d_out, double seq, hipEvent_t* ev3,
                         bool host_granules = false) {
     const bool timed = ev3 != nullptr;  // four time stamps: first search kernel's start, last one's end, fit kernel's start and end
@@ -1608,13 +1629,18 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
     if (host_granules) gout = gran_out(h, seq);
     if (do_search && h->stats) HIPC(hipMemsetAsync(h->counter.p, 0, FLH_COUNTER_WORDS * sizeof(u64), st));
     if (do_search && use_pass_kernel(h, host_granules)) {
-        // the whole searching pass in one launch (flh_pass.hip); timed: the kernel's own start and end stamps in ev3[0] / ev3[3]
+        // the whole searching pass in one launch (flh_pass.hip); timed: the kernel's own start and end stamps in ev3[0] / ev3[3].
+        // With the plane cache no later pass reads the neighbours' coordinates: the cache keeps their indices (flh_config.index_cache)
+        uint32_t* idx = (h->plane_cache && h->cfg.index_cache) ? h->nn_idx.p : nullptr;
         HIPC(flh::launch_pass(h->cfg.eigen_order, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap, h->cfg.max_sqdist,
                               h->cfg.plane_threshold, ext, h->nn_pts.p, h->nn_cnt.p, h->selected.p, h->plane_cache ? h->plane.p : nullptr,
                               h->partials.p, h->tickets.p, gout, seq, gran_group_size(h->N),
                               h->stats ? h->counter.p : nullptr, h->own_axis, h->own_lo, h->own_hi, st, timed ? ev3[0] : nullptr,
-                              timed ? ev3[3] : nullptr));
+                              timed ? ev3[3] : nullptr, idx));
+        h->nn_pts_valid = idx == nullptr;
     } else {
+        if (do_search) h->nn_pts_valid = true;  // (the search kernels write the coordinates)
+        else if (!h->planes_valid && ensure_nn_pts(h) != 0) return -1;  // a re-fit from the cached neighbours
         if (do_search)
             HIPC(flh::launch_search(h->cfg.lanes_per_query, h->grid, s, h->cur_body, (int)h->N, (uint32_t)h->pts_cap, h->cfg.max_sqdist,
                                     h->rmax, h->nn_pts.p, h->nn_cnt.p, h->selected.p, h->slow_list.p, h->slow_list2.p, h->slow_ub.p,
@@ -1643,6 +1669,7 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
 // demand: the hot path neither writes nor reads them.
 static int ensure_aux(flh_handle* h) {
     if (h->aux_valid || !h->have_eval || h->N == 0) return 0;
+    if (ensure_nn_pts(h) != 0) return -1;
     HIPC(hipSetDevice(h->device));
     HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, h->last_state, h->cur_body, h->nn_pts.p, (int)h->N, h->last_ext,
                          h->cfg.plane_threshold, h->selected.p, h->normvec.p, h->world.p, h->partials.p, h->part2.p, h->gram.p, 0.0,
@@ -1653,15 +1680,14 @@ static int ensure_aux(flh_handle* h) {
 static int ensure_d2(flh_handle* h) {
     if (h->d2_valid || h->N == 0) return 0;
     if (!h->searched_once) return fail("no search on this scan yet");
+    if (ensure_nn_pts(h) != 0) return -1;
     HIPC(hipSetDevice(h->device));
     HIPC(flh::launch_fill_d2(h->search_state, h->cur_body, h->nn_pts.p, (int)h->N, h->nn_d2.p, h->stream));
     h->d2_valid = true;
     return 0;
 }
 
-#ifdef FLH_EXP_PRELAUNCH
 static int pre_gone_relaunch(flh_handle* h, double seq, int ext);
-#endif
 // The group reducers of every rank write {value, sequence} granules straight into this rank's pinned buffer: per rank a
 // header (how many granules follow), then [group][slot].  Waits until every granule carries this evaluation's sequence
 // number, adding the groups up in (rank, group) order as they are seen complete (fixed order -> identical bits run to
@@ -1705,9 +1731,7 @@ static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
             if (_mm_cvtsd_f64(_mm_unpackhi_pd(x, x)) == seq) { *value = _mm_cvtsd_f64(x); return 0; }
             cpu_relax();
             if ((++spins & 0xFFFFFu) == 0) {
-#ifdef FLH_EXP_PRELAUNCH
                 if (pre_gone_relaunch(h, seq, ext) != 0) return -1;
-#endif
                 if (hipStreamQuery(st) != hipErrorNotReady) {  // this rank's kernel finished or failed
                     HIPC(hipStreamSynchronize(st));
                     const __m128d y = _mm_load_pd(gp);
@@ -1834,9 +1858,135 @@ void flh_unpack_gram(const double G[256], double HTH[144], double HTh[12], int64
     if (total_residual) *total_residual = G[14 * 16 + 13];
 }
 
-#ifdef FLH_EXP_PRELAUNCH
-#include "exp/flh_prelaunch_host.inc"
-#endif
+// ---- the pre-launched no-search pass (flh_eval_expect_next) ----------------------------------------------------------------
+// A filter that knows what its NEXT evaluation will probably be says so before it begins this one (the mirror esekf does:
+// include/fastlio_amd/esekfom.hpp).  For FLH_NEXT_NOSEARCH, flh_eval_begin -- after it has started its own pass -- enqueues
+// k_fit_mb for the next one: the launch call, the queue's processing and the dispatch ramp happen beside the pass that is running.
+// When the next flh_eval_begin asks for exactly that (a no-search evaluation of the same scan, not timed, nothing enqueued in
+// between) it writes the state into the mailbox instead of launching; anything else releases the waiting kernel with one store
+// (it retires within a microsecond or two) and goes the usual way.  A wrong expectation costs time, never correctness; a kernel
+// nobody comes for gives up after 20 ms (flh_mail_dev.hpp).  Measured (profiles/r05_call1/, same box, alternating): no-search
+// pass 18.3 -> 14.7 us; the experiment armed after EVERY pass and paid 2.3 us per searching pass for the releases, which the
+// filter's hints avoid (profiles/r05_call2/).
+static int pre_init(flh_handle* h) {
+    flh_handle::PreLaunch& p = h->pre;
+    if (p.host_box) return 0;
+    HIPC(hipHostMalloc((void**)&p.host_box, 16 * sizeof(double), hipHostMallocDefault));
+    HIPC(hipHostMalloc((void**)&p.status, 64, hipHostMallocDefault));
+    HIPC(hipMalloc((void**)&p.dev_box, 16 * sizeof(double)));
+    std::memset(p.host_box, 0, 16 * sizeof(double));
+    std::memset(p.status, 0, 64);
+    HIPC(hipMemset(p.dev_box, 0, 16 * sizeof(double)));
+    HIPC(hipDeviceSynchronize());
+    return 0;
+}
+static void pre_release(flh_handle* h) {
+    flh_handle::PreLaunch& p = h->pre;
+    if (p.host_box) (void)hipHostFree(p.host_box);
+    if (p.status) (void)hipHostFree(p.status);
+    if (p.dev_box) (void)hipFree(p.dev_box);
+    p.host_box = nullptr; p.status = nullptr; p.dev_box = nullptr;
+}
+// state (or nothing) + the {sequence, command} word, the word last
+static void pre_post(flh_handle* h, const StateDev* s, uint32_t cmd) {
+    flh_handle::PreLaunch& p = h->pre;
+    if (s) {
+        static_assert(sizeof(StateDev) == 14 * sizeof(double), "the mailbox carries StateDev as 14 doubles");
+        const double* src = reinterpret_cast<const double*>(s);
+        for (int i = 0; i < 14; ++i) p.host_box[i] = src[i];
+    }
+    const uint64_t w = ((uint64_t)cmd << 32) | (uint64_t)p.mseq;
+    __atomic_store_n(reinterpret_cast<uint64_t*>(p.host_box + 15), w, __ATOMIC_RELEASE);
+    p.armed = false;
+}
+static void pre_cancel(flh_handle* h) {
+    if (!h->pre.armed) return;
+    pre_post(h, nullptr, flh::kMailAbort);
+    h->pre.n_abort++;
+}
+// flh_eval_begin: may this evaluation be handed to the kernel that is waiting?  true: it has been (the caller skips its launch).
+static bool pre_try_go(flh_handle* h, const StateDev& s, const flh_handle::PendingEval& pe) {
+    flh_handle::PreLaunch& p = h->pre;
+    p.via_mail = false;
+    if (!p.armed) return false;
+    const bool fits = !pe.do_search && pe.granules && !pe.timed && pe.ext == p.ext && pe.seq == p.eval_seq && h->N == p.N &&
+                      h->cur_body == p.body && !h->map_pending && h->planes_valid && h->searched_once && !h->comm && h->peer_n == 1;
+    if (!fits) {
+        pre_cancel(h);
+        return false;
+    }
+    pre_post(h, &s, flh::kMailGo);
+    p.via_mail = true;
+    p.n_go++;
+    // what enqueue_eval notes down for a no-search evaluation
+    h->planes_valid = h->plane_cache;
+    h->aux_valid = false;
+    h->last_state = s;
+    h->last_ext = pe.ext;
+    h->have_eval = true;
+    return true;
+}
+// flh_eval_begin, after this evaluation's pass is under way: enqueue the next one's kernel ahead of its state -- when the caller
+// expects a no-search evaluation next (the expectation is consumed here, whatever it was)
+static int pre_arm(flh_handle* h, const flh_handle::PendingEval& pe) {
+    flh_handle::PreLaunch& p = h->pre;
+    const int expect = p.expect;
+    p.expect = FLH_NEXT_UNKNOWN;
+    if (p.off || p.armed || expect != FLH_NEXT_NOSEARCH) return 0;
+    const int red1 = gran_group_size(h->N);
+    // (timing_stride 1 = every evaluation carries events: the next one would be refused anyway)
+    const bool next_may_be_timed = h->timing_stride > 0 && !h->timing_search_only;
+    if (!pe.granules || h->peer_n != 1 || h->comm || !h->plane_cache || h->cfg.eigen_order != FLH_ORDER_SSE || h->cfg.plane_fit_dtype != 0 ||
+        h->N == 0 || red1 < 4 || next_may_be_timed || h->stats /* flh_eval_end waits for the stream then */ || !h->cur_body || !h->plane.p)
+        return 0;
+    if (pre_init(h) != 0) return -1;
+    p.mseq++;
+    p.eval_seq = (double)(h->seq + 1);
+    p.ext = pe.ext;
+    p.N = h->N;
+    p.body = h->cur_body;
+    flh::MailArgs m;
+    m.host_box = p.host_box;
+    m.dev_box = p.dev_box;
+    m.status = p.status;
+    m.seq = p.mseq;
+    HIPC(flh::launch_fit_mb(m, h->cur_body, (int)h->N, pe.ext, h->cfg.plane_threshold, h->selected.p, h->partials.p, p.eval_seq, h->tickets.p,
+                            h->slow_count.p, gran_out(h, p.eval_seq), red1, h->plane.p, h->stream));
+    p.armed = true;
+    p.n_armed++;
+    return 0;
+}
+// collect_granules' slow path: the evaluation went to the mailbox, but the kernel had given up before the mail arrived (it has
+// written nothing): launch the pass the usual way, once, and go on waiting for the same granules
+static int pre_gone_relaunch(flh_handle* h, double seq, int ext) {
+    flh_handle::PreLaunch& p = h->pre;
+    if (!p.via_mail) return 0;
+    const uint64_t st = __atomic_load_n(reinterpret_cast<uint64_t*>(p.status), __ATOMIC_ACQUIRE);
+    if (st == (((uint64_t)flh::kMailLost << 32) | (uint64_t)p.mseq)) return fail("flh_eval: a workgroup of the pre-launched pass never saw its state (flh_mail_dev.hpp)");
+    if (st != (((uint64_t)flh::kMailGone << 32) | (uint64_t)p.mseq)) return 0;
+    p.via_mail = false;
+    p.n_gone++;
+    return enqueue_eval(h, h->last_state, 0, ext, h->h_gram, seq, nullptr, true);
+}
+
+int flh_eval_expect_next(flh_handle* h, int kind) {
+    if (!h) return fail("flh_eval_expect_next: null handle");
+    if (kind != FLH_NEXT_UNKNOWN && kind != FLH_NEXT_NOSEARCH && kind != FLH_NEXT_NONE) return fail("flh_eval_expect_next: unknown kind");
+    h->pre.expect = h->pre.off ? FLH_NEXT_UNKNOWN : kind;
+    if (kind == FLH_NEXT_NONE) pre_cancel(h);  // nothing follows: a kernel that is still waiting is released now
+    return 0;
+}
+int flh_set_prelaunch(flh_handle* h, int on) {
+    if (!h) return fail("flh_set_prelaunch: null handle");
+    h->pre.off = on == 0;
+    if (h->pre.off) { pre_cancel(h); h->pre.expect = FLH_NEXT_UNKNOWN; }
+    return 0;
+}
+int flh_get_prelaunch_stats(const flh_handle* h, uint64_t out4[4]) {
+    if (!h || !out4) return fail("flh_get_prelaunch_stats: null argument");
+    out4[0] = h->pre.n_armed; out4[1] = h->pre.n_go; out4[2] = h->pre.n_abort; out4[3] = h->pre.n_gone;
+    return 0;
+}
 // One h_share_model evaluation in two halves: flh_eval_begin enqueues the pass and returns; flh_eval_end waits for its normal
 // equations.  Between the two the caller's thread is free for host work that does not depend on them (the mirror esekf projects
 // the covariance and inverts P / R there: a third of the 23x23 algebra of a pass leaves the critical path).
@@ -1865,12 +2015,9 @@ int flh_eval_begin(flh_handle* h, const double rot[4], const double pos[3], cons
     pe.granules = !h->comm && h->N > 0 && gran_group_size(h->N) > 0;
     pe.one_launch = pe.do_search && use_pass_kernel(h, pe.granules);
     if (h->peer_n > 1 && !pe.granules) return fail("flh_eval: a scan shard may not be empty when the ranks exchange granules (flh_peer_*)");
-#ifdef FLH_EXP_PRELAUNCH
     if (pre_try_go(h, s, pe)) {
         // the kernel of this evaluation was enqueued beside the previous pass: the state went to its mailbox
-    } else
-#endif
-    if (h->comm) {
+    } else if (h->comm) {
         // this rank's partial block stays in device memory, RCCL sums the ranks' blocks in place (256 doubles: latency-bound,
         // xGMI bandwidth is irrelevant), then one small kernel publishes the sum + sequence word to pinned host memory
         if (enqueue_eval(h, s, do_search, ext, h->gram.p, 0.0, ev3) != 0) return -1;
@@ -1880,9 +2027,7 @@ int flh_eval_begin(flh_handle* h, const double rot[4], const double pos[3], cons
     }
     if (h->stats && do_search) HIPC(hipMemcpyAsync(h->h_counter, h->counter.p, sizeof(u64), hipMemcpyDeviceToHost, st));
     if (do_search) { h->n_search_pass++; if (pe.one_launch) h->n_one_launch++; } else h->n_nosearch_pass++;
-#ifdef FLH_EXP_PRELAUNCH
     if (pre_arm(h, pe) != 0) return -1;
-#endif
     pe.active = true;
     return 0;
 }
@@ -2006,6 +2151,7 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
     }
     // (pointSearchSqDis is recomputed inside the kernels from the neighbour cache -- the search's own expression -- instead of
     // being materialised by k_fill_d2 first; the classification also writes the two lists' membership flags)
+    if (ensure_nn_pts(h) != 0) return -1;  // Nearest_Points' coordinates (laserMapping.cpp:436-466): one gather per scan, here
     HIPC(flh::launch_mi_classify(h->grid, h->grid.hash_mask + 1, (uint32_t)h->M, h->search_state, s_post, h->cur_body,
                                  h->nn_pts.p, h->nn_cnt.p, h->cfg.max_sqdist, (int)N, filter_size_map, flg_EKF_inited,
                                  h->live.p, h->mi_world.p, h->mi_cls.p, N > 0 ? h->mu_flags.p : nullptr, h->mi_far.p, st));
@@ -2105,6 +2251,7 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
     const StateDev s = make_state(x + 3, x + 0, x + 7, x + 11);
     if (map_settle(h) != 0) return -1;
     if (which != 0 && !h->searched_once) return fail("flh_time_kernel: fit kernel timed before any search");
+    if (which != 0 && ensure_nn_pts(h) != 0) return -1;
     HIPC(hipEventRecord(h->ev[0], st));
     for (int it = 0; it < iters; ++it) {
         if (which == 0) {
@@ -2116,6 +2263,7 @@ int flh_time_kernel(flh_handle* h, int which, const double x[FLH_NSTATE], int ex
             h->search_state = s;
             h->d2_valid = false;   // pointSearchSqDis on demand (ensure_d2) must be recomputed for the new neighbours
             h->planes_valid = false;
+            h->nn_pts_valid = true;
         } else {
             HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p,
                                  h->normvec.p, h->world.p, h->partials.p, h->part2.p, h->gram.p, 0.0, h->tickets.p, h->slow_count.p,
@@ -2158,7 +2306,7 @@ int flh_fetch_neighbors(flh_handle* h, int32_t* idx, float* d2, uint8_t* cnt) {
     const size_t N = h->N;
     if (N == 0) return 0;
     HIPC(hipSetDevice(h->device));
-    if (ensure_d2(h) != 0) return -1;
+    if (ensure_nn_pts(h) != 0 || ensure_d2(h) != 0) return -1;
     std::vector<float4> pts(5 * N);
     std::vector<float> dd(5 * N);
     std::vector<uint8_t> cc(N);
@@ -2245,9 +2393,7 @@ static int fetch_rows_peers(flh_handle* h, double* hx, double* hv, int64_t cap, 
 int flh_fetch_rows(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* n_rows) {
     if (!h || !n_rows) return fail("flh_fetch_rows: null argument");
     if (!h->have_eval) return fail("flh_fetch_rows: no evaluation yet");
-#ifdef FLH_EXP_PRELAUNCH
     pre_cancel(h);  // (the gain-form branch fetches rows between two passes of an update)
-#endif
     if (h->comm && h->comm_size > 1) return fetch_rows_gathered(h, hx, hv, cap, n_rows);
     if (h->peer_seg && h->peer_n > 1) return fetch_rows_peers(h, hx, hv, cap, n_rows);
     return fetch_rows_local(h, hx, hv, cap, n_rows);

@@ -14,9 +14,6 @@
 #include "../../include/fastlio_hip.h"
 
 typedef esekfom::esekf<state_ikfom, 12, input_ikfom> kf_t;
-#ifdef FLH_EXP_PRELAUNCH
-extern "C" int flh_exp_prelaunch(flh_handle* h, int enable);  // exp/flh_prelaunch_host.inc
-#endif
 
 struct flh_esekf {
     kf_t kf;
@@ -62,6 +59,10 @@ static void gpu_begin_adapter(state_ikfom& s, esekfom::dyn_share_datastruct<doub
     flh_esekf* e = static_cast<flh_esekf*>(ctx);
     fastlio_amd::h_share_model_begin(s, d, &e->gpu_ctx);
 }
+static void gpu_finish_adapter(void* ctx) {
+    flh_esekf* e = static_cast<flh_esekf*>(ctx);
+    fastlio_amd::h_share_model_finish(&e->gpu_ctx);
+}
 
 extern "C" {
 
@@ -72,7 +73,10 @@ flh_esekf* flh_esekf_create(flh_handle* handle, int maximum_iter, const double l
     double lim[FLH_NDOF];
     for (int i = 0; i < FLH_NDOF; ++i) lim[i] = limit ? limit[i] : 0.001;  // epsi, laserMapping.cpp:826-827
     e->kf.init_dyn_share(get_f, df_dx, df_dw, static_cast<kf_t::measurementModel_dyn_share_ctx*>(gpu_model_adapter), maximum_iter, lim, e);
-    if (handle) e->kf.set_meas_begin(gpu_begin_adapter);  // the pass runs on the device while the filter projects the covariance
+    if (handle) {
+        e->kf.set_meas_begin(gpu_begin_adapter);  // the pass runs on the device while the filter projects the covariance
+        e->kf.set_meas_finish(gpu_finish_adapter);
+    }
     return e;
 }
 void flh_esekf_destroy(flh_esekf* e) { delete e; }
@@ -81,7 +85,10 @@ void flh_esekf_set_meas_model(flh_esekf* e, flh_meas_fn h, void* ctx) {
     e->user_h = h;
     e->user_ctx = ctx;
     e->kf.set_meas_model(static_cast<kf_t::measurementModel_dyn_share_ctx*>(h ? user_model_adapter : gpu_model_adapter), e);
-    if (!h && e->gpu_ctx.handle) e->kf.set_meas_begin(gpu_begin_adapter);
+    if (!h && e->gpu_ctx.handle) {
+        e->kf.set_meas_begin(gpu_begin_adapter);
+        e->kf.set_meas_finish(gpu_finish_adapter);
+    }
 }
 void flh_esekf_change_x(flh_esekf* e, const double x[FLH_NSTATE]) {
     state_ikfom s = e->kf.get_x();
@@ -106,21 +113,13 @@ int flh_esekf_update(flh_esekf* e, double R, flh_update_stats* st) {
     if (!e) return -1;
     e->err.clear();
     double solve_time = 0;
-#ifdef FLH_EXP_PRELAUNCH  // (developer builds: the no-search passes of this update are enqueued ahead of their states)
-    if (e->gpu_ctx.handle && !e->user_h) (void)flh_exp_prelaunch(e->gpu_ctx.handle, 1);
-#endif
     try {
         e->kf.update_iterated_dyn_share_modified(R, solve_time);
     } catch (const std::exception& ex) {
-#ifdef FLH_EXP_PRELAUNCH
-        if (e->gpu_ctx.handle) (void)flh_exp_prelaunch(e->gpu_ctx.handle, 0);
-#endif
+        if (e->gpu_ctx.handle) (void)flh_eval_expect_next(e->gpu_ctx.handle, FLH_NEXT_NONE);  // (a pass enqueued ahead is released)
         e->err = ex.what();
         return -1;
     }
-#ifdef FLH_EXP_PRELAUNCH
-    if (e->gpu_ctx.handle) (void)flh_exp_prelaunch(e->gpu_ctx.handle, 0);
-#endif
     if (st) {
         const kf_t::update_stats& s = e->kf.last_stats();
         st->passes = s.passes;

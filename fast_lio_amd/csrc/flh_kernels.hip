@@ -26,6 +26,7 @@
 #include "flh_device.hpp"
 #include "flh_search_dev.hpp"
 #include "flh_fit_dev.hpp"
+#include "flh_mail_dev.hpp"
 
 namespace flh {
 
@@ -652,6 +653,26 @@ __global__ void __launch_bounds__(256) k_fill_d2(StateDev s_search, const float4
         nn_d2[(size_t)j * N + i] = (__float_as_uint(p.w) == 0xFFFFFFFFu) ? INFINITY : dist2(wx, wy, wz, p.x, p.y, p.z);
     }
 }
+// The neighbour cache of a one-launch searching pass holds map indices (flh_config.index_cache): whoever needs the coordinates
+// (map_incremental, a fetch, a re-fit without the plane cache) has them gathered once, off the update's critical path.
+__global__ void __launch_bounds__(256) k_nn_gather(const float4* __restrict__ map_orig, uint32_t n_ids, const uint32_t* __restrict__ nn_idx,
+                                                   int total, float4* __restrict__ nn_pts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t id = nn_idx[i];
+    float4 v = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+    if (id < n_ids) {
+        v = map_orig[id];
+        v.w = __uint_as_float(id);
+    }
+    nn_pts[i] = v;
+}
+hipError_t launch_nn_gather(const float4* map_orig, uint32_t n_ids, const uint32_t* nn_idx, int N, float4* nn_pts, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_nn_gather, dim3(cdiv(5ll * N, 256)), dim3(256), 0, st, map_orig, n_ids, nn_idx, 5 * N, nn_pts);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill_d2(const StateDev& s_search, const float4* body, const float4* nn_pts, int N, float* nn_d2, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_fill_d2, dim3(cdiv(N, 256)), dim3(256), 0, st, s_search, body, nn_pts, N, nn_d2);
@@ -704,6 +725,98 @@ void bounds_read_kernels(unsigned long long out[5]) { (void)hipMemcpyFromSymbol(
 
 }  // namespace flh
 
-#ifdef FLH_EXP_PRELAUNCH  // (developer builds: the pre-launched no-search pass)
-#include "exp/flh_fit_mb.inc"
-#endif
+// ------------------------------------------------------------------------------------------------
+// k_fit_mb: the no-search pass of flh_eval (k_fit<1, false, 2> on its granule path: plane cache, default summation order, group
+// sums as granules) as a kernel that is enqueued BEFORE its state is known (flh_mail_dev.hpp; flh_eval_expect_next).  What does
+// not depend on the state -- a point's flag, its body-frame coordinates, its cached plane -- is loaded before the wait, so that
+// when the state arrives only arithmetic is left.  From the state on the code is k_fit's, statement for statement: same units,
+// same quads, same summation tree -> the bits of k_fit<1, false, 2> at the same state (tests/test_gpu_parity.py).
+// ------------------------------------------------------------------------------------------------
+namespace flh {
+
+__global__ void __launch_bounds__(256)
+k_fit_mb(MailArgs mail, const float4* __restrict__ body, int N, int ext, float thr, uint8_t* __restrict__ selected,
+         double* __restrict__ partials, double seq, uint32_t* __restrict__ tickets, uint32_t* __restrict__ slow_count, GranOut gout,
+         int red1, int ncol, const float4* __restrict__ plane_cache) {
+    __shared__ double lds[4 * 64 * kTileStride];
+    __shared__ uint32_t s_ticket;
+    __shared__ uint32_t s_cmd;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ic = i < N ? i : (N > 0 ? N - 1 : 0);
+    const uint8_t sel_in = selected[ic];
+    const float4 b = body[ic];
+    const float4 pc = plane_cache[ic];
+    StateDev s;
+    if (!mailbox_wait(mail, s, &s_cmd)) return;  // aborted by the host, or nobody came: nothing was written
+
+    double v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = 0.0;
+    float wx = 0.f, wy = 0.f, wz = 0.f;
+    if (i < N) body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
+    if (i < N && sel_in) {  // laserMapping.cpp:674
+        float P[5][3];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { P[j][0] = 0.f; P[j][1] = 0.f; P[j][2] = 0.f; }
+        float pabcd[4], pd2;
+        bool ok;
+        const bool sel = fit_point<1, false, 2>(s, b.x, b.y, b.z, wx, wy, wz, P, pc, ext, thr, pabcd, ok, pd2, v);
+        selected[i] = sel ? 1 : 0;
+    }
+    tile_store(lds + wave * 64 * kTileStride, lane, v);
+    __syncthreads();
+    const v4f64 acc = tile_gram(lds + wave * 64 * kTileStride, lane);
+    const int col = lane & 15, kq = lane >> 4;
+    const int t = threadIdx.x;
+    const int nblk = gridDim.x;
+    const int nsl = gran_section_slots(ncol);
+    const int nunits = (N + 63) / 64 > 0 ? (N + 63) / 64 : 1;
+    __syncthreads();  // every wave has read its tile: the same LDS now holds the waves' blocks
+    double* Rq = lds;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rq[wave * 256 + (kq + 4 * r) * 16 + col] = acc[r];
+    __syncthreads();
+    {
+        const int slot = gram_slot(t >> 4, t & 15, ncol);
+        if (slot >= 0)
+            __hip_atomic_store((gdouble*)partials + (size_t)blockIdx.x * nsl + slot, ((Rq[t] + Rq[256 + t]) + Rq[512 + t]) + Rq[768 + t],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wave == 0) {  // the statistic slot, as k_fit keeps it
+        double stat = 0.0;
+        if (blockIdx.x == 0) {
+            uint32_t c = slow_count[lane];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+            stat = (double)c;
+            slow_count[lane] = 0;
+            slow_count[kStripes + lane] = 0;
+        }
+        if (lane == 0) __hip_atomic_store((gdouble*)partials + (size_t)blockIdx.x * nsl + (nsl - 1), stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int bpg = red1 / 4;
+    const int group = blockIdx.x / bpg;
+    const int gblocks = min(bpg, nblk - group * bpg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) s_ticket = __hip_atomic_fetch_add(&tickets[1 + group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != (uint32_t)(gblocks - 1)) return;
+    if (wave == 0) {
+        group_sum_publish<true>(partials, group, min(red1, nunits - group * red1), red1, nsl, (nunits + red1 - 1) / red1, gout, seq, lane);
+        if (lane == 0) tickets[1 + group] = 0;
+    }
+}
+
+hipError_t launch_fit_mb(const MailArgs& mail, const float4* body, int N, int ext, float thr, uint8_t* selected, double* partials,
+                         double seq, uint32_t* tickets, uint32_t* slow_count, const GranOut& gran, int red1, const float4* plane_cache,
+                         hipStream_t st) {
+    if (N <= 0 || !plane_cache || gran.n_dst < 1 || red1 < 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_fit_mb, dim3(fit_blocks(N)), dim3(256), 0, st, mail, body, N, ext, thr, selected, partials, seq, tickets,
+                       slow_count, gran, red1, ext ? 12 : 6, plane_cache);
+    return hipGetLastError();
+}
+
+}  // namespace flh

@@ -47,7 +47,10 @@ int pass_group_size(int N, int max_groups);      // workgroups per reduction gro
 hipError_t launch_pass(int order, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points, float max_sqdist,
                        float thr, int ext, float4* nn_pts, uint8_t* nn_cnt, uint8_t* selected, float4* plane_cache, double* partials,
                        uint32_t* tickets, const GranOut& gran, double seq, int red, unsigned long long* cand_counter,
-                       int own_axis, float own_lo, float own_hi, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                       int own_axis, float own_lo, float own_hi, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                       uint32_t* nn_idx = nullptr);  // nn_idx: the neighbour cache as map indices (flh_config.index_cache), else nn_pts
+// neighbour cache kept as indices -> coordinates (nn_pts[r * N + i] = {map_orig[id].xyz, id}; id == -1 or >= n_ids: an empty row)
+hipError_t launch_nn_gather(const float4* map_orig, uint32_t n_ids, const uint32_t* nn_idx, int N, float4* nn_pts, hipStream_t st);
 hipError_t launch_publish256(const double* src, double* out256, double seq, hipStream_t st);
 
 int fit_blocks(int N);
@@ -60,12 +63,11 @@ hipError_t launch_fit(int order, int half_fit, const StateDev& s, const float4* 
 hipError_t launch_fill_d2(const StateDev& s_search, const float4* body, const float4* nn_pts, int N, float* nn_d2, hipStream_t st);
 int gram_slots_host(int ncol);
 int gram_slot_host(int r, int c, int ncol);
-#ifdef FLH_EXP_PRELAUNCH  // (developer builds: exp/flh_fit_mb.inc)
+// the pre-launched no-search pass (flh_mail_dev.hpp)
 struct MailArgs;
 hipError_t launch_fit_mb(const MailArgs& mail, const float4* body, int N, int ext, float thr, uint8_t* selected, double* partials,
                          double seq, uint32_t* tickets, uint32_t* slow_count, const GranOut& gran, int red1, const float4* plane_cache,
                          hipStream_t st);
-#endif
 
 // ---- flh_mapinc.hip: map_incremental and the incremental map ----
 hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t map_points, const StateDev& s_search,

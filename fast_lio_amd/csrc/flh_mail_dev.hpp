@@ -1,4 +1,5 @@
-// exp/flh_mail_dev.hpp -- EXPERIMENT (developer builds only: tools/variant.py --define FLH_EXP_PRELAUNCH; compiled out of the product).
+// flh_mail_dev.hpp -- the mailbox of the pre-launched no-search pass (k_fit_mb, flh_kernels.hip; host side: flh_api.cpp,
+// flh_eval_expect_next).  Landed from round 4's experiment after its same-box A/B (profiles/r05_call1/).
 // A kernel that is ENQUEUED BEFORE the host knows the state it is to be evaluated at: the no-search pass that follows a pass
 // of the iterated update is launched while that pass still runs, becomes resident when it retires, and waits for a MAILBOX in
 // pinned host memory.  When the host has the next state it writes 14 doubles and a sequence word -- no launch call, no queue
@@ -18,7 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../flh_device.hpp"
+#include "flh_device.hpp"
 
 namespace flh {
 

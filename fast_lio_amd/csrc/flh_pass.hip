@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) PASS_ATTR
 k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist, float thr, int ext,
        int ncol, float4* __restrict__ nn_pts, uint8_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected,
        float4* __restrict__ plane_cache, double* __restrict__ partials, uint32_t* __restrict__ tickets, GranOut gout, double seq,
-       int red, u64* __restrict__ cand_counter, int own_axis, float own_lo, float own_hi) {
+       int red, u64* __restrict__ cand_counter, int own_axis, float own_lo, float own_hi, uint32_t* __restrict__ nn_idx) {
     __shared__ uint2 segs[kSegWords];
     __shared__ float park[kPassQueries * kParkStride];
     __shared__ uint32_t s_list[64];  // per wave: the slots (0..63) of its queries that go to phase B
@@ -116,7 +116,7 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
         }
         float ub_next;
         const bool done = ring_query<4, 1, false, 8, false, false>(g, rs, segs + grp * kSegA, lane, q, N, live, qx, qy, qz, INFINITY,
-                                                                   max_sqdist, 2, nn_pts, nn_cnt, selected, cand_counter, pk, ub_next);
+                                                                   max_sqdist, 2, nn_pts, nn_cnt, selected, cand_counter, pk, ub_next, nn_idx);
         const bool open = live && !done;
         if (lane == 0 && !(live && done)) {  // a settled query's status was written with its fifth neighbour
             pk[kParkStatus] = __uint_as_float(open ? kStOpen : kStIdle);
@@ -160,7 +160,7 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
             const float ub = pk[kParkUb];
             float ub_next;
             const bool done = ring_query<8, 2, true, 11, true, false, true, FLH_UNR_B>(g, rs, segs + grp * kSegB, lane, q0 + (int)slot, N, live, qx, qy, qz,
-                                                                      ub, max_sqdist, 2, nn_pts, nn_cnt, selected, cand_counter, pk, ub_next);
+                                                                      ub, max_sqdist, 2, nn_pts, nn_cnt, selected, cand_counter, pk, ub_next, nn_idx);
             (void)done;  // always settled: the block covers the gate radius (see the head of this file); a status left open is not fitted
             wave_sync();  // the segment tables are rewritten by the next trip
         }
@@ -238,7 +238,7 @@ int pass_group_size(int N, int max_groups) {
 hipError_t launch_pass(int order, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points, float max_sqdist,
                        float thr, int ext, float4* nn_pts, uint8_t* nn_cnt, uint8_t* selected, float4* plane_cache, double* partials,
                        uint32_t* tickets, const GranOut& out, double seq, int red, unsigned long long* cand_counter,
-                       int own_axis, float own_lo, float own_hi, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                       int own_axis, float own_lo, float own_hi, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t* nn_idx) {
     if (N <= 0 || out.n_dst < 1 || out.n_dst > kPeersMax) return hipErrorInvalidValue;
     const int ncol = ext ? 12 : 6;
     const dim3 grid(pass_blocks(N)), blk(256);
@@ -247,10 +247,10 @@ hipError_t launch_pass(int order, const GridParams& g, const StateDev& s, const 
         if (ev_start != nullptr || ev_stop != nullptr)                                                                                \
             hipExtLaunchKernelGGL((k_pass<O>), grid, blk, 0, st, ev_start, ev_stop, 0, g, s, body, N, map_points, max_sqdist, thr, ext, \
                                   ncol, nn_pts, nn_cnt, selected, plane_cache, partials, tickets, out, seq, red, cand_counter, own_axis, \
-                                  own_lo, own_hi);                                                                                     \
+                                  own_lo, own_hi, nn_idx);                                                                             \
         else                                                                                                                          \
             hipLaunchKernelGGL((k_pass<O>), grid, blk, 0, st, g, s, body, N, map_points, max_sqdist, thr, ext, ncol, nn_pts, nn_cnt,   \
-                               selected, plane_cache, partials, tickets, out, seq, red, cand_counter, own_axis, own_lo, own_hi);       \
+                               selected, plane_cache, partials, tickets, out, seq, red, cand_counter, own_axis, own_lo, own_hi, nn_idx); \
     } while (0)
     switch (order) {
         case 0: FLH_PASS(0); break;

@@ -189,11 +189,19 @@ struct RingRsrc {
     }
 };
 
+// One row of a query's result in the neighbour cache.  nn_idx != nullptr (flh_config.index_cache, the one-launch pass): only the
+// neighbour's map INDEX is kept (4 B instead of 16; -1 = none) -- no pass reads the coordinates from HBM again (the fit that
+// follows has them in LDS, later passes take the cached plane), whoever else wants them gathers them by index (k_nn_gather).
+__device__ __forceinline__ void nn_store(float4* __restrict__ nn_pts, uint32_t* __restrict__ nn_idx, size_t at, const float4& v) {
+    if (nn_idx) nn_idx[at] = __float_as_uint(v.w);
+    else nn_pts[at] = v;
+}
+
 // Group-wide merge of the lanes' sorted (d2, map index) lists and the query's result rows: 5 x (min butterfly, ballot, pop).
 template <int LPQ>
 __device__ __forceinline__ void top5_finish(Top5& L, const GridParams& g, int q, int N, int lane, float max_sqdist,
                                             float4* __restrict__ nn_pts, uint8_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected,
-                                            float* park) {
+                                            float* park, uint32_t* __restrict__ nn_idx = nullptr) {
     const int wl0 = (threadIdx.x & 63) & ~(LPQ - 1);
     const u64 gmask = (LPQ == 64 ? ~0ull : ((1ull << LPQ) - 1ull)) << wl0;
     u64 rk[5];
@@ -232,7 +240,7 @@ __device__ __forceinline__ void top5_finish(Top5& L, const GridParams& g, int q,
             const bool has = jr < cnt;
             float4 v = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
             if (has) v = g.pts[FLH_IDX(10, pp, g.pts_cap)];
-            nn_pts[FLH_IDX(11, (size_t)jr * N + q, (size_t)5 * N)] = v;
+            nn_store(nn_pts, nn_idx, FLH_IDX(11, (size_t)jr * N + q, (size_t)5 * N), v);
             if (park) { park[3 * jr] = v.x; park[3 * jr + 1] = v.y; park[3 * jr + 2] = v.z; }
         }
     }
@@ -252,7 +260,7 @@ template <int LPQ>
 __device__ __forceinline__ uint32_t exact_query(const GridParams& g, int q, int N, float qx, float qy, float qz, int cx, int cy,
                                                 int cz, float fx, float fy, float fz, float ub, int rmax, float max_sqdist,
                                                 int lane, float4* __restrict__ nn_pts, uint8_t* __restrict__ nn_cnt,
-                                                uint8_t* __restrict__ selected, float* park) {
+                                                uint8_t* __restrict__ selected, float* park, uint32_t* __restrict__ nn_idx = nullptr) {
     // cells with |offset| <= R cover the ball; +1 absorbs the position inside the centre cell
     const int r = min(rmax, (int)(sqrtf(ub) * g.inv_c) + 1);
     const float ubp = ub * 1.0001f + 1e-6f;
@@ -280,7 +288,7 @@ __device__ __forceinline__ uint32_t exact_query(const GridParams& g, int q, int 
             L.insert(make_key(dist2(qx, qy, qz, pv.x, pv.y, pv.z), pv.w), i);
         }
     }
-    top5_finish<LPQ>(L, g, q, N, lane, max_sqdist, nn_pts, nn_cnt, selected, park);
+    top5_finish<LPQ>(L, g, q, N, lane, max_sqdist, nn_pts, nn_cnt, selected, park, nn_idx);
     return ncand;
 }
 
@@ -305,7 +313,7 @@ __device__ __forceinline__ bool ring_query(const GridParams& g, const RingRsrc& 
                                            int lane, int q, int N, bool live, float qx, float qy, float qz, float ub_raw,
                                            float max_sqdist, int rmax, float4* __restrict__ nn_pts, uint8_t* __restrict__ nn_cnt,
                                            uint8_t* __restrict__ selected, u64* __restrict__ cand_counter, float* park,
-                                           float& ub_next) {
+                                           float& ub_next, uint32_t* __restrict__ nn_idx = nullptr) {
     static_assert(!WIN4 || (RING == 2 && BOUNDED), "the 4x4 window is for bounded ring-2 queries");
     constexpr int W = WIN4 ? 4 : 2 * RING + 1;     // rows per axis
     constexpr int NR = W * W;                      // (y,z) rows: each an x-run of at most 2 RING + 1 consecutive cells
@@ -574,7 +582,7 @@ __device__ __forceinline__ bool ring_query(const GridParams& g, const RingRsrc& 
                         e += (i < m && (da[i] < dv[r] || (da[i] == dv[r] && ia[i] < myid))) ? 1 : 0;
                 }
                 if (e < 5) {
-                    nn_pts[FLH_IDX(5, (size_t)e * N + q, (size_t)5 * N)] = pv[r];  // the squared distances are not stored: k_fill_d2 recomputes them on demand
+                    nn_store(nn_pts, nn_idx, FLH_IDX(5, (size_t)e * N + q, (size_t)5 * N), pv[r]);  // the squared distances are not stored: k_fill_d2 recomputes them on demand
                     if (park) { park[3 * e] = pv[r].x; park[3 * e + 1] = pv[r].y; park[3 * e + 2] = pv[r].z; }
                     if (e == 4) {
                         const bool gate = j < m && !(dv[r] > max_sqdist);  // laserMapping.cpp:671
@@ -617,13 +625,13 @@ __device__ __forceinline__ bool ring_query(const GridParams& g, const RingRsrc& 
                     if (t0 + (uint32_t)(w * LPQ) < T)
                         L.insert(make_key(dist2(qx, qy, qz, pv[w].x, pv[w].y, pv[w].z), pv[w].w), pos[w]);
             }
-            top5_finish<LPQ>(L, g, q, N, lane, max_sqdist, nn_pts, nn_cnt, selected, park);
+            top5_finish<LPQ>(L, g, q, N, lane, max_sqdist, nn_pts, nn_cnt, selected, park, nn_idx);
             done2 = true;
         }
         if (EXACT && live && !done2) {
             const float ubx = fminf(BOUNDED ? fminf(d5hi, ub_raw) : d5hi, max_sqdist);
             const uint32_t nc = exact_query<LPQ>(g, q, N, qx, qy, qz, cx, cy, cz, fx, fy, fz, ubx, rmax, max_sqdist, lane, nn_pts,
-                                                 nn_cnt, selected, park);
+                                                 nn_cnt, selected, park, nn_idx);
             if (cand_counter && lane == 0) atomicAdd(cand_counter, (u64)nc);
             done2 = true;
         }

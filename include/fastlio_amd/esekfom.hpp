@@ -36,25 +36,37 @@ struct dyn_share_datastruct {
     T HTH[144];  // row-major 12x12 = h_x^T h_x
     T HTh[12];   // h_x^T h
     T total_residual = 0;
+    // --- extension: what the filter expects the evaluation AFTER the one it is about to start to be (kNext*; set before every call
+    // of the measurement model).  A model on a GPU may enqueue that evaluation's kernel ahead of its state (flh_eval_expect_next);
+    // models that ignore it lose nothing.
+    int next_pass = 0;
 };
+enum { kNextUnknown = 0, kNextNoSearch = 1, kNextNone = 2 };  // = FLH_NEXT_* (include/fastlio_hip.h)
 
 // Measurement models of the reference's plain signature (esekfom.hpp:129) that come in two halves register their first half
 // here, keyed by the address of the model; init_dyn_share / set_meas_model look it up.  fastlio_amd::h_share_model does
 // (h_share_model.hpp), so the node's lines laserMapping.cpp:826-828 get the overlap without a change.
-struct split_model_entry { void* model; void* begin; };
+struct split_model_entry { void* model; void* begin; void* finish; };
 inline std::vector<split_model_entry>& split_models() {
     static std::vector<split_model_entry> v;
     return v;
 }
-inline bool register_split_model(void* model, void* begin) {
+// finish (optional): called when an update returns after it had announced a no-search pass that then did not come (kNextNoSearch
+// as the last hint): a model that acted on the hint takes it back (void(), reads the model's globals)
+inline bool register_split_model(void* model, void* begin, void* finish = nullptr) {
     for (auto& e : split_models())
-        if (e.model == model) { e.begin = begin; return true; }
-    split_models().push_back({model, begin});
+        if (e.model == model) { e.begin = begin; e.finish = finish; return true; }
+    split_models().push_back({model, begin, finish});
     return true;
 }
 inline void* find_split_begin(void* model) {
     for (const auto& e : split_models())
         if (e.model == model) return e.begin;
+    return nullptr;
+}
+inline void* find_split_finish(void* model) {
+    for (const auto& e : split_models())
+        if (e.model == model) return e.finish;
     return nullptr;
 }
 
@@ -82,6 +94,9 @@ class esekf {
     // Same arithmetic on the same operands: same bits.
     typedef void measurementModel_begin(state&, dyn_share_datastruct<scalar_type>&);
     typedef void measurementModel_begin_ctx(state&, dyn_share_datastruct<scalar_type>&, void* ctx);
+    // Optional: told when an update ends although its last hint (dyn_share_datastruct::next_pass) announced another no-search pass
+    typedef void measurementModel_finish();
+    typedef void measurementModel_finish_ctx(void* ctx);
 
     esekf(const state& x = state(), const cov& P = cov::Identity()) : x_(x), P_(P) {}
 
@@ -94,6 +109,8 @@ class esekf {
         h_ctx_ = nullptr;
         h_begin = reinterpret_cast<measurementModel_begin*>(find_split_begin(reinterpret_cast<void*>(h_dyn_share_in)));
         h_begin_ctx = nullptr;
+        h_finish = reinterpret_cast<measurementModel_finish*>(find_split_finish(reinterpret_cast<void*>(h_dyn_share_in)));
+        h_finish_ctx = nullptr;
     }
     // the same with a context pointer handed to the measurement model
     void init_dyn_share(processModel f_in, processMatrix1 f_x_in, processMatrix2 f_w_in,
@@ -105,15 +122,22 @@ class esekf {
         h_ctx_ = h_ctx;
         h_begin = nullptr;
         h_begin_ctx = nullptr;
+        h_finish = nullptr;
+        h_finish_ctx = nullptr;
     }
-    void set_meas_model(measurementModel_dyn_share_ctx h, void* ctx) { h_dyn_share = nullptr; h_dyn_share_ctx = h; h_ctx_ = ctx; h_begin = nullptr; h_begin_ctx = nullptr; }
+    void set_meas_model(measurementModel_dyn_share_ctx h, void* ctx) {
+        h_dyn_share = nullptr; h_dyn_share_ctx = h; h_ctx_ = ctx; h_begin = nullptr; h_begin_ctx = nullptr; h_finish = nullptr; h_finish_ctx = nullptr;
+    }
     void set_meas_model(measurementModel_dyn_share h) {
         h_dyn_share = h; h_dyn_share_ctx = nullptr; h_ctx_ = nullptr;
         h_begin = reinterpret_cast<measurementModel_begin*>(find_split_begin(reinterpret_cast<void*>(h)));
         h_begin_ctx = nullptr;
+        h_finish = reinterpret_cast<measurementModel_finish*>(find_split_finish(reinterpret_cast<void*>(h)));
+        h_finish_ctx = nullptr;
     }
     // first half of the _ctx model registered last (same context pointer); nullptr: the model is called in one piece
     void set_meas_begin(measurementModel_begin_ctx b) { h_begin_ctx = b; h_begin = nullptr; }
+    void set_meas_finish(measurementModel_finish_ctx f) { h_finish_ctx = f; h_finish = nullptr; }
 
     // esekfom.hpp:279-383 (dense path)
     void predict(double& dt, processnoisecovariance& Q, const input& i_in) {
@@ -195,6 +219,10 @@ class esekf {
             dyn_share.has_normal_eq = false;
             const auto t_h0 = clk::now();
             const bool searched = dyn_share.converge;
+            // What follows this pass, as far as it can be known before it (esekfom.hpp:1823-1834): nothing after the last one; a
+            // SEARCH after the last but one when no step has converged yet (:1829-1832 forces it); otherwise a no-search pass
+            // unless this pass's step converges (then: a search if it is the first to converge, the end of the update if the second)
+            dyn_share.next_pass = (i == maximum_iter - 1 || (!t && i == maximum_iter - 2)) ? kNextNone : kNextNoSearch;
             bool early = false;
             if ((h_dyn_share_ctx && h_begin_ctx) || (!h_dyn_share_ctx && h_begin)) {
                 // the measurement model is under way on the device: what :1655-1699 and the first inverse of :1782 compute from the
@@ -222,6 +250,7 @@ class esekf {
             stats_.searches += searched ? 1 : 0;
             if (!dyn_share.valid) {  // :1638-1641
                 if (pass_no < 8) stats_.pass_ms[pass_no] = std::chrono::duration<double, std::milli>(clk::now() - t_h0).count();
+                if (i == maximum_iter - 1) finish_hint(dyn_share);
                 continue;
             }
 
@@ -293,6 +322,7 @@ class esekf {
             if (!t && i == maximum_iter - 2) dyn_share.converge = true;  // :1829-1832
 
             if (t > 1 || i == maximum_iter - 1) {  // :1834-1928
+                finish_hint(dyn_share);
                 final_cov(P_, K_x, dx_, x_, x_propagated);
                 stats_.returned_in_loop = 1;
                 const double ms = std::chrono::duration<double, std::milli>(clk::now() - solve_start).count();
@@ -321,6 +351,13 @@ class esekf {
     const cov& get_P() const { return P_; }
 
    private:
+    // the update ends: a model that was told to expect another no-search pass is told that none comes
+    void finish_hint(dyn_share_datastruct<scalar_type>& d) {
+        if (d.next_pass != kNextNoSearch) return;
+        d.next_pass = kNextUnknown;
+        if (h_finish_ctx) h_finish_ctx(h_ctx_);
+        else if (h_finish) h_finish();
+    }
     void init_common(processModel f_in, processMatrix1 f_x_in, processMatrix2 f_w_in, int maximum_iteration,
                      const scalar_type* limit_vector) {
         f = f_in;
@@ -489,6 +526,8 @@ class esekf {
     void* h_ctx_ = nullptr;
     measurementModel_begin* h_begin = nullptr;
     measurementModel_begin_ctx* h_begin_ctx = nullptr;
+    measurementModel_finish* h_finish = nullptr;
+    measurementModel_finish_ctx* h_finish_ctx = nullptr;
     int maximum_iter = 0;
     scalar_type limit[n];
     dyn_share_datastruct<scalar_type> dyn_share_;

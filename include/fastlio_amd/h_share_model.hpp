@@ -43,6 +43,9 @@ inline void h_share_model_begin(state_ikfom& s, esekfom::dyn_share_datastruct<do
     const double offR[4] = {s.offset_R_L_I.x, s.offset_R_L_I.y, s.offset_R_L_I.z, s.offset_R_L_I.w};
     const double pos[3] = {s.pos[0], s.pos[1], s.pos[2]};
     const double offT[3] = {s.offset_T_L_I[0], s.offset_T_L_I[1], s.offset_T_L_I[2]};
+    // what the filter expects after this evaluation (esekfom.hpp: next_pass; kNext* = FLH_NEXT_*): the library may enqueue an
+    // expected no-search pass beside this one
+    (void)flh_eval_expect_next(ctx->handle, ekfom_data.next_pass);
     if (flh_eval_begin(ctx->handle, rot, pos, offR, offT, ekfom_data.converge ? 1 : 0, ctx->extrinsic_est_en ? 1 : 0) != 0)
         throw std::runtime_error(std::string("flh_eval failed: ") + flh_last_error());
     ctx->begun = true;
@@ -50,10 +53,17 @@ inline void h_share_model_begin(state_ikfom& s, esekfom::dyn_share_datastruct<do
 inline void h_share_model_begin(state_ikfom& s, esekfom::dyn_share_datastruct<double>& ekfom_data) {
     h_share_model_begin(s, ekfom_data, &g_hshare);
 }
+// The update ended although the filter had announced another no-search pass: a kernel enqueued for it is released
+inline void h_share_model_finish(void* ctx_) {
+    HShareContext* ctx = static_cast<HShareContext*>(ctx_);
+    if (ctx && ctx->handle) (void)flh_eval_expect_next(ctx->handle, FLH_NEXT_NONE);
+}
+inline void h_share_model_finish() { h_share_model_finish(&g_hshare); }
 namespace detail {
 inline const bool h_share_model_split_registered = esekfom::register_split_model(
     reinterpret_cast<void*>(static_cast<void (*)(state_ikfom&, esekfom::dyn_share_datastruct<double>&)>(&h_share_model)),
-    reinterpret_cast<void*>(static_cast<void (*)(state_ikfom&, esekfom::dyn_share_datastruct<double>&)>(&h_share_model_begin)));
+    reinterpret_cast<void*>(static_cast<void (*)(state_ikfom&, esekfom::dyn_share_datastruct<double>&)>(&h_share_model_begin)),
+    reinterpret_cast<void*>(static_cast<void (*)()>(&h_share_model_finish)));
 }
 
 inline void h_share_model(state_ikfom& s, esekfom::dyn_share_datastruct<double>& ekfom_data, void* ctx_) {

@@ -73,6 +73,16 @@ typedef struct flh_config {
                                every scan of a running odometry) gives the surviving points their ids and sorts them by brick in
                                one workgroup instead of the general path's scan + device-wide sort (one launch instead of eight,
                                same results); 0: the general path for every size.  Performance only */
+    int prelaunch;          /* 1 (default, also for < 0): flh_eval_expect_next is honoured -- the kernel of a no-search evaluation the
+                               caller announces is enqueued beside the pass before it and takes its state from a mailbox in pinned
+                               memory, so that its launch leaves the critical path (same bits); 0: hints are ignored.  Performance only */
+    int index_cache;        /* 1 (default, also for < 0): the one-launch searching pass leaves the five neighbours of a query as map
+                               INDICES (20 B per query); their coordinates are gathered on demand by whatever asks for them
+                               (flh_map_incremental, flh_fetch_neighbors, a re-fit without the plane cache); 0: the search writes
+                               the coordinates (80 B per query) itself.  Needs plane_cache; same results.  Performance only */
+    int pass_lanes;         /* lanes per query in the first search stage of the one-launch pass: 4, 8 or 16; 0 (default, also for
+                               < 0 and any other value): 4, and 16 for a scan (or a rank's shard of one) of at most 32768 points,
+                               where four lanes per query leave most of the GPU idle.  Same results.  Performance only */
 } flh_config;
 enum { FLH_ORDER_SEQ = 0, FLH_ORDER_SSE = 1, FLH_ORDER_PAIRWISE = 2, FLH_ORDER_NOVEC = 3 };
 
@@ -231,6 +241,22 @@ int flh_eval(flh_handle* h, const double rot_xyzw[4], const double pos[3], const
 int flh_eval_begin(flh_handle* h, const double rot_xyzw[4], const double pos[3], const double offR_xyzw[4], const double offT[3],
                    int do_search, int extrinsic_est_en);
 int flh_eval_end(flh_handle* h, double HTH[144], double HTh[12], int64_t* n_eff, double* total_residual);
+/* What the caller expects the evaluation AFTER its next flh_eval_begin to be -- a hint, consumed by that flh_eval_begin; a wrong
+ * hint costs time, never correctness.  The iterated update knows it before every pass (esekfom.hpp:1823-1834; the mirror filter
+ * include/fastlio_amd/esekfom.hpp says so through dyn_share_datastruct::next_pass).
+ *   FLH_NEXT_NOSEARCH  probably a no-search evaluation of the same scan, at a state not known yet: its kernel is enqueued beside
+ *                      the pass flh_eval_begin starts and waits (bounded: 20 ms) for the state, which the following
+ *                      flh_eval_begin then posts instead of launching.  Any other call that follows releases it.
+ *   FLH_NEXT_NONE      nothing of the kind follows: a kernel that is still waiting is released now
+ *   FLH_NEXT_UNKNOWN   no expectation (the default before every flh_eval_begin) */
+#define FLH_NEXT_UNKNOWN 0
+#define FLH_NEXT_NOSEARCH 1
+#define FLH_NEXT_NONE 2
+int flh_eval_expect_next(flh_handle* h, int kind);
+/* flh_config.prelaunch at run time (0: hints are ignored from now on, a waiting kernel is released); and the counters since creation:
+ * {kernels enqueued ahead, of them handed their state, released unused, given up before the host came (then launched the usual way)} */
+int flh_set_prelaunch(flh_handle* h, int on);
+int flh_get_prelaunch_stats(const flh_handle* h, uint64_t out[4]);
 
 /* Same evaluation, but the reduced 16x16 Gram block is left in DEVICE memory at d_gram256 (256
  * doubles, row-major G = sum_k v_k v_k^T with v = [row(12) | h | 1 | |pd2| | 0]) and the call
@@ -282,13 +308,6 @@ int flh_peer_rank(const flh_handle* h);
 /* Counters of the handle's evaluations since creation: {searching passes, of them as ONE launch (flh_config.pass_kernel),
  * queries that needed the second search (summed over those passes and, with peers, over the ranks), no-search passes}. */
 int flh_get_pass_stats(const flh_handle* h, uint64_t out[4]);
-/* Developer builds only (-DFLH_BOUNDS: every computed device index checked against its buffer's capacity): returns 1 and the
- * violation records of the four kernel translation units, 5 words each {count, site, index, capacity, workgroup}; the product
- * library checks nothing, returns 0 and zeros. */
-int flh_debug_bounds(flh_handle* h, uint64_t out[20]);
-/* Developer builds only (-DFLH_PASS_STAMPS): 12 words per wave of the last one-launch pass (8 time stamps
- * at 100 MHz, HW_ID, XCC_ID, the longest candidate list among the wave's queries, its open queries); returns 1, else 0. */
-int flh_debug_pass_stamps(flh_handle* h, uint64_t* out, size_t words);
 /* Map partitioned over the ranks (BASELINE configs[4]): this handle's map is one slab of the world plus a halo of at least
  * sqrt(max_sqdist) on either side; every rank holds the whole scan; a query is searched (and then fitted) only by the
  * rank whose half-open interval [lo, hi) of world coordinate `axis` (0/1/2) contains it.  The ranks' intervals must tile

@@ -1,0 +1,18 @@
+/* fastlio_hip_dev.h -- developer entry points of libfastlio_hip.so: instrumentation readers that only do something in variant builds
+ * made by tools/variant.py (-DFLH_BOUNDS, -DFLH_PASS_STAMPS).  Not part of the drop-in boundary (include/fastlio_hip.h); the
+ * product library exports them as stubs that return 0 so that the tools load against either build. */
+#pragma once
+#include "fastlio_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Developer builds only (-DFLH_BOUNDS: every computed device index checked against its buffer's capacity): returns 1 and the
+ * violation records of the four kernel translation units, 5 words each {count, site, index, capacity, workgroup}; the product
+ * library checks nothing, returns 0 and zeros. */
+int flh_debug_bounds(flh_handle* h, uint64_t out[20]);
+/* Developer builds only (-DFLH_PASS_STAMPS): 12 words per wave of the last one-launch pass (8 time stamps
+ * at 100 MHz, HW_ID, XCC_ID, the longest candidate list among the wave's queries, its open queries); returns 1, else 0. */
+int flh_debug_pass_stamps(flh_handle* h, uint64_t* out, size_t words);
+#ifdef __cplusplus
+}
+#endif

@@ -1,4 +1,4 @@
-// CPU model of the mailbox protocol of the FLH_EXP_PRELAUNCH experiment (fast_lio_amd/csrc/exp/flh_mail_dev.hpp,
+// CPU model of the mailbox protocol of the pre-launched no-search pass (fast_lio_amd/csrc/flh_mail_dev.hpp,
 // flh_prelaunch_host.inc): the DECISIONS of the device side (forwarder wave, every workgroup's wait) and of the host side (post
 // go / abort, the sequence numbers) restated with std::atomic and threads, driven through the cases the GPU code must survive:
 //   go          the state arrives, every workgroup of the launch runs once with exactly that state
@@ -28,7 +28,7 @@ static std::atomic<uint64_t> status{0};
 
 struct LaunchResult { int ran = 0, skipped = 0; bool state_ok = true; };
 
-// one workgroup of a launch waiting for sequence number seq; wg 0 is also the forwarder (exp/flh_mail_dev.hpp: mailbox_wait)
+// one workgroup of a launch waiting for sequence number seq; wg 0 is also the forwarder (flh_mail_dev.hpp: mailbox_wait)
 static void workgroup(int wg, uint32_t seq, std::atomic<int>* ran, std::atomic<int>* skipped, std::atomic<int>* bad_state) {
     if (wg == 0) {
         const auto t0 = clk::now();

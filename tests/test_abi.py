@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     L = capi.lib()
-    hdr = open(os.path.join(ROOT, "include", "fastlio_hip.h")).read()
+    # the drop-in boundary + the developer header (instrumentation readers, stubs in the product build)
+    hdr = open(os.path.join(ROOT, "include", "fastlio_hip.h")).read() + open(os.path.join(ROOT, "include", "fastlio_hip_dev.h")).read()
     declared = sorted(set(re.findall(r"\b(flh_[a-z_A-Z0-9]+)\s*\(", hdr)))
     declared = [d for d in declared if d not in ("flh_meas_fn",)]
     assert set(declared) == set(capi.EXPORTS), set(declared) ^ set(capi.EXPORTS)
@@ -58,4 +59,6 @@ def test_config_mirror_matches_the_c_struct():
     assert cfg.cell_size == 1.5 and cfg.max_sqdist == 5.0 and abs(cfg.plane_threshold - 0.1) < 1e-7
     assert not cfg.stream
     # "default" markers the library resolves in flh_create
-    assert (cfg.sort_queries, cfg.pass_kernel, cfg.eigen_order, cfg.undistort_first_point, cfg.plane_cache, cfg.fused_small_changes) == (-1,) * 6
+    assert (cfg.sort_queries, cfg.pass_kernel, cfg.eigen_order, cfg.undistort_first_point, cfg.plane_cache, cfg.fused_small_changes,
+            cfg.prelaunch, cfg.index_cache) == (-1,) * 8
+    assert cfg.pass_lanes == 0

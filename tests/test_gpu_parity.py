@@ -134,6 +134,79 @@ def test_full_update_matches_oracle(prob, ext):
     np.testing.assert_array_equal(kf.get_P(), Pn)
 
 
+def test_prelaunched_nosearch_pass_same_bits(prob):
+    """flh_eval_expect_next (the mirror filter announces a no-search pass; its kernel is enqueued beside the pass before it and takes
+    its state from a mailbox): (0) kernel against kernel at one state, (1) the iterated update with the hints honoured against the
+    oracle and, bit for bit, against the same update with flh_config.prelaunch = 0, (2) a host that comes after the waiting kernel
+    has given up (20 ms): the pass is launched the usual way, same bits; the counters show that the mailbox was really used."""
+    import time
+
+    pr, m, xp, P, _ = prob
+    ha, hb = capi.Handle(prelaunch=0), capi.Handle(prelaunch=1)
+    for hh in (ha, hb):
+        hh.map_build(pr.map_xyz)
+        hh.scan_upload(pr.body)
+        hh.set_timing_stride(0)  # (a timed evaluation is never handed to the mailbox)
+    # (0) one evaluation
+    ref_s, ref_n = ha.eval(xp, True, False), ha.eval(pr.x_true, False, False)
+    hb.expect_next(1)
+    got_s = hb.eval(xp, True, False)        # enqueues the next pass's kernel behind its own
+    c0 = hb.prelaunch_stats()
+    got_n = hb.eval(pr.x_true, False, False)  # handed over through the mailbox
+    c1 = hb.prelaunch_stats()
+    assert c0["armed"] == 1 and c1["go"] == 1 and c1["abort"] == 0
+    for a, b in ((got_s, ref_s), (got_n, ref_n)):
+        np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+        assert a[2] == b[2] and a[3] == b[3]
+    np.testing.assert_array_equal(hb.fetch_selected(), ha.fetch_selected())
+    # a hint that does not come true: the waiting kernel is released, the search runs the usual way
+    hb.expect_next(1)
+    hb.eval(xp, True, False)
+    got_s2 = hb.eval(xp, True, False)
+    np.testing.assert_array_equal(got_s2[0], ref_s[0])
+    assert hb.prelaunch_stats()["abort"] == 1
+    assert ha.prelaunch_stats() == {"armed": 0, "go": 0, "abort": 0, "gone": 0}
+    ha.expect_next(1); ha.eval(xp, True, False)
+    assert ha.prelaunch_stats()["armed"] == 0  # prelaunch = 0: hints are ignored
+    # (1) the whole update, both extrinsic settings, against the oracle and against the plain launches
+    sc = po.Scan(pr.body, nthreads=8)
+    for ext in (False, True):
+        res = []
+        for hh in (ha, hb):
+            hh.scan_upload(pr.body)
+            kf = capi.Esekf(hh, max_iter=3, extrinsic_est_en=ext)
+            kf.change_x(xp); kf.change_P(P)
+            st = kf.update(0.001)
+            res.append((kf.get_x().copy(), kf.get_P().copy(), st.passes, list(st.n_eff)[: st.passes], list(st.pass_search)[: st.passes],
+                        hh.fetch_selected().copy()))
+            kf.close()
+        a, b = res
+        assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes() and a[2:5] == b[2:5]
+        np.testing.assert_array_equal(a[5], b[5])
+        x_ref, P_ref, st_ref = sc.update_iterated(m, xp, P, extrinsic_est_en=ext)
+        assert b[2] == st_ref.passes and b[3] == list(st_ref.n_eff)[: st_ref.passes]
+        assert np.linalg.norm(b[0][0:3] - x_ref[0:3]) <= POSE_M
+        np.testing.assert_allclose(b[0], x_ref, rtol=REL_X, atol=1e-7)
+        np.testing.assert_allclose(b[1], P_ref, rtol=0, atol=REL_P * np.abs(P_ref).max())
+        np.testing.assert_array_equal(b[5], sc.selected)
+    c2 = hb.prelaunch_stats()
+    assert c2["go"] > c1["go"], c2  # the filter's hints put the no-search passes through the mailbox
+    # (2) lateness
+    hb.scan_upload(pr.body)
+    hb.expect_next(1)
+    o_s = hb.eval(xp, True, False)
+    time.sleep(0.05)                       # the waiting kernel gives up after 20 ms
+    o_n = hb.eval(pr.x_true, False, False)  # mail posted to nobody: flh_eval_end notices and launches the usual way
+    c3 = hb.prelaunch_stats()
+    assert c3["gone"] == c2["gone"] + 1
+    np.testing.assert_array_equal(o_s[0], ref_s[0]); np.testing.assert_array_equal(o_n[0], ref_n[0]); np.testing.assert_array_equal(o_n[1], ref_n[1])
+    assert o_n[2] == ref_n[2]
+    # nothing follows: a waiting kernel is released at once and other calls go on as usual
+    hb.expect_next(1); hb.eval(xp, True, False); hb.expect_next(2)
+    np.testing.assert_array_equal(hb.fetch_selected(), ha.fetch_selected())
+    ha.close(); hb.close()
+
+
 def test_staged_scan_ring_equals_direct_upload(prob):
     pr, m, xp, P, h = prob
     h.scan_upload(pr.body)

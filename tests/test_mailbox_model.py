@@ -1,4 +1,5 @@
-"""CPU models of experiments that only a GPU can run (fast_lio_amd/csrc/exp/, compiled out of the product)."""
+"""CPU model of the pre-launched no-search pass's mailbox protocol (fast_lio_amd/csrc/flh_mail_dev.hpp; only a GPU runs the real one:
+tests/test_gpu_parity.py)."""
 import os
 import subprocess
 
@@ -6,8 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_mailbox_protocol_model(tmp_path):
-    """FLH_EXP_PRELAUNCH: the decisions of the forwarder wave, of every workgroup's wait and of the host's post -- go, abort,
-    a launch that was passed over, a host that comes too late -- restated with threads and atomics (tests/cpp/mailbox_model.cpp)."""
+    """The decisions of the forwarder wave, of every workgroup's wait and of the host's post -- go, abort, a launch that was passed
+    over, a host that comes too late -- restated with threads and atomics (tests/cpp/mailbox_model.cpp)."""
     exe = tmp_path / "mailbox_model"
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "cpp", "mailbox_model.cpp"), "-o", str(exe)])
     r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
@@ -15,7 +16,7 @@ def test_mailbox_protocol_model(tmp_path):
 
 
 def test_product_library_exports_no_experiment():
-    """The experiments' entry points exist in developer builds only."""
+    """Experiments land or are deleted: the product exports no flh_exp_* entry point."""
     from fast_lio_amd import _build
 
     if not os.path.exists(_build.LIB):
@@ -23,4 +24,4 @@ def test_product_library_exports_no_experiment():
 
         pytest.skip("library not built")
     out = subprocess.run(["nm", "-D", "--defined-only", _build.LIB], stdout=subprocess.PIPE, check=True).stdout.decode()
-    assert "flh_exp_" not in out and "k_fit_mb" not in out
+    assert "flh_exp_" not in out
