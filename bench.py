@@ -179,6 +179,9 @@ def main():
     ap.add_argument("--sort", type=int, default=1, help="Morton-order the scan at staging (0 = keep input order)")
     ap.add_argument("--extrinsic-est", type=int, default=0)
     ap.add_argument("--plane-cache", type=int, default=-1, help="flh_config.plane_cache (-1 = the library's default: on)")
+    ap.add_argument("--prelaunch", type=int, default=-1, help="flh_config.prelaunch (-1 = the library's default: on; 0 = every pass is launched when its state is known)")
+    ap.add_argument("--index-cache", type=int, default=-1, help="flh_config.index_cache (-1 = default: the neighbour cache holds map indices; 0 = coordinates)")
+    ap.add_argument("--pass-lanes", type=int, default=0, help="flh_config.pass_lanes (0 = by scan size; 4 / 8 / 16 lanes per query in the one-launch pass's first stage)")
     ap.add_argument("--plane-fit-dtype", type=int, default=0,
                     help="1 = the fp16 plane-fit ABLATION of BASELINE configs[4] (not bit-exact, never a parity claim)")
     ap.add_argument("--timing-samples", type=int, default=16,
@@ -306,7 +309,8 @@ def main():
             f"gen {time.time() - t0:.1f}s")
 
     h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
-                    pass_kernel=args.pass_kernel, plane_cache=args.plane_cache, plane_fit_dtype=args.plane_fit_dtype)
+                    pass_kernel=args.pass_kernel, plane_cache=args.plane_cache, plane_fit_dtype=args.plane_fit_dtype,
+                    prelaunch=args.prelaunch, index_cache=args.index_cache, pass_lanes=args.pass_lanes)
     t0 = time.time()
     h.map_build(scene.map_xyz)
     t_build = time.time() - t0
@@ -427,7 +431,7 @@ def main():
         tok = [None]
         try:
             hs = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
-                             pass_kernel=args.pass_kernel)
+                             pass_kernel=args.pass_kernel, index_cache=args.index_cache, pass_lanes=args.pass_lanes)
             if rank == 0:  # the token every rank needs: RCCL's unique id / the name of the shared segment
                 tok = [capi.rccl_unique_id() if exchange == "rccl" else f"/flh_bench_{os.getpid()}"]
         except Exception as e:  # noqa: BLE001
@@ -618,6 +622,9 @@ def main():
     if instrumented:  # a -DFLH_BOUNDS developer build (tools/fault_hunt.sh): violations per translation unit {count, site, index, cap, block}
         out["debug_bounds"] = {"kernels": words[0:5], "pass": words[5:10], "mapinc": words[10:15], "scanprep": words[15:20]}
     ps = h.pass_stats()
+    out["prelaunched_nosearch_passes"] = dict(h.prelaunch_stats(), setting=args.prelaunch)  # kernels enqueued ahead / handed their state / released unused / given up
+    out["config"]["index_cache"] = args.index_cache
+    out["config"]["pass_lanes"] = args.pass_lanes
     out["second_stage_queries_per_search_pass"] = round(ps["second_stage_queries"] / max(ps["search_passes"], 1), 1)
     if roof is not None:
         tr = pmc_traffic(args)
@@ -748,7 +755,8 @@ def run_extra_legs_in_child(args):
 
     cmd = [sys.executable, os.path.abspath(__file__), "--leg", "extras", "--config", str(args.config), "--lpq", str(args.lpq),
            "--cell", str(args.cell), "--pass-kernel", str(args.pass_kernel), "--sort", str(args.sort),
-           "--extrinsic-est", str(args.extrinsic_est), "--steps", str(args.steps)]
+           "--extrinsic-est", str(args.extrinsic_est), "--steps", str(args.steps), "--index-cache", str(args.index_cache),
+           "--prelaunch", str(args.prelaunch)]
     if args.two_streams:
         cmd.append("--two-streams")
     try:
@@ -780,7 +788,8 @@ def extra_legs(args):
         a = capi.pinned_empty((N, 3), np.float32)
         a[:] = p.body
         bodies.append(a)
-    h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, sort_queries=args.sort, pass_kernel=args.pass_kernel)
+    h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, sort_queries=args.sort, pass_kernel=args.pass_kernel,
+                    index_cache=args.index_cache, prelaunch=args.prelaunch)
     h.map_build(scene.map_xyz)
     h.set_timing_stride(0)
     for s in range(S):
@@ -793,7 +802,8 @@ def extra_legs(args):
         # its 23x23 system the other's kernels run
         import threading
 
-        h2 = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, sort_queries=args.sort, pass_kernel=args.pass_kernel)
+        h2 = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, sort_queries=args.sort, pass_kernel=args.pass_kernel,
+                          index_cache=args.index_cache, prelaunch=args.prelaunch)
         h2.map_build(scene.map_xyz)
         h2.set_timing_stride(0)
         for s in range(S):

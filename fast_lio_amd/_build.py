@@ -21,7 +21,8 @@ HDRS = ["fastlio_hip.h", "fastlio_amd/esekfom.hpp", "fastlio_amd/mtk.hpp", "fast
 # -ffp-contract=off: the reference never fuses a*b+c (baseline x86-64 build); flags must match for
 # bit-exact point_selected_surf.  -fhip-fp32-correctly-rounded-divide-sqrt is hipcc's default; stated.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-result",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-result", "-Werror=undefined-internal",
+         "-Wl,--no-undefined",
          # host side (the 23x23 IEKF algebra between two launches): AVX2 without FMA contraction -- same results, wider
          "-Xarch_host", "-mavx2"]
 
@@ -52,6 +53,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return LIB
+
+
+REFALG = os.path.join(LIBDIR, "libfastlio_esekf_refalg.so")
+
+
+def build_reference_algebra(force: bool = False) -> str:
+    """The host filter alone (flh_esekf.cpp over include/fastlio_amd/esekfom.hpp) built with -DFASTLIO_AMD_REFERENCE_ALGEBRA -- the
+    reference's own operation sequence in the information-form step (esekfom.hpp:1782-1802: two 23 x 23 inverses) instead of the
+    product's 12 x 12 elimination -- as a second shared library whose flh_* calls resolve to libfastlio_hip.so.  g++, host only.
+    tests/test_gpu_parity.py runs a GPU update through it at the tolerances the product's form had to loosen."""
+    src = os.path.join(CSRC, "flh_esekf.cpp")
+    deps = [src, LIB] + [os.path.join(INCLUDE, f) for f in HDRS]
+    if not force and os.path.exists(REFALG) and all(os.path.getmtime(d) <= os.path.getmtime(REFALG) for d in deps if os.path.exists(d)):
+        return REFALG
+    cxx = shutil.which("g++") or hipcc()
+    subprocess.check_call([cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-mavx2",
+                           "-DFASTLIO_AMD_REFERENCE_ALGEBRA", src, "-o", REFALG, "-L" + LIBDIR, "-lfastlio_hip", "-Wl,-Bsymbolic",
+                           "-Wl,-rpath,$ORIGIN"])
+    return REFALG
 
 
 if __name__ == "__main__":

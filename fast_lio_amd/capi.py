@@ -168,7 +168,30 @@ def lib():
     path = _build.LIB
     if _build.needs_build():
         path = _build.build()
-    L = C.CDLL(path)
+    _lib = _declare(C.CDLL(path))
+    return _lib
+
+
+class using_library:
+    """Context manager: every call of this module goes through another build of the same ABI while it is active -- the tests'
+    way to run the filter of _build.build_reference_algebra() (whose flh_* calls resolve to the product library it links)."""
+
+    def __init__(self, path):
+        self._L = _declare(C.CDLL(path))
+
+    def __enter__(self):
+        global _lib
+        lib()
+        self._old, _lib = _lib, self._L
+        return self._L
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self._old
+
+
+def _declare(L):
+    """argument / result types of every entry point"""
     L.flh_last_error.restype = C.c_char_p
     L.flh_device_available.restype = C.c_int
     L.flh_default_config.argtypes = [C.POINTER(FlhConfig)]

@@ -1601,9 +1601,15 @@ static flh::GranOut gran_out(const flh_handle* h, double seq) {
     o.sect_off = (int)((size_t)h->peer_rank * kGranSect);
     return o;
 }
+// With an RCCL communicator the pass's block stays in device memory, but it is summed in the granules' tree (the group reducers
+// leave their totals in part2, the last group adds the groups: flh_fit_dev.hpp, groups_sum_device) -- so the one-launch pass runs
+// there too, and both kinds of pass produce the bits the host's granule sum would
+static bool device_tree(const flh_handle* h, bool host_granules) {
+    return !host_granules && h->comm != nullptr && h->N > 0 && gran_group_size(h->N) > 0;
+}
 // does a searching evaluation of the active scan run as ONE launch?
 static bool use_pass_kernel(const flh_handle* h, bool host_granules) {
-    return h->pass_ok && host_granules && h->N > 0;
+    return h->pass_ok && (host_granules || device_tree(h, host_granules)) && h->N > 0;
 }
 
 // The coordinates of the current neighbour cache, for whoever reads nn_pts: gathered from the indices a one-launch pass left
@@ -1636,7 +1642,7 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
                               h->cfg.plane_threshold, ext, h->nn_pts.p, h->nn_cnt.p, h->selected.p, h->plane_cache ? h->plane.p : nullptr,
                               h->partials.p, h->tickets.p, gout, seq, gran_group_size(h->N),
                               h->stats ? h->counter.p : nullptr, h->own_axis, h->own_lo, h->own_hi, st, timed ? ev3[0] : nullptr,
-                              timed ? ev3[3] : nullptr, idx));
+                              timed ? ev3[3] : nullptr, idx, flh::pass_lanes_for((int)h->N, h->cfg.pass_lanes), h->part2.p, d_out));
         h->nn_pts_valid = idx == nullptr;
     } else {
         if (do_search) h->nn_pts_valid = true;  // (the search kernels write the coordinates)
@@ -1648,7 +1654,7 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
                                     timed ? ev3[0] : nullptr, timed ? ev3[1] : nullptr));
         HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
                              h->world.p, h->partials.p, h->part2.p, d_out, seq, h->tickets.p, h->slow_count.p, gout,
-                             host_granules ? gran_group_size(h->N) : 0, 0, st, h->plane_cache ? h->plane.p : nullptr,
+                             (host_granules || device_tree(h, host_granules)) ? gran_group_size(h->N) : 0, 0, st, h->plane_cache ? h->plane.p : nullptr,
                              (do_search || !h->planes_valid) ? 1 : 2, timed ? ev3[2] : nullptr, timed ? ev3[3] : nullptr));
     }
     if (do_search) {
@@ -2013,7 +2019,7 @@ int flh_eval_begin(flh_handle* h, const double rot[4], const double pos[3], cons
     // group sums as granules in pinned memory (this rank's and, with peers, every rank's): not with an RCCL communicator (the
     // block is all-reduced on the device), not for an empty scan
     pe.granules = !h->comm && h->N > 0 && gran_group_size(h->N) > 0;
-    pe.one_launch = pe.do_search && use_pass_kernel(h, pe.granules);
+    pe.one_launch = pe.do_search && use_pass_kernel(h, pe.granules);  // (granules, or RCCL's device tree)
     if (h->peer_n > 1 && !pe.granules) return fail("flh_eval: a scan shard may not be empty when the ranks exchange granules (flh_peer_*)");
     if (pre_try_go(h, s, pe)) {
         // the kernel of this evaluation was enqueued beside the previous pass: the state went to its mailbox

@@ -325,7 +325,7 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
     const int col = lane & 15, kq = lane >> 4;
     const int t = threadIdx.x;
     const int nblk = gridDim.x;
-    if (gout.n_dst > 0) {
+    if (red1 > 0) {
         // ---- flh_eval's path: every WAVE is a unit of the cross-workgroup sum k_pass uses (64 points each, the same points in
         // the same lanes) and this block is a QUAD of that sum's tree (flh_fit_dev.hpp): its four waves are added in LDS,
         // ((w0 + w1) + w2) + w3, and ONE record goes to memory -- a no-search pass produces the bits a searching pass would at
@@ -366,8 +366,11 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
         __syncthreads();
         if (s_ticket != (uint32_t)(gblocks - 1)) return;  // block-uniform
         if (wave == 0) {
-            group_sum_publish<true>(partials, group, min(red1, nunits - group * red1), red1, nsl, (nunits + red1 - 1) / red1, gout, seq, lane);
+            group_sum_publish<true>(partials, group, min(red1, nunits - group * red1), red1, nsl, (nunits + red1 - 1) / red1, gout, seq, lane, part2);
             if (lane == 0) tickets[1 + group] = 0;  // re-arm this group's ticket for the next launch
+            // no granule output (an RCCL communicator is attached): the last group adds the groups into the device block, as the
+            // host would add granules -- the one-launch searching pass does the same, so both kinds of pass keep one tree
+            if (gout.n_dst == 0) groups_sum_device(part2, (nunits + red1 - 1) / red1, nsl, ncol, tickets, out256, lane);
         }
         return;
     }

@@ -45,12 +45,19 @@ namespace flh {
 #ifndef FLH_PASS_WAVES
 #define FLH_PASS_WAVES 7
 #endif
-#define PASS_ATTR __attribute__((amdgpu_waves_per_eu(FLH_PASS_WAVES, FLH_PASS_WAVES)))
+// (the wide variants run where the GPU is under-filled: one 1024-thread workgroup per CU is four waves per SIMD, registers are free)
+// (sixteen lanes: ONE 1024-thread workgroup per CU = four waves per SIMD; eight lanes: two 512-thread workgroups = four as well -- at
+// six waves per SIMD, three workgroups, the kernel spills)
+#define PASS_ATTR __attribute__((amdgpu_waves_per_eu(LPQ == 4 ? FLH_PASS_WAVES : 4, LPQ == 4 ? FLH_PASS_WAVES : 4)))
 constexpr int kPassQueries = 64;                       // scan points per workgroup
 constexpr int kSegA = ring_seg_slots<1>();             // 20 LDS table entries per phase-A group (64 groups)
-constexpr int kSegB = 2 * 16 + 2;                      // 34 per phase-B group (32 groups, 4x4 window)
-constexpr int kSegWords = (64 * kSegA > 32 * kSegB) ? 64 * kSegA : 32 * kSegB;
-static_assert(kSegWords * 8 >= 64 * kTileStride * 8, "the fit's transpose tile reuses the segment tables");
+constexpr int kSegB = 2 * 16 + 2;                      // 34 per phase-B group (8 LPQ groups of eight lanes, 4x4 window)
+// LPQ = lanes per query in phase A = the workgroup's size / 64: 4 (256 threads; a full-size scan), 8, 16 (1024 threads: a scan, or
+// a rank's shard of one, that leaves the GPU under-filled -- 12 500 points are 196 workgroups on 256 CUs, each running the
+// dependent chain of 16 queries per wave; with sixteen lanes per query a wave holds four queries, resolves two segments per lane
+// instead of five and walks a quarter of the candidates).  The unit, the fit wave and the summation tree are the same: same bits.
+template <int LPQ> constexpr int seg_words() { return (64 * kSegA > 8 * LPQ * kSegB) ? 64 * kSegA : 8 * LPQ * kSegB; }
+static_assert(seg_words<4>() * 8 >= 64 * kTileStride * 8, "the fit's transpose tile reuses the segment tables");
 // Developer instrumentation (tools/variant.py --define FLH_PASS_STAMPS, tools/pass_stamps.py): per-wave 100 MHz time stamps of the
 // phases of k_pass, read back with flh_debug_pass_stamps.  Compiled out of the product.
 #ifdef FLH_PASS_STAMPS
@@ -70,16 +77,19 @@ void pass_stamps_read(unsigned long long* out, size_t words) {
 #define STAMP(i)
 #endif
 
-template <int ORD>
-__global__ void __launch_bounds__(256) PASS_ATTR
+template <int ORD, int LPQ>
+__global__ void __launch_bounds__(64 * LPQ) PASS_ATTR
 k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist, float thr, int ext,
        int ncol, float4* __restrict__ nn_pts, uint8_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected,
        float4* __restrict__ plane_cache, double* __restrict__ partials, uint32_t* __restrict__ tickets, GranOut gout, double seq,
-       int red, u64* __restrict__ cand_counter, int own_axis, float own_lo, float own_hi, uint32_t* __restrict__ nn_idx) {
-    __shared__ uint2 segs[kSegWords];
+       int red, u64* __restrict__ cand_counter, int own_axis, float own_lo, float own_hi, uint32_t* __restrict__ nn_idx,
+       double* __restrict__ part2, double* __restrict__ out256) {
+    constexpr int NW = LPQ;          // waves of the workgroup
+    constexpr int QPW = 64 / LPQ;    // queries per wave in phase A
+    __shared__ uint2 segs[seg_words<LPQ>()];
     __shared__ float park[kPassQueries * kParkStride];
     __shared__ uint32_t s_list[64];  // per wave: the slots (0..63) of its queries that go to phase B
-    __shared__ uint32_t s_wcnt[4];
+    __shared__ uint32_t s_wcnt[NW];
     const int tid = threadIdx.x;
     // which 64 scan points (a unit of the summation tree) this workgroup takes: the LAST ones first.  Workgroups are dispatched in
     // blockIdx order over ~2 us, and the end of the scan's Morton order is its far field, whose waves are the slowest of the launch
@@ -96,7 +106,7 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
 
     // ---- phase A: every query of the workgroup, four lanes each
     {
-        const int grp = tid >> 2, lane = tid & 3, wave = tid >> 6, wl = tid & 63;
+        const int grp = tid / LPQ, lane = tid & (LPQ - 1), wave = tid >> 6, wl = tid & 63;
         bool live = q0 + grp < N;
         const int q = live ? q0 + grp : N - 1;
         const float4 b = body[q];
@@ -115,15 +125,15 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
             pk[kParkBody] = b.x; pk[kParkBody + 1] = b.y; pk[kParkBody + 2] = b.z;
         }
         float ub_next;
-        const bool done = ring_query<4, 1, false, 8, false, false>(g, rs, segs + grp * kSegA, lane, q, N, live, qx, qy, qz, INFINITY,
-                                                                   max_sqdist, 2, nn_pts, nn_cnt, selected, cand_counter, pk, ub_next, nn_idx);
+        const bool done = ring_query<LPQ, 1, false, 8, false, false>(g, rs, segs + grp * kSegA, lane, q, N, live, qx, qy, qz, INFINITY,
+                                                                     max_sqdist, 2, nn_pts, nn_cnt, selected, cand_counter, pk, ub_next, nn_idx);
         const bool open = live && !done;
         if (lane == 0 && !(live && done)) {  // a settled query's status was written with its fifth neighbour
             pk[kParkStatus] = __uint_as_float(open ? kStOpen : kStIdle);
             pk[kParkUb] = ub_next;
         }
         const u64 bal = __ballot(open && lane == 0);
-        if (open && lane == 0) s_list[FLH_IDX(401, wave * 16 + __popcll(bal & ((1ull << wl) - 1ull)), 64)] = (uint32_t)grp;
+        if (open && lane == 0) s_list[FLH_IDX(401, wave * QPW + __popcll(bal & ((1ull << wl) - 1ull)), 64)] = (uint32_t)grp;
         if (wl == 0) s_wcnt[wave] = (uint32_t)__popcll(bal);
 #ifdef FLH_PASS_STAMPS
         {
@@ -140,12 +150,13 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     __syncthreads();
     STAMP(2);  // the workgroup's phase A done
 
-    // ---- phase B: the workgroup's open queries, eight lanes each, 32 per trip
-    const uint32_t c0 = s_wcnt[0], c1 = s_wcnt[1], c2 = s_wcnt[2], c3 = s_wcnt[3];
-    const uint32_t n_open = (c0 + c1) + (c2 + c3);  // workgroup-uniform
+    // ---- phase B: the workgroup's open queries, eight lanes each, 8 LPQ per trip (32 with 256 threads)
+    uint32_t n_open = 0;  // workgroup-uniform
+#pragma unroll
+    for (int w_ = 0; w_ < NW; ++w_) n_open += s_wcnt[w_];
 #ifndef NO_PHASE_B
     if (n_open) {
-        for (uint32_t k0 = 0; k0 < n_open; k0 += 32) {
+        for (uint32_t k0 = 0; k0 < n_open; k0 += 8 * LPQ) {
             // (normally one trip: the lane-dependent set-up is kept inside it instead of being hoisted into registers that
             // would have to live across the whole loop)
             int tid_b = tid;
@@ -153,8 +164,8 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
             const int grp = tid_b >> 3, lane = tid_b & 7;
             const bool live = k0 + grp < n_open;
             uint32_t idx = live ? k0 + grp : 0u, w = 0;
-            if (idx >= c0) { idx -= c0; w = 1; if (idx >= c1) { idx -= c1; w = 2; if (idx >= c2) { idx -= c2; w = 3; } } }
-            const uint32_t slot = s_list[FLH_IDX(402, w * 16 + idx, 64)] & 63u;
+            for (uint32_t cw = s_wcnt[0]; idx >= cw && w + 1 < (uint32_t)NW; cw = s_wcnt[w]) { idx -= cw; ++w; }  // which wave's list, and where in it
+            const uint32_t slot = s_list[FLH_IDX(402, w * QPW + idx, 64)] & 63u;
             float* pk = park + slot * kParkStride;
             const float qx = pk[kParkWorld], qy = pk[kParkWorld + 1], qz = pk[kParkWorld + 2];
             const float ub = pk[kParkUb];
@@ -208,7 +219,9 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
 
     // ---- this workgroup's share of the normal equations -> HBM, the group's ticket, and for the last arriver the group's sum
     const int nsl = gran_section_slots(ncol);  // the last one: the number of queries that needed phase B (a statistic the host reports)
-    const uint32_t n_b = (s_wcnt[0] + s_wcnt[1]) + (s_wcnt[2] + s_wcnt[3]);  // (read again from LDS rather than kept in a register)
+    uint32_t n_b = 0;  // (read again from LDS rather than kept in a register)
+#pragma unroll
+    for (int w_ = 0; w_ < NW; ++w_) n_b += s_wcnt[w_];
     unit_partial_store(partials, unit, nsl, ncol, acc, wl, (double)n_b);
     const int nblk = gridDim.x;
     const int group = unit / red;
@@ -220,12 +233,15 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
     STAMP(6);  // ticket taken
     if (tk != (uint32_t)(gsize - 1)) return;
-    group_sum_publish<false>(partials, group, gsize, red, nsl, (nblk + red - 1) / red, gout, seq, wl);
+    group_sum_publish<false>(partials, group, gsize, red, nsl, (nblk + red - 1) / red, gout, seq, wl, part2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(7);  // (the group's last arriver) group sum published
     if (wl == 0) tickets[1 + group] = 0;  // re-arm this group's ticket for the next launch
+    // no granule output (an RCCL communicator is attached): the last group to arrive adds the groups into the 16x16 block in device memory
+    if (gout.n_dst == 0) groups_sum_device(part2, (nblk + red - 1) / red, nsl, ncol, tickets, out256, wl);
 }
 
+constexpr int kPassWide16Max = 16384, kPassWide8Max = 32768;  // scans (shards) up to these sizes run 16 / 8 lanes per query unless told otherwise
 int pass_blocks(int N) { return ((N > 0 ? N : 1) + kPassQueries - 1) / kPassQueries; }
 // workgroups per reduction group: 64, more when that would make more than max_groups groups
 int pass_group_size(int N, int max_groups) {
@@ -235,28 +251,42 @@ int pass_group_size(int N, int max_groups) {
     return red;
 }
 
+int pass_lanes_for(int N, int wanted) {
+    if (wanted == 4 || wanted == 8 || wanted == 16) return wanted;
+    if (N <= 0) return 4;
+    // sixteen lanes while every workgroup is resident at one per CU (256 x 64 points), eight while two per CU are
+    return N <= kPassWide16Max ? 16 : (N <= kPassWide8Max ? 8 : 4);
+}
+
 hipError_t launch_pass(int order, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points, float max_sqdist,
                        float thr, int ext, float4* nn_pts, uint8_t* nn_cnt, uint8_t* selected, float4* plane_cache, double* partials,
                        uint32_t* tickets, const GranOut& out, double seq, int red, unsigned long long* cand_counter,
-                       int own_axis, float own_lo, float own_hi, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t* nn_idx) {
-    if (N <= 0 || out.n_dst < 1 || out.n_dst > kPeersMax) return hipErrorInvalidValue;
+                       int own_axis, float own_lo, float own_hi, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t* nn_idx,
+                       int lanes, double* part2, double* out256) {
+    if (N <= 0 || out.n_dst < 0 || out.n_dst > kPeersMax || (out.n_dst == 0 && (!part2 || !out256))) return hipErrorInvalidValue;
     const int ncol = ext ? 12 : 6;
-    const dim3 grid(pass_blocks(N)), blk(256);
-#define FLH_PASS(O)                                                                                                                   \
+    if (order != 1) lanes = 4;  // the wide variants exist for the default summation order only
+    const dim3 grid(pass_blocks(N)), blk(64 * lanes);
+#define FLH_PASS(O, L)                                                                                                                \
     do {                                                                                                                              \
         if (ev_start != nullptr || ev_stop != nullptr)                                                                                \
-            hipExtLaunchKernelGGL((k_pass<O>), grid, blk, 0, st, ev_start, ev_stop, 0, g, s, body, N, map_points, max_sqdist, thr, ext, \
+            hipExtLaunchKernelGGL((k_pass<O, L>), grid, blk, 0, st, ev_start, ev_stop, 0, g, s, body, N, map_points, max_sqdist, thr, ext, \
                                   ncol, nn_pts, nn_cnt, selected, plane_cache, partials, tickets, out, seq, red, cand_counter, own_axis, \
-                                  own_lo, own_hi, nn_idx);                                                                             \
+                                  own_lo, own_hi, nn_idx, part2, out256);                                                              \
         else                                                                                                                          \
-            hipLaunchKernelGGL((k_pass<O>), grid, blk, 0, st, g, s, body, N, map_points, max_sqdist, thr, ext, ncol, nn_pts, nn_cnt,   \
-                               selected, plane_cache, partials, tickets, out, seq, red, cand_counter, own_axis, own_lo, own_hi, nn_idx); \
+            hipLaunchKernelGGL((k_pass<O, L>), grid, blk, 0, st, g, s, body, N, map_points, max_sqdist, thr, ext, ncol, nn_pts, nn_cnt, \
+                               selected, plane_cache, partials, tickets, out, seq, red, cand_counter, own_axis, own_lo, own_hi, nn_idx, \
+                               part2, out256);                                                                                        \
     } while (0)
     switch (order) {
-        case 0: FLH_PASS(0); break;
-        case 2: FLH_PASS(2); break;
-        case 3: FLH_PASS(3); break;
-        default: FLH_PASS(1); break;
+        case 0: FLH_PASS(0, 4); break;
+        case 2: FLH_PASS(2, 4); break;
+        case 3: FLH_PASS(3, 4); break;
+        default:
+            if (lanes == 16) FLH_PASS(1, 16);
+            else if (lanes == 8) FLH_PASS(1, 8);
+            else FLH_PASS(1, 4);
+            break;
     }
 #undef FLH_PASS
     return hipGetLastError();

@@ -81,8 +81,9 @@ typedef struct flh_config {
                                (flh_map_incremental, flh_fetch_neighbors, a re-fit without the plane cache); 0: the search writes
                                the coordinates (80 B per query) itself.  Needs plane_cache; same results.  Performance only */
     int pass_lanes;         /* lanes per query in the first search stage of the one-launch pass: 4, 8 or 16; 0 (default, also for
-                               < 0 and any other value): 4, and 16 for a scan (or a rank's shard of one) of at most 32768 points,
-                               where four lanes per query leave most of the GPU idle.  Same results.  Performance only */
+                               < 0 and any other value): 4 for a full-size scan, 8 for a scan (or a rank's shard of one) of at most
+                               32768 points and 16 for at most 16384, where four lanes per query leave most of the GPU idle (every
+                               workgroup is resident at once, the pass is the dependent chain of one).  Same results.  Performance only */
 } flh_config;
 enum { FLH_ORDER_SEQ = 0, FLH_ORDER_SSE = 1, FLH_ORDER_PAIRWISE = 2, FLH_ORDER_NOVEC = 3 };
 

@@ -54,8 +54,10 @@ def _props(h, body, x, ext=False):
 
 def test_config2_full_update_against_oracle():
     """BASELINE configs[1], the headline: the same helper as configs 4 and 5 -- flags, planes + pd2 (normvec), neighbour indices
-    AND their squared distances bit for bit, posterior within the bars -- plus the size-independent properties."""
-    assert _full_update_against_oracle(5_000_000, 100_000, "avia", 2, nthreads=16, props=True) > 50_000
+    AND their squared distances bit for bit, posterior within the bars -- plus the size-independent properties; then the same
+    with extrinsic_est_en = 1, the reference's default (src/laserMapping.cpp:789, config/horizon.yaml:20): the twelve-column rows
+    and the 93-slot granule sections at full size."""
+    assert _full_update_against_oracle(5_000_000, 100_000, "avia", 2, nthreads=16, props=True, exts=(False, True)) > 50_000
 
 
 def test_config4_properties_20M_map_130k_ouster():
@@ -67,7 +69,7 @@ def test_config4_properties_20M_map_130k_ouster():
     assert _props(h, pr.body, xp) > 30_000
     h.close()
 
-def _full_update_against_oracle(M, N, sensor, cfg, nthreads=32, props=True):
+def _full_update_against_oracle(M, N, sensor, cfg, nthreads=32, props=True, exts=(False,)):
     from oracle import pyoracle as po
 
     pr = synth.make_problem(M, N, sensor, cfg=cfg)
@@ -75,30 +77,35 @@ def _full_update_against_oracle(M, N, sensor, cfg, nthreads=32, props=True):
     h = capi.Handle()
     h.map_build(pr.map_xyz)
     assert h.M == M
-    h.scan_upload(pr.body)
-    kf = capi.Esekf(h, max_iter=3)
-    kf.change_x(xp)
-    kf.change_P(P)
-    st = kf.update(0.001)
     m = po.Map(pr.map_xyz)
     sc = po.Scan(pr.body, nthreads=nthreads)
-    x_ref, P_ref, st_ref = sc.update_iterated(m, xp, P)
-    assert st.passes == st_ref.passes and st.searches == st_ref.searches
-    assert list(st.n_eff)[: st.passes] == list(st_ref.n_eff)[: st_ref.passes]
-    np.testing.assert_array_equal(h.fetch_selected(), sc.selected)          # bit-exact point_selected_surf
-    sel = sc.selected.astype(bool)
-    np.testing.assert_array_equal(h.fetch_normvec()[sel].view(np.uint32), sc.normvec[sel].view(np.uint32))  # planes + pd2
-    x = kf.get_x()
-    assert np.linalg.norm(x[:3] - x_ref[:3]) <= 1e-4                          # pose within 1e-4 m
-    np.testing.assert_allclose(x, x_ref, rtol=1e-4, atol=1e-7)
-    np.testing.assert_allclose(kf.get_P(), P_ref, rtol=0, atol=1e-4 * np.abs(P_ref).max())
-    idx, d2, cnt = h.fetch_neighbors()
-    gate = (sc.nn_cnt == 5) & (sc.nn_d2[:, 4] <= 5.0)
-    np.testing.assert_array_equal(idx[gate], sc.nn_idx[gate])
-    np.testing.assert_array_equal(d2[gate].view(np.uint32), sc.nn_d2[gate].view(np.uint32))
-    n_sel = int(sel.sum())
+    n_sel = 0
+    for ext in exts:
+        h.scan_upload(pr.body)
+        kf = capi.Esekf(h, max_iter=3, extrinsic_est_en=ext)
+        kf.change_x(xp)
+        kf.change_P(P)
+        st = kf.update(0.001)
+        x_ref, P_ref, st_ref = sc.update_iterated(m, xp, P, extrinsic_est_en=ext)
+        assert st.passes == st_ref.passes and st.searches == st_ref.searches
+        assert list(st.n_eff)[: st.passes] == list(st_ref.n_eff)[: st_ref.passes]
+        np.testing.assert_array_equal(h.fetch_selected(), sc.selected)          # bit-exact point_selected_surf
+        sel = sc.selected.astype(bool)
+        np.testing.assert_array_equal(h.fetch_normvec()[sel].view(np.uint32), sc.normvec[sel].view(np.uint32))  # planes + pd2
+        x = kf.get_x()
+        assert np.linalg.norm(x[:3] - x_ref[:3]) <= 1e-4                          # pose within 1e-4 m
+        np.testing.assert_allclose(x, x_ref, rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(kf.get_P(), P_ref, rtol=0, atol=1e-4 * np.abs(P_ref).max())
+        idx, d2, cnt = h.fetch_neighbors()
+        gate = (sc.nn_cnt == 5) & (sc.nn_d2[:, 4] <= 5.0)
+        np.testing.assert_array_equal(idx[gate], sc.nn_idx[gate])
+        np.testing.assert_array_equal(d2[gate].view(np.uint32), sc.nn_d2[gate].view(np.uint32))
+        n_sel = int(sel.sum())
+        kf.close()
     if props:
         _props(h, pr.body, xp)
+        if True in exts:
+            _props(h, pr.body, xp, ext=True)
     h.close()
     return n_sel
 

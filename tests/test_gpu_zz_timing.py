@@ -165,7 +165,9 @@ def test_one_launch_pass_equals_three_launch_pass():
     the three-launch pass -- flags, neighbour ids in rank order, distances, planes, the normal equations (both add the same
     64-point units in the same order: flh_fit_dev.hpp) and with them the whole update must be identical bit for bit -- on a dense
     scan, on a thinned-out scan (many queries reach the second stage), on a ragged size, on seven points, and with a prior so
-    far off that most queries reach the second stage."""
+    far off that most queries reach the second stage.  The one-launch pass in all its shapes: four / eight / sixteen lanes per query
+    in its first stage (flh_config.pass_lanes: 256 / 512 / 1024 threads per 64-point unit; the wide ones are what a rank's shard of
+    a scan runs), and the neighbour cache kept as indices (flh_config.index_cache, the default) or as coordinates."""
     pr = synth.make_problem(200000, 20000, "avia", cfg=1)
     xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
     x_far = np.array(xp, dtype=np.float64)
@@ -174,8 +176,11 @@ def test_one_launch_pass_equals_three_launch_pass():
              "tiny": np.ascontiguousarray(pr.body[:7])}
     for name, body in scans.items():
         out = []
-        for one in (0, 1):
-            h = capi.Handle(pass_kernel=one)
+        variants = [dict(pass_kernel=0), dict(pass_kernel=1, pass_lanes=4), dict(pass_kernel=1, pass_lanes=8), dict(pass_kernel=1, pass_lanes=16),
+                    dict(pass_kernel=1, pass_lanes=4, index_cache=0), dict(pass_kernel=1, pass_lanes=0, index_cache=0)]
+        for kw in variants:
+            one = kw["pass_kernel"]
+            h = capi.Handle(**kw)
             h.map_build(pr.map_xyz)
             h.scan_upload(body)
             res = []
@@ -197,21 +202,24 @@ def test_one_launch_pass_equals_three_launch_pass():
             out.append((res, kf.get_x().copy(), kf.get_P().copy(), list(us.n_eff)[: us.passes]))
             kf.close()
             h.close()
-        (r0, x0, P0, n0), (r1, x1, P1, n1) = out
-        assert n0 == n1, name
-        np.testing.assert_array_equal(x0, x1, err_msg=name)
-        np.testing.assert_array_equal(P0, P1, err_msg=name)
-        for a, b in zip(r0, r1):
-            np.testing.assert_array_equal(a[4], b[4], err_msg=name + ": flags")
-            np.testing.assert_array_equal(a[6], b[6], err_msg=name + ": neighbour counts")
-            inside = a[7] <= 5.0                     # inside the gate the two must agree entry for entry
-            np.testing.assert_array_equal(a[5][inside], b[5][inside], err_msg=name + ": neighbour ids")
-            np.testing.assert_array_equal(a[7][inside].view(np.uint32), b[7][inside].view(np.uint32), err_msg=name + ": distances")
-            sel = a[4].astype(bool)
-            np.testing.assert_array_equal(a[8][sel].view(np.uint32), b[8][sel].view(np.uint32), err_msg=name + ": planes")
-            np.testing.assert_array_equal(a[0], b[0], err_msg=name)
-            np.testing.assert_array_equal(a[1], b[1], err_msg=name)
-            assert a[2] == b[2] and a[3] == b[3], name
+        scan_name = name
+        for vi in range(1, len(out)):
+            (r0, x0, P0, n0), (r1, x1, P1, n1) = out[0], out[vi]
+            name = f"{scan_name} {variants[vi]}"
+            assert n0 == n1, name
+            np.testing.assert_array_equal(x0, x1, err_msg=name)
+            np.testing.assert_array_equal(P0, P1, err_msg=name)
+            for a, b in zip(r0, r1):
+                np.testing.assert_array_equal(a[4], b[4], err_msg=name + ": flags")
+                np.testing.assert_array_equal(a[6], b[6], err_msg=name + ": neighbour counts")
+                inside = a[7] <= 5.0                     # inside the gate the two must agree entry for entry
+                np.testing.assert_array_equal(a[5][inside], b[5][inside], err_msg=name + ": neighbour ids")
+                np.testing.assert_array_equal(a[7][inside].view(np.uint32), b[7][inside].view(np.uint32), err_msg=name + ": distances")
+                sel = a[4].astype(bool)
+                np.testing.assert_array_equal(a[8][sel].view(np.uint32), b[8][sel].view(np.uint32), err_msg=name + ": planes")
+                np.testing.assert_array_equal(a[0], b[0], err_msg=name)
+                np.testing.assert_array_equal(a[1], b[1], err_msg=name)
+                assert a[2] == b[2] and a[3] == b[3], name
 
 
 def test_synchronous_and_asynchronous_staging_do_not_share_scratch_unguarded():

@@ -41,6 +41,7 @@ class FakeHandle:
     def peer_size(self): return 1
     def debug_bounds(self): return False, [0] * 20
     def pass_stats(self): return {"search_passes": 40, "one_launch_passes": 40, "second_stage_queries": 4000, "nosearch_passes": 40}
+    def prelaunch_stats(self): return {"armed": 80, "go": 78, "abort": 2, "gone": 0}
     def set_owned_interval(self, a, lo, hi): pass
     def map_incremental(self, x, fsm, inited, apply=True, counts=True): self.M += 10 if apply else 0; return (5, 5) if counts else None
     def map_change_stats(self): return {"enqueued_without_wait": 2, "replayed": 0}
