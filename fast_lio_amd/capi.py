@@ -99,7 +99,7 @@ EXPORTS = [
     "flh_esekf_last_error", "flh_rccl_unique_id", "flh_rccl_init_rank", "flh_rccl_init_all", "flh_rccl_destroy", "flh_rccl_size",
     "flh_rccl_rank", "flh_eval_group", "flh_set_owned_interval", "flh_esekf_run_scans", "flh_get_search_counters", "flh_set_timing_sampling",
     "flh_map_sync", "flh_eval_begin", "flh_eval_end", "flh_debug_bounds", "flh_debug_pass_stamps", "flh_peer_open", "flh_peer_init_all", "flh_peer_close", "flh_peer_size", "flh_peer_rank", "flh_get_pass_stats", "flh_map_change_stats",
-    "flh_eval_expect_next", "flh_set_prelaunch", "flh_get_prelaunch_stats",
+    "flh_eval_expect_next", "flh_set_prelaunch", "flh_get_prelaunch_stats", "flh_map_storage_stats",
 ]
 
 _lib = None
@@ -236,6 +236,7 @@ def _declare(L):
     L.flh_peer_close.restype = None
     L.flh_peer_size.argtypes = [C.c_void_p]
     L.flh_peer_rank.argtypes = [C.c_void_p]
+    L.flh_map_storage_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.flh_eval_expect_next.argtypes = [C.c_void_p, C.c_int]
     L.flh_set_prelaunch.argtypes = [C.c_void_p, C.c_int]
     L.flh_get_prelaunch_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -361,6 +362,11 @@ class Handle:
         _chk(lib().flh_map_stats(self._h, out), "flh_map_stats")
         return {"reindex": int(out[0]), "brickwise": int(out[1]), "slots_used": int(out[2]), "slots": int(out[3]),
                 "ids": int(out[4]), "bricks": int(out[5])}
+
+    def map_storage_stats(self) -> dict:
+        out = (C.c_uint64 * 4)()
+        _chk(lib().flh_map_storage_stats(self._h, out), "flh_map_storage_stats")
+        return {"points": int(out[0]), "slots_in_brick_ranges": int(out[1]), "bricks_purged": int(out[2]), "bricks": int(out[3])}
 
     def map_change_stats(self) -> dict:
         out = (C.c_uint64 * 2)()

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <random>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -82,6 +83,7 @@ struct PeerSeg {
     std::string name;
     int refs = 0;
     int n = 0;
+    struct flh_handle* members[8] = {};  // flh_peer_init_all (one process): the attached handles by rank
 };
 
 template <class T>
@@ -159,6 +161,7 @@ struct flh_handle {
     std::vector<uint32_t> id_pos;          // id -> position among the live points (flh_fetch_neighbors), built on demand
     bool id_pos_valid = false;
     uint64_t n_reindex = 0, n_inplace = 0; // full re-indexings / changes applied brick-wise since creation
+    uint64_t n_purged = 0;                 // bricks compacted in place after removals (k_brick_purge)
     DevBuf<u64> mb_k0, mb_k1;              // sort scratch of the index build and of the map updates (kept allocated)
     DevBuf<u64> vox_tab;                   // voxel hash table of a map change (key, best new point) x slots
     DevBuf<uint32_t> mb_v0, mb_v1, mb_bh, mb_br, mb_bstart, mb_aabb;
@@ -809,13 +812,14 @@ static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size
         HIPC(h->vox_tab.reserve(2 * (size_t)vcap));
         HIPC(hipMemsetAsync(h->vox_tab.p, 0xFF, 2 * (size_t)vcap * sizeof(unsigned long long), st));
     }
-    uint32_t* const d_alive_out = d_cnt ? h->mi_cnt.p + 2 : h->mu_incl.p + (n - 1);  // where the number of surviving points goes
+    // where the number of surviving points goes (with device-side lengths the general path's scan runs over the whole bound: the
+    // entries behind the change's true end count as "no point", k_add_insert)
+    const bool small_path = h->cfg.fused_small_changes != 0 && nu <= flh::small_change_max();
+    uint32_t* const d_alive_out = (d_cnt && small_path) ? h->mi_cnt.p + 2 : h->mu_incl.p + (n - 1);
     HIPC(flh::launch_add_insert(d_add, (uint32_t)n1, nu, ds, h->vox_tab.p, vcap, h->mu_alive.p, h->ctr.p, st, d_cnt));
     if (n1 > 0)
         HIPC(flh::launch_add_resolve(h->grid, h->map_sorted.p, d_add, h->vox_tab.p, vcap, (uint32_t)n1, ds, h->dead_id.p, h->live.p,
                                      h->ctr.p, h->mu_alive.p, st, d_cnt));
-    if (d_cnt && !(h->cfg.fused_small_changes != 0 && nu <= flh::small_change_max()))
-        return fail("map update: device-side list lengths need the one-workgroup path");
     if (h->cfg.fused_small_changes != 0 && nu <= flh::small_change_max()) {
         // a scan's worth of points: ids, brick keys and their sort in one workgroup (one launch instead of eight)
         HIPC(flh::launch_ins_sort_small(h->grid, d_add, h->mu_alive.p, nu, (uint32_t)h->n_ids, h->map_orig.p, h->dead_id.p, h->ins.p, bk0,
@@ -869,12 +873,16 @@ int flh_map_delete_boxes(flh_handle* h, const float* boxes, size_t nb) {
     hipStream_t st = h->stream;
     HIPC(h->mu_boxes.reserve(6 * nb));
     HIPC(hipMemcpyAsync(h->mu_boxes.p, boxes, 6 * nb * sizeof(float), hipMemcpyHostToDevice, st));
-    HIPC(hipMemsetAsync(h->ctr.p + 3, 0, sizeof(uint32_t), st));
+    HIPC(hipMemsetAsync(h->ctr.p + 3, 0, 2 * sizeof(uint32_t), st));
     HIPC(flh::launch_delete_boxes(h->grid, h->map_sorted.p, (uint32_t)h->alloc_top, h->mu_boxes.p, (int)nb, h->dead_id.p, h->live.p,
                                   h->ctr.p, st));
-    HIPC(hipMemcpyAsync(h->h_ctr, h->ctr.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    // bricks that have lost more than half of their range to tombstones are compacted where they lie, so that the searches of
+    // a long-running node do not go on reading what lasermap_fov_segment removed (a brick that RECEIVES points is rewritten anyway)
+    HIPC(flh::launch_brick_purge(h->grid, h->map_sorted.p, h->starts.p, h->live.p, h->ctr.p, (uint32_t)h->nbricks, (uint32_t)h->pts_cap, st));
+    HIPC(hipMemcpyAsync(h->h_ctr, h->ctr.p, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));  // boxes is the caller's
     h->M -= h->h_ctr[3];
+    h->n_purged += h->h_ctr[4];
     h->id_pos_valid = false;
     h->searched_once = false;
     return 0;
@@ -919,6 +927,24 @@ int flh_map_stats(const flh_handle* h, uint64_t out[6]) {
     if (!h || !out) return fail("flh_map_stats: null argument");
     if (map_settle(const_cast<flh_handle*>(h)) != 0) return -1;
     out[0] = h->n_reindex; out[1] = h->n_inplace; out[2] = h->alloc_top; out[3] = h->pts_cap; out[4] = h->n_ids; out[5] = h->nbricks;
+    return 0;
+}
+
+int flh_map_storage_stats(flh_handle* h, uint64_t out[4]) {
+    if (!h || !out) return fail("flh_map_storage_stats: null argument");
+    if (map_settle(h) != 0) return -1;
+    out[0] = h->M; out[1] = 0; out[2] = h->n_purged; out[3] = h->nbricks;
+    const size_t nb = h->nbricks;
+    if (nb == 0 || !h->starts.p) return 0;
+    HIPC(hipSetDevice(h->device));
+    std::vector<uint32_t> a(nb), b(nb);
+    const size_t pitch = (size_t)flh::kBrickStride * sizeof(uint32_t);
+    HIPC(hipMemcpy2DAsync(a.data(), sizeof(uint32_t), h->starts.p, pitch, sizeof(uint32_t), nb, hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipMemcpy2DAsync(b.data(), sizeof(uint32_t), h->starts.p + 64, pitch, sizeof(uint32_t), nb, hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    uint64_t span = 0;
+    for (size_t r = 0; r < nb; ++r) span += b[r] >= a[r] ? b[r] - a[r] : 0;
+    out[1] = span;
     return 0;
 }
 
@@ -1330,6 +1356,7 @@ static void stop_stager(flh_handle* h) {
 
 static int activate(flh_handle* h, flh_handle::Slot& sl, bool full_clear) {
     HIPC(hipSetDevice(h->device));
+    pre_cancel(h);  // (a pass enqueued ahead for the previous scan that never got its state)
     if (wait_slot(h, sl) != 0) return -1;
     // In a running stream the staging of this scan finished while the previous scan was updated: then no barrier packet goes in
     // front of the scan's first pass, one look at the event instead (same box, two alternating pairs, profiles/r05_call1/:
@@ -1407,12 +1434,21 @@ void* flh_host_alloc(size_t bytes) {
 }
 void flh_host_free(void* p) {
     if (!p) return;
+    // a staging that reads the buffer where it lies may still be under way (flh_scan_stage_async) -- on ANY device of this process
+    // (the buffer is not tied to a handle), so every device is waited for, and the range stays registered until then: a staging job
+    // that only now reaches the front of its queue still finds it and copies from it directly while it exists
+    int cur = 0, ndev = 0;
+    (void)hipGetDevice(&cur);
+    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+    for (int d = 0; d < ndev; ++d)
+        if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+    (void)hipSetDevice(cur);
+    (void)hipGetLastError();
     {
         std::lock_guard<std::mutex> lk(g_pin_mu);
         for (size_t i = 0; i < g_pin_ranges.size(); ++i)
             if (g_pin_ranges[i].first == (uintptr_t)p) { g_pin_ranges.erase(g_pin_ranges.begin() + (long)i); break; }
     }
-    (void)hipDeviceSynchronize();  // a staging that reads the buffer where it lies may still be under way (flh_scan_stage_async)
     (void)hipHostFree(p);
 }
 
@@ -1730,7 +1766,8 @@ static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
     for (int k = 0; k < nsl; ++k) sum[k] = 0.0;
     const double* base = h->h_gran + ((uint64_t)seq & 1u) * (size_t)h->peer_n * kGranSect * 2;
     uint64_t spins = 0;
-    const auto t_start = std::chrono::steady_clock::now();
+    bool retired = false;  // this rank's own kernel has been seen retired (from then on a peer's granules have 30 s)
+    auto t_retired = std::chrono::steady_clock::now();
     auto wait_for = [&](const double* gp, double* value) -> int {
         for (;;) {
             const __m128d x = _mm_load_pd(gp);  // one 16-byte read: {value, sequence}
@@ -1738,14 +1775,20 @@ static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
             cpu_relax();
             if ((++spins & 0xFFFFFu) == 0) {
                 if (pre_gone_relaunch(h, seq, ext) != 0) return -1;
+                // this rank's OWN section is waited for as long as its stream is busy (an evaluation queued behind a long map build
+                // or run under a profiler takes what it takes); only a PEER's section has a deadline, counted from the moment this
+                // rank's own kernel has retired
+                const bool own = gp >= base + (size_t)h->peer_rank * kGranSect * 2 && gp < base + (size_t)(h->peer_rank + 1) * kGranSect * 2;
                 if (hipStreamQuery(st) != hipErrorNotReady) {  // this rank's kernel finished or failed
                     HIPC(hipStreamSynchronize(st));
                     const __m128d y = _mm_load_pd(gp);
-                    const bool own = gp >= base + (size_t)h->peer_rank * kGranSect * 2 && gp < base + (size_t)(h->peer_rank + 1) * kGranSect * 2;
                     if (own && _mm_cvtsd_f64(_mm_unpackhi_pd(y, y)) != seq) return fail("flh_eval: kernel retired without publishing its result");
+                    if (!own) {
+                        if (!retired) { retired = true; t_retired = std::chrono::steady_clock::now(); }
+                        if (std::chrono::steady_clock::now() - t_retired > std::chrono::seconds(30))
+                            return fail("flh_eval: timed out waiting for a peer's granules (ranks out of step?)");
+                    }
                 }
-                if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30))
-                    return fail("flh_eval: timed out waiting for a peer's granules (ranks out of step?)");
             }
         }
     };
@@ -2142,6 +2185,7 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
     if (!h || !x) return fail("flh_map_incremental: null argument");
     if (!(filter_size_map > 0)) return fail("flh_map_incremental: filter_size_map must be > 0");
     if (!h->cur_body) return fail("flh_map_incremental: no active scan");
+    pre_cancel(h);
     if (map_settle(h) != 0) return -1;
     if (h->N > 0 && !h->searched_once)
         return fail("flh_map_incremental: the active scan has not been searched against the current map");
@@ -2178,12 +2222,17 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
         // one-workgroup path and nobody asked for the list lengths, Add_Points is enqueued right behind this kernel with the
         // lengths read on the device: the host does not stand in the middle of the call (a wait for the granule, then five
         // launches, while the device idles).  A change that outgrows the launches is replayed by map_settle().
+        // The launches are sized from the PREVIOUS change (+ 50 %): up to small_change_max() points the one-workgroup path, above
+        // it the general path (scan + device-wide sort over the bound, the entries behind the true end reading "no point").
         const uint32_t cap = flh::small_change_max();
-        if (apply && !n_add && !n_no_downsample && h->cfg.fused_small_changes != 0 && h->mi_pred_n <= cap - cap / 4) {
+        if (apply && !n_add && !n_no_downsample && h->mi_pred_n != 0xFFFFFFFFu) {
+            size_t bound = (size_t)h->mi_pred_n + h->mi_pred_n / 2 + 1024;
+            if (h->cfg.fused_small_changes != 0 && bound <= cap) bound = cap;
+            bound = std::min<size_t>(bound, N);
             h->mi_valid_N = N;
             h->mi_cls_seq = seq;
             ++h->n_mi_deferred;
-            return apply_map_changes(h, h->mu_add.p, std::min<size_t>(cap, N), 0, filter_size_map, h->mi_cnt.p);
+            return apply_map_changes(h, h->mu_add.p, bound, 0, filter_size_map, h->mi_cnt.p);
         }
         if (wait_granule(h, 0, seq, "flh_map_incremental") != 0) return -1;
         c1 = h->h_mi[0];
@@ -2674,7 +2723,21 @@ static int fetch_rows_gathered(flh_handle* h, double* hx, double* hv, int64_t ca
 // ---------------------------------------------------------------------------------------------
 constexpr int kPeerRowsMax = 64, kPeerRec = 2 + kPeerRowsMax * 13;  // a rank's record of the gathered row fetch: {tag, n, rows}
 static size_t peer_gran_bytes(int n) { return (size_t)n * 2 * (size_t)n * kGranSect * 16; }
-static size_t peer_seg_bytes(int n) { return peer_gran_bytes(n) + (size_t)n * kPeerRec * sizeof(double); }
+// Behind the granule windows and the row records: the attach handshake of flh_peer_open.  A name can outlive a crashed run, and a
+// rank > 0 that starts before rank 0 would map the stale segment (same size) while rank 0 unlinks it and creates another.  So an
+// attach only counts once rank 0 -- which has just created THIS segment -- has echoed the fresh random token the rank left in it;
+// a rank that gets no echo unmaps, opens the name again and retries.
+struct PeerHello {
+    std::atomic<uint64_t> hello[8];  // [rank]: a token of this attach attempt
+    std::atomic<uint64_t> echo[8];   // [rank]: rank 0's copy of it
+};
+static size_t peer_rows_end(int n) { return peer_gran_bytes(n) + (size_t)n * kPeerRec * sizeof(double); }
+static size_t peer_seg_bytes(int n) { return peer_rows_end(n) + sizeof(PeerHello); }
+static uint64_t fresh_token() {
+    std::random_device rd;
+    uint64_t t = ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((uint64_t)getpid() << 17);
+    return t ? t : 1;
+}
 static double* peer_rows(const PeerSeg* sg, int src) { return reinterpret_cast<double*>((char*)sg->host + peer_gran_bytes(sg->n)) + (size_t)src * kPeerRec; }
 
 static void peer_attach(flh_handle* h, PeerSeg* sg, int nranks, int rank) {
@@ -2685,6 +2748,7 @@ static void peer_attach(flh_handle* h, PeerSeg* sg, int nranks, int rank) {
     h->peer_rank = rank;
     for (int& g : h->sect_ng) g = 0;
     h->h_gran_own = h->h_gran;
+    if (!sg->shm) sg->members[rank] = h;  // one process, several handles: fetch_rows_peers fills in every member's rows itself
     h->h_gran = reinterpret_cast<double*>(sg->host) + (size_t)rank * window;
     h->gran_owned = false;
     for (int d = 0; d < nranks; ++d) h->gran_dst[d] = reinterpret_cast<double*>(sg->dev) + (size_t)d * window;
@@ -2698,34 +2762,67 @@ int flh_peer_open(flh_handle* h, const char* shm_name, int nranks, int rank) {
     if (h->peer_seg) return fail("flh_peer_open: the handle is already attached to peers");
     HIPC(hipSetDevice(h->device));
     const size_t bytes = peer_seg_bytes(nranks);
-    int fd = -1;
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto deadline = std::chrono::seconds(30);
+    void* m = MAP_FAILED;
     if (rank == 0) {
         (void)shm_unlink(shm_name);  // a stale segment of an earlier run
-        fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        int fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd < 0) return fail(std::string("flh_peer_open: shm_open(create): ") + std::strerror(errno));
         if (ftruncate(fd, (off_t)bytes) != 0) {
-            const std::string m = std::string("flh_peer_open: ftruncate: ") + std::strerror(errno);
+            const std::string em = std::string("flh_peer_open: ftruncate: ") + std::strerror(errno);
             close(fd);
             (void)shm_unlink(shm_name);
-            return fail(m);
+            return fail(em);
+        }
+        m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { (void)shm_unlink(shm_name); return fail(std::string("flh_peer_open: mmap: ") + std::strerror(errno)); }
+        // every other rank announces itself in THIS segment (ftruncate'd memory is zero-filled) and is answered
+        PeerHello* hs = reinterpret_cast<PeerHello*>((char*)m + peer_rows_end(nranks));
+        for (;;) {
+            int answered = 0;
+            for (int r = 1; r < nranks; ++r) {
+                const uint64_t v = hs->hello[r].load(std::memory_order_acquire);
+                if (v != 0) {
+                    if (hs->echo[r].load(std::memory_order_relaxed) != v) hs->echo[r].store(v, std::memory_order_release);
+                    ++answered;
+                }
+            }
+            if (answered == nranks - 1) break;
+            if (std::chrono::steady_clock::now() - t0 > deadline) {
+                munmap(m, bytes);
+                (void)shm_unlink(shm_name);
+                return fail("flh_peer_open: not every rank attached to the segment within 30 s");
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
     } else {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {  // wait for rank 0's segment at its full size (ftruncate'd memory is zero-filled)
-            fd = shm_open(shm_name, O_RDWR, 0600);
+        for (;;) {  // rank 0's segment at its full size -- and rank 0 ALIVE in it: its echo of a token written just now
+            int fd = shm_open(shm_name, O_RDWR, 0600);
             if (fd >= 0) {
                 struct stat sb;
-                if (fstat(fd, &sb) == 0 && (size_t)sb.st_size == bytes) break;
+                const bool sized = fstat(fd, &sb) == 0 && (size_t)sb.st_size == bytes;
+                void* mm = sized ? mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
                 close(fd);
-                fd = -1;
+                if (mm != MAP_FAILED) {
+                    PeerHello* hs = reinterpret_cast<PeerHello*>((char*)mm + peer_rows_end(nranks));
+                    const uint64_t tok = fresh_token();
+                    hs->hello[rank].store(tok, std::memory_order_release);
+                    const auto ta = std::chrono::steady_clock::now();
+                    bool ok = false;
+                    while (std::chrono::steady_clock::now() - ta < std::chrono::seconds(2)) {  // (a live rank 0 answers within a millisecond)
+                        if (hs->echo[rank].load(std::memory_order_acquire) == tok) { ok = true; break; }
+                        std::this_thread::sleep_for(std::chrono::microseconds(100));
+                    }
+                    if (ok) { m = mm; break; }
+                    munmap(mm, bytes);  // nobody answered: a segment left behind by an earlier run; rank 0 will replace it
+                }
             }
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return fail("flh_peer_open: rank 0's segment did not appear");
+            if (std::chrono::steady_clock::now() - t0 > deadline) return fail("flh_peer_open: rank 0's segment did not appear");
             std::this_thread::sleep_for(std::chrono::milliseconds(1));
         }
     }
-    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) return fail(std::string("flh_peer_open: mmap: ") + std::strerror(errno));
     hipError_t e = hipHostRegister(m, bytes, hipHostRegisterPortable | hipHostRegisterMapped);
     void* dev = nullptr;
     if (e == hipSuccess) e = hipHostGetDevicePointer(&dev, m, 0);
@@ -2770,6 +2867,11 @@ void flh_peer_close(flh_handle* h) {
     h->peer_n = 1;
     h->peer_rank = 0;
     for (int& g : h->sect_ng) g = 0;
+    // the handle's own buffer still holds granules tagged with sequence numbers of evaluations BEFORE the attach (which reset the
+    // count): cleared, so that a later evaluation whose number happens to equal one of them cannot take them for its own
+    std::memset(h->h_gran, 0, 2 * kGranSect * 16);
+    for (int i = 0; i < sg->n && i < FLH_MAX_PEERS; ++i)
+        if (sg->members[i] == h) sg->members[i] = nullptr;
     if (--sg->refs == 0) {
         if (sg->shm) {
             (void)hipHostUnregister(sg->host);
@@ -2824,13 +2926,13 @@ int flh_get_pass_stats(const flh_handle* h, uint64_t out[4]) {
 // flh_fetch_rows among peers: every rank's host leaves its rows (at most kPeerRowsMax: the gain-form branch runs when the GLOBAL
 // n_eff is below 23) in the shared segment, tagged with the sequence number of the evaluation they belong to, and reads the
 // others'.  Plain host stores and loads; no device work.
-static int fetch_rows_peers(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* n_rows) {
+// this rank's rows of the evaluation `tag` into its record of the shared segment
+static int peer_post_rows(flh_handle* h, double tag) {
     int64_t n_local = 0;
     if (fetch_rows_local(h, nullptr, nullptr, 0, &n_local) != 0) return -1;
     if (n_local > kPeerRowsMax) return fail("flh_fetch_rows: more rows on this rank than the gathered fetch carries (the information form needs none)");
     std::vector<double> lhx((size_t)std::max<int64_t>(n_local, 1) * 12), lhv((size_t)std::max<int64_t>(n_local, 1));
     if (n_local > 0 && fetch_rows_local(h, lhx.data(), lhv.data(), n_local, &n_local) != 0) return -1;
-    const double tag = (double)h->seq;
     double* mine = peer_rows(h->peer_seg, h->peer_rank);
     if (mine[0] != tag) {  // (a second fetch after the same evaluation finds the record in place)
         mine[1] = (double)n_local;
@@ -2840,6 +2942,21 @@ static int fetch_rows_peers(flh_handle* h, double* hx, double* hv, int64_t cap, 
         }
         std::atomic_thread_fence(std::memory_order_release);
         reinterpret_cast<std::atomic<double>*>(mine)->store(tag, std::memory_order_release);
+    }
+    return 0;
+}
+static int fetch_rows_peers(flh_handle* h, double* hx, double* hv, int64_t cap, int64_t* n_rows) {
+    const double tag = (double)h->seq;
+    if (!h->peer_seg->shm) {
+        // one process, several handles (flh_peer_init_all + flh_eval_group): nobody else will write the other handles' records --
+        // this thread drives them all -- so they are filled in here, every member's rows of its own last evaluation
+        for (int r = 0; r < h->peer_n; ++r) {
+            flh_handle* hm = h->peer_seg->members[r];
+            if (!hm || !hm->have_eval) return fail("flh_fetch_rows: a peer handle of this process has no evaluation to take rows from");
+            if (peer_post_rows(hm, tag) != 0) return -1;
+        }
+    } else if (peer_post_rows(h, tag) != 0) {
+        return -1;
     }
     const auto t0 = std::chrono::steady_clock::now();
     int64_t n = 0;

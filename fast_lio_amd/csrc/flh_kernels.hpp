@@ -101,6 +101,9 @@ hipError_t launch_add_resolve(const GridParams& g, float4* pts_rw, const float4*
                               const uint32_t* dev_counts = nullptr);
 hipError_t launch_delete_boxes(const GridParams& g, float4* pts_rw, uint32_t n_slots, const float* boxes, int nb, uint8_t* dead_id,
                                uint32_t* live, uint32_t* ctr, hipStream_t st);
+// after a removal: bricks whose live points fell below half of their storage range are compacted in place (ctr[4] += purged bricks)
+hipError_t launch_brick_purge(const GridParams& g, float4* pts, uint32_t* starts, const uint32_t* live, uint32_t* ctr, uint32_t nrows,
+                              uint32_t pts_cap, hipStream_t st);
 hipError_t launch_ins_prepare(const GridParams& g, const float4* add, const uint8_t* alive_new, const uint32_t* incl, uint32_t n,
                               uint32_t n_ids, float4* map_orig, uint8_t* dead_id, float4* ins, uint32_t* keys,
                               uint32_t* vals, uint32_t* ctr, hipStream_t st);

@@ -356,8 +356,14 @@ __global__ void __launch_bounds__(256) k_add_insert(const float4* __restrict__ a
                                                     uint32_t* __restrict__ ctr, MiCounts mc) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) { ctr[2] = 0u; ctr[3] = 0u; }
-    if (!mi_counts(mc, n1, n)) return;
-    if (i >= n) return;
+    const uint32_t launched = n;  // the points this launch was sized for (with device-side lengths: an upper bound)
+    const bool applies = mi_counts(mc, n1, n);
+    if (!applies || i >= n) {
+        // device-side lengths: the general path's scan and sort run over the whole bound, so what lies behind the change's true
+        // end (or all of it, when the change is larger than the launches and is not applied) must read "no point"
+        if (mc.p && i < launched) alive_new[i] = 0;
+        return;
+    }
     alive_new[i] = i < n1 ? 0 : 1;
     if (i >= n1) return;
     const float4 p = add[i];
@@ -662,6 +668,72 @@ k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g
     }
 }
 
+// Bricks that only LOSE points (Delete_Point_Boxes of lasermap_fov_segment, src/laserMapping.cpp:231-277, for the life of the
+// node): a removal tombstones its slot in place, so the brick's range keeps its length and every later search of its cells still
+// loads and evaluates the tombstones.  After a removal, every brick whose live points have fallen below half of its range is
+// compacted where it lies: the live points are re-sorted by local cell into the front of the range, the prefix table shrinks to
+// them, the rest of the range becomes slack again.  One workgroup per table row; a brick that needs nothing costs three loads.
+// The map's contents and index order do not change (ids stay), only what the search has to read.  ctr[4] counts the purged bricks.
+__global__ void __launch_bounds__(128)
+k_brick_purge(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g.starts */, const uint32_t* __restrict__ live,
+              uint32_t* __restrict__ ctr, uint32_t nrows, uint32_t pts_cap) {
+    __shared__ float4 buf[kTile];
+    __shared__ uint32_t hist[64], offs[64];
+    __shared__ uint32_t s_cnt;
+    const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (r >= nrows) return;
+    const uint32_t base = starts[(size_t)r * kBrickStride], end = starts[(size_t)r * kBrickStride + 64], lv = live[r];
+    const uint32_t span = end - base;
+    if (end < base || end > pts_cap || 2u * lv >= span || (span < 8u && lv != 0u)) return;  // block-uniform: nothing to gain
+    if (tid == 0) s_cnt = 0;
+    if (tid < 64) hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = base + tid; i < end; i += 128) {
+        const float4 p = pts[i];
+        if (!is_tombstone(p)) {
+            const uint32_t k = atomicAdd(&s_cnt, 1u);
+            if (k < (uint32_t)kTile) buf[k] = p;
+        }
+    }
+    __syncthreads();
+    const uint32_t total = s_cnt;
+    if (total > (uint32_t)kTile || total > span) return;  // (cannot happen: a range never holds more than the tile; leave it alone)
+    uint32_t cl[kTile / 128];
+#pragma unroll
+    for (int u = 0; u < kTile / 128; ++u) {
+        const uint32_t i = tid + u * 128;
+        cl[u] = 0;
+        if (i < total) {
+            const float4 p = buf[i];
+            int cx, cy, cz;
+            float fx, fy, fz;
+            cell_of(g, p.x, p.y, p.z, cx, cy, cz, fx, fy, fz);
+            cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
+            cl[u] = cell_local(cx, cy, cz);
+            atomicAdd(&hist[cl[u]], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int c = 0; c < 64; ++c) {
+            offs[c] = acc;
+            starts[(size_t)r * kBrickStride + c] = base + acc;
+            acc += hist[c];
+        }
+        starts[(size_t)r * kBrickStride + 64] = base + acc;
+        atomicAdd(ctr + 4, 1u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kTile / 128; ++u) {
+        const uint32_t i = tid + u * 128;
+        if (i < total) pts[base + atomicAdd(&offs[cl[u]], 1u)] = buf[i];
+    }
+    for (uint32_t i = base + total + tid; i < end; i += 128) pts[i] = tombstone();
+}
+
 // index-ordered array -> contiguous array of the live points, in order (download, full re-index)
 __global__ void __launch_bounds__(256) k_byte_flags(const uint8_t* __restrict__ in, uint32_t n, int invert, uint32_t* __restrict__ flags,
                                                     uint32_t* __restrict__ keys_sentinel) {
@@ -888,6 +960,12 @@ hipError_t launch_delete_boxes(const GridParams& g, float4* pts_rw, uint32_t n_s
                                uint32_t* live, uint32_t* ctr, hipStream_t st) {
     if (n_slots == 0 || nb == 0) return hipSuccess;
     hipLaunchKernelGGL(k_delete_boxes, dim3(cdiv2(n_slots, 256)), dim3(256), 0, st, g, pts_rw, n_slots, boxes, nb, dead_id, live, ctr);
+    return hipGetLastError();
+}
+hipError_t launch_brick_purge(const GridParams& g, float4* pts, uint32_t* starts, const uint32_t* live, uint32_t* ctr, uint32_t nrows,
+                              uint32_t pts_cap, hipStream_t st) {
+    if (nrows == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_brick_purge, dim3(nrows), dim3(128), 0, st, g, pts, starts, live, ctr, nrows, pts_cap);
     return hipGetLastError();
 }
 hipError_t launch_ins_prepare(const GridParams& g, const float4* add, const uint8_t* alive_new, const uint32_t* incl, uint32_t n,

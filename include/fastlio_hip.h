@@ -126,10 +126,15 @@ int flh_map_delete_boxes(flh_handle* h, const float* boxes, size_t nb);
  * per-brick storage ranges with slack; an insert rewrites only the bricks it touches and a removal tombstones its slot;
  * the whole index is rebuilt only when something no longer fits (a point outside the grid, storage or tables full). */
 int flh_map_stats(const flh_handle* h, uint64_t out[6]);
+/* What the searches have to read: out = {live map points, storage slots INSIDE the bricks' ranges (live points + the tombstones of
+ * removed ones that a search of those cells still loads), bricks compacted in place so far, bricks}.  After a removal
+ * (flh_map_delete_boxes, flh_fov_segment) every brick whose live points fell below half of its range is compacted where it lies,
+ * so out[1] stays below about twice out[0] however long lasermap_fov_segment (src/laserMapping.cpp:231-277) keeps removing. */
+int flh_map_storage_stats(flh_handle* h, uint64_t out[4]);
 /* flh_map_incremental with apply and without the two count outputs: out = {calls whose Add_Points was enqueued right behind the
- * classification, the list lengths read on the device (no wait of the host in the middle of the call: taken when the previous
- * change was at most 6144 points), of those the ones that turned out larger than their launches (8192 points) and were
- * replayed when their counters were collected}. */
+ * classification, the list lengths read on the device (no wait of the host in the middle of the call: taken from the second
+ * change on, the launches sized for the previous change's points + 50 %), of those the ones that turned out larger than their
+ * launches and were replayed when their counters were collected}. */
 int flh_map_change_stats(const flh_handle* h, uint64_t out[2]);
 /* The map in index order, 3 floats per point (what ikdtree.flatten / PCL_Storage hands back, :406-411). */
 int flh_map_download(flh_handle* h, float* xyz, size_t capacity_points);

@@ -274,6 +274,65 @@ def test_fov_segment_moves_cube_and_deletes_slabs(prob):
     assert total > 0
 
 
+def test_long_stream_of_removals_keeps_what_the_search_reads_bounded(prob):
+    """lasermap_fov_segment -> Delete_Point_Boxes runs for the life of the node (src/laserMapping.cpp:231-277): 200 steps of a
+    sensor wandering through the map, the local-map cube following it (slabs removed whenever it moves) and the scan's points going
+    back in around the sensor (Add_Points with down-sampling).  A removal tombstones slots in place; bricks that only lose points
+    are compacted once their live points fall below half of their range (k_brick_purge), so the slots inside the bricks' ranges --
+    what every later search of those cells loads -- stay below 2 x the live points (+ 8 per brick: ranges too short to bother with); the map
+    stays the oracle's point for point, and a search on it at the end is still exact."""
+    pr = prob
+    rng = np.random.default_rng(77)
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    orig = pr.map_xyz.astype(np.float32)
+    lo, hi = orig.min(0).astype(np.float64), orig.max(0).astype(np.float64)
+    ext = float((hi - lo).max())
+    cube, det = 0.9 * ext, 0.1 * ext
+    lm_g, lm_o = capi.FlhLocalMap(), po.LocalMap()
+    cur = orig
+    pos = np.median(orig, axis=0).astype(np.float64)
+    vel = np.array([0.035 * ext, 0.02 * ext, 0.0])
+    removed = added = moves = 0
+    worst = 0.0
+    for step in range(200):
+        pos = pos + vel
+        for d in range(2):  # bounce off the map's walls
+            if pos[d] < lo[d] + 0.1 * ext or pos[d] > hi[d] - 0.1 * ext:
+                vel[d] = -vel[d]
+        want = po.fov_segment(lm_o, pos, cube, det)
+        boxes, ndel = h.fov_segment(lm_g, pos, cube, det)
+        np.testing.assert_array_equal(boxes.view(np.uint32), want.view(np.uint32))
+        if len(want):
+            new = po.map_delete_boxes(cur, want)
+            assert ndel == len(cur) - len(new)
+            removed += ndel
+            moves += 1
+            cur = new
+        # the scan's points return around the sensor: jittered copies of the original map's points within reach
+        near = orig[np.linalg.norm(orig - pos.astype(np.float32), axis=1) < 0.12 * ext]
+        if len(near):
+            add = (near[rng.integers(0, len(near), 400)] + rng.normal(0, 0.05, (400, 3))).astype(np.float32)
+            before = len(cur)
+            cur = po.map_add(cur, add, True, DS)
+            h.map_add(add, True, DS)
+            added += len(cur) - before
+        st = h.map_storage_stats()
+        assert st["points"] == len(cur)
+        assert st["slots_in_brick_ranges"] <= 2 * st["points"] + 8 * st["bricks"], (step, st)
+        worst = max(worst, st["slots_in_brick_ranges"] / max(st["points"], 1))
+        if step % 25 == 24 or step == 199:
+            same_points(h.map_download(), cur, f"map after step {step}")
+    st = h.map_storage_stats()
+    ms = h.map_stats()
+    print(f"[200-step removal stream] cube moved {moves}x, {removed} points removed, {added} added, {len(cur)} left of {len(orig)}; "
+          f"bricks purged {st['bricks_purged']}, slots in brick ranges / points: worst {worst:.2f}, now "
+          f"{st['slots_in_brick_ranges'] / max(st['points'], 1):.2f}; re-indexings {ms['reindex']}, brick-wise changes {ms['brickwise']}")
+    assert moves >= 5 and removed > 10000 and st["bricks_purged"] > 0
+    assert search_matches(h, cur, pr.body, pr.x_true) >= 0
+    h.close()
+
+
 # ---------------------------------------------------------------------------------------------- 8(f) row 2
 def raw_scan(pr, n, seed):
     """An un-down-sampled scan: the down-sampled one plus dense clutter around its points (several per leaf)."""
@@ -477,7 +536,9 @@ def test_map_incremental_enqueued_without_the_hosts_wait():
     """The node's loop never asks map_incremental for its two list lengths; from the second small change on, Add_Points is then
     enqueued right behind the classification with the lengths read on the device (flh_map_change_stats counts them).  Same map
     as the oracle's after every scan -- and also after a change that outgrows its launches (a scan of 12 000 points over new
-    ground after a small one: more than 8 192 to insert), which the library replays when it collects the change's counters."""
+    ground after a small one: more than 8 192 to insert), which the library replays when it collects the change's counters.  The
+    launches are sized from the previous change: a second large change right after a large one goes through without the wait and
+    without a replay, on the general path (scan + device-wide sort over the bound, the lengths still read on the device)."""
     M, N = 250000, 9000
     pr0 = synth.make_problem(M, N, "velodyne", cfg=3)
     scene = pr0.scene
@@ -485,12 +546,13 @@ def test_map_incremental_enqueued_without_the_hosts_wait():
     h.map_build(pr0.map_xyz)
     cur = pr0.map_xyz.astype(np.float32)
     rng = np.random.default_rng(5)
-    for k in range(5):
+    large = (3, 5, 6)
+    for k in range(7):
         pr = synth.make_problem(M, N, "velodyne", cfg=3, scan_seed=10 + k, scene=scene)
         body = np.ascontiguousarray(pr.body[:4000])  # at most 4 000 points to insert: a change of a scan's usual size
-        if k == 3:  # new ground: points in the empty space above the scene, all of them inserted
+        if k in large:  # new ground: points in the empty space above the scene, all of them inserted
             far = rng.uniform(-60, 60, (12000, 3)).astype(np.float32)
-            far[:, 2] = rng.uniform(200, 260, 12000).astype(np.float32)
+            far[:, 2] = rng.uniform(200 + 100 * k, 260 + 100 * k, 12000).astype(np.float32)
             body = np.ascontiguousarray(far)
         m = po.Map(cur)
         h.scan_upload(body)
@@ -499,12 +561,13 @@ def test_map_incremental_enqueued_without_the_hosts_wait():
         sc.h_share_model(m, pr.x_true, True, False)
         w_ref, c_ref = sc.map_incremental_classify(m, pr.x_true, DS, True)
         assert h.map_incremental(pr.x_true, DS, True, apply=True, counts=(k == 0)) is None or k == 0
-        assert int((c_ref != 0).sum()) > (8192 if k == 3 else 0)
+        assert int((c_ref != 0).sum()) > (8192 if k in large else 0)
         cur = po.map_add(po.map_add(cur, w_ref[c_ref == 1], True, DS), w_ref[c_ref == 2], False, DS)
         same_points(h.map_download(), cur, f"map after scan {k}")
         assert search_matches(h, cur, pr.body[:3000], pr.x_true) > 500
     st = h.map_change_stats()
-    assert st["enqueued_without_wait"] >= 3 and st["replayed"] == 1, st
+    # k = 3 and k = 5 follow a small change (launches for 8 192 points: replayed); k = 6 follows a large one (launches for 19 000)
+    assert st["enqueued_without_wait"] >= 6 and st["replayed"] == 2, st
     h.close()
 
 

@@ -14,11 +14,20 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_two_processes_exchange_granules(tmp_path):
+@pytest.mark.parametrize("stale", [False, True])
+def test_two_processes_exchange_granules(tmp_path, stale):
+    """stale: a crashed earlier run has left a segment of the right size under the name, and rank 1 starts two seconds before
+    rank 0 -- it maps the stale segment first; the attach handshake (nobody echoes its token there) sends it back to the name
+    until rank 0 has replaced the segment (it used to sit in the stale one until both ranks timed out)."""
     world = 2
-    name = f"/flh_peers_test_{os.getpid()}"
+    name = f"/flh_peers_test_{os.getpid()}_{int(stale)}"
     outs = [str(tmp_path / f"r{r}.npz") for r in range(world)]
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_peer_worker.py"), str(r), str(world), name, outs[r]],
+    worker = os.path.join(HERE, "_peer_worker.py")
+    if stale:
+        subprocess.run([sys.executable, worker, "0", str(world), name, str(tmp_path / "none.npz"), "crash"], timeout=300,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert os.path.exists("/dev/shm" + name), "the crashed run was meant to leave its segment behind"
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), name, outs[r]] + (["2.0"] if stale and r == 0 else []),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
     for p in procs:
