@@ -181,7 +181,6 @@ def main():
     ap.add_argument("--plane-cache", type=int, default=-1, help="flh_config.plane_cache (-1 = the library's default: on)")
     ap.add_argument("--prelaunch", type=int, default=-1, help="flh_config.prelaunch (-1 = the library's default: on; 0 = every pass is launched when its state is known)")
     ap.add_argument("--index-cache", type=int, default=-1, help="flh_config.index_cache (-1 = default: the neighbour cache holds map indices; 0 = coordinates)")
-    ap.add_argument("--pass-lanes", type=int, default=0, help="flh_config.pass_lanes (0 = by scan size; 4 / 8 / 16 lanes per query in the one-launch pass's first stage)")
     ap.add_argument("--plane-fit-dtype", type=int, default=0,
                     help="1 = the fp16 plane-fit ABLATION of BASELINE configs[4] (not bit-exact, never a parity claim)")
     ap.add_argument("--timing-samples", type=int, default=16,
@@ -310,7 +309,7 @@ def main():
 
     h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
                     pass_kernel=args.pass_kernel, plane_cache=args.plane_cache, plane_fit_dtype=args.plane_fit_dtype,
-                    prelaunch=args.prelaunch, index_cache=args.index_cache, pass_lanes=args.pass_lanes)
+                    prelaunch=args.prelaunch, index_cache=args.index_cache)
     t0 = time.time()
     h.map_build(scene.map_xyz)
     t_build = time.time() - t0
@@ -337,13 +336,13 @@ def main():
     def run(kfx, hx, jobs, n_warm, n_steps):
         """W untimed warm-up scans, then EXACTLY n_steps scans inside one native call (flh_esekf_run_scans: the node's main
         loop, scan i+1 staged while scan i updates) bracketed by barrier + device synchronisation; max over ranks."""
-        # the stream does not stop at the boundary of the timed region: the first timed scan is staged while the last
-        # warm-up scan updates, exactly as every later scan is staged while its predecessor updates
-        kfx.run_scans(jobs, 0, n_warm, ring=RING, map_incremental=with_map_inserts, stage_next=True)
-        # keep Python's cyclic GC out of the timed region, as timeit does
+        # Everything that costs the HOST time and leaves the device idle -- Python's cyclic GC (kept out of the timed region, as
+        # timeit does; after scene generation a collection takes tens of milliseconds), the creation of the event pool -- happens
+        # BEFORE the warm-up, so that the W warm-up scans are immediately followed by the K timed ones: round 5's call 2 showed the
+        # contract's first region 7 % below its own repeats (profiles/r05_call2/: 6 515 vs 6 970-7 030 scans/s) with the idle gap
+        # between warm-up and measurement, which hands the first timed scans a device that has clocked down again.
         gc.collect()
         gc.disable()
-        sync()
         # The kernels of a sampled evaluation carry HIP events (read after the timed region); that costs the host ~10 us per
         # sampled evaluation, so only SEARCHING evaluations are sampled -- the roofline is the search's -- every n-th of them,
         # n odd: a scan's first and later searches alternate, an odd stride samples both kinds alike
@@ -351,7 +350,11 @@ def main():
         # under a profiler (rocprofv3 sets ROCP_TOOL_LIBRARIES) no events: its trace IS the kernel timing and stays free of the
         # events' cost (--event-stride forces them: DESIGN.md 6, the fault hunt)
         hx.set_timing_sampling(args.event_stride if args.event_stride > 0 else (0 if PROFILED else stride + 1 - (stride & 1)), True)
-        hx.counters(reset=True)
+        # the stream does not stop at the boundary of the timed region: the first timed scan is staged while the last
+        # warm-up scan updates, exactly as every later scan is staged while its predecessor updates
+        kfx.run_scans(jobs, 0, n_warm, ring=RING, map_incremental=with_map_inserts, stage_next=True)
+        sync()
+        hx.counters(reset=True)  # (the warm-up's samples are dropped)
         t1 = time.perf_counter()
         rs = kfx.run_scans(jobs, n_warm, n_steps, ring=RING, map_incremental=with_map_inserts, first_staged=n_warm > 0)
         sync()
@@ -431,7 +434,7 @@ def main():
         tok = [None]
         try:
             hs = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
-                             pass_kernel=args.pass_kernel, index_cache=args.index_cache, pass_lanes=args.pass_lanes)
+                             pass_kernel=args.pass_kernel, index_cache=args.index_cache)
             if rank == 0:  # the token every rank needs: RCCL's unique id / the name of the shared segment
                 tok = [capi.rccl_unique_id() if exchange == "rccl" else f"/flh_bench_{os.getpid()}"]
         except Exception as e:  # noqa: BLE001
@@ -624,7 +627,6 @@ def main():
     ps = h.pass_stats()
     out["prelaunched_nosearch_passes"] = dict(h.prelaunch_stats(), setting=args.prelaunch)  # kernels enqueued ahead / handed their state / released unused / given up
     out["config"]["index_cache"] = args.index_cache
-    out["config"]["pass_lanes"] = args.pass_lanes
     out["second_stage_queries_per_search_pass"] = round(ps["second_stage_queries"] / max(ps["search_passes"], 1), 1)
     if roof is not None:
         tr = pmc_traffic(args)

@@ -36,7 +36,6 @@ class FlhConfig(C.Structure):
         ("fused_small_changes", C.c_int),
         ("prelaunch", C.c_int),
         ("index_cache", C.c_int),
-        ("pass_lanes", C.c_int),
     ]
 
 
@@ -301,7 +300,7 @@ class Handle:
     def __init__(self, cell_size: float = 1.5, lanes_per_query: int = 4, device: int = -1, stream: int | None = None,
                  plane_threshold: float = 0.1, max_sqdist: float = 5.0, sort_queries: int = -1, pass_kernel: int = -1,
                  eigen_order: int = -1, plane_fit_dtype: int = 0, undistort_first_point: int = -1, plane_cache: int = -1,
-                 fused_small_changes: int = -1, prelaunch: int = -1, index_cache: int = -1, pass_lanes: int = 0):
+                 fused_small_changes: int = -1, prelaunch: int = -1, index_cache: int = -1):
         L = lib()
         cfg = FlhConfig()
         L.flh_default_config(C.byref(cfg))
@@ -320,7 +319,6 @@ class Handle:
         cfg.fused_small_changes = fused_small_changes
         cfg.prelaunch = prelaunch
         cfg.index_cache = index_cache
-        cfg.pass_lanes = pass_lanes
         self._h = C.c_void_p()
         _chk(L.flh_create(C.byref(cfg), C.byref(self._h)), "flh_create")
         self._keep = []

@@ -92,10 +92,13 @@ struct DevBuf {
     size_t cap = 0;
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
+        const size_t old = cap;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        size_t want = n + n / 8 + 64;
+        // a buffer that has to grow grows by half at least: a run of slightly larger requests (the per-scan map changes of a stream)
+        // costs one reallocation -- hipFree waits for the device -- not one per request
+        size_t want = std::max(n + n / 8 + 64, old + old / 2);
         hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
         if (e == hipSuccess) cap = want;
         return e;
@@ -180,6 +183,7 @@ struct flh_handle {
     size_t N = 0;
     DevBuf<float4> world, nn_pts, normvec;
     DevBuf<uint32_t> nn_idx;               // the neighbour cache as map indices (flh_config.index_cache): what a one-launch pass writes
+    DevBuf<double> gsum;                   // RCCL path: [kGranGroups][slots] group totals of a pass, all-reduced in place (rows behind this rank's groups: zero)
     DevBuf<float4> plane;     // flh_config.plane_cache: (a, b, c, d) of the last searching pass's fits, reused by no-search passes
     bool plane_cache = false;
     bool planes_valid = false;  // `plane` holds the fits of the CURRENT neighbour cache (written by the fit that followed the last search)
@@ -362,7 +366,6 @@ void flh_default_config(flh_config* c) {
     c->fused_small_changes = -1;
     c->prelaunch = -1;
     c->index_cache = -1;
-    c->pass_lanes = 0;
 }
 
 int flh_create(const flh_config* cfg_in, flh_handle** out) {
@@ -385,7 +388,6 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.fused_small_changes != 0) cfg.fused_small_changes = 1;
     if (cfg.prelaunch != 0) cfg.prelaunch = 1;
     if (cfg.index_cache != 0) cfg.index_cache = 1;
-    if (cfg.pass_lanes != 4 && cfg.pass_lanes != 8 && cfg.pass_lanes != 16) cfg.pass_lanes = 0;
     if (cfg.lanes_per_query != 0) cfg.lanes_per_query = 4;  // 0 = exact kernel for every query
     flh_handle* h = new flh_handle();
     h->cfg = cfg;
@@ -461,7 +463,7 @@ void flh_destroy(flh_handle* h) {
     h->map_orig.release(); h->map_next.release(); h->mb_aabb.release(); h->mu_add.release(); h->mi_world.release(); h->mi_cnt.release(); h->mi_far.release();
     h->mu_alive.release(); h->mi_cls.release(); h->mu_flags.release(); h->mu_incl.release(); h->mu_boxes.release();
     h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_list2.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
-    h->world.release(); h->nn_pts.release(); h->normvec.release(); h->plane.release(); h->nn_idx.release();
+    h->world.release(); h->nn_pts.release(); h->normvec.release(); h->plane.release(); h->nn_idx.release(); h->gsum.release();
     h->nn_d2.release(); h->nn_cnt.release(); h->selected.release(); h->vox_tab.release();
     h->partials.release(); h->part2.release(); h->gram.release(); h->gather_buf.release(); h->counter.release();
     for (auto& sl : h->slots) {
@@ -1020,6 +1022,10 @@ static int prepare_scan_buffers(flh_handle* h, size_t N, bool full_clear) {
         HIPC(hipMemsetAsync(h->nn_d2.p, 0x7F, 5 * n1 * sizeof(float), st));    // large finite; rewritten by search
         HIPC(hipMemsetAsync(h->normvec.p, 0, n1 * sizeof(float4), st));
         HIPC(hipMemsetAsync(h->world.p, 0, n1 * sizeof(float4), st));
+    }
+    if (h->comm) {  // the all-reduced group totals: rows behind this scan's groups must read zero (k_publish_groups keeps them so)
+        HIPC(h->gsum.reserve((size_t)kGranGroups * kGranSlots));
+        HIPC(hipMemsetAsync(h->gsum.p, 0, (size_t)kGranGroups * kGranSlots * sizeof(double), st));
     }
     h->N = N;
     for (int& g : h->sect_ng) g = 0;  // the peers' shards change with the scan
@@ -1637,11 +1643,13 @@ static flh::GranOut gran_out(const flh_handle* h, double seq) {
     o.sect_off = (int)((size_t)h->peer_rank * kGranSect);
     return o;
 }
-// With an RCCL communicator the pass's block stays in device memory, but it is summed in the granules' tree (the group reducers
-// leave their totals in part2, the last group adds the groups: flh_fit_dev.hpp, groups_sum_device) -- so the one-launch pass runs
-// there too, and both kinds of pass produce the bits the host's granule sum would
+// With an RCCL communicator the pass's sums stay in device memory, but in the granules' tree: the group reducers leave their totals
+// in gsum[group][slot], RCCL adds the ranks' totals in place, and the publish kernel adds the groups in the host's order
+// (k_publish_groups) -- so the one-launch pass runs there too, both kinds of pass keep one tree, and one rank reproduces flh_eval's
+// bits.  Every rank of the communicator must take this path or none (the collective's size differs): an EMPTY shard takes it
+// (its totals are zeros), a scan beyond the granule limit (1.6 M points per rank) does not on any rank.
 static bool device_tree(const flh_handle* h, bool host_granules) {
-    return !host_granules && h->comm != nullptr && h->N > 0 && gran_group_size(h->N) > 0;
+    return !host_granules && h->comm != nullptr && h->gsum.p != nullptr && (h->N == 0 || gran_group_size(h->N) > 0);
 }
 // does a searching evaluation of the active scan run as ONE launch?
 static bool use_pass_kernel(const flh_handle* h, bool host_granules) {
@@ -1659,7 +1667,7 @@ static int ensure_nn_pts(flh_handle* h) {
 }
 
 static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext, double* d_out, double seq, hipEvent_t* ev3,
-                        bool host_granules = false) {
+                        bool host_granules = false, bool rccl = false) {
     const bool timed = ev3 != nullptr;  // four time stamps: first search kernel's start, last one's end, fit kernel's start and end
     hipStream_t st = h->stream;
     if (h->map_pending && map_settle(h) != 0) return -1;  // a map change under way: its counters (and a re-index it asked for) first
@@ -1669,8 +1677,15 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
         return fail("flh_eval: do_search == 0 before any search on this scan (the reference always searches on the first pass)");
     flh::GranOut gout{};
     if (host_granules) gout = gran_out(h, seq);
+    const bool tree = rccl && device_tree(h, host_granules);  // (rccl: called by flh_eval's / flh_eval_group's all-reduce path)
+    if (tree) d_out = h->gsum.p;  // group totals instead of the 16x16 block (rccl_allreduce_publish)
+    if (tree && h->N == 0) {      // an empty shard: nothing to launch, its totals are the zeros the buffer holds
+        h->last_state = s; h->last_ext = ext; h->have_eval = true; h->aux_valid = false;
+        if (do_search) { h->last_search_was_later = h->searched_once; h->searched_once = true; h->d2_valid = false; h->search_state = s; }
+        return 0;
+    }
     if (do_search && h->stats) HIPC(hipMemsetAsync(h->counter.p, 0, FLH_COUNTER_WORDS * sizeof(u64), st));
-    if (do_search && use_pass_kernel(h, host_granules)) {
+    if (do_search && h->pass_ok && (host_granules || tree) && h->N > 0) {
         // the whole searching pass in one launch (flh_pass.hip); timed: the kernel's own start and end stamps in ev3[0] / ev3[3].
         // With the plane cache no later pass reads the neighbours' coordinates: the cache keeps their indices (flh_config.index_cache)
         uint32_t* idx = (h->plane_cache && h->cfg.index_cache) ? h->nn_idx.p : nullptr;
@@ -1678,7 +1693,7 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
                               h->cfg.plane_threshold, ext, h->nn_pts.p, h->nn_cnt.p, h->selected.p, h->plane_cache ? h->plane.p : nullptr,
                               h->partials.p, h->tickets.p, gout, seq, gran_group_size(h->N),
                               h->stats ? h->counter.p : nullptr, h->own_axis, h->own_lo, h->own_hi, st, timed ? ev3[0] : nullptr,
-                              timed ? ev3[3] : nullptr, idx, flh::pass_lanes_for((int)h->N, h->cfg.pass_lanes), h->part2.p, d_out));
+                              timed ? ev3[3] : nullptr, idx, tree ? h->gsum.p : nullptr));
         h->nn_pts_valid = idx == nullptr;
     } else {
         if (do_search) h->nn_pts_valid = true;  // (the search kernels write the coordinates)
@@ -1690,7 +1705,7 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
                                     timed ? ev3[0] : nullptr, timed ? ev3[1] : nullptr));
         HIPC(flh::launch_fit(h->cfg.eigen_order, h->cfg.plane_fit_dtype, s, h->cur_body, h->nn_pts.p, (int)h->N, ext, h->cfg.plane_threshold, h->selected.p, h->normvec.p,
                              h->world.p, h->partials.p, h->part2.p, d_out, seq, h->tickets.p, h->slow_count.p, gout,
-                             (host_granules || device_tree(h, host_granules)) ? gran_group_size(h->N) : 0, 0, st, h->plane_cache ? h->plane.p : nullptr,
+                             (host_granules || tree) ? gran_group_size(h->N) : 0, 0, st, h->plane_cache ? h->plane.p : nullptr,
                              (do_search || !h->planes_valid) ? 1 : 2, timed ? ev3[2] : nullptr, timed ? ev3[3] : nullptr));
     }
     if (do_search) {
@@ -2062,14 +2077,14 @@ int flh_eval_begin(flh_handle* h, const double rot[4], const double pos[3], cons
     // group sums as granules in pinned memory (this rank's and, with peers, every rank's): not with an RCCL communicator (the
     // block is all-reduced on the device), not for an empty scan
     pe.granules = !h->comm && h->N > 0 && gran_group_size(h->N) > 0;
-    pe.one_launch = pe.do_search && use_pass_kernel(h, pe.granules);  // (granules, or RCCL's device tree)
+    pe.one_launch = pe.do_search && use_pass_kernel(h, pe.granules);  // (granules, or RCCL's group totals)
     if (h->peer_n > 1 && !pe.granules) return fail("flh_eval: a scan shard may not be empty when the ranks exchange granules (flh_peer_*)");
     if (pre_try_go(h, s, pe)) {
         // the kernel of this evaluation was enqueued beside the previous pass: the state went to its mailbox
     } else if (h->comm) {
         // this rank's partial block stays in device memory, RCCL sums the ranks' blocks in place (256 doubles: latency-bound,
         // xGMI bandwidth is irrelevant), then one small kernel publishes the sum + sequence word to pinned host memory
-        if (enqueue_eval(h, s, do_search, ext, h->gram.p, 0.0, ev3) != 0) return -1;
+        if (enqueue_eval(h, s, do_search, ext, h->gram.p, 0.0, ev3, false, true) != 0) return -1;
         if (rccl_allreduce_publish(h, pe.seq) != 0) return -1;
     } else if (enqueue_eval(h, s, do_search, ext, h->h_gram, pe.seq, ev3, pe.granules) != 0) {
         return -1;
@@ -2612,6 +2627,14 @@ int flh_rccl_size(const flh_handle* h) { return h ? h->comm_size : 0; }
 int flh_rccl_rank(const flh_handle* h) { return h ? h->comm_rank : -1; }
 
 static int rccl_allreduce_publish(flh_handle* h, double seq) {
+    if (device_tree(h, false)) {  // group totals (see device_tree): [kGranGroups][slots of this column count], summed over the ranks in place
+        const int ncol = h->last_ext ? 12 : 6, nsl = flh::gram_slots_host(ncol) + 1;
+        const int red = h->N ? gran_group_size(h->N) : 0;
+        const int ng_own = red > 0 ? (flh::pass_blocks((int)h->N) + red - 1) / red : 0;
+        NCCLC(g_rccl.AllReduce(h->gsum.p, h->gsum.p, (size_t)kGranGroups * nsl, ncclDouble, ncclSum, h->comm, h->stream));
+        HIPC(flh::launch_publish_groups(h->gsum.p, ng_own, kGranGroups, nsl, ncol, h->h_gram, seq, h->stream));
+        return 0;
+    }
     NCCLC(g_rccl.AllReduce(h->gram.p, h->gram.p, 256, ncclDouble, ncclSum, h->comm, h->stream));
     HIPC(flh::launch_publish256(h->gram.p, h->h_gram, seq, h->stream));
     return 0;
@@ -2649,18 +2672,33 @@ int flh_eval_group(flh_handle* const* handles, int n, const double state[FLH_NST
     for (int i = 0; i < n; ++i) {
         flh_handle* h = handles[i];
         HIPC(hipSetDevice(h->device));
-        if (enqueue_eval(h, s, do_search, ext, h->gram.p, 0.0, nullptr) != 0) return -1;
+        if (enqueue_eval(h, s, do_search, ext, h->gram.p, 0.0, nullptr, false, true) != 0) return -1;
     }
     flh_handle* h0 = handles[0];
     const double seq = (double)(++h0->seq);
+    bool tree = true;  // the granules' tree on every handle, or on none (the collective's size)
+    for (int i = 0; i < n; ++i) tree = tree && device_tree(handles[i], false);
+    const int ncol = ext ? 12 : 6, nsl = flh::gram_slots_host(ncol) + 1;
     NCCLC(g_rccl.GroupStart());
     for (int i = 0; i < n; ++i) {
         flh_handle* h = handles[i];
-        NCCLC(g_rccl.AllReduce(h->gram.p, h->gram.p, 256, ncclDouble, ncclSum, h->comm, h->stream));
+        if (tree) NCCLC(g_rccl.AllReduce(h->gsum.p, h->gsum.p, (size_t)kGranGroups * nsl, ncclDouble, ncclSum, h->comm, h->stream));
+        else NCCLC(g_rccl.AllReduce(h->gram.p, h->gram.p, 256, ncclDouble, ncclSum, h->comm, h->stream));
     }
     NCCLC(g_rccl.GroupEnd());
+    if (tree) {  // every handle's rows behind its own groups go back to zero (k_publish_groups); handle 0's block goes to the host
+        for (int i = n - 1; i >= 0; --i) {
+            flh_handle* h = handles[i];
+            const int red = h->N ? gran_group_size(h->N) : 0;
+            const int ng_own = red > 0 ? (flh::pass_blocks((int)h->N) + red - 1) / red : 0;
+            HIPC(hipSetDevice(h->device));
+            HIPC(flh::launch_publish_groups(h->gsum.p, ng_own, kGranGroups, nsl, ncol, h->h_gram, i == 0 ? seq : -1.0, h->stream));
+        }
+    } else {
+        HIPC(hipSetDevice(h0->device));
+        HIPC(flh::launch_publish256(h0->gram.p, h0->h_gram, seq, h0->stream));
+    }
     HIPC(hipSetDevice(h0->device));
-    HIPC(flh::launch_publish256(h0->gram.p, h0->h_gram, seq, h0->stream));
     const volatile double* flag = h0->h_gram + 255;
     uint64_t spins = 0;
     while (*flag != seq) {

@@ -195,35 +195,10 @@ __device__ __forceinline__ void group_sum_publish(const double* partials, int gr
         const double total = hi ? other + s0 : s0 + other;  // lower half + upper half on both sides
         if (hi == 0 && slot < nsl) {
             if (gout.n_dst > 0) publish_granule(gout, 1 + (size_t)group * nsl + slot, total, seq);
-            else __hip_atomic_store((gdouble*)part2 + (size_t)group * nsl + slot, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the device adds the groups (groups_sum_device)
+            else part2[(size_t)group * nsl + slot] = total;  // group totals in device memory: the ranks' are all-reduced, k_publish_groups adds the groups
         }
     }
     if (gout.n_dst > 0 && wl == 0 && group == 0) publish_granule(gout, 0, (double)(ngroups * nsl), seq);  // the section's header
-}
-
-// The end of the sum ON THE DEVICE, for evaluations whose block stays in device memory (an RCCL communicator is attached: the
-// ranks' blocks are all-reduced in place): the group reducers have left their totals in part2 (group_sum_publish with n_dst == 0);
-// the last of them to arrive adds the groups in group order -- exactly the additions the host performs on granules, so the block
-// holds the bits flh_eval's host sum would -- and writes the whole 16 x 16 block (mirrored lower triangle, zeros elsewhere).
-// One wave.  tickets[0] counts the groups and is re-armed here.
-__device__ __forceinline__ void groups_sum_device(const double* part2, int ngroups, int nsl, int ncol, uint32_t* tickets, double* out256, int wl) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint32_t tk = 0;
-    if (wl == 0) tk = __hip_atomic_fetch_add(&tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
-    if (tk != (uint32_t)(ngroups - 1)) return;
-    const gdouble* gp2 = (const gdouble*)part2;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int idx = wl + 64 * e, r = idx >> 4, c = idx & 15;
-        int slot = gram_slot(r, c, ncol);
-        if (slot < 0 && c < 12 && r > c) slot = gram_slot(c, r, ncol);  // the block is symmetric bit for bit
-        double sum = 0.0;
-        if (slot >= 0)
-            for (int gi = 0; gi < ngroups; ++gi) sum += __hip_atomic_load(gp2 + (size_t)gi * nsl + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        out256[idx] = sum;
-    }
-    if (wl == 0) tickets[0] = 0;
 }
 
 }  // namespace flh

@@ -366,11 +366,10 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
         __syncthreads();
         if (s_ticket != (uint32_t)(gblocks - 1)) return;  // block-uniform
         if (wave == 0) {
-            group_sum_publish<true>(partials, group, min(red1, nunits - group * red1), red1, nsl, (nunits + red1 - 1) / red1, gout, seq, lane, part2);
+            // (gout.n_dst == 0 -- an RCCL communicator is attached -- : the group's totals stay in device memory, out256[group][slot],
+            // as the one-launch searching pass leaves them: both kinds of pass keep one tree)
+            group_sum_publish<true>(partials, group, min(red1, nunits - group * red1), red1, nsl, (nunits + red1 - 1) / red1, gout, seq, lane, out256);
             if (lane == 0) tickets[1 + group] = 0;  // re-arm this group's ticket for the next launch
-            // no granule output (an RCCL communicator is attached): the last group adds the groups into the device block, as the
-            // host would add granules -- the one-launch searching pass does the same, so both kinds of pass keep one tree
-            if (gout.n_dst == 0) groups_sum_device(part2, (nunits + red1 - 1) / red1, nsl, ncol, tickets, out256, lane);
         }
         return;
     }
@@ -635,6 +634,37 @@ __global__ void __launch_bounds__(256) k_publish256(const double* __restrict__ s
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) __hip_atomic_store(out256 + 255, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// The RCCL path of a pass summed in the granules' tree: `totals` holds [group][slot] sums (this rank's group totals, all-reduced over
+// the ranks in place; rows of groups this rank does not have are zero).  Every thread owns one entry of the 16 x 16 block, adds
+// its slot over ALL kGroups rows in group order -- the host's order over granules, so one rank reproduces flh_eval's bits -- and
+// hands the block to the host like k_publish256.  Rows behind this rank's own groups are zeroed again for the next pass (the
+// all-reduce left the other ranks' sums there).
+__global__ void __launch_bounds__(256) k_publish_groups(double* __restrict__ totals, int ngroups_own, int ngroups_all, int nsl, int ncol,
+                                                        double* __restrict__ out256, double seq) {
+    const int t = threadIdx.x, r = t >> 4, c = t & 15;
+    int slot = gram_slot(r, c, ncol);
+    if (slot < 0 && c < 12 && r > c) slot = gram_slot(c, r, ncol);  // the block is symmetric bit for bit
+    double sum = 0.0;
+    if (slot >= 0) {
+        for (int g0 = 0; g0 < ngroups_all; g0 += 32) {
+            double v[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) v[j] = (g0 + j < ngroups_all) ? totals[(size_t)(g0 + j) * nsl + slot] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (g0 + j < ngroups_all) sum += v[j];
+        }
+    }
+    if (t != 255) __hip_atomic_store(out256 + t, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // every entry has been read
+    if (t == 0) __hip_atomic_store(out256 + 255, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int i = ngroups_own * nsl + t; i < ngroups_all * nsl; i += 256) totals[i] = 0.0;
+}
+hipError_t launch_publish_groups(double* totals, int ngroups_own, int ngroups_all, int nsl, int ncol, double* out256, double seq, hipStream_t st) {
+    hipLaunchKernelGGL(k_publish_groups, dim3(1), dim3(256), 0, st, totals, ngroups_own, ngroups_all, nsl, ncol, out256, seq);
+    return hipGetLastError();
 }
 hipError_t launch_publish256(const double* src, double* out256, double seq, hipStream_t st) {
     hipLaunchKernelGGL(k_publish256, dim3(1), dim3(256), 0, st, src, out256, seq);

@@ -48,10 +48,10 @@ hipError_t launch_pass(int order, const GridParams& g, const StateDev& s, const 
                        float thr, int ext, float4* nn_pts, uint8_t* nn_cnt, uint8_t* selected, float4* plane_cache, double* partials,
                        uint32_t* tickets, const GranOut& gran, double seq, int red, unsigned long long* cand_counter,
                        int own_axis, float own_lo, float own_hi, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
-                       uint32_t* nn_idx = nullptr,  // nn_idx: the neighbour cache as map indices (flh_config.index_cache), else nn_pts
-                       int lanes = 4,               // lanes per query of the first search stage: 4, 8, 16 (pass_lanes_for)
-                       double* part2 = nullptr, double* out256 = nullptr);  // gran.n_dst == 0: the group sums are added on the device into out256
-int pass_lanes_for(int N, int wanted);  // flh_config.pass_lanes -> 4 / 8 / 16 for a scan of N points
+                       uint32_t* nn_idx = nullptr,       // nn_idx: the neighbour cache as map indices (flh_config.index_cache), else nn_pts
+                       double* group_totals = nullptr);  // gran.n_dst == 0 (an RCCL communicator): the group sums go to group_totals[group][slot]
+// the all-reduced group totals -> the 16x16 block in pinned host memory + the sequence word (the RCCL path's last kernel)
+hipError_t launch_publish_groups(double* totals, int ngroups_own, int ngroups_all, int nsl, int ncol, double* out256, double seq, hipStream_t st);
 // neighbour cache kept as indices -> coordinates (nn_pts[r * N + i] = {map_orig[id].xyz, id}; id == -1 or >= n_ids: an empty row)
 hipError_t launch_nn_gather(const float4* map_orig, uint32_t n_ids, const uint32_t* nn_idx, int N, float4* nn_pts, hipStream_t st);
 hipError_t launch_publish256(const double* src, double* out256, double seq, hipStream_t st);

@@ -6,11 +6,13 @@
 // the neighbours written to HBM and read back in between.  Here a workgroup owns 64 consecutive (Morton-ordered) scan points
 // from the transform to their share of the normal equations:
 //
-//   phase A   ring_query<4,1>: four lanes per query over the 3x3x3 cell block, all 64 queries at once.  Results go to the
-//             neighbour cache in HBM (later passes and map_incremental read it) AND stay in LDS for the fit.
+//   phase A   ring_query<4,1>: four lanes per query over the 3x3x3 cell block, all 64 queries at once.  Results go to the neighbour cache in HBM --
+//             as map indices by default (flh_config.index_cache), map_incremental and the fetches gather coordinates from them --
+//             AND stay in LDS for the fit.
 //   phase B   the queries phase A could not settle (5th neighbour not provably inside the block: at the prior, the far field of
-//             the scan; a handful later) are searched again by the same workgroup, eight lanes per query, over the 5x5x5 block
-//             clipped to the ball of phase A's bound (ring_query<8,2>, which also finishes distance ties with 64-bit keys).
+//             the scan; a handful later) are searched again by the same workgroup, eight lanes per query, over a 4x4 window of
+//             the 5x5x5 block's rows clipped to the ball of phase A's bound (ring_query<8,2,...,WIN4>, which also finishes
+//             distance ties with 64-bit keys).
 //             Workgroup-local on purpose: no global work list, no second launch, no spin-waits, and the order in which rows
 //             enter the sums does not depend on timing.
 //   fit       ONE wave takes the 64 queries' neighbours from LDS (lane = query): esti_plane, residual, gate, Jacobian row
@@ -19,11 +21,13 @@
 //             three waves have retired by then.
 //   reduce    workgroups are grouped `red` at a time; the last one of a group to finish sums the group's partials in workgroup
 //             order and hands them to the host as 16-byte {value, sequence} granules in pinned memory (to every rank's buffer
-//             when the scan is sharded over GPUs); the host adds the groups in group order.  Fixed order -> identical bits
-//             run to run.
+//             when the scan is sharded over GPUs); the host adds the groups in group order.  With an RCCL communicator the
+//             group sums stay in device memory, RCCL adds the ranks' and the publish kernel the groups, in the same order.
+//             Fixed order -> identical bits run to run.
 //
-// Requires cells >= sqrt(max_sqdist) / 1.998 (the 5x5x5 block then covers the gate radius, so phase B settles everything it
-// is given; flh_api.cpp checks and otherwise runs the three-launch pass of flh_kernels.hip).
+// Requires cells >= sqrt(max_sqdist) / 1.499 (1.5 m for the default gate: phase B's 4x4 window of rows then covers the ball of a
+// bounded query, so it settles everything it is given; flh_create checks -- pass_ok -- and otherwise runs the three-launch pass of
+// flh_kernels.hip).
 #include "flh_kernels.hpp"
 
 #include <hip/hip_runtime.h>
@@ -46,18 +50,17 @@ namespace flh {
 #define FLH_PASS_WAVES 7
 #endif
 // (the wide variants run where the GPU is under-filled: one 1024-thread workgroup per CU is four waves per SIMD, registers are free)
-// (sixteen lanes: ONE 1024-thread workgroup per CU = four waves per SIMD; eight lanes: two 512-thread workgroups = four as well -- at
-// six waves per SIMD, three workgroups, the kernel spills)
-#define PASS_ATTR __attribute__((amdgpu_waves_per_eu(LPQ == 4 ? FLH_PASS_WAVES : 4, LPQ == 4 ? FLH_PASS_WAVES : 4)))
+#define PASS_ATTR __attribute__((amdgpu_waves_per_eu(FLH_PASS_WAVES, FLH_PASS_WAVES)))
 constexpr int kPassQueries = 64;                       // scan points per workgroup
 constexpr int kSegA = ring_seg_slots<1>();             // 20 LDS table entries per phase-A group (64 groups)
-constexpr int kSegB = 2 * 16 + 2;                      // 34 per phase-B group (8 LPQ groups of eight lanes, 4x4 window)
-// LPQ = lanes per query in phase A = the workgroup's size / 64: 4 (256 threads; a full-size scan), 8, 16 (1024 threads: a scan, or
-// a rank's shard of one, that leaves the GPU under-filled -- 12 500 points are 196 workgroups on 256 CUs, each running the
-// dependent chain of 16 queries per wave; with sixteen lanes per query a wave holds four queries, resolves two segments per lane
-// instead of five and walks a quarter of the candidates).  The unit, the fit wave and the summation tree are the same: same bits.
-template <int LPQ> constexpr int seg_words() { return (64 * kSegA > 8 * LPQ * kSegB) ? 64 * kSegA : 8 * LPQ * kSegB; }
-static_assert(seg_words<4>() * 8 >= 64 * kTileStride * 8, "the fit's transpose tile reuses the segment tables");
+constexpr int kSegB = 2 * 16 + 2;                      // 34 per phase-B group (32 groups of eight lanes, 4x4 window)
+// Four lanes per query in phase A (256 threads per unit).  Round 5 built the kernel for 8 and 16 lanes per query as well (512 /
+// 1024 threads per unit) for scans and shards that leave the GPU under-filled, and measured it (profiles/r05_call2/exchange_probe.txt,
+// a rank's share of an 8-way shard, 12 500 points: 38.0 / 36.6 / 39.1 us per searching pass at 4 / 8 / 16 lanes; 25 000 points:
+// 40.1 / 39.9 / 50.9): no gain -- a small pass is the latency chain of one workgroup (launch, dependent misses, fit, ticket, group
+// sum, publish: 22 us for 64 points), not phase A's issue -- so the wide variants were deleted again.
+constexpr int kSegWords = (64 * kSegA > 32 * kSegB) ? 64 * kSegA : 32 * kSegB;
+static_assert(kSegWords * 8 >= 64 * kTileStride * 8, "the fit's transpose tile reuses the segment tables");
 // Developer instrumentation (tools/variant.py --define FLH_PASS_STAMPS, tools/pass_stamps.py): per-wave 100 MHz time stamps of the
 // phases of k_pass, read back with flh_debug_pass_stamps.  Compiled out of the product.
 #ifdef FLH_PASS_STAMPS
@@ -77,16 +80,17 @@ void pass_stamps_read(unsigned long long* out, size_t words) {
 #define STAMP(i)
 #endif
 
-template <int ORD, int LPQ>
-__global__ void __launch_bounds__(64 * LPQ) PASS_ATTR
+template <int ORD>
+__global__ void __launch_bounds__(256) PASS_ATTR
 k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist, float thr, int ext,
        int ncol, float4* __restrict__ nn_pts, uint8_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected,
        float4* __restrict__ plane_cache, double* __restrict__ partials, uint32_t* __restrict__ tickets, GranOut gout, double seq,
        int red, u64* __restrict__ cand_counter, int own_axis, float own_lo, float own_hi, uint32_t* __restrict__ nn_idx,
-       double* __restrict__ part2, double* __restrict__ out256) {
-    constexpr int NW = LPQ;          // waves of the workgroup
+       double* __restrict__ group_totals) {
+    constexpr int LPQ = 4;           // lanes per query in phase A
+    constexpr int NW = 4;            // waves of the workgroup
     constexpr int QPW = 64 / LPQ;    // queries per wave in phase A
-    __shared__ uint2 segs[seg_words<LPQ>()];
+    __shared__ uint2 segs[kSegWords];
     __shared__ float park[kPassQueries * kParkStride];
     __shared__ uint32_t s_list[64];  // per wave: the slots (0..63) of its queries that go to phase B
     __shared__ uint32_t s_wcnt[NW];
@@ -150,7 +154,7 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     __syncthreads();
     STAMP(2);  // the workgroup's phase A done
 
-    // ---- phase B: the workgroup's open queries, eight lanes each, 8 LPQ per trip (32 with 256 threads)
+    // ---- phase B: the workgroup's open queries, eight lanes each, 32 per trip
     uint32_t n_open = 0;  // workgroup-uniform
 #pragma unroll
     for (int w_ = 0; w_ < NW; ++w_) n_open += s_wcnt[w_];
@@ -233,15 +237,14 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
     STAMP(6);  // ticket taken
     if (tk != (uint32_t)(gsize - 1)) return;
-    group_sum_publish<false>(partials, group, gsize, red, nsl, (nblk + red - 1) / red, gout, seq, wl, part2);
+    // (gout.n_dst == 0 -- an RCCL communicator is attached -- : the group's totals stay in device memory, group_totals[group][slot];
+    // the ranks' totals are all-reduced and the publish kernel adds the groups in the host's order, flh_kernels.hip)
+    group_sum_publish<false>(partials, group, gsize, red, nsl, (nblk + red - 1) / red, gout, seq, wl, group_totals);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(7);  // (the group's last arriver) group sum published
     if (wl == 0) tickets[1 + group] = 0;  // re-arm this group's ticket for the next launch
-    // no granule output (an RCCL communicator is attached): the last group to arrive adds the groups into the 16x16 block in device memory
-    if (gout.n_dst == 0) groups_sum_device(part2, (nblk + red - 1) / red, nsl, ncol, tickets, out256, wl);
 }
 
-constexpr int kPassWide16Max = 16384, kPassWide8Max = 32768;  // scans (shards) up to these sizes run 16 / 8 lanes per query unless told otherwise
 int pass_blocks(int N) { return ((N > 0 ? N : 1) + kPassQueries - 1) / kPassQueries; }
 // workgroups per reduction group: 64, more when that would make more than max_groups groups
 int pass_group_size(int N, int max_groups) {
@@ -251,42 +254,30 @@ int pass_group_size(int N, int max_groups) {
     return red;
 }
 
-int pass_lanes_for(int N, int wanted) {
-    if (wanted == 4 || wanted == 8 || wanted == 16) return wanted;
-    if (N <= 0) return 4;
-    // sixteen lanes while every workgroup is resident at one per CU (256 x 64 points), eight while two per CU are
-    return N <= kPassWide16Max ? 16 : (N <= kPassWide8Max ? 8 : 4);
-}
-
 hipError_t launch_pass(int order, const GridParams& g, const StateDev& s, const float4* body, int N, uint32_t map_points, float max_sqdist,
                        float thr, int ext, float4* nn_pts, uint8_t* nn_cnt, uint8_t* selected, float4* plane_cache, double* partials,
                        uint32_t* tickets, const GranOut& out, double seq, int red, unsigned long long* cand_counter,
                        int own_axis, float own_lo, float own_hi, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t* nn_idx,
-                       int lanes, double* part2, double* out256) {
-    if (N <= 0 || out.n_dst < 0 || out.n_dst > kPeersMax || (out.n_dst == 0 && (!part2 || !out256))) return hipErrorInvalidValue;
+                       double* group_totals) {
+    if (N <= 0 || out.n_dst < 0 || out.n_dst > kPeersMax || (out.n_dst == 0 && !group_totals)) return hipErrorInvalidValue;
     const int ncol = ext ? 12 : 6;
-    if (order != 1) lanes = 4;  // the wide variants exist for the default summation order only
-    const dim3 grid(pass_blocks(N)), blk(64 * lanes);
-#define FLH_PASS(O, L)                                                                                                                \
+    const dim3 grid(pass_blocks(N)), blk(256);
+#define FLH_PASS(O)                                                                                                                   \
     do {                                                                                                                              \
         if (ev_start != nullptr || ev_stop != nullptr)                                                                                \
-            hipExtLaunchKernelGGL((k_pass<O, L>), grid, blk, 0, st, ev_start, ev_stop, 0, g, s, body, N, map_points, max_sqdist, thr, ext, \
+            hipExtLaunchKernelGGL((k_pass<O>), grid, blk, 0, st, ev_start, ev_stop, 0, g, s, body, N, map_points, max_sqdist, thr, ext, \
                                   ncol, nn_pts, nn_cnt, selected, plane_cache, partials, tickets, out, seq, red, cand_counter, own_axis, \
-                                  own_lo, own_hi, nn_idx, part2, out256);                                                              \
+                                  own_lo, own_hi, nn_idx, group_totals);                                                               \
         else                                                                                                                          \
-            hipLaunchKernelGGL((k_pass<O, L>), grid, blk, 0, st, g, s, body, N, map_points, max_sqdist, thr, ext, ncol, nn_pts, nn_cnt, \
+            hipLaunchKernelGGL((k_pass<O>), grid, blk, 0, st, g, s, body, N, map_points, max_sqdist, thr, ext, ncol, nn_pts, nn_cnt, \
                                selected, plane_cache, partials, tickets, out, seq, red, cand_counter, own_axis, own_lo, own_hi, nn_idx, \
-                               part2, out256);                                                                                        \
+                               group_totals);                                                                                         \
     } while (0)
     switch (order) {
-        case 0: FLH_PASS(0, 4); break;
-        case 2: FLH_PASS(2, 4); break;
-        case 3: FLH_PASS(3, 4); break;
-        default:
-            if (lanes == 16) FLH_PASS(1, 16);
-            else if (lanes == 8) FLH_PASS(1, 8);
-            else FLH_PASS(1, 4);
-            break;
+        case 0: FLH_PASS(0); break;
+        case 2: FLH_PASS(2); break;
+        case 3: FLH_PASS(3); break;
+        default: FLH_PASS(1); break;
     }
 #undef FLH_PASS
     return hipGetLastError();

@@ -222,7 +222,8 @@ class esekf {
             // What follows this pass, as far as it can be known before it (esekfom.hpp:1823-1834): nothing after the last one; a
             // SEARCH after the last but one when no step has converged yet (:1829-1832 forces it); otherwise a no-search pass
             // unless this pass's step converges (then: a search if it is the first to converge, the end of the update if the second)
-            dyn_share.next_pass = (i == maximum_iter - 1 || (!t && i == maximum_iter - 2)) ? kNextNone : kNextNoSearch;
+            // (kNextNone is for the END of the update -- finish_hint -- where a kernel enqueued ahead is released)
+            dyn_share.next_pass = (i == maximum_iter - 1 || (!t && i == maximum_iter - 2)) ? kNextUnknown : kNextNoSearch;
             bool early = false;
             if ((h_dyn_share_ctx && h_begin_ctx) || (!h_dyn_share_ctx && h_begin)) {
                 // the measurement model is under way on the device: what :1655-1699 and the first inverse of :1782 compute from the

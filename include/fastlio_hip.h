@@ -80,10 +80,6 @@ typedef struct flh_config {
                                INDICES (20 B per query); their coordinates are gathered on demand by whatever asks for them
                                (flh_map_incremental, flh_fetch_neighbors, a re-fit without the plane cache); 0: the search writes
                                the coordinates (80 B per query) itself.  Needs plane_cache; same results.  Performance only */
-    int pass_lanes;         /* lanes per query in the first search stage of the one-launch pass: 4, 8 or 16; 0 (default, also for
-                               < 0 and any other value): 4 for a full-size scan, 8 for a scan (or a rank's shard of one) of at most
-                               32768 points and 16 for at most 16384, where four lanes per query leave most of the GPU idle (every
-                               workgroup is resident at once, the pass is the dependent chain of one).  Same results.  Performance only */
 } flh_config;
 enum { FLH_ORDER_SEQ = 0, FLH_ORDER_SSE = 1, FLH_ORDER_PAIRWISE = 2, FLH_ORDER_NOVEC = 3 };
 
@@ -253,8 +249,9 @@ int flh_eval_end(flh_handle* h, double HTH[144], double HTh[12], int64_t* n_eff,
  *   FLH_NEXT_NOSEARCH  probably a no-search evaluation of the same scan, at a state not known yet: its kernel is enqueued beside
  *                      the pass flh_eval_begin starts and waits (bounded: 20 ms) for the state, which the following
  *                      flh_eval_begin then posts instead of launching.  Any other call that follows releases it.
- *   FLH_NEXT_NONE      nothing of the kind follows: a kernel that is still waiting is released now
- *   FLH_NEXT_UNKNOWN   no expectation (the default before every flh_eval_begin) */
+ *   FLH_NEXT_UNKNOWN   no expectation (the default before every flh_eval_begin): nothing is enqueued ahead
+ *   FLH_NEXT_NONE      no evaluation follows at all (the update has ended): a kernel that is still waiting is released NOW --
+ *                      not to be said before a flh_eval_begin whose own kernel may be the one that is waiting */
 #define FLH_NEXT_UNKNOWN 0
 #define FLH_NEXT_NOSEARCH 1
 #define FLH_NEXT_NONE 2

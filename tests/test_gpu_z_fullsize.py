@@ -91,7 +91,17 @@ def _full_update_against_oracle(M, N, sensor, cfg, nthreads=32, props=True, exts
         assert list(st.n_eff)[: st.passes] == list(st_ref.n_eff)[: st_ref.passes]
         np.testing.assert_array_equal(h.fetch_selected(), sc.selected)          # bit-exact point_selected_surf
         sel = sc.selected.astype(bool)
-        np.testing.assert_array_equal(h.fetch_normvec()[sel].view(np.uint32), sc.normvec[sel].view(np.uint32))  # planes + pd2
+        nv = h.fetch_normvec()[sel]
+        if not ext:
+            np.testing.assert_array_equal(nv.view(np.uint32), sc.normvec[sel].view(np.uint32))  # planes + pd2
+        else:
+            # The plane normals depend on the neighbours only: bit for bit.  pd2 is taken at the LAST pass's state, and with
+            # extrinsic estimation the product's 12 x 12 information form and the reference's double inversion (the oracle's) leave
+            # that state 1e-10 .. 1e-8 apart -- enough to move the fp32 world coordinate of a few points by an
+            # ulp, i.e. pd2 (a small difference of large terms) by 1e-4 relative.  The flags above were still identical.
+            np.testing.assert_array_equal(nv[:, :3].view(np.uint32), sc.normvec[sel][:, :3].view(np.uint32))
+            np.testing.assert_allclose(nv[:, 3], sc.normvec[sel][:, 3], rtol=2e-3, atol=2e-6)
+            assert (nv[:, 3].view(np.uint32) != sc.normvec[sel][:, 3].view(np.uint32)).mean() < 0.02
         x = kf.get_x()
         assert np.linalg.norm(x[:3] - x_ref[:3]) <= 1e-4                          # pose within 1e-4 m
         np.testing.assert_allclose(x, x_ref, rtol=1e-4, atol=1e-7)

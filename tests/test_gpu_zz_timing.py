@@ -165,9 +165,8 @@ def test_one_launch_pass_equals_three_launch_pass():
     the three-launch pass -- flags, neighbour ids in rank order, distances, planes, the normal equations (both add the same
     64-point units in the same order: flh_fit_dev.hpp) and with them the whole update must be identical bit for bit -- on a dense
     scan, on a thinned-out scan (many queries reach the second stage), on a ragged size, on seven points, and with a prior so
-    far off that most queries reach the second stage.  The one-launch pass in all its shapes: four / eight / sixteen lanes per query
-    in its first stage (flh_config.pass_lanes: 256 / 512 / 1024 threads per 64-point unit; the wide ones are what a rank's shard of
-    a scan runs), and the neighbour cache kept as indices (flh_config.index_cache, the default) or as coordinates."""
+    far off that most queries reach the second stage.  The one-launch pass with the neighbour cache kept as indices
+    (flh_config.index_cache, the default) and as coordinates."""
     pr = synth.make_problem(200000, 20000, "avia", cfg=1)
     xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
     x_far = np.array(xp, dtype=np.float64)
@@ -176,8 +175,7 @@ def test_one_launch_pass_equals_three_launch_pass():
              "tiny": np.ascontiguousarray(pr.body[:7])}
     for name, body in scans.items():
         out = []
-        variants = [dict(pass_kernel=0), dict(pass_kernel=1, pass_lanes=4), dict(pass_kernel=1, pass_lanes=8), dict(pass_kernel=1, pass_lanes=16),
-                    dict(pass_kernel=1, pass_lanes=4, index_cache=0), dict(pass_kernel=1, pass_lanes=0, index_cache=0)]
+        variants = [dict(pass_kernel=0), dict(pass_kernel=1), dict(pass_kernel=1, index_cache=0)]
         for kw in variants:
             one = kw["pass_kernel"]
             h = capi.Handle(**kw)

@@ -47,19 +47,16 @@ base = None
 for G in (1, 2, 4, 8):
     idx = fdist.morton_shard(pr.body, 0, G)
     shard = np.ascontiguousarray(pr.body[idx])
-    for lanes in (4, 8, 16):  # lanes per query of the one-launch pass's first stage (flh_config.pass_lanes; 0 = by size)
-        if G == 1 and lanes == 16:
-            continue  # (1 563 workgroups of 1 024 threads: six rounds, of no interest)
-        h = capi.Handle(pass_lanes=lanes)
-        h.map_build(pr.map_xyz)
-        h.scan_upload(shard)
-        h.set_timing_stride(0)
-        t = passes(lambda x, s: h.eval(x, s, False))
-        if G == 1 and lanes == 4:
-            base = t
-        print(f"  one rank's share of a {G}-way shard ({len(idx):6d} points), {lanes:2d} lanes per query: {t[0]:6.1f} / {t[1]:6.1f} / {t[2]:6.1f}"
-              f"   => pass speed-up bound {base[0] / t[0]:.2f} / {base[1] / t[1]:.2f} / {base[2] / t[2]:.2f}")
-        h.close()
+    h = capi.Handle()
+    h.map_build(pr.map_xyz)
+    h.scan_upload(shard)
+    h.set_timing_stride(0)
+    t = passes(lambda x, s: h.eval(x, s, False))
+    if G == 1:
+        base = t
+    print(f"  one rank's share of a {G}-way shard ({len(idx):6d} points): {t[0]:6.1f} / {t[1]:6.1f} / {t[2]:6.1f}"
+          f"   => pass speed-up bound {base[0] / t[0]:.2f} / {base[1] / t[1]:.2f} / {base[2] / t[2]:.2f}")
+    h.close()
 
 # the exchange
 h = capi.Handle()
@@ -87,8 +84,8 @@ try:
     h.scan_upload(pr.body)
     h.set_timing_stride(0)
     t = passes(lambda x, s: h.eval(x, s, False))
-    print(f"  RCCL all-reduce + publish kernel, one rank:      {t[0]:6.1f} / {t[1]:6.1f} / {t[2]:6.1f}   (one-launch searching pass, the groups "
-          f"added on the device: {h.pass_stats()['one_launch_passes']} of {h.pass_stats()['search_passes']} searching passes in one launch)")
+    print(f"  RCCL all-reduce + publish kernel, one rank:      {t[0]:6.1f} / {t[1]:6.1f} / {t[2]:6.1f}   (one-launch searching pass, the group totals "
+          f"all-reduced: {h.pass_stats()['one_launch_passes']} of {h.pass_stats()['search_passes']} searching passes in one launch)")
     h.close()
 except Exception as e:  # noqa: BLE001
     print("  RCCL:", repr(e)[:200])
