@@ -88,7 +88,7 @@ def pmc_traffic(args):
     import glob
 
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_summary_config{args.config}.csv")))
-    if not found or args.lpq != 4 or args.cell != 1.5:
+    if not found or args.lpq != 4 or args.cell != 1.5 or args.index_cache == 0:  # (the summary was taken on the default neighbour cache)
         return None
     path = found[-1]  # the latest round's
     meta = {}

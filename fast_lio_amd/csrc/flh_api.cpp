@@ -787,23 +787,26 @@ static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size
     }
     if (n == 0) return 0;
     const uint32_t nu = (uint32_t)n;
-    HIPC(h->mu_alive.reserve(n));
-    HIPC(h->mb_k0.reserve(n)); HIPC(h->mb_k1.reserve(n)); HIPC(h->mb_v0.reserve(n)); HIPC(h->mb_v1.reserve(n));
-    HIPC(h->mu_flags.reserve(n)); HIPC(h->mu_incl.reserve(n));
+    // (scratch sized for what the NEXT change's launches will be sized for -- this change's points + 50 % + 1024, see
+    // flh_map_incremental -- so that a stream's second change does not reallocate everything its first one allocated)
+    const size_t nr = d_cnt ? n : n + n / 2 + 1024;
+    HIPC(h->mu_alive.reserve(nr));
+    HIPC(h->mb_k0.reserve(nr)); HIPC(h->mb_k1.reserve(nr)); HIPC(h->mb_v0.reserve(nr)); HIPC(h->mb_v1.reserve(nr));
+    HIPC(h->mu_flags.reserve(nr)); HIPC(h->mu_incl.reserve(nr));
     size_t tb_sort = 0, tb_scan = 0;
     uint32_t* const bk0 = reinterpret_cast<uint32_t*>(h->mb_k0.p);  // the brick keys of the surviving points are 32-bit
     uint32_t* const bk1 = reinterpret_cast<uint32_t*>(h->mb_k1.p);
-    HIPC(flh::sort_brick_pairs(nullptr, tb_sort, bk0, bk1, h->mb_v0.p, h->mb_v1.p, nu, st));
-    HIPC(flh::inclusive_sum(nullptr, tb_scan, h->mu_flags.p, h->mu_incl.p, nu, st));
+    HIPC(flh::sort_brick_pairs(nullptr, tb_sort, bk0, bk1, h->mb_v0.p, h->mb_v1.p, (uint32_t)nr, st));
+    HIPC(flh::inclusive_sum(nullptr, tb_scan, h->mu_flags.p, h->mu_incl.p, (uint32_t)nr, st));
     HIPC(h->mb_tmp.reserve(std::max(tb_sort, tb_scan)));
     // room for every point of the change (the survivors are at most n): allocated up front, nothing to wait for in between
-    HIPC(h->map_orig.grow(h->n_ids + n, h->n_ids, st));
+    HIPC(h->map_orig.grow(h->n_ids + n, h->n_ids, st));  // (grow() allocates a quarter more than asked: a stream seldom reallocates)
     {
         const size_t before = h->dead_id.cap;
         HIPC(h->dead_id.grow(h->n_ids + n, h->n_ids, st));
         if (h->dead_id.cap != before) HIPC(hipMemsetAsync(h->dead_id.p + h->n_ids, 0, h->dead_id.cap - h->n_ids, st));
     }
-    HIPC(h->ins.reserve(n));
+    HIPC(h->ins.reserve(nr));
 #ifdef FLH_BOUNDS
     h->grid.ids_cap = std::min(h->map_orig.cap, h->dead_id.cap);
 #endif
@@ -811,7 +814,7 @@ static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size
     // then meets the points the map already holds there
     const uint32_t vcap = flh::vox_table_slots((uint32_t)n1);
     if (n1 > 0) {
-        HIPC(h->vox_tab.reserve(2 * (size_t)vcap));
+        HIPC(h->vox_tab.reserve(2 * (size_t)flh::vox_table_slots((uint32_t)std::min<size_t>(nr, 0x7FFFFFFFu))));
         HIPC(hipMemsetAsync(h->vox_tab.p, 0xFF, 2 * (size_t)vcap * sizeof(unsigned long long), st));
     }
     // where the number of surviving points goes (with device-side lengths the general path's scan runs over the whole bound: the

@@ -98,9 +98,10 @@ def _full_update_against_oracle(M, N, sensor, cfg, nthreads=32, props=True, exts
             # The plane normals depend on the neighbours only: bit for bit.  pd2 is taken at the LAST pass's state, and with
             # extrinsic estimation the product's 12 x 12 information form and the reference's double inversion (the oracle's) leave
             # that state 1e-10 .. 1e-8 apart -- enough to move the fp32 world coordinate of a few points by an
-            # ulp, i.e. pd2 (a small difference of large terms) by 1e-4 relative.  The flags above were still identical.
+            # ulp (8e-6 m at 100 m), i.e. pd2 -- a sum of four terms of that size -- by a few of them (measured on the MI355X: 0.2 %
+            # of the points differ at all, by at most 3.1e-5 m).  The flags above were still identical.
             np.testing.assert_array_equal(nv[:, :3].view(np.uint32), sc.normvec[sel][:, :3].view(np.uint32))
-            np.testing.assert_allclose(nv[:, 3], sc.normvec[sel][:, 3], rtol=2e-3, atol=2e-6)
+            np.testing.assert_allclose(nv[:, 3], sc.normvec[sel][:, 3], rtol=0, atol=2e-4)
             assert (nv[:, 3].view(np.uint32) != sc.normvec[sel][:, 3].view(np.uint32)).mean() < 0.02
         x = kf.get_x()
         assert np.linalg.norm(x[:3] - x_ref[:3]) <= 1e-4                          # pose within 1e-4 m
