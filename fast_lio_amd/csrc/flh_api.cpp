@@ -305,6 +305,8 @@ struct flh_handle {
     //              the host came more than 20 ms late -- the pass is launched the usual way, pre_gone_relaunch)
     struct PreLaunch {
         bool off = false, armed = false, via_mail = false;
+        bool searches = false;    // flh_config.prelaunch = 2: predicted SEARCHING passes are enqueued ahead too
+        bool armed_search = false, via_search = false;  // the kind of the kernel that is waiting / of the evaluation that went through the mailbox
         int expect = 0;
         uint32_t mseq = 0;
         double eval_seq = 0;
@@ -386,7 +388,7 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.undistort_first_point != 0) cfg.undistort_first_point = 1;
     if (cfg.plane_cache != 0) cfg.plane_cache = 1;
     if (cfg.fused_small_changes != 0) cfg.fused_small_changes = 1;
-    if (cfg.prelaunch != 0) cfg.prelaunch = 1;
+    if (cfg.prelaunch != 0 && cfg.prelaunch != 2) cfg.prelaunch = 1;
     if (cfg.index_cache != 0) cfg.index_cache = 1;
     if (cfg.lanes_per_query != 0) cfg.lanes_per_query = 4;  // 0 = exact kernel for every query
     flh_handle* h = new flh_handle();
@@ -433,6 +435,7 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     }
     h->plane_cache = cfg.plane_cache != 0;
     h->pre.off = cfg.prelaunch == 0;
+    h->pre.searches = cfg.prelaunch == 2;
     h->rmax = (int)std::ceil((std::sqrt((double)cfg.max_sqdist) + 2e-3 * cfg.cell_size) / cfg.cell_size);
     if (h->rmax < 1) h->rmax = 1;
     {
@@ -1976,16 +1979,25 @@ static bool pre_try_go(flh_handle* h, const StateDev& s, const flh_handle::Pendi
     flh_handle::PreLaunch& p = h->pre;
     p.via_mail = false;
     if (!p.armed) return false;
-    const bool fits = !pe.do_search && pe.granules && !pe.timed && pe.ext == p.ext && pe.seq == p.eval_seq && h->N == p.N &&
-                      h->cur_body == p.body && !h->map_pending && h->planes_valid && h->searched_once && !h->comm && h->peer_n == 1;
+    const bool fits = pe.do_search == p.armed_search && pe.granules && !pe.timed && pe.ext == p.ext && pe.seq == p.eval_seq && h->N == p.N &&
+                      h->cur_body == p.body && !h->map_pending && (pe.do_search || (h->planes_valid && h->searched_once)) && !h->comm &&
+                      h->peer_n == 1;
     if (!fits) {
         pre_cancel(h);
         return false;
     }
     pre_post(h, &s, flh::kMailGo);
     p.via_mail = true;
+    p.via_search = pe.do_search;
     p.n_go++;
-    // what enqueue_eval notes down for a no-search evaluation
+    // what enqueue_eval notes down for such an evaluation
+    if (pe.do_search) {
+        h->last_search_was_later = h->searched_once;
+        h->searched_once = true;
+        h->d2_valid = false;
+        h->search_state = s;
+        h->nn_pts_valid = !(h->plane_cache && h->cfg.index_cache && h->nn_idx.p);
+    }
     h->planes_valid = h->plane_cache;
     h->aux_valid = false;
     h->last_state = s;
@@ -1999,12 +2011,15 @@ static int pre_arm(flh_handle* h, const flh_handle::PendingEval& pe) {
     flh_handle::PreLaunch& p = h->pre;
     const int expect = p.expect;
     p.expect = FLH_NEXT_UNKNOWN;
-    if (p.off || p.armed || expect != FLH_NEXT_NOSEARCH) return 0;
+    const bool srch = expect == FLH_NEXT_SEARCH;
+    if (p.off || p.armed || (expect != FLH_NEXT_NOSEARCH && !(srch && p.searches))) return 0;
     const int red1 = gran_group_size(h->N);
-    // (timing_stride 1 = every evaluation carries events: the next one would be refused anyway)
-    const bool next_may_be_timed = h->timing_stride > 0 && !h->timing_search_only;
+    // an evaluation that carries events is never handed to the mailbox: will the next one of this kind?  (flh_eval_begin counts
+    // the evaluations its stride applies to -- the searching ones only with flh_set_timing_sampling(n, 1))
+    const bool next_timed = h->timing_stride > 0 && (!h->timing_search_only || srch) && (h->eval_no % (uint64_t)h->timing_stride) == 0;
     if (!pe.granules || h->peer_n != 1 || h->comm || !h->plane_cache || h->cfg.eigen_order != FLH_ORDER_SSE || h->cfg.plane_fit_dtype != 0 ||
-        h->N == 0 || red1 < 4 || next_may_be_timed || h->stats /* flh_eval_end waits for the stream then */ || !h->cur_body || !h->plane.p)
+        h->N == 0 || red1 < 4 || next_timed || h->stats /* flh_eval_end waits for the stream then */ || !h->cur_body || !h->plane.p ||
+        (srch && (!h->pass_ok || h->own_axis >= 0)))
         return 0;
     if (pre_init(h) != 0) return -1;
     p.mseq++;
@@ -2017,8 +2032,17 @@ static int pre_arm(flh_handle* h, const flh_handle::PendingEval& pe) {
     m.dev_box = p.dev_box;
     m.status = p.status;
     m.seq = p.mseq;
-    HIPC(flh::launch_fit_mb(m, h->cur_body, (int)h->N, pe.ext, h->cfg.plane_threshold, h->selected.p, h->partials.p, p.eval_seq, h->tickets.p,
-                            h->slow_count.p, gran_out(h, p.eval_seq), red1, h->plane.p, h->stream));
+    if (srch) {
+        // the one-launch searching pass, waiting for its state (k_pass<1, true>); everything else as enqueue_eval launches it
+        uint32_t* idx = h->cfg.index_cache ? h->nn_idx.p : nullptr;
+        HIPC(flh::launch_pass(FLH_ORDER_SSE, h->grid, StateDev{}, h->cur_body, (int)h->N, (uint32_t)h->pts_cap, h->cfg.max_sqdist, h->cfg.plane_threshold,
+                              pe.ext, h->nn_pts.p, h->nn_cnt.p, h->selected.p, h->plane.p, h->partials.p, h->tickets.p, gran_out(h, p.eval_seq),
+                              p.eval_seq, red1, nullptr, -1, 0.f, 0.f, h->stream, nullptr, nullptr, idx, nullptr, &m));
+    } else {
+        HIPC(flh::launch_fit_mb(m, h->cur_body, (int)h->N, pe.ext, h->cfg.plane_threshold, h->selected.p, h->partials.p, p.eval_seq, h->tickets.p,
+                                h->slow_count.p, gran_out(h, p.eval_seq), red1, h->plane.p, h->stream));
+    }
+    p.armed_search = srch;
     p.armed = true;
     p.n_armed++;
     return 0;
@@ -2033,12 +2057,12 @@ static int pre_gone_relaunch(flh_handle* h, double seq, int ext) {
     if (st != (((uint64_t)flh::kMailGone << 32) | (uint64_t)p.mseq)) return 0;
     p.via_mail = false;
     p.n_gone++;
-    return enqueue_eval(h, h->last_state, 0, ext, h->h_gram, seq, nullptr, true);
+    return enqueue_eval(h, h->last_state, p.via_search ? 1 : 0, ext, h->h_gram, seq, nullptr, true);
 }
 
 int flh_eval_expect_next(flh_handle* h, int kind) {
     if (!h) return fail("flh_eval_expect_next: null handle");
-    if (kind != FLH_NEXT_UNKNOWN && kind != FLH_NEXT_NOSEARCH && kind != FLH_NEXT_NONE) return fail("flh_eval_expect_next: unknown kind");
+    if (kind != FLH_NEXT_UNKNOWN && kind != FLH_NEXT_NOSEARCH && kind != FLH_NEXT_NONE && kind != FLH_NEXT_SEARCH) return fail("flh_eval_expect_next: unknown kind");
     h->pre.expect = h->pre.off ? FLH_NEXT_UNKNOWN : kind;
     if (kind == FLH_NEXT_NONE) pre_cancel(h);  // nothing follows: a kernel that is still waiting is released now
     return 0;
@@ -2046,6 +2070,7 @@ int flh_eval_expect_next(flh_handle* h, int kind) {
 int flh_set_prelaunch(flh_handle* h, int on) {
     if (!h) return fail("flh_set_prelaunch: null handle");
     h->pre.off = on == 0;
+    h->pre.searches = on == 2;
     if (h->pre.off) { pre_cancel(h); h->pre.expect = FLH_NEXT_UNKNOWN; }
     return 0;
 }
