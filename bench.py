@@ -179,7 +179,9 @@ def main():
     ap.add_argument("--sort", type=int, default=1, help="Morton-order the scan at staging (0 = keep input order)")
     ap.add_argument("--extrinsic-est", type=int, default=0)
     ap.add_argument("--plane-cache", type=int, default=-1, help="flh_config.plane_cache (-1 = the library's default: on)")
-    ap.add_argument("--prelaunch", type=int, default=-1, help="flh_config.prelaunch (-1 / 1 = announced no-search passes are enqueued ahead; 2 = announced searching passes too; 0 = every pass is launched when its state is known)")
+    ap.add_argument("--ring", type=int, default=RING,
+                    help="staging slots cycled by the pipelined loop; with 3 or more, two scans are staged ahead (on two lanes), with 2 one")
+    ap.add_argument("--prelaunch", type=int, default=-1, help="flh_config.prelaunch (-1 = the library's default: on; 0 = every pass is launched when its state is known)")
     ap.add_argument("--index-cache", type=int, default=-1, help="flh_config.index_cache (-1 = default: the neighbour cache holds map indices; 0 = coordinates)")
     ap.add_argument("--plane-fit-dtype", type=int, default=0,
                     help="1 = the fp16 plane-fit ABLATION of BASELINE configs[4] (not bit-exact, never a parity claim)")
@@ -352,11 +354,11 @@ def main():
         hx.set_timing_sampling(args.event_stride if args.event_stride > 0 else (0 if PROFILED else stride + 1 - (stride & 1)), True)
         # the stream does not stop at the boundary of the timed region: the first timed scan is staged while the last
         # warm-up scan updates, exactly as every later scan is staged while its predecessor updates
-        kfx.run_scans(jobs, 0, n_warm, ring=RING, map_incremental=with_map_inserts, stage_next=True)
+        kfx.run_scans(jobs, 0, n_warm, ring=args.ring, map_incremental=with_map_inserts, stage_next=True)
         sync()
         hx.counters(reset=True)  # (the warm-up's samples are dropped)
         t1 = time.perf_counter()
-        rs = kfx.run_scans(jobs, n_warm, n_steps, ring=RING, map_incremental=with_map_inserts, first_staged=n_warm > 0)
+        rs = kfx.run_scans(jobs, n_warm, n_steps, ring=args.ring, map_incremental=with_map_inserts, first_staged=n_warm > 0)
         sync()
         dt_ = time.perf_counter() - t1
         gc.enable()
@@ -579,7 +581,7 @@ def main():
                                     f", normal equations summed per pass ({used if run_shard_leg else args.exchange})"
                                     if mode in ("shard", "partition") else
                                     f"{G} independent scan streams (one per rank), replicated map, no collective in the data path")),
-                   "distinct_scans": S, "cell_size_m": args.cell, "lanes_per_query": args.lpq,
+                   "distinct_scans": S, "staging_ring": args.ring, "cell_size_m": args.cell, "lanes_per_query": args.lpq,
                    "searching_pass": "one launch (k_pass)" if one_launch else "three launches (two search stages + fit)",
                    "plane_cache": args.plane_cache, "plane_fit": "fp16 ABLATION (not bit-exact)" if args.plane_fit_dtype else "fp32 (reference-exact)",
                    "event_reading": "deferred (recorded inside the timed region, read after it)"},

@@ -454,9 +454,8 @@ class Handle:
         """flh_eval_expect_next: 0 unknown, 1 a no-search evaluation probably follows the next one, 2 nothing follows."""
         _chk(lib().flh_eval_expect_next(self._h, kind), "flh_eval_expect_next")
 
-    def set_prelaunch(self, on) -> None:
-        """0 / False: off; 1 / True: announced no-search passes; 2: announced searching passes too."""
-        _chk(lib().flh_set_prelaunch(self._h, int(on)), "flh_set_prelaunch")
+    def set_prelaunch(self, on: bool) -> None:
+        _chk(lib().flh_set_prelaunch(self._h, 1 if on else 0), "flh_set_prelaunch")
 
     def prelaunch_stats(self) -> dict:
         out = (C.c_uint64 * 4)()

@@ -269,6 +269,7 @@ struct flh_handle {
         bool pending = false;           // handed to the staging thread, not finished yet (guarded by st_mu)
         int async_rc = 0;
         std::string async_err;
+        hipStream_t last_stream = nullptr;  // the stream the slot was staged on last (a staging on the other one waits for it)
     };
     struct StageJob { int slot; const void* pts; size_t stride; size_t N; };
     std::thread stager;                 // flh_scan_stage_async's worker
@@ -286,6 +287,14 @@ struct flh_handle {
     DevBuf<float4> fw_in, fw_out;       // flh_frame_world / flh_points_body_to_world
     Slot slots[FLH_MAX_SLOTS + 1];      // [FLH_MAX_SLOTS] backs flh_scan_upload
     hipStream_t copy_stream = nullptr;
+    // A second staging LANE (its own stream and its own scratch) for the plain staging of odd slots: the staging of a 100 000-point
+    // scan occupies its stream for ~130 us (H2D 42 + re-stride, Morton sort, gather 80-90: profiles/r05_call4/) -- as long as the
+    // update of a scan -- so with one lane the update waits for its scan whenever anything jitters.  With two, the scans after
+    // next and after that are staged side by side (flh_esekf_run_scans keeps two in flight).
+    hipStream_t copy_stream2 = nullptr;
+    DevBuf<unsigned char> st2_bytes, st2_tmp;
+    DevBuf<float4> st2_raw;
+    DevBuf<uint32_t> st2_m0, st2_m1, st2_v0, st2_v1;
     const float4* cur_body = nullptr;   // the active slot's buffer
     Slot* cur = nullptr;
     // staging scratch (copy stream)
@@ -305,8 +314,6 @@ struct flh_handle {
     //              the host came more than 20 ms late -- the pass is launched the usual way, pre_gone_relaunch)
     struct PreLaunch {
         bool off = false, armed = false, via_mail = false;
-        bool searches = false;    // flh_config.prelaunch = 2: predicted SEARCHING passes are enqueued ahead too
-        bool armed_search = false, via_search = false;  // the kind of the kernel that is waiting / of the evaluation that went through the mailbox
         int expect = 0;
         uint32_t mseq = 0;
         double eval_seq = 0;
@@ -388,7 +395,7 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.undistort_first_point != 0) cfg.undistort_first_point = 1;
     if (cfg.plane_cache != 0) cfg.plane_cache = 1;
     if (cfg.fused_small_changes != 0) cfg.fused_small_changes = 1;
-    if (cfg.prelaunch != 0 && cfg.prelaunch != 2) cfg.prelaunch = 1;
+    if (cfg.prelaunch != 0) cfg.prelaunch = 1;
     if (cfg.index_cache != 0) cfg.index_cache = 1;
     if (cfg.lanes_per_query != 0) cfg.lanes_per_query = 4;  // 0 = exact kernel for every query
     flh_handle* h = new flh_handle();
@@ -435,7 +442,6 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     }
     h->plane_cache = cfg.plane_cache != 0;
     h->pre.off = cfg.prelaunch == 0;
-    h->pre.searches = cfg.prelaunch == 2;
     h->rmax = (int)std::ceil((std::sqrt((double)cfg.max_sqdist) + 2e-3 * cfg.cell_size) / cfg.cell_size);
     if (h->rmax < 1) h->rmax = 1;
     {
@@ -457,6 +463,7 @@ void flh_destroy(flh_handle* h) {
     pre_cancel(h);
     flh_rccl_destroy(h);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    if (h->copy_stream2) (void)hipStreamSynchronize(h->copy_stream2);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     release_build_scratch(h);
     h->dead_id.release(); h->cap_end.release(); h->live.release(); h->mb_cap.release(); h->mb_capincl.release(); h->ctr.release();
@@ -483,6 +490,8 @@ void flh_destroy(flh_handle* h) {
     h->ds_raw.release(); h->ds_und.release(); h->ds_poses.release(); h->ds_blockmin.release(); h->ds_flags.release(); h->ds_incl.release();
     h->st_raw.release(); h->st_k0.release(); h->st_k1.release(); h->st_m0.release(); h->st_m1.release(); h->st_v0.release(); h->st_v1.release(); h->st_tmp.release();
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->copy_stream2) (void)hipStreamDestroy(h->copy_stream2);
+    h->st2_bytes.release(); h->st2_tmp.release(); h->st2_raw.release(); h->st2_m0.release(); h->st2_m1.release(); h->st2_v0.release(); h->st2_v1.release();
     if (h->h_gram) (void)hipHostFree(h->h_gram);
     flh_peer_close(h);
     if (h->h_gran && h->gran_owned) (void)hipHostFree(h->h_gran);
@@ -1078,33 +1087,51 @@ static bool is_pinned_host(const void* p, size_t bytes) {
     return false;
 }
 
-static int stage_prepare(flh_handle* h, flh_handle::Slot& sl) {
+// A staging lane: a stream and the scratch of the plain staging on it.  Lane 0 is the copy stream every staging path uses; lane 1
+// serves the plain staging (flh_scan_stage / _async) of odd slots, so that two scans can be staged side by side.
+struct StageLane {
+    hipStream_t cs;
+    DevBuf<unsigned char>&bytes, &tmp;
+    DevBuf<float4>& raw;
+    DevBuf<uint32_t>&m0, &m1, &v0, &v1;
+};
+static StageLane stage_lane(flh_handle* h, int which) {
+    if (which) return StageLane{h->copy_stream2, h->st2_bytes, h->st2_tmp, h->st2_raw, h->st2_m0, h->st2_m1, h->st2_v0, h->st2_v1};
+    return StageLane{h->copy_stream, h->st_bytes, h->st_tmp, h->st_raw, h->st_m0, h->st_m1, h->st_v0, h->st_v1};
+}
+static int stage_prepare(flh_handle* h, flh_handle::Slot& sl, int lane = 0) {
     HIPC(hipSetDevice(h->device));
     if (!h->copy_stream) HIPC(create_stream(&h->copy_stream, false));
+    if (lane && !h->copy_stream2) HIPC(create_stream(&h->copy_stream2, false));
     if (!sl.ready) HIPC(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
     if (!sl.h2d_done) HIPC(hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
+    // the slot's buffer was last written on the other lane's stream: this staging's writes come after those
+    hipStream_t cs = lane ? h->copy_stream2 : h->copy_stream;
+    if (sl.used && sl.last_stream && sl.last_stream != cs) HIPC(hipStreamWaitEvent(cs, sl.ready, 0));
+    sl.last_stream = cs;
     sl.host_valid = false;
     return 0;
 }
 
 // Device side of the plain staging: st_raw (N float4, original order) + keys/vals are in place on the copy stream.
-static int stage_sorted(flh_handle* h, flh_handle::Slot& sl, size_t N, bool have_keys) {
-    hipStream_t cs = h->copy_stream;
+static int stage_sorted(flh_handle* h, flh_handle::Slot& sl, size_t N, bool have_keys, int lane = 0) {
+    const StageLane L = stage_lane(h, lane);
+    hipStream_t cs = L.cs;
     const size_t n1 = N ? N : 1;
     HIPC(sl.body.reserve(n1));
     const bool do_sort = h->cfg.sort_queries != 0 && N > 1;
     if (do_sort) {
         const uint32_t Nu = (uint32_t)N;
-        HIPC(h->st_m0.reserve(N)); HIPC(h->st_m1.reserve(N)); HIPC(h->st_v0.reserve(N)); HIPC(h->st_v1.reserve(N));
-        if (!have_keys) HIPC(flh::launch_scan_keys(h->st_raw.p, Nu, 0.5f, h->st_m0.p, h->st_v0.p, cs));
+        HIPC(L.m0.reserve(N)); HIPC(L.m1.reserve(N)); HIPC(L.v0.reserve(N)); HIPC(L.v1.reserve(N));
+        if (!have_keys) HIPC(flh::launch_scan_keys(L.raw.p, Nu, 0.5f, L.m0.p, L.v0.p, cs));
         size_t tb = 0;
-        HIPC(flh::sort_scan_pairs(nullptr, tb, h->st_m0.p, h->st_m1.p, h->st_v0.p, h->st_v1.p, Nu, cs));
-        HIPC(h->st_tmp.reserve(tb));
-        tb = h->st_tmp.cap;
-        HIPC(flh::sort_scan_pairs(h->st_tmp.p, tb, h->st_m0.p, h->st_m1.p, h->st_v0.p, h->st_v1.p, Nu, cs));
-        HIPC(flh::launch_scan_gather(h->st_raw.p, h->st_v1.p, Nu, sl.body.p, cs));
+        HIPC(flh::sort_scan_pairs(nullptr, tb, L.m0.p, L.m1.p, L.v0.p, L.v1.p, Nu, cs));
+        HIPC(L.tmp.reserve(tb));
+        tb = L.tmp.cap;
+        HIPC(flh::sort_scan_pairs(L.tmp.p, tb, L.m0.p, L.m1.p, L.v0.p, L.v1.p, Nu, cs));
+        HIPC(flh::launch_scan_gather(L.raw.p, L.v1.p, Nu, sl.body.p, cs));
     } else {
-        HIPC(flh::launch_scan_gather(h->st_raw.p, nullptr, (uint32_t)N, sl.body.p, cs));
+        HIPC(flh::launch_scan_gather(L.raw.p, nullptr, (uint32_t)N, sl.body.p, cs));
     }
     HIPC(hipEventRecord(sl.ready, cs));
     sl.N = N;
@@ -1117,12 +1144,14 @@ static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size
     if (N > 0 && !pts) return fail("scan staging: null points");
     if ((stride_bytes < 12 || (stride_bytes & 3)) && N > 0) return fail("scan staging: stride_bytes must be a multiple of 4 and >= 12");
     if (N >= (1ull << 26)) return fail("scan staging: N too large");
-    if (stage_prepare(h, sl) != 0) return -1;
-    hipStream_t cs = h->copy_stream;
+    const int lane = (int)((&sl - h->slots) & 1);  // odd slots: the second lane (the ring's scans alternate)
+    if (stage_prepare(h, sl, lane) != 0) return -1;
+    const StageLane L = stage_lane(h, lane);
+    hipStream_t cs = L.cs;
     const size_t n1 = N ? N : 1;
     const size_t bytes = N * stride_bytes;
-    HIPC(h->st_raw.reserve(n1));
-    HIPC(h->st_bytes.reserve(bytes ? bytes : 4));
+    HIPC(L.raw.reserve(n1));
+    HIPC(L.bytes.reserve(bytes ? bytes : 4));
     bool direct = false;
     if (N > 0) {
         direct = is_pinned_host(pts, bytes);
@@ -1132,14 +1161,14 @@ static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size
             std::memcpy(sl.pin, pts, bytes);
             src = sl.pin;
         }
-        HIPC(hipMemcpyAsync(h->st_bytes.p, src, bytes, hipMemcpyHostToDevice, cs));
+        HIPC(hipMemcpyAsync(L.bytes.p, src, bytes, hipMemcpyHostToDevice, cs));
         HIPC(hipEventRecord(sl.h2d_done, cs));
     }
     const bool do_sort = h->cfg.sort_queries != 0 && N > 1;
-    if (do_sort) { HIPC(h->st_m0.reserve(N)); HIPC(h->st_v0.reserve(N)); }
-    HIPC(flh::launch_scan_restride(h->st_bytes.p, (uint32_t)stride_bytes, 0, 0, (uint32_t)N, 0.5f, h->st_raw.p,
-                                   do_sort ? h->st_m0.p : nullptr, do_sort ? h->st_v0.p : nullptr, nullptr, cs));
-    if (stage_sorted(h, sl, N, do_sort) != 0) return -1;
+    if (do_sort) { HIPC(L.m0.reserve(N)); HIPC(L.v0.reserve(N)); }
+    HIPC(flh::launch_scan_restride(L.bytes.p, (uint32_t)stride_bytes, 0, 0, (uint32_t)N, 0.5f, L.raw.p,
+                                   do_sort ? L.m0.p : nullptr, do_sort ? L.v0.p : nullptr, nullptr, cs));
+    if (stage_sorted(h, sl, N, do_sort, lane) != 0) return -1;
     if (direct && wait_reusable && N > 0) HIPC(hipEventSynchronize(sl.h2d_done));
     return 0;
 }
@@ -1979,25 +2008,16 @@ static bool pre_try_go(flh_handle* h, const StateDev& s, const flh_handle::Pendi
     flh_handle::PreLaunch& p = h->pre;
     p.via_mail = false;
     if (!p.armed) return false;
-    const bool fits = pe.do_search == p.armed_search && pe.granules && !pe.timed && pe.ext == p.ext && pe.seq == p.eval_seq && h->N == p.N &&
-                      h->cur_body == p.body && !h->map_pending && (pe.do_search || (h->planes_valid && h->searched_once)) && !h->comm &&
-                      h->peer_n == 1;
+    const bool fits = !pe.do_search && pe.granules && !pe.timed && pe.ext == p.ext && pe.seq == p.eval_seq && h->N == p.N &&
+                      h->cur_body == p.body && !h->map_pending && h->planes_valid && h->searched_once && !h->comm && h->peer_n == 1;
     if (!fits) {
         pre_cancel(h);
         return false;
     }
     pre_post(h, &s, flh::kMailGo);
     p.via_mail = true;
-    p.via_search = pe.do_search;
     p.n_go++;
-    // what enqueue_eval notes down for such an evaluation
-    if (pe.do_search) {
-        h->last_search_was_later = h->searched_once;
-        h->searched_once = true;
-        h->d2_valid = false;
-        h->search_state = s;
-        h->nn_pts_valid = !(h->plane_cache && h->cfg.index_cache && h->nn_idx.p);
-    }
+    // what enqueue_eval notes down for a no-search evaluation
     h->planes_valid = h->plane_cache;
     h->aux_valid = false;
     h->last_state = s;
@@ -2011,15 +2031,12 @@ static int pre_arm(flh_handle* h, const flh_handle::PendingEval& pe) {
     flh_handle::PreLaunch& p = h->pre;
     const int expect = p.expect;
     p.expect = FLH_NEXT_UNKNOWN;
-    const bool srch = expect == FLH_NEXT_SEARCH;
-    if (p.off || p.armed || (expect != FLH_NEXT_NOSEARCH && !(srch && p.searches))) return 0;
+    if (p.off || p.armed || expect != FLH_NEXT_NOSEARCH) return 0;
     const int red1 = gran_group_size(h->N);
-    // an evaluation that carries events is never handed to the mailbox: will the next one of this kind?  (flh_eval_begin counts
-    // the evaluations its stride applies to -- the searching ones only with flh_set_timing_sampling(n, 1))
-    const bool next_timed = h->timing_stride > 0 && (!h->timing_search_only || srch) && (h->eval_no % (uint64_t)h->timing_stride) == 0;
+    // (timing_stride 1 = every evaluation carries events: the next one would be refused anyway)
+    const bool next_may_be_timed = h->timing_stride > 0 && !h->timing_search_only;
     if (!pe.granules || h->peer_n != 1 || h->comm || !h->plane_cache || h->cfg.eigen_order != FLH_ORDER_SSE || h->cfg.plane_fit_dtype != 0 ||
-        h->N == 0 || red1 < 4 || next_timed || h->stats /* flh_eval_end waits for the stream then */ || !h->cur_body || !h->plane.p ||
-        (srch && (!h->pass_ok || h->own_axis >= 0)))
+        h->N == 0 || red1 < 4 || next_may_be_timed || h->stats /* flh_eval_end waits for the stream then */ || !h->cur_body || !h->plane.p)
         return 0;
     if (pre_init(h) != 0) return -1;
     p.mseq++;
@@ -2032,17 +2049,8 @@ static int pre_arm(flh_handle* h, const flh_handle::PendingEval& pe) {
     m.dev_box = p.dev_box;
     m.status = p.status;
     m.seq = p.mseq;
-    if (srch) {
-        // the one-launch searching pass, waiting for its state (k_pass<1, true>); everything else as enqueue_eval launches it
-        uint32_t* idx = h->cfg.index_cache ? h->nn_idx.p : nullptr;
-        HIPC(flh::launch_pass(FLH_ORDER_SSE, h->grid, StateDev{}, h->cur_body, (int)h->N, (uint32_t)h->pts_cap, h->cfg.max_sqdist, h->cfg.plane_threshold,
-                              pe.ext, h->nn_pts.p, h->nn_cnt.p, h->selected.p, h->plane.p, h->partials.p, h->tickets.p, gran_out(h, p.eval_seq),
-                              p.eval_seq, red1, nullptr, -1, 0.f, 0.f, h->stream, nullptr, nullptr, idx, nullptr, &m));
-    } else {
-        HIPC(flh::launch_fit_mb(m, h->cur_body, (int)h->N, pe.ext, h->cfg.plane_threshold, h->selected.p, h->partials.p, p.eval_seq, h->tickets.p,
-                                h->slow_count.p, gran_out(h, p.eval_seq), red1, h->plane.p, h->stream));
-    }
-    p.armed_search = srch;
+    HIPC(flh::launch_fit_mb(m, h->cur_body, (int)h->N, pe.ext, h->cfg.plane_threshold, h->selected.p, h->partials.p, p.eval_seq, h->tickets.p,
+                            h->slow_count.p, gran_out(h, p.eval_seq), red1, h->plane.p, h->stream));
     p.armed = true;
     p.n_armed++;
     return 0;
@@ -2057,12 +2065,12 @@ static int pre_gone_relaunch(flh_handle* h, double seq, int ext) {
     if (st != (((uint64_t)flh::kMailGone << 32) | (uint64_t)p.mseq)) return 0;
     p.via_mail = false;
     p.n_gone++;
-    return enqueue_eval(h, h->last_state, p.via_search ? 1 : 0, ext, h->h_gram, seq, nullptr, true);
+    return enqueue_eval(h, h->last_state, 0, ext, h->h_gram, seq, nullptr, true);
 }
 
 int flh_eval_expect_next(flh_handle* h, int kind) {
     if (!h) return fail("flh_eval_expect_next: null handle");
-    if (kind != FLH_NEXT_UNKNOWN && kind != FLH_NEXT_NOSEARCH && kind != FLH_NEXT_NONE && kind != FLH_NEXT_SEARCH) return fail("flh_eval_expect_next: unknown kind");
+    if (kind != FLH_NEXT_UNKNOWN && kind != FLH_NEXT_NOSEARCH && kind != FLH_NEXT_NONE) return fail("flh_eval_expect_next: unknown kind");
     h->pre.expect = h->pre.off ? FLH_NEXT_UNKNOWN : kind;
     if (kind == FLH_NEXT_NONE) pre_cancel(h);  // nothing follows: a kernel that is still waiting is released now
     return 0;
@@ -2070,7 +2078,6 @@ int flh_eval_expect_next(flh_handle* h, int kind) {
 int flh_set_prelaunch(flh_handle* h, int on) {
     if (!h) return fail("flh_set_prelaunch: null handle");
     h->pre.off = on == 0;
-    h->pre.searches = on == 2;
     if (h->pre.off) { pre_cancel(h); h->pre.expect = FLH_NEXT_UNKNOWN; }
     return 0;
 }

@@ -179,6 +179,18 @@ int flh_esekf_run_scans(flh_esekf* e, const flh_scan_job* jobs, int n_jobs, int6
     };
     const int64_t last = first + count;  // one past the last scan of this call; `last` itself is staged only with FLH_RUN_STAGE_NEXT
     auto may_stage = [&](int64_t k) { return k < last || (k == last && (flags & FLH_RUN_STAGE_NEXT)); };
+    // Up to TWO scans are in flight on the staging side while one is updated (the library stages even and odd slots on two lanes):
+    // a scan's staging occupies its stream for about as long as an update takes, so with one in flight the update waits for its
+    // scan whenever anything jitters.  A ring of two slots can hold only one ahead.
+    const int64_t ahead = ring >= 3 ? 2 : 1;
+    int64_t staged_upto = (flags & FLH_RUN_FIRST_STAGED) ? first + 1 : first;  // scans [first, staged_upto) have been handed to the staging thread
+    auto stage_ahead = [&](int64_t i) -> int {  // while scan i is updated, scans up to i + ahead are staged
+        while (staged_upto <= i + ahead && may_stage(staged_upto)) {
+            if (stage(staged_upto) != 0) return -1;
+            ++staged_upto;
+        }
+        return 0;
+    };
     // an error return must not leave the staging thread reading the caller's buffers: wait for every slot of the ring first
     auto bail = [&]() -> int {
         const std::string keep = e->err;
@@ -186,10 +198,9 @@ int flh_esekf_run_scans(flh_esekf* e, const flh_scan_job* jobs, int n_jobs, int6
         e->err = keep;
         return -1;
     };
-    if (count > 0 && !(flags & FLH_RUN_FIRST_STAGED) && stage(first) != 0) return bail();
     for (int64_t i = first; i < first + count; ++i) {
         const flh_scan_job& j = jobs[i % n_jobs];
-        if (may_stage(i + 1) && stage(i + 1) != 0) return bail();  // scan i+1 crosses PCIe while scan i updates
+        if (stage_ahead(i) != 0) return bail();  // scans i+1, i+2 cross PCIe while scan i updates (scan i itself first, if nobody has staged it)
         flh_update_stats st;
         if (flh_esekf_update_scan(e, j.slot >= 0 ? j.slot : (int)(i % ring), j.x, j.P, R, &st) != 0) return bail();
         rs.scans++;

@@ -41,7 +41,6 @@ hipError_t launch_search(int lpq, const GridParams& g, const StateDev& s, const 
                          int own_axis, float own_lo, float own_hi, hipStream_t st,
                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);  // optional: time stamps of the first kernel's start / the last one's end
 
-struct MailArgs;  // flh_mail_dev.hpp
 // ---- flh_pass.hip: a searching pass as ONE launch (search, fit, Gram, group sums -> granules) ----
 int pass_blocks(int N);                          // workgroups (64 scan points each)
 int pass_group_size(int N, int max_groups);      // workgroups per reduction group
@@ -50,8 +49,7 @@ hipError_t launch_pass(int order, const GridParams& g, const StateDev& s, const 
                        uint32_t* tickets, const GranOut& gran, double seq, int red, unsigned long long* cand_counter,
                        int own_axis, float own_lo, float own_hi, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
                        uint32_t* nn_idx = nullptr,       // nn_idx: the neighbour cache as map indices (flh_config.index_cache), else nn_pts
-                       double* group_totals = nullptr,   // gran.n_dst == 0 (an RCCL communicator): the group sums go to group_totals[group][slot]
-                       const MailArgs* mail = nullptr);  // the pre-launched form: the state comes through a mailbox (flh_mail_dev.hpp), `s` is ignored
+                       double* group_totals = nullptr);  // gran.n_dst == 0 (an RCCL communicator): the group sums go to group_totals[group][slot]
 // the all-reduced group totals -> the 16x16 block in pinned host memory + the sequence word (the RCCL path's last kernel)
 hipError_t launch_publish_groups(double* totals, int ngroups_own, int ngroups_all, int nsl, int ncol, double* out256, double seq, hipStream_t st);
 // neighbour cache kept as indices -> coordinates (nn_pts[r * N + i] = {map_orig[id].xyz, id}; id == -1 or >= n_ids: an empty row)
@@ -69,6 +67,7 @@ hipError_t launch_fill_d2(const StateDev& s_search, const float4* body, const fl
 int gram_slots_host(int ncol);
 int gram_slot_host(int r, int c, int ncol);
 // the pre-launched no-search pass (flh_mail_dev.hpp)
+struct MailArgs;
 hipError_t launch_fit_mb(const MailArgs& mail, const float4* body, int N, int ext, float thr, uint8_t* selected, double* partials,
                          double seq, uint32_t* tickets, uint32_t* slow_count, const GranOut& gran, int red1, const float4* plane_cache,
                          hipStream_t st);

@@ -43,10 +43,7 @@ __device__ __forceinline__ double lane_bcast_f64(double v, int src) {  // src: c
 }
 
 // Called by ALL threads of a workgroup (256) before anything else.  Returns false (workgroup-uniform) when the launch is to do
-// nothing.  On success s holds the state.  s_cmd: one word of LDS.  NAP: s_sleep argument between two looks at the forwarded word
-// (64 clocks each: 1 for the 391 workgroups of the no-search pass, 8 for the 1 563 of a searching pass -- four times the pollers on
-// one L2 line).
-template <int NAP = 1>
+// nothing.  On success s holds the state.  s_cmd: one word of LDS.
 __device__ __forceinline__ bool mailbox_wait(const MailArgs& m, StateDev& s, uint32_t* s_cmd) {
     typedef __attribute__((address_space(1))) const unsigned long long gcu64;
     typedef __attribute__((address_space(1))) unsigned long long gu64;
@@ -91,7 +88,7 @@ __device__ __forceinline__ bool mailbox_wait(const MailArgs& m, StateDev& s, uin
                 __hip_atomic_store((gu64*)m.status, ((unsigned long long)kMailLost << 32) | m.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
-            __builtin_amdgcn_s_sleep(NAP);
+            __builtin_amdgcn_s_sleep(1);
         }
         *s_cmd = (uint32_t)(w >> 32);
     }

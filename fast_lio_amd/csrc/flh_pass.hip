@@ -36,7 +36,6 @@
 #include "flh_device.hpp"
 #include "flh_search_dev.hpp"
 #include "flh_fit_dev.hpp"
-#include "flh_mail_dev.hpp"
 
 namespace flh {
 
@@ -60,6 +59,10 @@ constexpr int kSegB = 2 * 16 + 2;                      // 34 per phase-B group (
 // a rank's share of an 8-way shard, 12 500 points: 38.0 / 36.6 / 39.1 us per searching pass at 4 / 8 / 16 lanes; 25 000 points:
 // 40.1 / 39.9 / 50.9): no gain -- a small pass is the latency chain of one workgroup (launch, dependent misses, fit, ticket, group
 // sum, publish: 22 us for 64 points), not phase A's issue -- so the wide variants were deleted again.
+// Also built, measured and deleted in round 5: the pre-launched form of this kernel (k_pass<1, true>: enqueued beside the pass before it,
+// every workgroup waiting for its state in a mailbox, as k_fit_mb does for the no-search pass).  With 1 563 workgroups waiting the
+// hand-over is slower than a launch: searching pass 47.6 -> 49.7 us, value 7 605 -> 7 389 scans/s, three alternating pairs
+// (profiles/r05_call5/) -- what tools/mailbox_probe.cpp had predicted (profiles/r05_call1/mailbox_probe.txt).
 constexpr int kSegWords = (64 * kSegA > 32 * kSegB) ? 64 * kSegA : 32 * kSegB;
 static_assert(kSegWords * 8 >= 64 * kTileStride * 8, "the fit's transpose tile reuses the segment tables");
 // Developer instrumentation (tools/variant.py --define FLH_PASS_STAMPS, tools/pass_stamps.py): per-wave 100 MHz time stamps of the
@@ -81,20 +84,13 @@ void pass_stamps_read(unsigned long long* out, size_t words) {
 #define STAMP(i)
 #endif
 
-// MB: the pre-launched form (flh_eval_expect_next(FLH_NEXT_SEARCH), flh_config.prelaunch = 2): the kernel is enqueued beside the
-// pass before it and every workgroup waits for the state in a mailbox (flh_mail_dev.hpp) instead of taking it from its arguments.
-template <int ORD, bool MB>
+template <int ORD>
 __global__ void __launch_bounds__(256) PASS_ATTR
-k_pass(GridParams g, StateDev s_arg, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist, float thr, int ext,
+k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_t map_points, float max_sqdist, float thr, int ext,
        int ncol, float4* __restrict__ nn_pts, uint8_t* __restrict__ nn_cnt, uint8_t* __restrict__ selected,
        float4* __restrict__ plane_cache, double* __restrict__ partials, uint32_t* __restrict__ tickets, GranOut gout, double seq,
        int red, u64* __restrict__ cand_counter, int own_axis, float own_lo, float own_hi, uint32_t* __restrict__ nn_idx,
-       double* __restrict__ group_totals, MailArgs mail) {
-    StateDev s = s_arg;
-    if (MB) {
-        __shared__ uint32_t s_cmd;
-        if (!mailbox_wait<8>(mail, s, &s_cmd)) return;  // released unused, or nobody came: nothing was written
-    }
+       double* __restrict__ group_totals) {
     constexpr int LPQ = 4;           // lanes per query in phase A
     constexpr int NW = 4;            // waves of the workgroup
     constexpr int QPW = 64 / LPQ;    // queries per wave in phase A
@@ -266,28 +262,21 @@ hipError_t launch_pass(int order, const GridParams& g, const StateDev& s, const 
                        float thr, int ext, float4* nn_pts, uint8_t* nn_cnt, uint8_t* selected, float4* plane_cache, double* partials,
                        uint32_t* tickets, const GranOut& out, double seq, int red, unsigned long long* cand_counter,
                        int own_axis, float own_lo, float own_hi, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t* nn_idx,
-                       double* group_totals, const MailArgs* mail) {
+                       double* group_totals) {
     if (N <= 0 || out.n_dst < 0 || out.n_dst > kPeersMax || (out.n_dst == 0 && !group_totals)) return hipErrorInvalidValue;
-    if (mail && order != 1) return hipErrorInvalidValue;  // the pre-launched form exists for the default summation order
-    const MailArgs m0 = mail ? *mail : MailArgs{nullptr, nullptr, nullptr, 0u};
     const int ncol = ext ? 12 : 6;
     const dim3 grid(pass_blocks(N)), blk(256);
 #define FLH_PASS(O)                                                                                                                   \
     do {                                                                                                                              \
         if (ev_start != nullptr || ev_stop != nullptr)                                                                                \
-            hipExtLaunchKernelGGL((k_pass<O, false>), grid, blk, 0, st, ev_start, ev_stop, 0, g, s, body, N, map_points, max_sqdist, thr, ext, \
+            hipExtLaunchKernelGGL((k_pass<O>), grid, blk, 0, st, ev_start, ev_stop, 0, g, s, body, N, map_points, max_sqdist, thr, ext, \
                                   ncol, nn_pts, nn_cnt, selected, plane_cache, partials, tickets, out, seq, red, cand_counter, own_axis, \
-                                  own_lo, own_hi, nn_idx, group_totals, m0);                                                           \
+                                  own_lo, own_hi, nn_idx, group_totals);                                                               \
         else                                                                                                                          \
-            hipLaunchKernelGGL((k_pass<O, false>), grid, blk, 0, st, g, s, body, N, map_points, max_sqdist, thr, ext, ncol, nn_pts, nn_cnt, \
+            hipLaunchKernelGGL((k_pass<O>), grid, blk, 0, st, g, s, body, N, map_points, max_sqdist, thr, ext, ncol, nn_pts, nn_cnt, \
                                selected, plane_cache, partials, tickets, out, seq, red, cand_counter, own_axis, own_lo, own_hi, nn_idx, \
-                               group_totals, m0);                                                                                     \
+                               group_totals);                                                                                         \
     } while (0)
-    if (mail) {
-        hipLaunchKernelGGL((k_pass<1, true>), grid, blk, 0, st, g, s, body, N, map_points, max_sqdist, thr, ext, ncol, nn_pts, nn_cnt, selected,
-                           plane_cache, partials, tickets, out, seq, red, cand_counter, own_axis, own_lo, own_hi, nn_idx, group_totals, m0);
-        return hipGetLastError();
-    }
     switch (order) {
         case 0: FLH_PASS(0); break;
         case 2: FLH_PASS(2); break;

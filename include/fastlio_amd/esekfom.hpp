@@ -41,7 +41,7 @@ struct dyn_share_datastruct {
     // models that ignore it lose nothing.
     int next_pass = 0;
 };
-enum { kNextUnknown = 0, kNextNoSearch = 1, kNextNone = 2, kNextSearch = 3 };  // = FLH_NEXT_* (include/fastlio_hip.h)
+enum { kNextUnknown = 0, kNextNoSearch = 1, kNextNone = 2 };  // = FLH_NEXT_* (include/fastlio_hip.h)
 
 // Measurement models of the reference's plain signature (esekfom.hpp:129) that come in two halves register their first half
 // here, keyed by the address of the model; init_dyn_share / set_meas_model look it up.  fastlio_amd::h_share_model does
@@ -223,7 +223,7 @@ class esekf {
             // SEARCH after the last but one when no step has converged yet (:1829-1832 forces it); otherwise a no-search pass
             // unless this pass's step converges (then: a search if it is the first to converge, the end of the update if the second)
             // (kNextNone is for the END of the update -- finish_hint -- where a kernel enqueued ahead is released)
-            dyn_share.next_pass = i == maximum_iter - 1 ? kNextUnknown : ((!t && i == maximum_iter - 2) ? kNextSearch : kNextNoSearch);
+            dyn_share.next_pass = (i == maximum_iter - 1 || (!t && i == maximum_iter - 2)) ? kNextUnknown : kNextNoSearch;
             bool early = false;
             if ((h_dyn_share_ctx && h_begin_ctx) || (!h_dyn_share_ctx && h_begin)) {
                 // the measurement model is under way on the device: what :1655-1699 and the first inverse of :1782 compute from the
@@ -354,7 +354,7 @@ class esekf {
    private:
     // the update ends: a model that was told to expect another no-search pass is told that none comes
     void finish_hint(dyn_share_datastruct<scalar_type>& d) {
-        if (d.next_pass != kNextNoSearch && d.next_pass != kNextSearch) return;
+        if (d.next_pass != kNextNoSearch) return;
         d.next_pass = kNextUnknown;
         if (h_finish_ctx) h_finish_ctx(h_ctx_);
         else if (h_finish) h_finish();

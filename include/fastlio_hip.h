@@ -75,8 +75,7 @@ typedef struct flh_config {
                                same results); 0: the general path for every size.  Performance only */
     int prelaunch;          /* 1 (default, also for < 0): flh_eval_expect_next is honoured -- the kernel of a no-search evaluation the
                                caller announces is enqueued beside the pass before it and takes its state from a mailbox in pinned
-                               memory, so that its launch leaves the critical path (same bits); 2: announced SEARCHING evaluations
-                               too (the one-launch pass, all of its 1 563 workgroups waiting); 0: hints are ignored.  Performance only */
+                               memory, so that its launch leaves the critical path (same bits); 0: hints are ignored.  Performance only */
     int index_cache;        /* 1 (default, also for < 0): the one-launch searching pass leaves the five neighbours of a query as map
                                INDICES (20 B per query); their coordinates are gathered on demand by whatever asks for them
                                (flh_map_incremental, flh_fetch_neighbors, a re-fit without the plane cache); 0: the search writes
@@ -250,18 +249,14 @@ int flh_eval_end(flh_handle* h, double HTH[144], double HTh[12], int64_t* n_eff,
  *   FLH_NEXT_NOSEARCH  probably a no-search evaluation of the same scan, at a state not known yet: its kernel is enqueued beside
  *                      the pass flh_eval_begin starts and waits (bounded: 20 ms) for the state, which the following
  *                      flh_eval_begin then posts instead of launching.  Any other call that follows releases it.
- *   FLH_NEXT_SEARCH    a SEARCHING evaluation of the same scan follows for certain (esekfom.hpp:1829-1832 forces one after the last
- *                      but one pass when no step has converged): with flh_config.prelaunch = 2 its one-launch kernel is enqueued
- *                      ahead in the same way
  *   FLH_NEXT_UNKNOWN   no expectation (the default before every flh_eval_begin): nothing is enqueued ahead
  *   FLH_NEXT_NONE      no evaluation follows at all (the update has ended): a kernel that is still waiting is released NOW --
  *                      not to be said before a flh_eval_begin whose own kernel may be the one that is waiting */
 #define FLH_NEXT_UNKNOWN 0
 #define FLH_NEXT_NOSEARCH 1
 #define FLH_NEXT_NONE 2
-#define FLH_NEXT_SEARCH 3
 int flh_eval_expect_next(flh_handle* h, int kind);
-/* flh_config.prelaunch at run time (0: hints are ignored from now on, a waiting kernel is released; 1; 2); and the counters since creation:
+/* flh_config.prelaunch at run time (0: hints are ignored from now on, a waiting kernel is released); and the counters since creation:
  * {kernels enqueued ahead, of them handed their state, released unused, given up before the host came (then launched the usual way)} */
 int flh_set_prelaunch(flh_handle* h, int on);
 int flh_get_prelaunch_stats(const flh_handle* h, uint64_t out[4]);
