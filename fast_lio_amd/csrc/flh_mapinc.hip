@@ -406,8 +406,8 @@ k_add_resolve(GridParams g, float4* pts_rw /* = g.pts */, const float4* __restri
         uint32_t n_all = n;
         if (!mi_counts(mc, n, n_all)) return;  // n = the points inserted with down-sampling
     }
-    // eight lanes per new point (it was 106 us with one thread per voxel); since round 5 they share the POINTS of each cell the
-    // voxel box overlaps rather than the cells (see the loop below)
+    // eight lanes per point: the cells the voxel box overlaps are dealt to the lanes, so the directory probe -> prefix table
+    // -> points chain of each cell runs side by side instead of one after the other (it was 106 us with one thread per voxel)
     constexpr int L = 8;
     const uint32_t j = (blockIdx.x * 256 + threadIdx.x) / L;
     const int lane = threadIdx.x & (L - 1);
@@ -437,13 +437,10 @@ k_add_resolve(GridParams g, float4* pts_rw /* = g.pts */, const float4* __restri
     int n_exist = 0;
     float best_ed = INFINITY;
     uint32_t best_e = 0xFFFFFFFFu;
-    // A half-metre voxel lies inside ONE 1.5 m search cell most of the time (eight at most): the lanes share each cell's POINTS --
-    // dealt round-robin, all of a lane's loads independent -- instead of taking a cell each and walking its 8-16 points one after
-    // the other (which left seven of the eight lanes idle behind one serial chain: 21 us for a scan's change, round 4's profile).
-    for (int c = 0; c < ncell; ++c) {
+    for (int c = lane; c < ncell; c += L) {
         const int z = c0z + c / (sx * sy), y = c0y + (c / sx) % sy, x = c0x + c % sx;
-        const uint2 ce = lookup_cell(g, x, y, z);  // (the same address in all lanes of the group)
-        for (uint32_t i = ce.x + (uint32_t)lane; i < ce.x + ce.y; i += (uint32_t)L) {
+        const uint2 ce = lookup_cell(g, x, y, z);
+        for (uint32_t i = ce.x; i < ce.x + ce.y; ++i) {
             const float4 q = pts_rw[FLH_IDX(210, i, g.pts_cap)];
             if (is_tombstone(q)) continue;
             long long qx, qy, qz;
@@ -466,11 +463,11 @@ k_add_resolve(GridParams g, float4* pts_rw /* = g.pts */, const float4* __restri
     if (n_exist == 1 && !new_wins) return;      // the single existing point stays; every new point is dropped
     // otherwise the voxel is emptied except for the winner
     if (n_exist > 0) {
-        for (int c = 0; c < ncell; ++c) {
+        for (int c = lane; c < ncell; c += L) {
             const int z = c0z + c / (sx * sy), y = c0y + (c / sx) % sy, x = c0x + c % sx;
             uint32_t rank;
             const uint2 ce = lookup_cell_rank(g, x, y, z, rank);
-            for (uint32_t i = ce.x + (uint32_t)lane; i < ce.x + ce.y; i += (uint32_t)L) {
+            for (uint32_t i = ce.x; i < ce.x + ce.y; ++i) {
                 const float4 q = pts_rw[i];
                 if (is_tombstone(q)) continue;
                 long long qx, qy, qz;
