@@ -29,3 +29,15 @@ def test_staging_thread_hand_over(tmp_path):
     the hand-over needs (tests/cpp/stager_check.cpp)."""
     r = _host_program(tmp_path, "stager_check")
     assert r.returncode == 0 and "every job handed over and reported" in r.stdout.decode(), r.stdout.decode()
+
+
+def test_run_scans_stages_two_scans_ahead_once_each_in_order(tmp_path):
+    """flh_esekf_run_scans' staging schedule with the C ABI underneath replaced by recording fakes (tests/cpp/run_scans_check.cpp):
+    two scans ahead with a ring of three or more slots (the library stages them on two lanes), one with two; every scan staged
+    exactly once, in order, into slot index % ring; never past what a call may stage -- also across bench.py's two-call pattern
+    (warm-up with FLH_RUN_STAGE_NEXT, measurement with FLH_RUN_FIRST_STAGED); activation only after staging."""
+    exe = tmp_path / "run_scans_check"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "run_scans_check.cpp"),
+                           "-o", str(exe)])
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode == 0 and "every scan staged once" in r.stdout.decode(), r.stdout.decode()
