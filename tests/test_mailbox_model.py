@@ -25,3 +25,16 @@ def test_product_library_exports_no_experiment():
         pytest.skip("library not built")
     out = subprocess.run(["nm", "-D", "--defined-only", _build.LIB], stdout=subprocess.PIPE, check=True).stdout.decode()
     assert "flh_exp_" not in out
+
+
+def test_filter_hints_for_every_schedule(tmp_path):
+    """What the mirrored filter tells its measurement model before every pass (dyn_share_datastruct::next_pass -> flh_eval_expect_next)
+    and at the end of an update (the finish hook), through the schedules an update can take (tests/cpp/hint_check.cpp): a no-search
+    pass is announced unless nothing follows or a search is certain; "nothing follows" is never said BEFORE a pass (it releases a
+    waiting kernel: round 5's first version said it there and released the kernel the pass was to use); an announced pass that does
+    not come because the update ends is taken back."""
+    exe = tmp_path / "hint_check"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "hint_check.cpp"),
+                           "-o", str(exe)])
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode == 0 and "hints as specified" in r.stdout.decode(), r.stdout.decode()
