@@ -572,8 +572,8 @@ def main():
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {sensor} {N}-pt scan vs {M}-pt box-city map, "
                                f"max_iteration=3, R=0.001, extrinsic_est_en={int(ext)}"
                                + (", map_incremental after every update" if with_map_inserts else ""),
-                   "timed_region": ("scan handed over as a page-locked host buffer, staged (H2D + re-stride + Morton sort) on the "
-                                    "copy stream while the previous scan updates, then the full iterated update"
+                   "timed_region": ("scan handed over as a page-locked host buffer, staged (H2D + re-stride + Morton sort) on a "
+                                    "copy stream while earlier scans update (up to two scans staged ahead, on two lanes), then the full iterated update"
                                     if mode not in ("shard", "partition") else "scan shards resident in HBM, full iterated update"),
                    "parallelism": ("1 GPU" if G == 1 else
                                    ((f"map partitioned over {G} ranks (slabs + halo), whole scan on every rank, queries owned by position"
