@@ -4,10 +4,10 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/r05_flaky; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-for i in 1 2 3 4 5; do
+for i in $(seq ${TIMING_ROUNDS:-5}); do
   timeout 600 python -m pytest -q -m gpu tests/test_gpu_parity.py::test_prelaunched_nosearch_pass_same_bits tests/test_gpu_peers.py tests/test_gpu_map.py::test_map_incremental_enqueued_without_the_hosts_wait tests/test_gpu_parity.py::test_async_staging_equals_synchronous_staging tests/test_gpu_parity.py::test_run_scans_native_loop_equals_scan_by_scan_updates 2>&1 | tail -1 | tee -a $O/timing_tests.txt
 done
 for i in 1 2; do
-  timeout 900 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -1 | tee -a $O/full_suite.txt
+  timeout 900 python -m pytest tests/ -x -q -m gpu 2>&1 | grep -E " (passed|failed|error)" | tail -1 | tee -a $O/full_suite.txt
 done
 exit 0
