@@ -183,6 +183,7 @@ def main():
                     help="staging slots cycled by the pipelined loop; with 3 or more, two scans are staged ahead (on two lanes), with 2 one")
     ap.add_argument("--prelaunch", type=int, default=-1, help="flh_config.prelaunch (-1 = the library's default: on; 0 = every pass is launched when its state is known)")
     ap.add_argument("--index-cache", type=int, default=-1, help="flh_config.index_cache (-1 = default: the neighbour cache holds map indices; 0 = coordinates)")
+    ap.add_argument("--stage-sort", type=int, default=-1, help="flh_config.stage_sort (-1 / 1 = the library's own two staging kernels; 0 = restride + vendor radix sort + gather)")
     ap.add_argument("--plane-fit-dtype", type=int, default=0,
                     help="1 = the fp16 plane-fit ABLATION of BASELINE configs[4] (not bit-exact, never a parity claim)")
     ap.add_argument("--timing-samples", type=int, default=16,
@@ -311,7 +312,7 @@ def main():
 
     h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
                     pass_kernel=args.pass_kernel, plane_cache=args.plane_cache, plane_fit_dtype=args.plane_fit_dtype,
-                    prelaunch=args.prelaunch, index_cache=args.index_cache)
+                    prelaunch=args.prelaunch, index_cache=args.index_cache, stage_sort=args.stage_sort)
     t0 = time.time()
     h.map_build(scene.map_xyz)
     t_build = time.time() - t0
@@ -436,7 +437,7 @@ def main():
         tok = [None]
         try:
             hs = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, device=local_rank, sort_queries=args.sort,
-                             pass_kernel=args.pass_kernel, index_cache=args.index_cache)
+                             pass_kernel=args.pass_kernel, index_cache=args.index_cache, stage_sort=args.stage_sort)
             if rank == 0:  # the token every rank needs: RCCL's unique id / the name of the shared segment
                 tok = [capi.rccl_unique_id() if exchange == "rccl" else f"/flh_bench_{os.getpid()}"]
         except Exception as e:  # noqa: BLE001
@@ -629,6 +630,7 @@ def main():
     ps = h.pass_stats()
     out["prelaunched_nosearch_passes"] = dict(h.prelaunch_stats(), setting=args.prelaunch)  # kernels enqueued ahead / handed their state / released unused / given up
     out["config"]["index_cache"] = args.index_cache
+    out["config"]["stage_sort"] = args.stage_sort
     out["second_stage_queries_per_search_pass"] = round(ps["second_stage_queries"] / max(ps["search_passes"], 1), 1)
     if roof is not None:
         tr = pmc_traffic(args)
@@ -759,7 +761,7 @@ def run_extra_legs_in_child(args):
 
     cmd = [sys.executable, os.path.abspath(__file__), "--leg", "extras", "--config", str(args.config), "--lpq", str(args.lpq),
            "--cell", str(args.cell), "--pass-kernel", str(args.pass_kernel), "--sort", str(args.sort),
-           "--extrinsic-est", str(args.extrinsic_est), "--steps", str(args.steps), "--index-cache", str(args.index_cache),
+           "--extrinsic-est", str(args.extrinsic_est), "--steps", str(args.steps), "--index-cache", str(args.index_cache), "--stage-sort", str(args.stage_sort),
            "--prelaunch", str(args.prelaunch)]
     if args.two_streams:
         cmd.append("--two-streams")
@@ -793,7 +795,7 @@ def extra_legs(args):
         a[:] = p.body
         bodies.append(a)
     h = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, sort_queries=args.sort, pass_kernel=args.pass_kernel,
-                    index_cache=args.index_cache, prelaunch=args.prelaunch)
+                    index_cache=args.index_cache, stage_sort=args.stage_sort, prelaunch=args.prelaunch)
     h.map_build(scene.map_xyz)
     h.set_timing_stride(0)
     for s in range(S):
@@ -807,7 +809,7 @@ def extra_legs(args):
         import threading
 
         h2 = capi.Handle(cell_size=args.cell, lanes_per_query=args.lpq, sort_queries=args.sort, pass_kernel=args.pass_kernel,
-                          index_cache=args.index_cache, prelaunch=args.prelaunch)
+                          index_cache=args.index_cache, stage_sort=args.stage_sort, prelaunch=args.prelaunch)
         h2.map_build(scene.map_xyz)
         h2.set_timing_stride(0)
         for s in range(S):

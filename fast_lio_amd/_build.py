@@ -13,7 +13,7 @@ if os.environ.get("FLH_LIB"):  # developer tools only (tools/variant.py builds):
     LIB = os.environ["FLH_LIB"]
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-SOURCES = ["flh_kernels.hip", "flh_pass.hip", "flh_mapinc.hip", "flh_scanprep.hip", "flh_api.cpp", "flh_esekf.cpp"]
+SOURCES = ["flh_kernels.hip", "flh_pass.hip", "flh_mapinc.hip", "flh_scanprep.hip", "flh_stage.hip", "flh_api.cpp", "flh_esekf.cpp"]
 DEPS = SOURCES + ["flh_device.hpp", "flh_kernels.hpp", "flh_search_dev.hpp", "flh_fit_dev.hpp", "flh_mail_dev.hpp"]
 HDRS = ["fastlio_hip.h", "fastlio_amd/esekfom.hpp", "fastlio_amd/mtk.hpp", "fastlio_amd/smallmat.hpp",
         "fastlio_amd/use-ikfom.hpp", "fastlio_amd/h_share_model.hpp", "fastlio_amd/local_map.hpp", "fastlio_amd/imu_processing.hpp"]

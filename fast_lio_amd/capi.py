@@ -36,6 +36,7 @@ class FlhConfig(C.Structure):
         ("fused_small_changes", C.c_int),
         ("prelaunch", C.c_int),
         ("index_cache", C.c_int),
+        ("stage_sort", C.c_int),
     ]
 
 
@@ -97,7 +98,7 @@ EXPORTS = [
     "flh_scan_stage_async", "flh_scan_wait", "flh_host_alloc", "flh_host_free", "flh_frame_world", "flh_points_body_to_world",
     "flh_esekf_last_error", "flh_rccl_unique_id", "flh_rccl_init_rank", "flh_rccl_init_all", "flh_rccl_destroy", "flh_rccl_size",
     "flh_rccl_rank", "flh_eval_group", "flh_set_owned_interval", "flh_esekf_run_scans", "flh_get_search_counters", "flh_set_timing_sampling",
-    "flh_map_sync", "flh_eval_begin", "flh_eval_end", "flh_debug_bounds", "flh_debug_pass_stamps", "flh_peer_open", "flh_peer_init_all", "flh_peer_close", "flh_peer_size", "flh_peer_rank", "flh_get_pass_stats", "flh_map_change_stats",
+    "flh_map_sync", "flh_eval_begin", "flh_eval_end", "flh_debug_bounds", "flh_debug_pass_stamps", "flh_debug_scan_order", "flh_peer_open", "flh_peer_init_all", "flh_peer_close", "flh_peer_size", "flh_peer_rank", "flh_get_pass_stats", "flh_map_change_stats",
     "flh_eval_expect_next", "flh_set_prelaunch", "flh_get_prelaunch_stats", "flh_map_storage_stats",
 ]
 
@@ -252,6 +253,7 @@ def _declare(L):
     L.flh_scan_stage_downsampled.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float,
                                              C.POINTER(C.c_size_t)]
     L.flh_fetch_scan.argtypes = [C.c_void_p, C.c_void_p]
+    L.flh_debug_scan_order.argtypes = [C.c_void_p, C.c_void_p]
     L.flh_scan_stage_undistorted.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
                                              C.c_int, _f64p, C.c_float, C.c_void_p, C.POINTER(C.c_size_t)]
     L.flh_get_counters.argtypes = [C.c_void_p, _f64p, C.c_int]
@@ -300,7 +302,7 @@ class Handle:
     def __init__(self, cell_size: float = 1.5, lanes_per_query: int = 4, device: int = -1, stream: int | None = None,
                  plane_threshold: float = 0.1, max_sqdist: float = 5.0, sort_queries: int = -1, pass_kernel: int = -1,
                  eigen_order: int = -1, plane_fit_dtype: int = 0, undistort_first_point: int = -1, plane_cache: int = -1,
-                 fused_small_changes: int = -1, prelaunch: int = -1, index_cache: int = -1):
+                 fused_small_changes: int = -1, prelaunch: int = -1, index_cache: int = -1, stage_sort: int = -1):
         L = lib()
         cfg = FlhConfig()
         L.flh_default_config(C.byref(cfg))
@@ -319,6 +321,7 @@ class Handle:
         cfg.fused_small_changes = fused_small_changes
         cfg.prelaunch = prelaunch
         cfg.index_cache = index_cache
+        cfg.stage_sort = stage_sort
         self._h = C.c_void_p()
         _chk(L.flh_create(C.byref(cfg), C.byref(self._h)), "flh_create")
         self._keep = []
@@ -427,6 +430,9 @@ class Handle:
     def peer_size(self) -> int:
         return int(lib().flh_peer_size(self._h))
 
+    def peer_rank(self) -> int:
+        return int(lib().flh_peer_rank(self._h))
+
     def debug_bounds(self):
         """(instrumented?, [20 words]) -- see flh_debug_bounds."""
         out = (C.c_uint64 * 20)()
@@ -522,6 +528,12 @@ class Handle:
                                               und.ctypes.data if want_undistorted else None, C.byref(n_out)),
              "flh_scan_stage_undistorted")
         return int(n_out.value), (und[: len(a)].copy() if want_undistorted else None)
+
+    def scan_order(self) -> np.ndarray:
+        """order[i] = original index of the scan point at internal (Morton) position i -- flh_debug_scan_order."""
+        out = np.zeros(self.N, np.uint32)
+        _chk(lib().flh_debug_scan_order(self._h, out.ctypes.data), "flh_debug_scan_order")
+        return out
 
     def fetch_scan(self) -> np.ndarray:
         out = np.zeros((self.N, 3), np.float32)

@@ -263,6 +263,8 @@ struct flh_handle {
         bool host_valid = false;
         size_t N = 0;
         hipEvent_t ready = nullptr, h2d_done = nullptr;
+        hipEvent_t consumed = nullptr;  // recorded on the handle's stream behind the last ENQUEUED-AND-NOT-AWAITED reader of body
+        bool consumed_set = false;      // (map_incremental's classification); the slot's next staging waits for it
         bool used = false;
         unsigned char* pin = nullptr;   // pinned staging buffer (pageable caller memory goes through it)
         size_t pin_cap = 0;
@@ -375,6 +377,7 @@ void flh_default_config(flh_config* c) {
     c->fused_small_changes = -1;
     c->prelaunch = -1;
     c->index_cache = -1;
+    c->stage_sort = -1;
 }
 
 int flh_create(const flh_config* cfg_in, flh_handle** out) {
@@ -397,6 +400,7 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.fused_small_changes != 0) cfg.fused_small_changes = 1;
     if (cfg.prelaunch != 0) cfg.prelaunch = 1;
     if (cfg.index_cache != 0) cfg.index_cache = 1;
+    if (cfg.stage_sort != 0) cfg.stage_sort = 1;
     if (cfg.lanes_per_query != 0) cfg.lanes_per_query = 4;  // 0 = exact kernel for every query
     flh_handle* h = new flh_handle();
     h->cfg = cfg;
@@ -440,7 +444,10 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
         flh_destroy(h);
         return fail("hipMalloc failed");
     }
-    h->plane_cache = cfg.plane_cache != 0;
+    // The plane cache (and with it the index-only neighbour cache) exists for the default summation order and the fp32 fit only:
+    // launch_fit re-fits from the neighbours' COORDINATES for every other order, so those must stay in nn_pts (with the
+    // cache left on, a no-search pass of eigen_order 0 / 2 / 3 read coordinates nobody had written).
+    h->plane_cache = cfg.plane_cache != 0 && cfg.eigen_order == FLH_ORDER_SSE && cfg.plane_fit_dtype == 0;
     h->pre.off = cfg.prelaunch == 0;
     h->rmax = (int)std::ceil((std::sqrt((double)cfg.max_sqdist) + 2e-3 * cfg.cell_size) / cfg.cell_size);
     if (h->rmax < 1) h->rmax = 1;
@@ -481,6 +488,7 @@ void flh_destroy(flh_handle* h) {
         sl.dense.release();
         if (sl.ready) (void)hipEventDestroy(sl.ready);
         if (sl.h2d_done) (void)hipEventDestroy(sl.h2d_done);
+        if (sl.consumed) (void)hipEventDestroy(sl.consumed);
         if (sl.pin) (void)hipHostFree(sl.pin);
     }
     if (h->pin_in) (void)hipHostFree(h->pin_in);
@@ -1108,10 +1116,19 @@ static int stage_prepare(flh_handle* h, flh_handle::Slot& sl, int lane = 0) {
     // the slot's buffer was last written on the other lane's stream: this staging's writes come after those
     hipStream_t cs = lane ? h->copy_stream2 : h->copy_stream;
     if (sl.used && sl.last_stream && sl.last_stream != cs) HIPC(hipStreamWaitEvent(cs, sl.ready, 0));
+    // a kernel of the handle's stream that nobody waited for (map_incremental without the host's wait) may still be reading the
+    // slot's scan: this staging's writes come after it
+    if (sl.consumed_set) {
+        HIPC(hipStreamWaitEvent(cs, sl.consumed, 0));
+        sl.consumed_set = false;
+    }
     sl.last_stream = cs;
     sl.host_valid = false;
     return 0;
 }
+
+// the library's own staging kernels (flh_stage.hip) take this scan?
+static bool own_stage_sort(const flh_handle* h, size_t N) { return h->cfg.stage_sort != 0 && N <= flh::stage_sort_max(); }
 
 // Device side of the plain staging: st_raw (N float4, original order) + keys/vals are in place on the copy stream.
 static int stage_sorted(flh_handle* h, flh_handle::Slot& sl, size_t N, bool have_keys, int lane = 0) {
@@ -1120,7 +1137,10 @@ static int stage_sorted(flh_handle* h, flh_handle::Slot& sl, size_t N, bool have
     const size_t n1 = N ? N : 1;
     HIPC(sl.body.reserve(n1));
     const bool do_sort = h->cfg.sort_queries != 0 && N > 1;
-    if (do_sort) {
+    if (do_sort && !have_keys && own_stage_sort(h, N)) {  // float4 records in L.raw: the library's own two kernels
+        HIPC(L.m0.reserve(N)); HIPC(L.v0.reserve(N)); HIPC(L.m1.reserve(flh::stage_sample_words((uint32_t)N)));
+        HIPC(flh::launch_stage_sort(L.raw.p, 16u, (uint32_t)N, 0.5f, L.m0.p, L.v0.p, L.m1.p, sl.body.p, cs));
+    } else if (do_sort) {
         const uint32_t Nu = (uint32_t)N;
         HIPC(L.m0.reserve(N)); HIPC(L.m1.reserve(N)); HIPC(L.v0.reserve(N)); HIPC(L.v1.reserve(N));
         if (!have_keys) HIPC(flh::launch_scan_keys(L.raw.p, Nu, 0.5f, L.m0.p, L.v0.p, cs));
@@ -1166,9 +1186,19 @@ static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size
     }
     const bool do_sort = h->cfg.sort_queries != 0 && N > 1;
     if (do_sort) { HIPC(L.m0.reserve(N)); HIPC(L.v0.reserve(N)); }
-    HIPC(flh::launch_scan_restride(L.bytes.p, (uint32_t)stride_bytes, 0, 0, (uint32_t)N, 0.5f, L.raw.p,
-                                   do_sort ? L.m0.p : nullptr, do_sort ? L.v0.p : nullptr, nullptr, cs));
-    if (stage_sorted(h, sl, N, do_sort, lane) != 0) return -1;
+    if (do_sort && own_stage_sort(h, N)) {
+        // two launches straight from the records as they crossed PCIe: key + tile sort in LDS, then merge by rank + gather
+        HIPC(sl.body.reserve(n1));
+        HIPC(L.m1.reserve(flh::stage_sample_words((uint32_t)N)));
+        HIPC(flh::launch_stage_sort(L.bytes.p, (uint32_t)stride_bytes, (uint32_t)N, 0.5f, L.m0.p, L.v0.p, L.m1.p, sl.body.p, cs));
+        HIPC(hipEventRecord(sl.ready, cs));
+        sl.N = N;
+        sl.used = true;
+    } else {
+        HIPC(flh::launch_scan_restride(L.bytes.p, (uint32_t)stride_bytes, 0, 0, (uint32_t)N, 0.5f, L.raw.p,
+                                       do_sort ? L.m0.p : nullptr, do_sort ? L.v0.p : nullptr, nullptr, cs));
+        if (stage_sorted(h, sl, N, do_sort, lane) != 0) return -1;
+    }
     if (direct && wait_reusable && N > 0) HIPC(hipEventSynchronize(sl.h2d_done));
     return 0;
 }
@@ -1528,6 +1558,15 @@ int flh_fetch_scan(flh_handle* h, float* xyz) {
     if (h->N > 0 && !xyz) return fail("flh_fetch_scan: null buffer");
     if (ensure_host_copy(h, *h->cur) != 0) return -1;
     if (h->N > 0) std::memcpy(xyz, h->cur->h_body.data(), sizeof(float) * 3 * h->N);
+    return 0;
+}
+
+int flh_debug_scan_order(flh_handle* h, uint32_t* order) {
+    if (!h) return fail("flh_debug_scan_order: null handle");
+    if (!h->cur) return fail("flh_debug_scan_order: no active scan");
+    if (h->N > 0 && !order) return fail("flh_debug_scan_order: null buffer");
+    if (ensure_host_copy(h, *h->cur) != 0) return -1;
+    if (h->N > 0) std::memcpy(order, h->cur->h_perm.data(), sizeof(uint32_t) * h->N);
     return 0;
 }
 
@@ -2255,6 +2294,13 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
     HIPC(flh::launch_mi_classify(h->grid, h->grid.hash_mask + 1, (uint32_t)h->M, h->search_state, s_post, h->cur_body,
                                  h->nn_pts.p, h->nn_cnt.p, h->cfg.max_sqdist, (int)N, filter_size_map, flg_EKF_inited,
                                  h->live.p, h->mi_world.p, h->mi_cls.p, N > 0 ? h->mu_flags.p : nullptr, h->mi_far.p, st));
+    if (h->cur && apply && !n_add && !n_no_downsample) {
+        // the last readers of the scan's slot are enqueued; on the no-wait path below nobody waits for them before the ring
+        // comes round to this slot again (flh_esekf_run_scans stages two scans ahead): the slot's next staging does
+        if (!h->cur->consumed) HIPC(hipEventCreateWithFlags(&h->cur->consumed, hipEventDisableTiming));
+        HIPC(hipEventRecord(h->cur->consumed, st));
+        h->cur->consumed_set = true;
+    }
     uint32_t c1 = 0, c2 = 0;
     if (N > 0) {
         size_t tb = 0;

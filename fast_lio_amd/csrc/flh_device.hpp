@@ -53,6 +53,23 @@ struct GridParams {
 
 constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
 
+// The scan's staging key (flh_kernels.hip "Scan staging", flh_stage.hip): 32-bit Morton code of the BODY-frame coordinates, 0.5 m
+// quantum, x and y 11 bits (+-512 m), z 10 bits (+-256 m); the low 10 bits of the three interleaved, the 11th bits of x and y on top.
+__device__ __forceinline__ uint32_t spread3_10(uint32_t v) {  // 10 bits -> every third bit
+    uint32_t x = v & 0x3FFu;
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+__device__ __forceinline__ uint32_t scan_morton(float x, float y, float z, float inv_q) {
+    const uint32_t ix = (uint32_t)fminf(fmaxf(x * inv_q + 1024.f, 0.f), 2047.f);
+    const uint32_t iy = (uint32_t)fminf(fmaxf(y * inv_q + 1024.f, 0.f), 2047.f);
+    const uint32_t iz = (uint32_t)fminf(fmaxf(z * inv_q + 512.f, 0.f), 1023.f);
+    return spread3_10(ix) | (spread3_10(iy) << 1) | (spread3_10(iz) << 2) | ((ix >> 10) << 30) | ((iy >> 10) << 31);
+}
+
 // Eigen QuaternionBase::_transformVector: uv = q.vec x v; uv += uv; v + w*uv + q.vec x uv
 __device__ __forceinline__ void quat_rot(const double q[4], double vx, double vy, double vz, double& rx,
                                          double& ry, double& rz) {

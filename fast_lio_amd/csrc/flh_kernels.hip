@@ -448,20 +448,7 @@ k_fit(StateDev s, const float4* __restrict__ body, const float4* __restrict__ nn
 // (+-512 m), z 10 bits (+-256 m); the low 10 bits of the three interleaved, the 11th bits of x and y on top.  32-bit keys
 // halve what the sort moves per pass next to the 42-bit keys of round 2 (rocPRIM merge-sorts arrays of this size: block
 // sort + 7 merge passes, all on the copy stream beside the previous scan's update).
-__device__ __forceinline__ uint32_t spread3_10(uint32_t v) {  // 10 bits -> every third bit
-    uint32_t x = v & 0x3FFu;
-    x = (x | (x << 16)) & 0x030000FFu;
-    x = (x | (x << 8)) & 0x0300F00Fu;
-    x = (x | (x << 4)) & 0x030C30C3u;
-    x = (x | (x << 2)) & 0x09249249u;
-    return x;
-}
-__device__ __forceinline__ uint32_t scan_morton(float x, float y, float z, float inv_q) {
-    const uint32_t ix = (uint32_t)fminf(fmaxf(x * inv_q + 1024.f, 0.f), 2047.f);
-    const uint32_t iy = (uint32_t)fminf(fmaxf(y * inv_q + 1024.f, 0.f), 2047.f);
-    const uint32_t iz = (uint32_t)fminf(fmaxf(z * inv_q + 512.f, 0.f), 1023.f);
-    return spread3_10(ix) | (spread3_10(iy) << 1) | (spread3_10(iz) << 2) | ((ix >> 10) << 30) | ((iy >> 10) << 31);
-}
+// (spread3_10 / scan_morton: flh_device.hpp -- flh_stage.hip forms the same key)
 __global__ void __launch_bounds__(256) k_scan_keys(const float4* __restrict__ raw, uint32_t N, float inv_q,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;

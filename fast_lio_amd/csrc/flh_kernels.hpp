@@ -31,6 +31,12 @@ hipError_t sort_scan_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* kin, ui
                            uint32_t N, hipStream_t st);
 hipError_t launch_scan_gather(const float4* raw, const uint32_t* perm, uint32_t N, float4* body, hipStream_t st);
 
+// ---- flh_stage.hip: the staging as two launches (records -> stable Morton order as float4, .w = original index) ----
+uint32_t stage_sort_max();                 // the largest scan they take
+uint32_t stage_sample_words(uint32_t N);   // scratch for the tiles' samples
+hipError_t launch_stage_sort(const void* records, uint32_t stride_bytes, uint32_t N, float quantum, uint32_t* tile_keys,
+                             uint32_t* tile_idx, uint32_t* samples, float4* body, hipStream_t st);
+
 int list_stripes();
 uint32_t list_stripe_cap(int N);
 // the three-launch searching pass's search: lpq = 4 (first stage, four lanes per query, + second stage) or 0 (the general exact

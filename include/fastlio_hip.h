@@ -79,7 +79,11 @@ typedef struct flh_config {
     int index_cache;        /* 1 (default, also for < 0): the one-launch searching pass leaves the five neighbours of a query as map
                                INDICES (20 B per query); their coordinates are gathered on demand by whatever asks for them
                                (flh_map_incremental, flh_fetch_neighbors, a re-fit without the plane cache); 0: the search writes
-                               the coordinates (80 B per query) itself.  Needs plane_cache; same results.  Performance only */
+                               the coordinates (80 B per query) itself.  Needs plane_cache (which exists for eigen_order =
+                               FLH_ORDER_SSE and plane_fit_dtype = 0 only); same results.  Performance only */
+    int stage_sort;         /* 1 (default, also for < 0): a scan of up to 262 144 points is staged by the library's own two kernels
+                               (tile sort in LDS + merge by rank, flh_stage.hip); 0: k_scan_restride + the vendor library's radix sort
+                               + gather (twelve launches; also what larger scans take).  Same order, same bits.  Performance only */
 } flh_config;
 enum { FLH_ORDER_SEQ = 0, FLH_ORDER_SSE = 1, FLH_ORDER_PAIRWISE = 2, FLH_ORDER_NOVEC = 3 };
 

@@ -13,6 +13,9 @@ int flh_debug_bounds(flh_handle* h, uint64_t out[20]);
 /* Developer builds only (-DFLH_PASS_STAMPS): 12 words per wave of the last one-launch pass (8 time stamps
  * at 100 MHz, HW_ID, XCC_ID, the longest candidate list among the wave's queries, its open queries); returns 1, else 0. */
 int flh_debug_pass_stamps(flh_handle* h, uint64_t* out, size_t words);
+/* The active scan's device order: order[i] = original index of the point at internal position i (what the staging's sort produced;
+ * the tests compare the library's own staging kernels with the vendor sort through it). */
+int flh_debug_scan_order(flh_handle* h, uint32_t* order);
 #ifdef __cplusplus
 }
 #endif

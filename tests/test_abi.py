@@ -60,4 +60,4 @@ def test_config_mirror_matches_the_c_struct():
     assert not cfg.stream
     # "default" markers the library resolves in flh_create
     assert (cfg.sort_queries, cfg.pass_kernel, cfg.eigen_order, cfg.undistort_first_point, cfg.plane_cache, cfg.fused_small_changes,
-            cfg.prelaunch, cfg.index_cache) == (-1,) * 8
+            cfg.prelaunch, cfg.index_cache, cfg.stage_sort) == (-1,) * 9

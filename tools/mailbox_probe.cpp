@@ -11,6 +11,10 @@
 //              state from pinned host memory (wait-direct) or from device memory behind a one-workgroup forwarder kernel
 //              (wait-forward).
 //
+//   gate       (round 6) a ONE-WAVE gate kernel spins on the mailbox and forwards the state to device memory; the
+//              pass kernel is queued BEHIND it on the same stream and reads the state from device memory: no workgroup of the big
+//              kernel ever waits, the price is one kernel boundary between the gate's exit and the pass's first wave.
+//
 // Reported per variant: host writes the mailbox -> host sees the last workgroup's flag (the critical path of a pass beside its
 // work), with the host idle in between and with 3 us of host work between the flag and the next mailbox write (the 23x23
 // algebra: it gives the queue time to bring the next kernel up).
@@ -124,6 +128,24 @@ __global__ void __launch_bounds__(256) k_from_dev(const double* dev_state, doubl
     finish(s_state, sink, done_cnt, host_flag, seq);
 }
 
+// the gate: one wave polls the mailbox, forwards the state to device memory, exits -- the kernel queued behind it then starts
+__global__ void __launch_bounds__(64) k_gate(const Mail* mail, double* dev_state, uint32_t* err, uint32_t seq) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool ok = true;
+    while (__hip_atomic_load(&mail->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok) {
+        if (threadIdx.x == 0) __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    if (threadIdx.x < kState) {
+        const double v = __hip_atomic_load(&mail->state[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&dev_state[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 struct Ctx {
     hipStream_t st;
     Mail* mail;            // pinned
@@ -152,8 +174,8 @@ static void post_mail(const Ctx& c, uint32_t seq, bool signal) {
     if (signal && c.sig) __atomic_store_n(c.sig, seq, __ATOMIC_RELEASE);
 }
 
-enum Variant { LAUNCH, SPIN, WAIT_DIRECT, WAIT_FORWARD };
-static const char* vname(Variant v) { return v == LAUNCH ? "launch      " : v == SPIN ? "spin        " : v == WAIT_DIRECT ? "wait-direct " : "wait-forward"; }
+enum Variant { LAUNCH, SPIN, WAIT_DIRECT, WAIT_FORWARD, GATE };
+static const char* vname(Variant v) { return v == LAUNCH ? "launch      " : v == SPIN ? "spin        " : v == WAIT_DIRECT ? "wait-direct " : v == GATE ? "gate        " : "wait-forward"; }
 
 static void enqueue(const Ctx& c, Variant v, int G, uint32_t seq) {
     switch (v) {
@@ -164,6 +186,10 @@ static void enqueue(const Ctx& c, Variant v, int G, uint32_t seq) {
         case WAIT_DIRECT:
             CK(hipStreamWaitValue32(c.st, c.sig, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
             hipLaunchKernelGGL(k_wait_direct, dim3(G), dim3(256), 0, c.st, c.mail, c.sink, c.done_cnt, c.host_flag, seq);
+            break;
+        case GATE:
+            hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c.st, c.mail, c.dev_state, c.err, seq);
+            hipLaunchKernelGGL(k_from_dev, dim3(G), dim3(256), 0, c.st, c.dev_state, c.sink, c.done_cnt, c.host_flag, seq);
             break;
         case WAIT_FORWARD:
             CK(hipStreamWaitValue32(c.st, c.sig, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
@@ -190,7 +216,7 @@ static double run(const Ctx& c, Variant v, int G, double host_work_us, uint32_t&
             for (int k = 0; k < kState; ++k) s.v[k] = (double)seq + 0.001 * k;
             hipLaunchKernelGGL(k_launch, dim3(G), dim3(256), 0, c.st, s, c.sink, c.done_cnt, c.host_flag, seq);
         } else {
-            post_mail(c, seq, v != SPIN);
+            post_mail(c, seq, v != SPIN && v != GATE);
         }
         if (!wait_flag(c, seq)) {
             std::printf("%s G=%d: the host gave up waiting for pass %u (error word %u)\n", vname(v), G, seq, *c.err);
@@ -241,7 +267,7 @@ int main() {
     std::printf("hipStreamWaitValue32 %s\n", c.sig ? "available" : "NOT available: the wait variants are skipped");
     uint32_t seq = 0;
     const int R = 3000;
-    for (Variant v : {LAUNCH, SPIN, WAIT_DIRECT, WAIT_FORWARD}) {  // the wait variants last: an unsupported signal write must not cost the others
+    for (Variant v : {LAUNCH, SPIN, GATE, WAIT_DIRECT, WAIT_FORWARD}) {  // the wait variants last: an unsupported signal write must not cost the others
         if ((v == WAIT_DIRECT || v == WAIT_FORWARD) && !c.sig) continue;
         for (int G : {1, 64, 1563}) {
             for (double hw : {0.0, 3.0}) {
