@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <random>
+#include <set>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -172,6 +173,9 @@ struct flh_handle {
     DevBuf<float4> mu_add, mi_world;       // incremental update: points to insert; map_incremental's world points
     DevBuf<uint8_t> mu_alive, mi_cls;
     DevBuf<uint32_t> mu_flags, mu_incl;
+    DevBuf<uint32_t> mi_blk[2];        // map_incremental: the two lists' members per block of 256 original indices (double buffer)
+    uint32_t mi_blk_dirty[2] = {0, 0}; // words of each half its last use wrote (zeroed by the other half's compaction)
+    int mi_par = 0;                    // the half the next call's classification counts into
     DevBuf<float> mu_boxes;
     size_t mi_valid_N = (size_t)-1;        // N of the scan the last classification belongs to
     StateDev search_state{};               // state of the last do_search evaluation (Nearest_Points refer to it)
@@ -380,6 +384,9 @@ void flh_default_config(flh_config* c) {
     c->stage_sort = -1;
 }
 
+static std::mutex g_dev_mu;
+static std::set<int> g_devices_used;  // devices a handle of this process has been created on (flh_host_free waits for these only)
+
 int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (!out) return fail("flh_create: out == NULL");
     *out = nullptr;
@@ -412,6 +419,10 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
         }
     }
     (void)hipGetDevice(&h->device);
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        g_devices_used.insert(h->device);
+    }
     if (cfg.stream) {
         h->stream = (hipStream_t)cfg.stream;
     } else {
@@ -478,7 +489,7 @@ void flh_destroy(flh_handle* h) {
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     if (h->h_mi) (void)hipHostFree(h->h_mi);
     h->map_orig.release(); h->map_next.release(); h->mb_aabb.release(); h->mu_add.release(); h->mi_world.release(); h->mi_cnt.release(); h->mi_far.release();
-    h->mu_alive.release(); h->mi_cls.release(); h->mu_flags.release(); h->mu_incl.release(); h->mu_boxes.release();
+    h->mu_alive.release(); h->mi_cls.release(); h->mu_flags.release(); h->mu_incl.release(); h->mi_blk[0].release(); h->mi_blk[1].release(); h->mu_boxes.release();
     h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_list2.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
     h->world.release(); h->nn_pts.release(); h->normvec.release(); h->plane.release(); h->nn_idx.release(); h->gsum.release();
     h->nn_d2.release(); h->nn_cnt.release(); h->selected.release(); h->vox_tab.release();
@@ -1138,8 +1149,8 @@ static int stage_sorted(flh_handle* h, flh_handle::Slot& sl, size_t N, bool have
     HIPC(sl.body.reserve(n1));
     const bool do_sort = h->cfg.sort_queries != 0 && N > 1;
     if (do_sort && !have_keys && own_stage_sort(h, N)) {  // float4 records in L.raw: the library's own two kernels
-        HIPC(L.m0.reserve(N)); HIPC(L.v0.reserve(N)); HIPC(L.m1.reserve(flh::stage_sample_words((uint32_t)N)));
-        HIPC(flh::launch_stage_sort(L.raw.p, 16u, (uint32_t)N, 0.5f, L.m0.p, L.v0.p, L.m1.p, sl.body.p, cs));
+        HIPC(L.tmp.reserve((size_t)flh::stage_scratch_words64((uint32_t)N) * 8u));
+        HIPC(flh::launch_stage_sort(L.raw.p, 16u, (uint32_t)N, 0.5f, (unsigned long long*)L.tmp.p, sl.body.p, cs));
     } else if (do_sort) {
         const uint32_t Nu = (uint32_t)N;
         HIPC(L.m0.reserve(N)); HIPC(L.m1.reserve(N)); HIPC(L.v0.reserve(N)); HIPC(L.v1.reserve(N));
@@ -1189,8 +1200,8 @@ static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size
     if (do_sort && own_stage_sort(h, N)) {
         // two launches straight from the records as they crossed PCIe: key + tile sort in LDS, then merge by rank + gather
         HIPC(sl.body.reserve(n1));
-        HIPC(L.m1.reserve(flh::stage_sample_words((uint32_t)N)));
-        HIPC(flh::launch_stage_sort(L.bytes.p, (uint32_t)stride_bytes, (uint32_t)N, 0.5f, L.m0.p, L.v0.p, L.m1.p, sl.body.p, cs));
+        HIPC(L.tmp.reserve((size_t)flh::stage_scratch_words64((uint32_t)N) * 8u));
+        HIPC(flh::launch_stage_sort(L.bytes.p, (uint32_t)stride_bytes, (uint32_t)N, 0.5f, (unsigned long long*)L.tmp.p, sl.body.p, cs));
         HIPC(hipEventRecord(sl.ready, cs));
         sl.N = N;
         sl.used = true;
@@ -1505,21 +1516,26 @@ void* flh_host_alloc(size_t bytes) {
 }
 void flh_host_free(void* p) {
     if (!p) return;
-    // a staging that reads the buffer where it lies may still be under way (flh_scan_stage_async) -- on ANY device of this process
-    // (the buffer is not tied to a handle), so every device is waited for, and the range stays registered until then: a staging job
-    // that only now reaches the front of its queue still finds it and copies from it directly while it exists
-    int cur = 0, ndev = 0;
-    (void)hipGetDevice(&cur);
-    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
-    for (int d = 0; d < ndev; ++d)
-        if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
-    (void)hipSetDevice(cur);
-    (void)hipGetLastError();
+    // The range leaves the registry FIRST: a staging job that only now reaches the front of its queue takes the bounce buffer instead
+    // of a direct DMA from memory that is about to go.  Then every device THIS LIBRARY has a handle on in this process is
+    // waited for -- a staging that reads the buffer where it lies may still be under way (flh_scan_stage_async), and the buffer is
+    // not tied to a handle -- but no other device: in a one-rank-per-GPU process that would create contexts on the other ranks' GPUs.
     {
         std::lock_guard<std::mutex> lk(g_pin_mu);
         for (size_t i = 0; i < g_pin_ranges.size(); ++i)
             if (g_pin_ranges[i].first == (uintptr_t)p) { g_pin_ranges.erase(g_pin_ranges.begin() + (long)i); break; }
     }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    std::vector<int> devs;
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        devs.assign(g_devices_used.begin(), g_devices_used.end());
+    }
+    for (int d : devs)
+        if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+    (void)hipSetDevice(cur);
+    (void)hipGetLastError();
     (void)hipHostFree(p);
 }
 
@@ -1753,6 +1769,11 @@ static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext
     if (host_granules) gout = gran_out(h, seq);
     const bool tree = rccl && device_tree(h, host_granules);  // (rccl: called by flh_eval's / flh_eval_group's all-reduce path)
     if (tree) d_out = h->gsum.p;  // group totals instead of the 16x16 block (rccl_allreduce_publish)
+    if (tree && h->have_eval && h->last_ext != ext) {
+        // gsum is indexed [group][slots of this column count]: with another column count the rows behind this rank's groups sit
+        // elsewhere, and what the previous all-reduce left there would be added again on every rank
+        HIPC(hipMemsetAsync(h->gsum.p, 0, (size_t)kGranGroups * kGranSlots * sizeof(double), st));
+    }
     if (tree && h->N == 0) {      // an empty shard: nothing to launch, its totals are the zeros the buffer holds
         h->last_state = s; h->last_ext = ext; h->have_eval = true; h->aux_valid = false;
         if (do_search) { h->last_search_was_later = h->searched_once; h->searched_once = true; h->d2_valid = false; h->search_state = s; }
@@ -2283,17 +2304,29 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
     const size_t N = h->N;
     const StateDev s_post = make_state(x + 3, x + 0, x + 7, x + 11);
     HIPC(h->mi_world.reserve(N ? N : 1)); HIPC(h->mi_cls.reserve(N ? N : 1));
-    if (N > 0) { HIPC(h->mu_flags.reserve(2 * N)); HIPC(h->mu_incl.reserve(2 * N)); }
     if (h->mi_far.cap < N + 1) {  // (re)allocated: the list's counter starts at zero; every call leaves it there
         HIPC(h->mi_far.reserve(N + 1));
         HIPC(hipMemsetAsync(h->mi_far.p, 0, sizeof(uint32_t), st));
     }
     // (pointSearchSqDis is recomputed inside the kernels from the neighbour cache -- the search's own expression -- instead of
-    // being materialised by k_fill_d2 first; the classification also writes the two lists' membership flags)
-    if (ensure_nn_pts(h) != 0) return -1;  // Nearest_Points' coordinates (laserMapping.cpp:436-466): one gather per scan, here
+    // being materialised by k_fill_d2 first.)  Nearest_Points' coordinates (laserMapping.cpp:436-466): where the last search left map
+    // indices (flh_config.index_cache) the kernels read them from the id-ordered array on the spot -- round 5 gathered them into
+    // nn_pts first, a kernel and 7.5 us per scan of the config-3 stream.
+    uint32_t* const nn_idx = (!h->nn_pts_valid && h->nn_idx.p) ? h->nn_idx.p : nullptr;
+    // the two lists' members per block of 256 original indices: a double buffer (the compaction of this call zeroes the other half
+    // for the next one -- no memset launch); [0 .. words) of a half were written by its last use
+    const uint32_t blk_words = flh::cls_block_words((int)N);
+    for (int k = 0; k < 2; ++k)
+        if (h->mi_blk[k].cap < blk_words) {
+            HIPC(h->mi_blk[k].reserve((size_t)blk_words + blk_words / 2 + 64));
+            HIPC(hipMemsetAsync(h->mi_blk[k].p, 0, h->mi_blk[k].cap * sizeof(uint32_t), st));
+            h->mi_blk_dirty[k] = 0;
+        }
+    const int par = h->mi_par;  // (flips when the pair classify + compaction has run: N > 0)
     HIPC(flh::launch_mi_classify(h->grid, h->grid.hash_mask + 1, (uint32_t)h->M, h->search_state, s_post, h->cur_body,
-                                 h->nn_pts.p, h->nn_cnt.p, h->cfg.max_sqdist, (int)N, filter_size_map, flg_EKF_inited,
-                                 h->live.p, h->mi_world.p, h->mi_cls.p, N > 0 ? h->mu_flags.p : nullptr, h->mi_far.p, st));
+                                 h->nn_pts.p, nn_idx, h->map_orig.p, (uint32_t)h->n_ids, h->nn_cnt.p, h->cfg.max_sqdist, (int)N,
+                                 filter_size_map, flg_EKF_inited, h->live.p, h->mi_world.p, h->mi_cls.p,
+                                 N > 0 ? h->mi_blk[par].p : nullptr, h->mi_far.p, st));
     if (h->cur && apply && !n_add && !n_no_downsample) {
         // the last readers of the scan's slot are enqueued; on the no-wait path below nobody waits for them before the ring
         // comes round to this slot again (flh_esekf_run_scans stages two scans ahead): the slot's next staging does
@@ -2303,17 +2336,17 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
     }
     uint32_t c1 = 0, c2 = 0;
     if (N > 0) {
-        size_t tb = 0;
-        HIPC(flh::inclusive_sum(nullptr, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)(2 * N), st));
-        HIPC(h->mb_tmp.reserve(tb));
-        tb = h->mb_tmp.cap;
-        HIPC(flh::inclusive_sum(h->mb_tmp.p, tb, h->mu_flags.p, h->mu_incl.p, (uint32_t)(2 * N), st));
-        // the two lists hold at most N points together: compacted without knowing their lengths; the kernel hands the lengths to
-        // the host as a granule in pinned memory (no copy, no stream synchronisation)
+        // the two lists hold at most N points together: compacted without knowing their lengths (one kernel: the blocks' counts
+        // added up by every workgroup, no library scan); the kernel hands the lengths to the host as a granule in pinned memory
+        // (no copy, no stream synchronisation)
         HIPC(h->mu_add.reserve(N + 1));
         HIPC(h->mi_cnt.reserve(4));
         const uint32_t seq = ++h->mi_seq;
-        HIPC(flh::launch_cls_compact(h->mi_world.p, h->mi_cls.p, h->mu_incl.p, (int)N, h->mu_add.p, h->h_mi, seq, st, h->mi_cnt.p));
+        HIPC(flh::launch_cls_compact(h->mi_world.p, h->mi_cls.p, h->mi_blk[par].p, h->mi_blk[par ^ 1].p, h->mi_blk_dirty[par ^ 1], (int)N,
+                                     h->mu_add.p, h->h_mi, seq, st, h->mi_cnt.p));
+        h->mi_blk_dirty[par ^ 1] = 0;
+        h->mi_blk_dirty[par] = blk_words;
+        h->mi_par ^= 1;
         // A running odometry inserts about as many points with every scan.  When the previous change was comfortably within the
         // one-workgroup path and nobody asked for the list lengths, Add_Points is enqueued right behind this kernel with the
         // lengths read on the device: the host does not stand in the middle of the call (a wait for the granule, then five

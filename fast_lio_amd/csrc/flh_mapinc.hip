@@ -39,9 +39,27 @@ static inline int cdiv2(long long a, long long b) { return (int)((a + b - 1) / b
 // found is smaller than the distance from the query to that cube's faces -- a few hundred directory probes when the nearest
 // point is some tens of metres away.  Only when the shells grow past the directory itself (a query very far from everything)
 // the remaining work is done by scanning the whole directory twice (bound, then exact).
+// The neighbour cache as map_incremental reads it: coordinates (nn_pts) or -- what a one-launch searching pass leaves,
+// flh_config.index_cache -- map indices, whose coordinates are read from the id-ordered array on the spot (round 5 gathered them
+// into nn_pts with a kernel of its own first: 7.5 us and a launch per scan of the config-3 stream).  Row r of query i: at = r N + i.
+struct NnSrc {
+    float4* pts;
+    uint32_t* idx;           // nullptr: pts holds the coordinates
+    const float4* map_orig;
+    uint32_t n_ids;
+};
+__device__ __forceinline__ float4 nn_get(const NnSrc& s, size_t at) {
+    if (!s.idx) return s.pts[at];
+    const uint32_t id = s.idx[at];
+    if (id >= s.n_ids) return make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));  // an empty row (k_nn_gather's rule)
+    float4 v = s.map_orig[FLH_IDX(232, id, s.n_ids)];
+    v.w = __uint_as_float(id);
+    return v;
+}
+
 // the shell search of ONE query by one wave (see above); wx, wy, wz = the world position the last search used
 __device__ __forceinline__ void far_search(const GridParams& g, int q, int lane, float wx, float wy, float wz, uint32_t hash_size,
-                                           const uint32_t* __restrict__ live, float4* __restrict__ nn_pts) {
+                                           const uint32_t* __restrict__ live, const NnSrc& nn) {
     const unsigned long long* __restrict__ hash64 = reinterpret_cast<const unsigned long long*>(g.hash);
     const float bw = 4.0f * g.c;
     const float w[3] = {wx, wy, wz};
@@ -159,7 +177,10 @@ __device__ __forceinline__ void far_search(const GridParams& g, int q, int lane,
         const u64 other = __shfl_xor(gbest, o, 64);
         gbest = other < gbest ? other : gbest;
     }
-    if (gbest != ~0ull && best == gbest) nn_pts[q] = best_p;  // unique: the key carries the index
+    if (gbest != ~0ull && best == gbest) {  // unique: the key carries the index
+        if (nn.idx) nn.idx[q] = __float_as_uint(best_p.w);
+        else nn.pts[q] = best_p;
+    }
 }
 
 // k_far_nearest: one THREAD per query decides whether its cached nearest neighbour is the true one (it is when it lies inside the
@@ -169,7 +190,7 @@ __device__ __forceinline__ void far_search(const GridParams& g, int q, int lane,
 // and not one after the other by the wave that found them.  k_mi_classify re-arms the counter.
 __global__ void __launch_bounds__(256)
 k_far_nearest(StateDev s_search, const float4* __restrict__ body, const uint8_t* __restrict__ nn_cnt, float max_sqdist, int N,
-              const float4* __restrict__ nn_pts, uint32_t* __restrict__ far) {
+              NnSrc nn, uint32_t* __restrict__ far) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     bool need = false;
@@ -179,7 +200,7 @@ k_far_nearest(StateDev s_search, const float4* __restrict__ body, const uint8_t*
         body_to_world(s_search, b.x, b.y, b.z, wx, wy, wz);  // the world position the last search used
         need = true;
         if (nn_cnt[q] != 0) {
-            const float4 p0 = nn_pts[q];
+            const float4 p0 = nn_get(nn, (size_t)q);
             if (__float_as_uint(p0.w) != 0xFFFFFFFFu && dist2(wx, wy, wz, p0.x, p0.y, p0.z) <= max_sqdist) need = false;
         }
     }
@@ -192,7 +213,7 @@ k_far_nearest(StateDev s_search, const float4* __restrict__ body, const uint8_t*
 }
 __global__ void __launch_bounds__(256)
 k_far_search(GridParams g, StateDev s_search, const float4* __restrict__ body, uint32_t hash_size, const uint32_t* __restrict__ live,
-             float4* __restrict__ nn_pts, const uint32_t* __restrict__ far, int N) {
+             NnSrc nn, const uint32_t* __restrict__ far, int N) {
     const uint32_t n = min(far[0], (uint32_t)N);
     const int lane = threadIdx.x & 63;
     for (uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n; k += gridDim.x * 4) {  // wave-uniform
@@ -200,15 +221,15 @@ k_far_search(GridParams g, StateDev s_search, const float4* __restrict__ body, u
         const float4 b = body[q];
         float wx, wy, wz;
         body_to_world(s_search, b.x, b.y, b.z, wx, wy, wz);
-        far_search(g, q, lane, wx, wy, wz, hash_size, live, nn_pts);
+        far_search(g, q, lane, wx, wy, wz, hash_size, live, nn);
     }
 }
 
 // Outputs are in ORIGINAL scan order (the body buffer is Morton-ordered; .w carries the original index).
 __global__ void __launch_bounds__(256)
-k_mi_classify(StateDev s, StateDev s_search, const float4* __restrict__ body, const float4* __restrict__ nn_pts,
+k_mi_classify(StateDev s, StateDev s_search, const float4* __restrict__ body, NnSrc nn,
               const uint8_t* __restrict__ nn_cnt, float max_sqdist, int N, uint32_t map_points,
-              double fsm, int ekf_inited, float4* __restrict__ world_out, uint8_t* __restrict__ cls, uint32_t* __restrict__ flags,
+              double fsm, int ekf_inited, float4* __restrict__ world_out, uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cnt,
               uint32_t* __restrict__ far) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0 && far) far[0] = 0u;  // k_far_search (before this kernel on the stream) has read the list: empty for the next call
@@ -229,7 +250,7 @@ k_mi_classify(StateDev s, StateDev s_search, const float4* __restrict__ body, co
         const float my = (float)(floor((double)wy / fsm) * fsm + 0.5 * fsm);
         const float mz = (float)(floor((double)wz / fsm) * fsm + 0.5 * fsm);
         const float dist = dist2(wx, wy, wz, mx, my, mz);  // calc_dist (:446)
-        const float4 n0 = nn_pts[i];                       // points_near[0] (from the search, or k_far_nearest)
+        const float4 n0 = nn_get(nn, (size_t)i);           // points_near[0] (from the search, or k_far_search)
         if (fabs((double)(n0.x - mx)) > 0.5 * fsm && fabs((double)(n0.y - my)) > 0.5 * fsm &&
             fabs((double)(n0.z - mz)) > 0.5 * fsm) {       // :447
             c = 2;
@@ -237,7 +258,7 @@ k_mi_classify(StateDev s, StateDev s_search, const float4* __restrict__ body, co
             bool need_add = true;
             if (true_cnt >= 5) {  // points_near.size() < NUM_MATCH_POINTS -> break (:454)
                 for (int r = 0; r < cnt; ++r) {
-                    const float4 pn = nn_pts[(size_t)r * N + i];
+                    const float4 pn = r == 0 ? n0 : nn_get(nn, (size_t)r * N + i);
                     // pointSearchSqDis[r], the expression (and bits) the search compared (k_fill_d2 writes the same on demand)
                     const float d2r = (__float_as_uint(pn.w) == 0xFFFFFFFFu) ? INFINITY : dist2(sx, sy, sz, pn.x, pn.y, pn.z);
                     if (!(d2r <= max_sqdist)) break;  // beyond the bound: not a vetted neighbour, and too far to veto
@@ -248,9 +269,9 @@ k_mi_classify(StateDev s, StateDev s_search, const float4* __restrict__ body, co
         }
     }
     cls[FLH_IDX(206, o, N)] = c;
-    if (flags) {  // the two lists' membership flags, in ORIGINAL scan order: class 1 (down-sampled insert), then class 2 (plain insert)
-        flags[o] = c == 1 ? 1u : 0u;
-        flags[(size_t)N + o] = c == 2 ? 1u : 0u;
+    if (blk_cnt && c) {  // members of the two lists per block of 256 ORIGINAL indices (integer atomics: order-independent); the lists
+        const uint32_t nb = ((uint32_t)N + 255u) >> 8;  // are in original scan order: class 1 (down-sampled insert), then class 2
+        atomicAdd(blk_cnt + (c == 1 ? 0u : nb) + (o >> 8), 1u);
     }
 }
 
@@ -261,19 +282,52 @@ __device__ __forceinline__ void publish_granule(uint32_t* dst, uint32_t a, uint3
     const u32x4g v = {a, b, c, seq};
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
 }
-// Also hands the two list lengths on: to the host as a granule {PointToAdd, PointToAdd + PointNoNeedDownsample, 0, seq} (it sizes
-// the launches of Add_Points with them; a copy + stream synchronisation would cost more than this whole kernel), and to dev_counts
-// in device memory, where the kernels of an Add_Points enqueued WITHOUT waiting for the granule read them (MiCounts below).
+// The two lists of map_incremental (src/laserMapping.cpp:463-466: PointToAdd, PointNoNeedDownsample) compacted in ORIGINAL scan
+// order, class 1 first -- ONE kernel (round 5: two library scan kernels over 2 N flags + this one).  k_mi_classify left the
+// lists' members per block of 256 original indices (blk_cnt[0 .. nb): class 1, [nb .. 2 nb): class 2); every workgroup adds up
+// the blocks before its own (and all of them: the class-1 total is where class 2 starts) -- at most a few words per thread -- and
+// places its own 256 entries by ballot.  Also hands the two list lengths on: to the host as a granule {PointToAdd, PointToAdd +
+// PointNoNeedDownsample, 0, seq} (it sizes the launches of Add_Points with them; a copy + stream synchronisation would cost more
+// than this whole kernel), and to dev_counts in device memory, where the kernels of an Add_Points enqueued WITHOUT waiting for the
+// granule read them (MiCounts below).  cnt_next[0 .. next_words): the NEXT call's counters (the other half of a double buffer) as
+// their last use left them, zeroed here.
 __global__ void __launch_bounds__(256) k_cls_compact(const float4* __restrict__ world, const uint8_t* __restrict__ cls,
-                                                     const uint32_t* __restrict__ incl, int N, float4* __restrict__ out,
+                                                     const uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ cnt_next,
+                                                     uint32_t next_words, int N, float4* __restrict__ out,
                                                      uint32_t* __restrict__ host_counts, uint32_t seq, uint32_t* __restrict__ dev_counts) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0 && host_counts) publish_granule(host_counts, incl[N - 1], incl[2 * N - 1], 0u, seq);
-    if (i == 0 && dev_counts) { dev_counts[0] = incl[N - 1]; dev_counts[1] = incl[2 * N - 1]; }
-    if (i >= N) return;
-    const uint8_t c = cls[i];
-    if (c == 1) out[FLH_IDX(207, incl[i] - 1, N)] = world[i];
-    else if (c == 2) out[FLH_IDX(208, incl[N + i] - 1, N)] = world[i];
+    __shared__ uint32_t s_red[4][4], s_wave[4][2];
+    const uint32_t nb = ((uint32_t)N + 255u) >> 8, b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t v[4] = {0u, 0u, 0u, 0u};  // class 1 before this block, class 1 in all, class 2 before, class 2 in all
+    for (uint32_t j = (uint32_t)tid; j < nb; j += 256u) {
+        const uint32_t c1 = blk_cnt[j], c2 = blk_cnt[nb + j];
+        v[1] += c1; v[3] += c2;
+        if (j < b) { v[0] += c1; v[2] += c2; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+        if (lane == 0) s_red[wave][k] = v[k];
+    }
+    const int i = (int)(b * 256u) + tid;
+    const uint8_t c = i < N ? cls[i] : (uint8_t)0;
+    const unsigned long long m1 = __ballot(c == 1), m2 = __ballot(c == 2), lt = (1ull << lane) - 1ull;
+    if (lane == 0) { s_wave[wave][0] = (uint32_t)__popcll(m1); s_wave[wave][1] = (uint32_t)__popcll(m2); }
+    __syncthreads();
+    uint32_t before1 = 0, total1 = 0, before2 = 0, total2 = 0, w1 = 0, w2 = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        before1 += s_red[w][0]; total1 += s_red[w][1]; before2 += s_red[w][2]; total2 += s_red[w][3];
+        if (w < wave) { w1 += s_wave[w][0]; w2 += s_wave[w][1]; }
+    }
+    if (b == 0 && tid == 0) {
+        if (host_counts) publish_granule(host_counts, total1, total1 + total2, 0u, seq);
+        if (dev_counts) { dev_counts[0] = total1; dev_counts[1] = total1 + total2; }
+    }
+    for (uint32_t j = b * 256u + (uint32_t)tid; j < next_words; j += gridDim.x * 256u) cnt_next[j] = 0u;  // (what its last use left)
+    if (c == 1) out[FLH_IDX(207, before1 + w1 + (uint32_t)__popcll(m1 & lt), N)] = world[i];
+    else if (c == 2) out[FLH_IDX(208, total1 + before2 + w2 + (uint32_t)__popcll(m2 & lt), N)] = world[i];
 }
 
 // exact AABB of a point array: ordered-uint encoding of floats + atomics
@@ -884,23 +938,26 @@ hipError_t launch_ins_sort_small(const GridParams& g, const float4* add, const u
 }
 
 // ------------------------------------------------------------------------------------------------
+uint32_t cls_block_words(int N) { return 2u * (((uint32_t)(N > 0 ? N : 1) + 255u) >> 8); }
 hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t map_points, const StateDev& s_search,
-                              const StateDev& s_post, const float4* body, float4* nn_pts, const uint8_t* nn_cnt,
-                              float max_sqdist, int N, double fsm, int ekf_inited, const uint32_t* live,
-                              float4* world_out, uint8_t* cls, uint32_t* flags, uint32_t* far, hipStream_t st) {
+                              const StateDev& s_post, const float4* body, float4* nn_pts, uint32_t* nn_idx, const float4* map_orig,
+                              uint32_t n_ids, const uint8_t* nn_cnt, float max_sqdist, int N, double fsm, int ekf_inited,
+                              const uint32_t* live, float4* world_out, uint8_t* cls, uint32_t* blk_cnt, uint32_t* far, hipStream_t st) {
     if (N <= 0) return hipSuccess;
+    const NnSrc nn{nn_pts, nn_idx, map_orig, n_ids};
     if (map_points > 0 && ekf_inited) {
-        hipLaunchKernelGGL(k_far_nearest, dim3(cdiv2(N, 256)), dim3(256), 0, st, s_search, body, nn_cnt, max_sqdist, N, nn_pts, far);
-        hipLaunchKernelGGL(k_far_search, dim3(min(cdiv2(N, 4), 512)), dim3(256), 0, st, g, s_search, body, hash_size, live, nn_pts, far, N);
+        hipLaunchKernelGGL(k_far_nearest, dim3(cdiv2(N, 256)), dim3(256), 0, st, s_search, body, nn_cnt, max_sqdist, N, nn, far);
+        hipLaunchKernelGGL(k_far_search, dim3(min(cdiv2(N, 4), 512)), dim3(256), 0, st, g, s_search, body, hash_size, live, nn, far, N);
     }
-    hipLaunchKernelGGL(k_mi_classify, dim3(cdiv2(N, 256)), dim3(256), 0, st, s_post, s_search, body, nn_pts, nn_cnt, max_sqdist, N,
-                       map_points, fsm, ekf_inited, world_out, cls, flags, far);
+    hipLaunchKernelGGL(k_mi_classify, dim3(cdiv2(N, 256)), dim3(256), 0, st, s_post, s_search, body, nn, nn_cnt, max_sqdist, N,
+                       map_points, fsm, ekf_inited, world_out, cls, blk_cnt, far);
     return hipGetLastError();
 }
-hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* incl, int N, float4* out,
-                              uint32_t* host_counts, uint32_t seq, hipStream_t st, uint32_t* dev_counts) {
+hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* blk_cnt, uint32_t* cnt_next, uint32_t next_words,
+                              int N, float4* out, uint32_t* host_counts, uint32_t seq, hipStream_t st, uint32_t* dev_counts) {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_cls_compact, dim3(cdiv2(N, 256)), dim3(256), 0, st, world, cls, incl, N, out, host_counts, seq, dev_counts);
+    hipLaunchKernelGGL(k_cls_compact, dim3(cdiv2(N, 256)), dim3(256), 0, st, world, cls, blk_cnt, cnt_next, next_words, N, out,
+                       host_counts, seq, dev_counts);
     return hipGetLastError();
 }
 // the counters of a map change and the number of points it inserted, as two granules, each carrying the sequence word (system-scope

@@ -55,8 +55,9 @@ typedef struct flh_config {
     int pass_kernel;        /* 1 (default, also for < 0): a SEARCHING pass is ONE launch -- 5-NN, plane fit, residual gate, Jacobian
                                rows, H^T H / H^T h and their group sums in one kernel (k_pass); 0: the three-launch pass (two search
                                stages, then the fit).  Same results bit for bit.  The one-launch pass needs cells of at least
-                               sqrt(max_sqdist) / 1.49 (1.5 m for the default gate) and lanes_per_query = 4; otherwise, with
-                               plane_fit_dtype = 1, and with an RCCL communicator attached the three-launch pass runs */
+                               sqrt(max_sqdist) / 1.49 (1.5 m for the default gate) and lanes_per_query = 4; otherwise, and with
+                               plane_fit_dtype = 1, the three-launch pass runs.  (With an RCCL communicator attached the one-launch
+                               pass runs too: its group totals stay in device memory for the all-reduce) */
     int eigen_order;        /* fp32 summation order of esti_plane's reductions (include/common_lib.h:241 runs Eigen's
                                ColPivHouseholderQR, whose reduction order depends on how Eigen was vectorised):
                                FLH_ORDER_SEQ / _SSE / _PAIRWISE / _NOVEC; <0 -> FLH_ORDER_SSE (Eigen 3.3.x, x86-64 + SSE2:
@@ -290,9 +291,12 @@ void flh_unpack_gram(const double gram256[256], double HTH[144], double HTh[12],
  *       rank 0 unlinks the name.
  *     one process, several handles: flh_peer_init_all, then flh_eval_group.
  *
- * RCCL (flh_rccl_*): the ranks' 16x16 Gram blocks all-reduced on the device (ncclAllReduce of 256 doubles on the handle's stream)
- *   and published by one small kernel.  Once a handle has a communicator, flh_eval all-reduces before it returns.  RCCL is
- *   loaded on first use.  A handle has at most one of the two.
+ * RCCL (flh_rccl_*): the pass kernels' group reducers leave their GROUP TOTALS in device memory (64 groups x 31 doubles, 94 with
+ *   the extrinsic columns), ncclAllReduce adds the ranks' totals in place on the handle's stream, and one small kernel adds the
+ *   groups in the host's order and publishes the 16x16 block -- the summation tree of the single-GPU path, so one rank reproduces
+ *   its bits (scans beyond the granule limit of 1.6 M points per rank all-reduce the 256 doubles of the block instead).  Once a
+ *   handle has a communicator, flh_eval all-reduces before it returns.  RCCL is loaded on first use.  A handle has at most one
+ *   of the two.
  *   one process per GPU: rank 0 calls flh_rccl_unique_id, hands the 128 bytes to the others by any means (MPI, a file,
  *     torch.distributed), every rank calls flh_rccl_init_rank.
  *   one process, several GPUs: flh_rccl_init_all over one handle per device, then flh_eval_group (enqueues on every device
