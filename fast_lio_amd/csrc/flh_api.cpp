@@ -407,7 +407,7 @@ int flh_create(const flh_config* cfg_in, flh_handle** out) {
     if (cfg.fused_small_changes != 0) cfg.fused_small_changes = 1;
     if (cfg.prelaunch != 0) cfg.prelaunch = 1;
     if (cfg.index_cache != 0) cfg.index_cache = 1;
-    if (cfg.stage_sort != 0) cfg.stage_sort = 1;
+    if (cfg.stage_sort != 0 && cfg.stage_sort != 2) cfg.stage_sort = 1;
     if (cfg.lanes_per_query != 0) cfg.lanes_per_query = 4;  // 0 = exact kernel for every query
     flh_handle* h = new flh_handle();
     h->cfg = cfg;
@@ -526,7 +526,8 @@ void flh_destroy(flh_handle* h) {
 }
 
 static int map_settle(flh_handle* h);
-static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size_t n2, double ds, const uint32_t* d_cnt = nullptr);
+static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size_t n2, double ds, const uint32_t* d_cnt = nullptr,
+                             bool table_is_empty = false);
 int flh_map_sync(flh_handle* h) {
     if (!h) return fail("flh_map_sync: null handle");
     return map_settle(h);
@@ -806,7 +807,8 @@ static int map_settle(flh_handle* h) {
 // d_add holds n1 points to insert WITH down-sampling followed by n2 points to insert as they are.  Everything is enqueued on
 // the handle's stream with launch sizes the host knows (n1, n2; the number of points that survive the down-sampling stays on the
 // device: n bounds it, and entries beyond it carry a sentinel key); the change's counters are collected by map_settle().
-static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size_t n2, double ds, const uint32_t* d_cnt) {
+static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size_t n2, double ds, const uint32_t* d_cnt,
+                             bool table_is_empty) {  // table_is_empty: the caller's last kernel has emptied vox_tab for exactly this change
     hipStream_t st = h->stream;
     if (map_settle(h) != 0) return -1;
     // d_cnt: the true {n1, n} live on the device (mi_cnt); n1 = n2's sum is then only the bound the launches are sized for
@@ -846,7 +848,7 @@ static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size
     const uint32_t vcap = flh::vox_table_slots((uint32_t)n1);
     if (n1 > 0) {
         HIPC(h->vox_tab.reserve(2 * (size_t)flh::vox_table_slots((uint32_t)std::min<size_t>(nr, 0x7FFFFFFFu))));
-        HIPC(hipMemsetAsync(h->vox_tab.p, 0xFF, 2 * (size_t)vcap * sizeof(unsigned long long), st));
+        if (!table_is_empty) HIPC(hipMemsetAsync(h->vox_tab.p, 0xFF, 2 * (size_t)vcap * sizeof(unsigned long long), st));
     }
     // where the number of surviving points goes (with device-side lengths the general path's scan runs over the whole bound: the
     // entries behind the change's true end count as "no point", k_add_insert)
@@ -1139,7 +1141,12 @@ static int stage_prepare(flh_handle* h, flh_handle::Slot& sl, int lane = 0) {
 }
 
 // the library's own staging kernels (flh_stage.hip) take this scan?
-static bool own_stage_sort(const flh_handle* h, size_t N) { return h->cfg.stage_sort != 0 && N <= flh::stage_sort_max(); }
+// (stage_sort 1, the default: up to 131 072 points -- tiles of 4 096; above that the merge's work, which grows with the SQUARE of the
+// scan, loses to the vendor sort in the pipeline: config 5, 200 000 points, 5 933 vs 6 245 scans/s, profiles/r06_call6/.  2: wherever
+// the kernels can, 262 144 points)
+static bool own_stage_sort(const flh_handle* h, size_t N) {
+    return h->cfg.stage_sort != 0 && N <= (h->cfg.stage_sort == 2 ? flh::stage_sort_max() : flh::stage_sort_max() / 2);
+}
 
 // Device side of the plain staging: st_raw (N float4, original order) + keys/vals are in place on the copy stream.
 static int stage_sorted(flh_handle* h, flh_handle::Slot& sl, size_t N, bool have_keys, int lane = 0) {
@@ -1149,8 +1156,8 @@ static int stage_sorted(flh_handle* h, flh_handle::Slot& sl, size_t N, bool have
     HIPC(sl.body.reserve(n1));
     const bool do_sort = h->cfg.sort_queries != 0 && N > 1;
     if (do_sort && !have_keys && own_stage_sort(h, N)) {  // float4 records in L.raw: the library's own two kernels
-        HIPC(L.tmp.reserve((size_t)flh::stage_scratch_words64((uint32_t)N) * 8u));
-        HIPC(flh::launch_stage_sort(L.raw.p, 16u, (uint32_t)N, 0.5f, (unsigned long long*)L.tmp.p, sl.body.p, cs));
+        HIPC(L.tmp.reserve((size_t)flh::stage_scratch_words((uint32_t)N) * 4u));
+        HIPC(flh::launch_stage_sort(L.raw.p, 16u, (uint32_t)N, 0.5f, (uint32_t*)L.tmp.p, sl.body.p, cs));
     } else if (do_sort) {
         const uint32_t Nu = (uint32_t)N;
         HIPC(L.m0.reserve(N)); HIPC(L.m1.reserve(N)); HIPC(L.v0.reserve(N)); HIPC(L.v1.reserve(N));
@@ -1200,8 +1207,8 @@ static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size
     if (do_sort && own_stage_sort(h, N)) {
         // two launches straight from the records as they crossed PCIe: key + tile sort in LDS, then merge by rank + gather
         HIPC(sl.body.reserve(n1));
-        HIPC(L.tmp.reserve((size_t)flh::stage_scratch_words64((uint32_t)N) * 8u));
-        HIPC(flh::launch_stage_sort(L.bytes.p, (uint32_t)stride_bytes, (uint32_t)N, 0.5f, (unsigned long long*)L.tmp.p, sl.body.p, cs));
+        HIPC(L.tmp.reserve((size_t)flh::stage_scratch_words((uint32_t)N) * 4u));
+        HIPC(flh::launch_stage_sort(L.bytes.p, (uint32_t)stride_bytes, (uint32_t)N, 0.5f, (uint32_t*)L.tmp.p, sl.body.p, cs));
         HIPC(hipEventRecord(sl.ready, cs));
         sl.N = N;
         sl.used = true;
@@ -2342,26 +2349,37 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
         HIPC(h->mu_add.reserve(N + 1));
         HIPC(h->mi_cnt.reserve(4));
         const uint32_t seq = ++h->mi_seq;
+        // A running odometry inserts about as many points with every scan.  When nobody asked for the list lengths, Add_Points is
+        // enqueued right behind the compaction with the lengths read on the device: the host does not stand in the middle of the
+        // call (a wait for the granule, then five launches, while the device idles).  A change that outgrows the launches is
+        // replayed by map_settle().  The launches are sized from the PREVIOUS change (+ 50 %): up to small_change_max() points the
+        // one-workgroup path, above it the general path (scan + device-wide sort over the bound, the entries behind the true end
+        // reading "no point").
+        const uint32_t cap = flh::small_change_max();
+        const bool no_wait = apply && !n_add && !n_no_downsample && h->mi_pred_n != 0xFFFFFFFFu;
+        size_t bound = 0;
+        unsigned long long* tab_fill = nullptr;
+        uint32_t tab_words = 0;
+        if (no_wait) {
+            bound = (size_t)h->mi_pred_n + h->mi_pred_n / 2 + 1024;
+            if (h->cfg.fused_small_changes != 0 && bound <= cap) bound = cap;
+            bound = std::min<size_t>(bound, N);
+            if (bound > 0) {  // the voxel table of that Add_Points is emptied by the compaction kernel on its way (no fill launch)
+                tab_words = 2u * flh::vox_table_slots((uint32_t)bound);
+                HIPC(h->vox_tab.reserve(tab_words));
+                tab_fill = h->vox_tab.p;
+            }
+        }
         HIPC(flh::launch_cls_compact(h->mi_world.p, h->mi_cls.p, h->mi_blk[par].p, h->mi_blk[par ^ 1].p, h->mi_blk_dirty[par ^ 1], (int)N,
-                                     h->mu_add.p, h->h_mi, seq, st, h->mi_cnt.p));
+                                     h->mu_add.p, h->h_mi, seq, st, h->mi_cnt.p, tab_fill, tab_words));
         h->mi_blk_dirty[par ^ 1] = 0;
         h->mi_blk_dirty[par] = blk_words;
         h->mi_par ^= 1;
-        // A running odometry inserts about as many points with every scan.  When the previous change was comfortably within the
-        // one-workgroup path and nobody asked for the list lengths, Add_Points is enqueued right behind this kernel with the
-        // lengths read on the device: the host does not stand in the middle of the call (a wait for the granule, then five
-        // launches, while the device idles).  A change that outgrows the launches is replayed by map_settle().
-        // The launches are sized from the PREVIOUS change (+ 50 %): up to small_change_max() points the one-workgroup path, above
-        // it the general path (scan + device-wide sort over the bound, the entries behind the true end reading "no point").
-        const uint32_t cap = flh::small_change_max();
-        if (apply && !n_add && !n_no_downsample && h->mi_pred_n != 0xFFFFFFFFu) {
-            size_t bound = (size_t)h->mi_pred_n + h->mi_pred_n / 2 + 1024;
-            if (h->cfg.fused_small_changes != 0 && bound <= cap) bound = cap;
-            bound = std::min<size_t>(bound, N);
+        if (no_wait) {
             h->mi_valid_N = N;
             h->mi_cls_seq = seq;
             ++h->n_mi_deferred;
-            return apply_map_changes(h, h->mu_add.p, bound, 0, filter_size_map, h->mi_cnt.p);
+            return apply_map_changes(h, h->mu_add.p, bound, 0, filter_size_map, h->mi_cnt.p, tab_fill != nullptr);
         }
         if (wait_granule(h, 0, seq, "flh_map_incremental") != 0) return -1;
         c1 = h->h_mi[0];

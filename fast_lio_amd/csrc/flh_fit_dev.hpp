@@ -165,6 +165,82 @@ __device__ __forceinline__ void group_sum_publish(const double* partials, int gr
     // 17.8 / 18.0 us, 7 431 / 7 399 -> 7 512 / 7 484 scans/s).  k_pass's reducer keeps sixteen loads per trip: thirty-two do
     // not fit its 72 registers
     constexpr int QB = QUADS ? 8 : 4;
+    if (QUADS && nsl > 64 && nsl <= 96) {
+        // the extrinsic columns (94 slots = three trips of 32): k_fit's reducer takes its three slots at once -- the 24 loads of a
+        // round in flight together, one round trip where round 5 made three (extrinsic_est_en = 1 is the reference's default,
+        // src/laserMapping.cpp:789).  Per slot the same additions in the same order: the same bits.
+        constexpr int NT = 3;
+        double s3[NT] = {0.0, 0.0, 0.0};
+        for (int q0 = qlo; q0 < qhi; q0 += QB) {
+            double qv[NT][QB];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const int slot = sl + 32 * tt;
+                const int sc = slot < nsl ? slot : nsl - 1;
+#pragma unroll
+                for (int j = 0; j < QB; ++j)
+                    qv[tt][j] = (q0 + j < qhi) ? __hip_atomic_load(gpart + (size_t)((u0 >> 2) + q0 + j) * nsl + sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                               : 0.0;
+            }
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int j = 0; j < QB; ++j)
+                    if (q0 + j < qhi) s3[tt] += qv[tt][j];
+        }
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int slot = sl + 32 * tt;
+            const double other = __shfl_xor(s3[tt], 32, 64);
+            const double total = hi ? other + s3[tt] : s3[tt] + other;  // lower half + upper half on both sides
+            if (hi == 0 && slot < nsl) {
+                if (gout.n_dst > 0) publish_granule(gout, 1 + (size_t)group * nsl + slot, total, seq);
+                else part2[(size_t)group * nsl + slot] = total;
+            }
+        }
+        if (gout.n_dst > 0 && wl == 0 && group == 0) publish_granule(gout, 0, (double)(ngroups * nsl), seq);  // the section's header
+        return;
+    }
+    if (!QUADS && nsl > 64 && nsl <= 96) {
+        // k_pass with the extrinsic columns: the three slots of a lane side by side, two quads of units (24 loads) per round --
+        // four round trips where three trips of two made six.  Per slot the same additions in the same order: the same bits.
+        constexpr int NT = 3, Q2 = 2;
+        double s3[NT] = {0.0, 0.0, 0.0};
+        for (int q0 = qlo; q0 < qhi; q0 += Q2) {
+            double pv[NT][4 * Q2];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const int slot = sl + 32 * tt;
+                const int sc = slot < nsl ? slot : nsl - 1;
+#pragma unroll
+                for (int j = 0; j < 4 * Q2; ++j) {
+                    const int u = 4 * q0 + j;  // unit inside the group
+                    pv[tt][j] = (q0 + (j >> 2) < qhi && u < gsize)
+                                    ? __hip_atomic_load(gpart + (size_t)(u0 + u) * nsl + sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : 0.0;
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int j = 0; j < Q2; ++j) {
+                    const double qv = ((pv[tt][4 * j] + pv[tt][4 * j + 1]) + pv[tt][4 * j + 2]) + pv[tt][4 * j + 3];
+                    if (q0 + j < qhi) s3[tt] += qv;
+                }
+        }
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int slot = sl + 32 * tt;
+            const double other = __shfl_xor(s3[tt], 32, 64);
+            const double total = hi ? other + s3[tt] : s3[tt] + other;  // lower half + upper half on both sides
+            if (hi == 0 && slot < nsl) {
+                if (gout.n_dst > 0) publish_granule(gout, 1 + (size_t)group * nsl + slot, total, seq);
+                else part2[(size_t)group * nsl + slot] = total;
+            }
+        }
+        if (gout.n_dst > 0 && wl == 0 && group == 0) publish_granule(gout, 0, (double)(ngroups * nsl), seq);  // the section's header
+        return;
+    }
     for (int slot = sl; slot < ((nsl + 31) & ~31); slot += 32) {
         const int sc = slot < nsl ? slot : nsl - 1;
         double s0 = 0.0;

@@ -32,10 +32,10 @@ hipError_t sort_scan_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* kin, ui
 hipError_t launch_scan_gather(const float4* raw, const uint32_t* perm, uint32_t N, float4* body, hipStream_t st);
 
 // ---- flh_stage.hip: the staging as two launches (records -> stable Morton order as float4, .w = original index) ----
-uint32_t stage_sort_max();                    // the largest scan they take
-uint32_t stage_scratch_words64(uint32_t N);   // scratch: the tiles' sorted composites + their samples, in 64-bit words
-hipError_t launch_stage_sort(const void* records, uint32_t stride_bytes, uint32_t N, float quantum, unsigned long long* scratch,
-                             float4* body, hipStream_t st);
+uint32_t stage_sort_max();                 // the largest scan they take
+uint32_t stage_scratch_words(uint32_t N);  // scratch: sorted keys + their original indices + the tiles' samples, in 32-bit words
+hipError_t launch_stage_sort(const void* records, uint32_t stride_bytes, uint32_t N, float quantum, uint32_t* scratch, float4* body,
+                             hipStream_t st);
 
 int list_stripes();
 uint32_t list_stripe_cap(int N);
@@ -89,7 +89,8 @@ hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t 
                               const uint32_t* live, float4* world_out, uint8_t* cls, uint32_t* blk_cnt /* may be null */,
                               uint32_t* far /* N + 1 words, far[0] == 0 on entry and on exit */, hipStream_t st);
 hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* blk_cnt, uint32_t* cnt_next, uint32_t next_words,
-                              int N, float4* out, uint32_t* host_counts, uint32_t seq, hipStream_t st, uint32_t* dev_counts = nullptr);
+                              int N, float4* out, uint32_t* host_counts, uint32_t seq, hipStream_t st, uint32_t* dev_counts = nullptr,
+                              unsigned long long* tab_fill = nullptr, uint32_t tab_words = 0);  // tab_fill: a voxel table to empty (0xFF) on the way
 // dev_counts (the launches of a map change below): {n1, n} in device memory, read by the kernels instead of the host's values, which
 // then only size the launches; a change larger than that does nothing and k_map_publish raises kMapChangeNotApplied
 constexpr uint32_t kMapChangeNotApplied = 0x80000000u;

@@ -290,11 +290,12 @@ __device__ __forceinline__ void publish_granule(uint32_t* dst, uint32_t a, uint3
 // PointNoNeedDownsample, 0, seq} (it sizes the launches of Add_Points with them; a copy + stream synchronisation would cost more
 // than this whole kernel), and to dev_counts in device memory, where the kernels of an Add_Points enqueued WITHOUT waiting for the
 // granule read them (MiCounts below).  cnt_next[0 .. next_words): the NEXT call's counters (the other half of a double buffer) as
-// their last use left them, zeroed here.
+// their last use left them, zeroed here.  tab_fill[0 .. tab_words): the voxel table of the Add_Points behind this kernel, emptied here.
 __global__ void __launch_bounds__(256) k_cls_compact(const float4* __restrict__ world, const uint8_t* __restrict__ cls,
                                                      const uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ cnt_next,
                                                      uint32_t next_words, int N, float4* __restrict__ out,
-                                                     uint32_t* __restrict__ host_counts, uint32_t seq, uint32_t* __restrict__ dev_counts) {
+                                                     uint32_t* __restrict__ host_counts, uint32_t seq, uint32_t* __restrict__ dev_counts,
+                                                     u64* __restrict__ tab_fill, uint32_t tab_words) {
     __shared__ uint32_t s_red[4][4], s_wave[4][2];
     const uint32_t nb = ((uint32_t)N + 255u) >> 8, b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -326,6 +327,9 @@ __global__ void __launch_bounds__(256) k_cls_compact(const float4* __restrict__ 
         if (dev_counts) { dev_counts[0] = total1; dev_counts[1] = total1 + total2; }
     }
     for (uint32_t j = b * 256u + (uint32_t)tid; j < next_words; j += gridDim.x * 256u) cnt_next[j] = 0u;  // (what its last use left)
+    // the voxel table of the Add_Points that is enqueued right behind this kernel arrives empty (0xFF: empty keys, maximal values)
+    // without a fill launch of its own
+    for (uint32_t j = b * 256u + (uint32_t)tid; j < tab_words; j += gridDim.x * 256u) tab_fill[j] = ~0ull;
     if (c == 1) out[FLH_IDX(207, before1 + w1 + (uint32_t)__popcll(m1 & lt), N)] = world[i];
     else if (c == 2) out[FLH_IDX(208, total1 + before2 + w2 + (uint32_t)__popcll(m2 & lt), N)] = world[i];
 }
@@ -491,19 +495,64 @@ k_add_resolve(GridParams g, float4* pts_rw /* = g.pts */, const float4* __restri
     int n_exist = 0;
     float best_ed = INFINITY;
     uint32_t best_e = 0xFFFFFFFFu;
-    for (int c = lane; c < ncell; c += L) {
-        const int z = c0z + c / (sx * sy), y = c0y + (c / sx) % sy, x = c0x + c % sx;
-        const uint2 ce = lookup_cell(g, x, y, z);
-        for (uint32_t i = ce.x; i < ce.x + ce.y; ++i) {
-            const float4 q = pts_rw[FLH_IDX(210, i, g.pts_cap)];
-            if (is_tombstone(q)) continue;
-            long long qx, qy, qz;
-            vox_of(q.x, q.y, q.z, ds, qx, qy, qz);
-            if (qx != kx || qy != ky || qz != kz) continue;
-            ++n_exist;
-            const float d = dist_to_center(q.x, q.y, q.z, kx, ky, kz, ds);
-            const uint32_t id = __float_as_uint(q.w);
-            if (d < best_ed || (d == best_ed && id < best_e)) { best_ed = d; best_e = id; }  // tie: lower index
+    // ---- the usual case (round 6): the voxel box overlaps at most eight search cells, one per lane.  The lane resolves its cell
+    // ONCE (directory probe -> prefix table), loads the cell's points four at a time, drops those outside a float box around the
+    // voxel (a superset of it: the corners rounded to float and widened) before the exact fp64 voxel test, and REMEMBERS the few
+    // points of the voxel it finds (a map down-sampled to this voxel size holds one or two) -- so that emptying the voxel below
+    // needs no second walk.  Round 5 walked every cell twice, one dependent load per point: ~25 dependent round trips, 21 us.
+    // Other voxels' groups may change slots of this cell meanwhile, never a point of THIS voxel: what was remembered is what a
+    // second walk would find.
+    constexpr int kKeep = 4;
+    uint32_t mslot[kKeep], mid[kKeep];
+    int nm = 0;
+    uint32_t my_rank = kEmptyKey, my_start = 0, my_cnt = 0;
+    const bool one_cell_per_lane = ncell <= L;  // (group-uniform)
+    if (one_cell_per_lane) {
+        if (lane < ncell) {
+            const int c = lane;
+            const int z = c0z + c / (sx * sy), y = c0y + (c / sx) % sy, x = c0x + c % sx;
+            const uint2 ce = lookup_cell_rank(g, x, y, z, my_rank);
+            my_start = ce.x;
+            my_cnt = ce.y;
+        }
+        const float ex = fmaxf(fabsf(bx0), fabsf(bx1)) * 1e-6f + 1e-30f, ey = fmaxf(fabsf(by0), fabsf(by1)) * 1e-6f + 1e-30f,
+                    ez = fmaxf(fabsf(bz0), fabsf(bz1)) * 1e-6f + 1e-30f;
+        for (uint32_t i0 = 0; i0 < my_cnt; i0 += 4u) {
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = pts_rw[FLH_IDX(210, my_start + min(i0 + (uint32_t)u, my_cnt - 1u), g.pts_cap)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + (uint32_t)u >= my_cnt || is_tombstone(q[u])) continue;
+                if (!(q[u].x >= bx0 - ex && q[u].x <= bx1 + ex && q[u].y >= by0 - ey && q[u].y <= by1 + ey && q[u].z >= bz0 - ez &&
+                      q[u].z <= bz1 + ez))
+                    continue;
+                long long qx, qy, qz;
+                vox_of(q[u].x, q[u].y, q[u].z, ds, qx, qy, qz);
+                if (qx != kx || qy != ky || qz != kz) continue;
+                const uint32_t id = __float_as_uint(q[u].w);
+                if (nm < kKeep) { mslot[nm] = my_start + i0 + (uint32_t)u; mid[nm] = id; }
+                ++nm;
+                ++n_exist;
+                const float d = dist_to_center(q[u].x, q[u].y, q[u].z, kx, ky, kz, ds);
+                if (d < best_ed || (d == best_ed && id < best_e)) { best_ed = d; best_e = id; }  // tie: lower index
+            }
+        }
+    } else {
+        for (int c = lane; c < ncell; c += L) {
+            const int z = c0z + c / (sx * sy), y = c0y + (c / sx) % sy, x = c0x + c % sx;
+            const uint2 ce = lookup_cell(g, x, y, z);
+            for (uint32_t i = ce.x; i < ce.x + ce.y; ++i) {
+                const float4 q = pts_rw[FLH_IDX(210, i, g.pts_cap)];
+                if (is_tombstone(q)) continue;
+                long long qx, qy, qz;
+                vox_of(q.x, q.y, q.z, ds, qx, qy, qz);
+                if (qx != kx || qy != ky || qz != kz) continue;
+                ++n_exist;
+                const float d = dist_to_center(q.x, q.y, q.z, kx, ky, kz, ds);
+                const uint32_t id = __float_as_uint(q.w);
+                if (d < best_ed || (d == best_ed && id < best_e)) { best_ed = d; best_e = id; }  // tie: lower index
+            }
         }
     }
 #pragma unroll
@@ -517,22 +566,34 @@ k_add_resolve(GridParams g, float4* pts_rw /* = g.pts */, const float4* __restri
     if (n_exist == 1 && !new_wins) return;      // the single existing point stays; every new point is dropped
     // otherwise the voxel is emptied except for the winner
     if (n_exist > 0) {
-        for (int c = lane; c < ncell; c += L) {
-            const int z = c0z + c / (sx * sy), y = c0y + (c / sx) % sy, x = c0x + c % sx;
-            uint32_t rank;
-            const uint2 ce = lookup_cell_rank(g, x, y, z, rank);
-            for (uint32_t i = ce.x; i < ce.x + ce.y; ++i) {
-                const float4 q = pts_rw[i];
-                if (is_tombstone(q)) continue;
-                long long qx, qy, qz;
-                vox_of(q.x, q.y, q.z, ds, qx, qy, qz);
-                if (qx != kx || qy != ky || qz != kz) continue;
-                const uint32_t id = __float_as_uint(q.w);
-                if (new_wins || id != best_e) {
-                    dead_id[FLH_IDX(211, id, g.ids_cap)] = 1;
-                    pts_rw[FLH_IDX(212, i, g.pts_cap)] = tombstone();
-                    atomicSub(live + FLH_IDX(213, rank, g.rows_cap), 1u);
+        if (one_cell_per_lane && nm <= kKeep) {
+            for (int m = 0; m < nm; ++m) {
+                if (new_wins || mid[m] != best_e) {
+                    dead_id[FLH_IDX(211, mid[m], g.ids_cap)] = 1;
+                    pts_rw[FLH_IDX(212, mslot[m], g.pts_cap)] = tombstone();
+                    atomicSub(live + FLH_IDX(213, my_rank, g.rows_cap), 1u);
                     atomicAdd(ctr + 3, 1u);
+                }
+            }
+        } else {
+            // (more points of the voxel in one cell than a lane remembers, or a voxel box over more than eight cells: walk again)
+            for (int c = lane; c < ncell; c += L) {
+                const int z = c0z + c / (sx * sy), y = c0y + (c / sx) % sy, x = c0x + c % sx;
+                uint32_t rank;
+                const uint2 ce = lookup_cell_rank(g, x, y, z, rank);
+                for (uint32_t i = ce.x; i < ce.x + ce.y; ++i) {
+                    const float4 q = pts_rw[i];
+                    if (is_tombstone(q)) continue;
+                    long long qx, qy, qz;
+                    vox_of(q.x, q.y, q.z, ds, qx, qy, qz);
+                    if (qx != kx || qy != ky || qz != kz) continue;
+                    const uint32_t id = __float_as_uint(q.w);
+                    if (new_wins || id != best_e) {
+                        dead_id[FLH_IDX(211, id, g.ids_cap)] = 1;
+                        pts_rw[FLH_IDX(212, i, g.pts_cap)] = tombstone();
+                        atomicSub(live + FLH_IDX(213, rank, g.rows_cap), 1u);
+                        atomicAdd(ctr + 3, 1u);
+                    }
                 }
             }
         }
@@ -954,10 +1015,11 @@ hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t 
     return hipGetLastError();
 }
 hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* blk_cnt, uint32_t* cnt_next, uint32_t next_words,
-                              int N, float4* out, uint32_t* host_counts, uint32_t seq, hipStream_t st, uint32_t* dev_counts) {
+                              int N, float4* out, uint32_t* host_counts, uint32_t seq, hipStream_t st, uint32_t* dev_counts,
+                              unsigned long long* tab_fill, uint32_t tab_words) {
     if (N <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_cls_compact, dim3(cdiv2(N, 256)), dim3(256), 0, st, world, cls, blk_cnt, cnt_next, next_words, N, out,
-                       host_counts, seq, dev_counts);
+                       host_counts, seq, dev_counts, tab_fill, tab_words);
     return hipGetLastError();
 }
 // the counters of a map change and the number of points it inserted, as two granules, each carrying the sequence word (system-scope

@@ -18,9 +18,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fast_lio_amd import capi, synth  # noqa: E402
 from fast_lio_amd import dist as fdist  # noqa: E402
 
-M, N = 5_000_000, 100_000
-REPS = 150
-pr = synth.make_problem(M, N, "avia", cfg=2)
+import argparse
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", type=int, default=2, help="BASELINE config: 2 (100k vs 5M, sharded), 4 (130k Ouster vs 20M, sharded), "
+                                                      "5 (200k MID-360 vs 50M, map PARTITIONED into slabs + halo, whole scan on every rank)")
+ap.add_argument("--reps", type=int, default=150)
+ap.add_argument("--only-shares", action="store_true", help="skip the exchange legs (peer granules, RCCL)")
+args = ap.parse_args()
+CFG = {2: (5_000_000, 100_000, "avia"), 4: (20_000_000, 130_000, "ouster64"), 5: (50_000_000, 200_000, "mid360")}
+M, N, SENSOR = CFG[args.config]
+REPS = args.reps
+pr = synth.make_problem(M, N, SENSOR, cfg=args.config)
 xp, P = synth.propagate_prior_cov(capi.predict_fn, pr.x_prior)
 
 
@@ -41,9 +50,33 @@ def passes(ev):
     return a, b, c
 
 
-print(f"BASELINE configs[1]: {N} scan points, {M} map points; {REPS} repetitions per figure; us per pass (search at the prior / "
+print(f"BASELINE configs[{args.config - 1}]: {N} scan points, {M} map points; {REPS} repetitions per figure; us per pass (search at the prior / "
       f"search at the true state / no search)")
 base = None
+if args.config == 5:
+    # the map partitioned: a rank's work is the WHOLE scan against its slab (+ halo), fitting only the queries it owns; the pass
+    # ends with the slowest rank, so every rank of a G-way partition is measured and the maximum reported
+    for G in (1, 2, 4, 8):
+        axis, edges = fdist.partition_bounds(pr.map_xyz, G)
+        worst, sizes = None, []
+        for r in range(G):
+            keep = fdist.partition_slab(pr.map_xyz, axis, edges, r, fdist.HALO_DEFAULT)
+            h = capi.Handle()
+            h.map_build(pr.map_xyz[keep])
+            if G > 1:
+                h.set_owned_interval(axis, edges[r], edges[r + 1])
+            h.scan_upload(pr.body)
+            h.set_timing_stride(0)
+            t = passes(lambda x, s: h.eval(x, s, False))
+            sizes.append(int(keep.sum()) if keep.dtype == bool else len(keep))
+            worst = t if worst is None else tuple(max(a, b) for a, b in zip(worst, t))
+            h.close()
+        if G == 1:
+            base = worst
+        print(f"  slowest rank of a {G}-way partition (slabs of {min(sizes)}..{max(sizes)} map points, whole scan): "
+              f"{worst[0]:6.1f} / {worst[1]:6.1f} / {worst[2]:6.1f}   => pass speed-up bound {base[0] / worst[0]:.2f} / "
+              f"{base[1] / worst[1]:.2f} / {base[2] / worst[2]:.2f}")
+    sys.exit(0)
 for G in (1, 2, 4, 8):
     idx = fdist.morton_shard(pr.body, 0, G)
     shard = np.ascontiguousarray(pr.body[idx])
@@ -58,6 +91,8 @@ for G in (1, 2, 4, 8):
           f"   => pass speed-up bound {base[0] / t[0]:.2f} / {base[1] / t[1]:.2f} / {base[2] / t[2]:.2f}")
     h.close()
 
+if args.only_shares:
+    sys.exit(0)
 # the exchange
 h = capi.Handle()
 capi.peer_init_all([h])
