@@ -75,5 +75,12 @@ try:
 except Exception as e:
     print("no line", e)
 PY
+# extrinsic_est_en = 1 (the reference's default) against 0, alternating on this box
+for rep in 1 2; do
+  for ext in 0 1; do
+    timeout $T python bench.py --steps 300 --warmup 30 --cpu-scans 0 --no-extra-legs --extrinsic-est $ext > $O/r${RND}_bench_config2_ext${ext}_$rep.json 2> $O/ext.err
+    echo "extrinsic_est=$ext rep $rep: $(python tools/bench_line.py $O/r${RND}_bench_config2_ext${ext}_$rep.json)"
+  done
+done
 el "all done"
 exit 0
