@@ -1141,11 +1141,11 @@ static int stage_prepare(flh_handle* h, flh_handle::Slot& sl, int lane = 0) {
 }
 
 // the library's own staging kernels (flh_stage.hip) take this scan?
-// (stage_sort 1, the default: up to 131 072 points -- tiles of 4 096; above that the merge's work, which grows with the SQUARE of the
-// scan, loses to the vendor sort in the pipeline: config 5, 200 000 points, 5 933 vs 6 245 scans/s, profiles/r06_call6/.  2: wherever
-// the kernels can, 262 144 points)
+// (stage_sort 1, the default: up to 28 tiles of 4 096 = 114 688 points.  The merge's work grows with the SQUARE of the scan: same-box
+// pairs against the vendor sort, pipelined: 100 000 points +4.0 % (profiles/r06_call8/), 130 000 points -1.8 % (r06_call10/),
+// 200 000 points -5 % (r06_call6/).  2: wherever the kernels can run, 262 144 points)
 static bool own_stage_sort(const flh_handle* h, size_t N) {
-    return h->cfg.stage_sort != 0 && N <= (h->cfg.stage_sort == 2 ? flh::stage_sort_max() : flh::stage_sort_max() / 2);
+    return h->cfg.stage_sort != 0 && N <= (h->cfg.stage_sort == 2 ? (size_t)flh::stage_sort_max() : (size_t)28 * 4096);
 }
 
 // Device side of the plain staging: st_raw (N float4, original order) + keys/vals are in place on the copy stream.

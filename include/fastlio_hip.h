@@ -82,7 +82,7 @@ typedef struct flh_config {
                                (flh_map_incremental, flh_fetch_neighbors, a re-fit without the plane cache); 0: the search writes
                                the coordinates (80 B per query) itself.  Needs plane_cache (which exists for eigen_order =
                                FLH_ORDER_SSE and plane_fit_dtype = 0 only); same results.  Performance only */
-    int stage_sort;         /* 1 (default, also for < 0): a scan of up to 131 072 points is staged by the library's own two kernels
+    int stage_sort;         /* 1 (default, also for < 0): a scan of up to 114 688 points is staged by the library's own two kernels
                                (tile sort in LDS + merge by rank, flh_stage.hip); 2: up to 262 144 points; 0: k_scan_restride + the
                                vendor library's radix sort + gather (twelve launches; also what larger scans take).  Same order,
                                same bits.  Performance only */
