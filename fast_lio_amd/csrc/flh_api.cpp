@@ -2056,13 +2056,24 @@ static void pre_release(flh_handle* h) {
 // state (or nothing) + the {sequence, command} word, the word last
 static void pre_post(flh_handle* h, const StateDev* s, uint32_t cmd) {
     flh_handle::PreLaunch& p = h->pre;
+    static_assert(sizeof(StateDev) == 14 * sizeof(double), "the mailbox carries StateDev as 14 doubles");
+    // two 64-byte lines, each seven doubles of the state + a word {checksum of the line, cmd, seq} written after them
+    // (flh_mail_dev.hpp: the forwarder's poll is the read of the state)
     if (s) {
-        static_assert(sizeof(StateDev) == 14 * sizeof(double), "the mailbox carries StateDev as 14 doubles");
         const double* src = reinterpret_cast<const double*>(s);
-        for (int i = 0; i < 14; ++i) p.host_box[i] = src[i];
+        for (int i = 0; i < 7; ++i) { p.host_box[i] = src[i]; p.host_box[8 + i] = src[7 + i]; }
     }
-    const uint64_t w = ((uint64_t)cmd << 32) | (uint64_t)p.mseq;
-    __atomic_store_n(reinterpret_cast<uint64_t*>(p.host_box + 15), w, __ATOMIC_RELEASE);
+    uint64_t ck[2] = {0, 0};
+    for (int l = 0; l < 2; ++l)
+        for (int i = 0; i < 7; ++i) {
+            uint64_t bits;
+            std::memcpy(&bits, p.host_box + 8 * l + i, 8);
+            ck[l] ^= flh::mail_mix(bits, i);
+        }
+    for (int l = 0; l < 2; ++l) {
+        const uint64_t w = ((uint64_t)flh::mail_fold(ck[l]) << 40) | ((uint64_t)(cmd & 0xFFu) << 32) | (uint64_t)p.mseq;
+        __atomic_store_n(reinterpret_cast<uint64_t*>(p.host_box + 8 * l + 7), w, __ATOMIC_RELEASE);
+    }
     p.armed = false;
 }
 static void pre_cancel(flh_handle* h) {

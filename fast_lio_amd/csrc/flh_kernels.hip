@@ -761,6 +761,7 @@ k_fit_mb(MailArgs mail, const float4* __restrict__ body, int N, int ext, float t
     __shared__ double lds[4 * 64 * kTileStride];
     __shared__ uint32_t s_ticket;
     __shared__ uint32_t s_cmd;
+    __shared__ double s_box[16];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -769,7 +770,7 @@ k_fit_mb(MailArgs mail, const float4* __restrict__ body, int N, int ext, float t
     const float4 b = body[ic];
     const float4 pc = plane_cache[ic];
     StateDev s;
-    if (!mailbox_wait(mail, s, &s_cmd)) return;  // aborted by the host, or nobody came: nothing was written
+    if (!mailbox_wait(mail, s, &s_cmd, s_box)) return;  // aborted by the host, or nobody came: nothing was written
 
     double v[16];
 #pragma unroll

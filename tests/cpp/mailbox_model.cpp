@@ -1,6 +1,8 @@
 // CPU model of the mailbox protocol of the pre-launched no-search pass (fast_lio_amd/csrc/flh_mail_dev.hpp,
 // flh_prelaunch_host.inc): the DECISIONS of the device side (forwarder wave, every workgroup's wait) and of the host side (post
 // go / abort, the sequence numbers) restated with std::atomic and threads, driven through the cases the GPU code must survive:
+//   (round 6: a box is two 64-byte lines, each carrying its own {checksum, command, sequence} word, and a poll reads all sixteen
+//   words at once -- possibly torn against the writer; the checksums catch that)
 //   go          the state arrives, every workgroup of the launch runs once with exactly that state
 //   abort       the launch does nothing
 //   passed over the host has already posted a LATER launch's mail when this launch's forwarder looks: treated as an abort
@@ -13,6 +15,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <random>
 #include <thread>
 #include <vector>
@@ -22,52 +25,79 @@ constexpr uint32_t kGo = 1, kAbort = 2, kGone = 1, kLost = 2;
 constexpr auto kForwardPatience = std::chrono::milliseconds(20);
 constexpr auto kSpinPatience = std::chrono::milliseconds(400);
 
-struct Box { std::atomic<double> d[15]; std::atomic<uint64_t> word{0}; };
+// sixteen 64-bit words = two 64-byte lines: words 0..6 / 8..14 the state's doubles, words 7 / 15 = checksum << 40 | cmd << 32 | seq
+struct Box { std::atomic<uint64_t> w[16]; };
 static Box host_box, dev_box;
 static std::atomic<uint64_t> status{0};
 
+static uint64_t mail_mix(uint64_t bits, int i) { return (bits ^ (bits >> 29)) * (0x9E3779B97F4A7C15ull * (uint64_t)(2 * i + 1)); }
+static uint32_t mail_fold(uint64_t x) { return (uint32_t)((x ^ (x >> 24) ^ (x >> 48)) & 0xFFFFFFull); }
+static uint64_t bits_of(double d) { uint64_t u; std::memcpy(&u, &d, 8); return u; }
+static double double_of(uint64_t u) { double d; std::memcpy(&d, &u, 8); return d; }
+
 struct LaunchResult { int ran = 0, skipped = 0; bool state_ok = true; };
+
+// flh_mail_dev.hpp: mail_poll -- ONE read of the sixteen words (here: sixteen relaxed loads in any order, i.e. possibly torn against
+// the writer); true when both lines announce `seq` with one command and both checksums hold
+static bool poll(Box& box, uint32_t seq, uint64_t (&u)[16], uint32_t& cmd, bool& passed_over) {
+    for (int i = 15; i >= 0; --i) u[i] = box.w[i].load(std::memory_order_relaxed);  // (words first: the worst order for tearing)
+    const int32_t a0 = (int32_t)((uint32_t)u[7] - seq), a1 = (int32_t)((uint32_t)u[15] - seq);
+    passed_over = a0 > 0 || a1 > 0;
+    cmd = (uint32_t)(u[7] >> 32) & 0xFFu;
+    if (passed_over || a0 != 0 || a1 != 0 || (((u[7] ^ u[15]) >> 32) & 0xFFu) != 0) return false;
+    for (int l = 0; l < 2; ++l) {
+        uint64_t ck = 0;
+        for (int i = 0; i < 7; ++i) ck ^= mail_mix(u[8 * l + i], i);
+        if (mail_fold(ck) != (uint32_t)(u[8 * l + 7] >> 40)) return false;
+    }
+    return true;
+}
+static void write_box(Box& box, const uint64_t (&u)[16]) {  // the lines' doubles, then the two words that announce them
+    for (int i = 0; i < 16; ++i)
+        if ((i & 7) != 7) box.w[i].store(u[i], std::memory_order_relaxed);
+    std::atomic_thread_fence(std::memory_order_release);
+    box.w[7].store(u[7], std::memory_order_release);
+    box.w[15].store(u[15], std::memory_order_release);
+}
 
 // one workgroup of a launch waiting for sequence number seq; wg 0 is also the forwarder (flh_mail_dev.hpp: mailbox_wait)
 static void workgroup(int wg, uint32_t seq, std::atomic<int>* ran, std::atomic<int>* skipped, std::atomic<int>* bad_state) {
     if (wg == 0) {
         const auto t0 = clk::now();
-        uint64_t w = 0;
-        bool ok = true;
+        uint64_t u[16];
+        uint32_t cmd = 0;
+        bool gone = false;
         for (;;) {
-            w = host_box.word.load(std::memory_order_acquire);
-            const int32_t ahead = (int32_t)((uint32_t)w - seq);
-            if (ahead >= 0) {
-                if (ahead > 0) w = ((uint64_t)kAbort << 32) | seq;
-                break;
-            }
-            if (clk::now() - t0 > kForwardPatience) { ok = false; break; }
+            bool over = false;
+            if (poll(host_box, seq, u, cmd, over)) break;
+            if (over) { cmd = kAbort; break; }
+            if (clk::now() - t0 > kForwardPatience) { gone = true; cmd = kAbort; break; }
             std::this_thread::yield();
         }
-        if (ok) {
-            if ((uint32_t)(w >> 32) == kGo)
-                for (int i = 0; i < 14; ++i) dev_box.d[i].store(host_box.d[i].load(std::memory_order_relaxed), std::memory_order_relaxed);
-        } else {
-            w = ((uint64_t)kAbort << 32) | seq;
-            status.store(((uint64_t)kGone << 32) | seq, std::memory_order_release);
+        if (gone) status.store(((uint64_t)kGone << 32) | seq, std::memory_order_release);
+        if (cmd != kGo) {
+            uint64_t ck = 0;
+            for (int i = 0; i < 7; ++i) ck ^= mail_mix(0, i);
+            for (int i = 0; i < 16; ++i) u[i] = (i & 7) == 7 ? (((uint64_t)mail_fold(ck) << 40) | ((uint64_t)kAbort << 32) | seq) : 0;
         }
-        dev_box.word.store(w, std::memory_order_release);
+        write_box(dev_box, u);
     }
     const auto t0 = clk::now();
-    uint64_t w = 0;
+    uint64_t u[16];
+    uint32_t cmd = 0;
     for (;;) {
-        w = dev_box.word.load(std::memory_order_acquire);
-        if ((uint32_t)w == seq) break;
+        bool over = false;
+        if (poll(dev_box, seq, u, cmd, over)) break;
         if (clk::now() - t0 > kSpinPatience) {
-            w = ((uint64_t)kAbort << 32) | seq;
+            cmd = kAbort;
             status.store(((uint64_t)kLost << 32) | seq, std::memory_order_release);
             break;
         }
         std::this_thread::yield();
     }
-    if ((uint32_t)(w >> 32) != kGo) { skipped->fetch_add(1); return; }
+    if (cmd != kGo) { skipped->fetch_add(1); return; }
     for (int i = 0; i < 14; ++i)
-        if (dev_box.d[i].load(std::memory_order_relaxed) != (double)seq + 0.01 * i) bad_state->fetch_add(1);
+        if (double_of(u[i < 7 ? i : i + 1]) != (double)seq + 0.01 * i) bad_state->fetch_add(1);
     ran->fetch_add(1);
 }
 
@@ -81,11 +111,18 @@ static LaunchResult run_launch(uint32_t seq, int nwg) {  // a launch: all its wo
     return r;
 }
 
-// the host's post (flh_prelaunch_host.inc: pre_post): state, then the {sequence, command} word
+// the host's post (flh_api.cpp: pre_post): the lines' doubles, then each line's {checksum, command, sequence} word
 static void post(uint32_t seq, uint32_t cmd) {
+    uint64_t u[16];
+    for (int i = 0; i < 16; ++i) u[i] = host_box.w[i].load(std::memory_order_relaxed);
     if (cmd == kGo)
-        for (int i = 0; i < 14; ++i) host_box.d[i].store((double)seq + 0.01 * i, std::memory_order_relaxed);
-    host_box.word.store(((uint64_t)cmd << 32) | seq, std::memory_order_release);
+        for (int i = 0; i < 14; ++i) u[i < 7 ? i : i + 1] = bits_of((double)seq + 0.01 * i);
+    for (int l = 0; l < 2; ++l) {
+        uint64_t ck = 0;
+        for (int i = 0; i < 7; ++i) ck ^= mail_mix(u[8 * l + i], i);
+        u[8 * l + 7] = ((uint64_t)mail_fold(ck) << 40) | ((uint64_t)cmd << 32) | seq;
+    }
+    write_box(host_box, u);
 }
 
 int main() {
