@@ -43,6 +43,7 @@ void bounds_read_kernels(unsigned long long out[5]);
 void bounds_read_pass(unsigned long long out[5]);
 void bounds_read_mapinc(unsigned long long out[5]);
 void bounds_read_scanprep(unsigned long long out[5]);
+void bounds_read_stage(unsigned long long out[5]);
 }
 #endif
 #ifdef FLH_PASS_STAMPS
@@ -3079,6 +3080,11 @@ int flh_debug_bounds(flh_handle* h, uint64_t out[20]) {
     flh::bounds_read_pass(r); for (int i = 0; i < 5; ++i) out[5 + i] = r[i];
     flh::bounds_read_mapinc(r); for (int i = 0; i < 5; ++i) out[10 + i] = r[i];
     flh::bounds_read_scanprep(r); for (int i = 0; i < 5; ++i) out[15 + i] = r[i];
+    flh::bounds_read_stage(r);  // (the staging kernels, flh_stage.hip: reported with the scan front end's record)
+    if (r[0]) {
+        if (out[15] == 0) for (int i = 1; i < 5; ++i) out[15 + i] = r[i];
+        out[15] += r[0];
+    }
     return 1;
 #else
     return 0;

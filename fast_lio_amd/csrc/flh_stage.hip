@@ -340,4 +340,8 @@ hipError_t launch_stage_sort(const void* records, uint32_t stride_bytes, uint32_
     return hipGetLastError();
 }
 
+#ifdef FLH_BOUNDS
+void bounds_read_stage(unsigned long long out[5]) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bounds), sizeof(BoundsRec)); }
+#endif
+
 }  // namespace flh

@@ -33,7 +33,7 @@ def morton_key(xyz: np.ndarray) -> np.ndarray:
 @pytest.fixture(scope="module")
 def handles():
     pr = synth.make_problem(200000, 20000, "avia", cfg=1)
-    own = capi.Handle(stage_sort=2)   # (2: the library's own kernels wherever they can run -- 262 144 points; 1, the default: 131 072)
+    own = capi.Handle(stage_sort=2)   # (2: the library's own kernels wherever they can run -- 262 144 points; 1, the default: 114 688)
     lib = capi.Handle(stage_sort=0)
     for h in (own, lib):
         h.map_build(pr.map_xyz)
