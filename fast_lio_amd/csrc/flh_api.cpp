@@ -2383,7 +2383,7 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
             }
         }
         HIPC(flh::launch_cls_compact(h->mi_world.p, h->mi_cls.p, h->mi_blk[par].p, h->mi_blk[par ^ 1].p, h->mi_blk_dirty[par ^ 1], (int)N,
-                                     h->mu_add.p, h->h_mi, seq, st, h->mi_cnt.p, tab_fill, tab_words));
+                                     h->mu_add.p, h->h_mi, seq, st, h->mi_cnt.p, tab_fill, tab_words, h->mi_far.p));
         h->mi_blk_dirty[par ^ 1] = 0;
         h->mi_blk_dirty[par] = blk_words;
         h->mi_par ^= 1;

@@ -90,7 +90,8 @@ hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t 
                               uint32_t* far /* N + 1 words, far[0] == 0 on entry and on exit */, hipStream_t st);
 hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* blk_cnt, uint32_t* cnt_next, uint32_t next_words,
                               int N, float4* out, uint32_t* host_counts, uint32_t seq, hipStream_t st, uint32_t* dev_counts = nullptr,
-                              unsigned long long* tab_fill = nullptr, uint32_t tab_words = 0);  // tab_fill: a voxel table to empty (0xFF) on the way
+                              unsigned long long* tab_fill = nullptr, uint32_t tab_words = 0,  // tab_fill: a voxel table to empty (0xFF) on the way
+                              uint32_t* far = nullptr);  // far: launch_mi_classify's list, re-armed (far[0] = 0) for the next call
 // dev_counts (the launches of a map change below): {n1, n} in device memory, read by the kernels instead of the host's values, which
 // then only size the launches; a change larger than that does nothing and k_map_publish raises kMapChangeNotApplied
 constexpr uint32_t kMapChangeNotApplied = 0x80000000u;

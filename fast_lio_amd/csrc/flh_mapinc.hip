@@ -2,7 +2,8 @@
 //
 //   k_mi_classify     map_incremental's add/skip decision per scan point (src/laserMapping.cpp:427-474), fed
 //                     from the device-resident neighbour cache the last search left behind
-//   k_far_nearest     points_near[0] of the few scan points with no map point inside the search bound (shell search over bricks)
+//   k_far_search      points_near[0] of the few scan points with no map point inside the search bound (shell search over bricks),
+//                     and their decision (k_mi_classify lists them)
 //   k_add_insert / k_add_resolve   ikdtree.Add_Points(points, downsample) (:470-471): per filter_size_map voxel the point
 //                     nearest to the voxel centre survives [ikd-Tree semantics, recalled-upstream; the oracle
 //                     (oracle_path.c: orc_map_add) states them]; the new points are grouped by voxel in a hash table (no sort)
@@ -33,7 +34,7 @@ static inline int cdiv2(long long a, long long b) { return (int)((a + b - 1) / b
 // order, entries beyond it are merely some map points (whatever the visited cells held).  The reference's search is
 // unbounded.  The two still agree on every decision below: a neighbour that can veto the insert lies within
 // sqrt(3)*fsm of the point (well inside the bound), and the one case that needs a neighbour outside the bound --
-// points_near[0] of a point with NO map point inside it -- is served by k_far_nearest first.
+// points_near[0] of a point with NO map point inside it -- is served by k_far_search.
 // One wave per query.  Bricks are visited in cubic shells around the query's brick (shell r = the bricks at Chebyshev distance
 // r): after shell r everything within the cube of (2r+1)^3 bricks is known, so the search ends as soon as the best distance
 // found is smaller than the distance from the query to that cube's faces -- a few hundred directory probes when the nearest
@@ -58,8 +59,9 @@ __device__ __forceinline__ float4 nn_get(const NnSrc& s, size_t at) {
 }
 
 // the shell search of ONE query by one wave (see above); wx, wy, wz = the world position the last search used
-__device__ __forceinline__ void far_search(const GridParams& g, int q, int lane, float wx, float wy, float wz, uint32_t hash_size,
-                                           const uint32_t* __restrict__ live, const NnSrc& nn) {
+// Returns the nearest point to every lane (.w = its id; 0xFFFFFFFF: the map holds no live point).
+__device__ __forceinline__ float4 far_search(const GridParams& g, int q, int lane, float wx, float wy, float wz, uint32_t hash_size,
+                                             const uint32_t* __restrict__ live, const NnSrc& nn) {
     const unsigned long long* __restrict__ hash64 = reinterpret_cast<const unsigned long long*>(g.hash);
     const float bw = 4.0f * g.c;
     const float w[3] = {wx, wy, wz};
@@ -181,68 +183,16 @@ __device__ __forceinline__ void far_search(const GridParams& g, int q, int lane,
         if (nn.idx) nn.idx[q] = __float_as_uint(best_p.w);
         else nn.pts[q] = best_p;
     }
+    if (gbest == ~0ull) return make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
+    const int wl = __ffsll((long long)__ballot(best == gbest)) - 1;  // the lane that holds it
+    return make_float4(__shfl(best_p.x, wl, 64), __shfl(best_p.y, wl, 64), __shfl(best_p.z, wl, 64), __shfl(best_p.w, wl, 64));
 }
 
-// k_far_nearest: one THREAD per query decides whether its cached nearest neighbour is the true one (it is when it lies inside the
-// search bound: pointSearchSqDis[0], recomputed here with the search's own expression) -- all but a handful of a scan's points; the
-// others are listed (far[0] = their number, far[1..] = the queries; one atomic per wave).  k_far_search: one WAVE per listed query
-// (grid-stride), so that a cluster of far points -- Morton neighbours, the first scans over new ground -- is searched side by side
-// and not one after the other by the wave that found them.  k_mi_classify re-arms the counter.
-__global__ void __launch_bounds__(256)
-k_far_nearest(StateDev s_search, const float4* __restrict__ body, const uint8_t* __restrict__ nn_cnt, float max_sqdist, int N,
-              NnSrc nn, uint32_t* __restrict__ far) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    bool need = false;
-    if (q < N) {
-        const float4 b = body[q];
-        float wx, wy, wz;
-        body_to_world(s_search, b.x, b.y, b.z, wx, wy, wz);  // the world position the last search used
-        need = true;
-        if (nn_cnt[q] != 0) {
-            const float4 p0 = nn_get(nn, (size_t)q);
-            if (__float_as_uint(p0.w) != 0xFFFFFFFFu && dist2(wx, wy, wz, p0.x, p0.y, p0.z) <= max_sqdist) need = false;
-        }
-    }
-    const unsigned long long bal = __ballot(need);
-    if (bal == 0ull) return;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(far, (uint32_t)__popcll(bal));
-    base = (uint32_t)__shfl((int)base, 0, 64);
-    if (need) far[1 + FLH_IDX(231, base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull)), N)] = (uint32_t)q;
-}
-__global__ void __launch_bounds__(256)
-k_far_search(GridParams g, StateDev s_search, const float4* __restrict__ body, uint32_t hash_size, const uint32_t* __restrict__ live,
-             NnSrc nn, const uint32_t* __restrict__ far, int N) {
-    const uint32_t n = min(far[0], (uint32_t)N);
-    const int lane = threadIdx.x & 63;
-    for (uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n; k += gridDim.x * 4) {  // wave-uniform
-        const int q = (int)far[1 + k];
-        const float4 b = body[q];
-        float wx, wy, wz;
-        body_to_world(s_search, b.x, b.y, b.z, wx, wy, wz);
-        far_search(g, q, lane, wx, wy, wz, hash_size, live, nn);
-    }
-}
-
-// Outputs are in ORIGINAL scan order (the body buffer is Morton-ordered; .w carries the original index).
-__global__ void __launch_bounds__(256)
-k_mi_classify(StateDev s, StateDev s_search, const float4* __restrict__ body, NnSrc nn,
-              const uint8_t* __restrict__ nn_cnt, float max_sqdist, int N, uint32_t map_points,
-              double fsm, int ekf_inited, float4* __restrict__ world_out, uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cnt,
-              uint32_t* __restrict__ far) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0 && far) far[0] = 0u;  // k_far_search (before this kernel on the stream) has read the list: empty for the next call
-    if (i >= N) return;
-    const float4 b = body[i];
-    const uint32_t o = __float_as_uint(b.w);
-    float wx, wy, wz;
-    body_to_world(s, b.x, b.y, b.z, wx, wy, wz);  // pointBodyToWorld with the POSTERIOR state (:436)
-    float sx, sy, sz;
-    body_to_world(s_search, b.x, b.y, b.z, sx, sy, sz);  // where the last search saw the point: pointSearchSqDis is measured from there
-    world_out[FLH_IDX(205, o, N)] = make_float4(wx, wy, wz, 0.f);
-    const int cnt = nn_cnt[i];                              // found inside the bound, ascending
-    const int true_cnt = map_points < 5u ? (int)map_points : 5;  // what the unbounded search returns
+// map_incremental's decision for ONE scan point (src/laserMapping.cpp:441-466) given points_near[0] = n0: 0 = skip, 1 = PointToAdd,
+// 2 = PointNoNeedDownsample.  (wx, wy, wz): the point at the POSTERIOR state (:436); (sx, sy, sz): where the last search saw it --
+// pointSearchSqDis is measured from there, with the search's own expression (and bits).
+__device__ __forceinline__ uint8_t mi_decide(const NnSrc& nn, int i, int N, int cnt, int true_cnt, int ekf_inited, double fsm, float max_sqdist,
+                                             float wx, float wy, float wz, float sx, float sy, float sz, const float4& n0) {
     uint8_t c = 1;  // Nearest_Points[i].empty() || !flg_EKF_inited -> PointToAdd (:463-466)
     if (true_cnt > 0 && ekf_inited) {
         // mid_point members are float: each is a double expression narrowed to float (:443-445)
@@ -250,7 +200,6 @@ k_mi_classify(StateDev s, StateDev s_search, const float4* __restrict__ body, Nn
         const float my = (float)(floor((double)wy / fsm) * fsm + 0.5 * fsm);
         const float mz = (float)(floor((double)wz / fsm) * fsm + 0.5 * fsm);
         const float dist = dist2(wx, wy, wz, mx, my, mz);  // calc_dist (:446)
-        const float4 n0 = nn_get(nn, (size_t)i);           // points_near[0] (from the search, or k_far_search)
         if (fabs((double)(n0.x - mx)) > 0.5 * fsm && fabs((double)(n0.y - my)) > 0.5 * fsm &&
             fabs((double)(n0.z - mz)) > 0.5 * fsm) {       // :447
             c = 2;
@@ -268,10 +217,76 @@ k_mi_classify(StateDev s, StateDev s_search, const float4* __restrict__ body, Nn
             c = need_add ? 1 : 0;
         }
     }
+    return c;
+}
+// the class of original index o goes on record: cls[o], and the two lists' members per block of 256 ORIGINAL indices (integer
+// atomics: order-independent); the lists are in original scan order: class 1 (down-sampled insert), then class 2
+__device__ __forceinline__ void mi_record(uint8_t c, uint32_t o, int N, uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cnt) {
     cls[FLH_IDX(206, o, N)] = c;
-    if (blk_cnt && c) {  // members of the two lists per block of 256 ORIGINAL indices (integer atomics: order-independent); the lists
-        const uint32_t nb = ((uint32_t)N + 255u) >> 8;  // are in original scan order: class 1 (down-sampled insert), then class 2
+    if (blk_cnt && c) {
+        const uint32_t nb = ((uint32_t)N + 255u) >> 8;
         atomicAdd(blk_cnt + (c == 1 ? 0u : nb) + (o >> 8), 1u);
+    }
+}
+
+// k_mi_classify: one THREAD per query (Morton order; outputs in ORIGINAL scan order: .w of the body point carries the index).  A
+// query whose cached nearest neighbour lies inside the search bound -- all but a handful of a scan's points -- is decided on the
+// spot.  The others (no map point inside the bound: points_near[0] of the reference's UNBOUNDED search lies beyond it) are LISTED
+// (far[0] = their number, far[1..] = the queries; one atomic per wave) when defer_far is set, and k_far_search -- one WAVE per
+// listed query (grid-stride), so that a cluster of far points is searched side by side -- finds their nearest map point by the
+// shell search and decides them.  (Round 5: a kernel of its own listed them before the classification; k_cls_compact re-arms the
+// counter.)
+__global__ void __launch_bounds__(256)
+k_mi_classify(StateDev s, StateDev s_search, const float4* __restrict__ body, NnSrc nn,
+              const uint8_t* __restrict__ nn_cnt, float max_sqdist, int N, uint32_t map_points,
+              double fsm, int ekf_inited, float4* __restrict__ world_out, uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cnt,
+              uint32_t* __restrict__ far, int defer_far) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool need = false;
+    if (i < N) {
+        const float4 b = body[i];
+        const uint32_t o = __float_as_uint(b.w);
+        float wx, wy, wz;
+        body_to_world(s, b.x, b.y, b.z, wx, wy, wz);  // pointBodyToWorld with the POSTERIOR state (:436)
+        float sx, sy, sz;
+        body_to_world(s_search, b.x, b.y, b.z, sx, sy, sz);  // the world position the last search used
+        world_out[FLH_IDX(205, o, N)] = make_float4(wx, wy, wz, 0.f);
+        const int cnt = nn_cnt[i];                              // found inside the bound, ascending
+        const int true_cnt = map_points < 5u ? (int)map_points : 5;  // what the unbounded search returns
+        const float4 n0 = nn_get(nn, (size_t)i);               // points_near[0] as the bounded search left it
+        if (defer_far) {
+            need = true;
+            if (cnt != 0 && __float_as_uint(n0.w) != 0xFFFFFFFFu && dist2(sx, sy, sz, n0.x, n0.y, n0.z) <= max_sqdist) need = false;
+        }
+        if (!need) mi_record(mi_decide(nn, i, N, cnt, true_cnt, ekf_inited, fsm, max_sqdist, wx, wy, wz, sx, sy, sz, n0), o, N, cls, blk_cnt);
+    }
+    const unsigned long long bal = __ballot(need);
+    if (bal == 0ull) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(far, (uint32_t)__popcll(bal));
+    base = (uint32_t)__shfl((int)base, 0, 64);
+    if (need) far[1 + FLH_IDX(231, base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull)), N)] = (uint32_t)i;
+}
+__global__ void __launch_bounds__(256)
+k_far_search(GridParams g, StateDev s, StateDev s_search, const float4* __restrict__ body, uint32_t hash_size, const uint32_t* __restrict__ live,
+             NnSrc nn, const uint8_t* __restrict__ nn_cnt, float max_sqdist, uint32_t map_points, double fsm, int ekf_inited,
+             uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cnt, const uint32_t* __restrict__ far, int N) {
+    const uint32_t n = min(far[0], (uint32_t)N);
+    const int lane = threadIdx.x & 63;
+    for (uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n; k += gridDim.x * 4) {  // wave-uniform
+        const int q = (int)far[1 + k];
+        const float4 b = body[q];
+        float sx, sy, sz;
+        body_to_world(s_search, b.x, b.y, b.z, sx, sy, sz);
+        const float4 n0 = far_search(g, q, lane, sx, sy, sz, hash_size, live, nn);  // (also left in row 0 of the neighbour cache)
+        if (lane == 0) {
+            float wx, wy, wz;
+            body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
+            const int true_cnt = map_points < 5u ? (int)map_points : 5;
+            mi_record(mi_decide(nn, q, N, (int)nn_cnt[q], true_cnt, ekf_inited, fsm, max_sqdist, wx, wy, wz, sx, sy, sz, n0),
+                      __float_as_uint(b.w), N, cls, blk_cnt);
+        }
     }
 }
 
@@ -295,7 +310,7 @@ __global__ void __launch_bounds__(256) k_cls_compact(const float4* __restrict__ 
                                                      const uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ cnt_next,
                                                      uint32_t next_words, int N, float4* __restrict__ out,
                                                      uint32_t* __restrict__ host_counts, uint32_t seq, uint32_t* __restrict__ dev_counts,
-                                                     u64* __restrict__ tab_fill, uint32_t tab_words) {
+                                                     u64* __restrict__ tab_fill, uint32_t tab_words, uint32_t* __restrict__ far) {
     __shared__ uint32_t s_red[4][4], s_wave[4][2];
     const uint32_t nb = ((uint32_t)N + 255u) >> 8, b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -323,6 +338,7 @@ __global__ void __launch_bounds__(256) k_cls_compact(const float4* __restrict__ 
         if (w < wave) { w1 += s_wave[w][0]; w2 += s_wave[w][1]; }
     }
     if (b == 0 && tid == 0) {
+        if (far) far[0] = 0u;  // k_far_search (before this kernel on the stream) has read the list: empty for the next call
         if (host_counts) publish_granule(host_counts, total1, total1 + total2, 0u, seq);
         if (dev_counts) { dev_counts[0] = total1; dev_counts[1] = total1 + total2; }
     }
@@ -1006,20 +1022,20 @@ hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t 
                               const uint32_t* live, float4* world_out, uint8_t* cls, uint32_t* blk_cnt, uint32_t* far, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     const NnSrc nn{nn_pts, nn_idx, map_orig, n_ids};
-    if (map_points > 0 && ekf_inited) {
-        hipLaunchKernelGGL(k_far_nearest, dim3(cdiv2(N, 256)), dim3(256), 0, st, s_search, body, nn_cnt, max_sqdist, N, nn, far);
-        hipLaunchKernelGGL(k_far_search, dim3(min(cdiv2(N, 4), 512)), dim3(256), 0, st, g, s_search, body, hash_size, live, nn, far, N);
-    }
+    const int defer_far = (map_points > 0 && ekf_inited) ? 1 : 0;  // else Nearest_Points[i] is empty / nobody looks at it (:463-466)
     hipLaunchKernelGGL(k_mi_classify, dim3(cdiv2(N, 256)), dim3(256), 0, st, s_post, s_search, body, nn, nn_cnt, max_sqdist, N,
-                       map_points, fsm, ekf_inited, world_out, cls, blk_cnt, far);
+                       map_points, fsm, ekf_inited, world_out, cls, blk_cnt, far, defer_far);
+    if (defer_far)
+        hipLaunchKernelGGL(k_far_search, dim3(min(cdiv2(N, 4), 512)), dim3(256), 0, st, g, s_post, s_search, body, hash_size, live, nn, nn_cnt,
+                           max_sqdist, map_points, fsm, ekf_inited, cls, blk_cnt, far, N);
     return hipGetLastError();
 }
 hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* blk_cnt, uint32_t* cnt_next, uint32_t next_words,
                               int N, float4* out, uint32_t* host_counts, uint32_t seq, hipStream_t st, uint32_t* dev_counts,
-                              unsigned long long* tab_fill, uint32_t tab_words) {
+                              unsigned long long* tab_fill, uint32_t tab_words, uint32_t* far) {
     if (N <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_cls_compact, dim3(cdiv2(N, 256)), dim3(256), 0, st, world, cls, blk_cnt, cnt_next, next_words, N, out,
-                       host_counts, seq, dev_counts, tab_fill, tab_words);
+                       host_counts, seq, dev_counts, tab_fill, tab_words, far);
     return hipGetLastError();
 }
 // the counters of a map change and the number of points it inserted, as two granules, each carrying the sequence word (system-scope
