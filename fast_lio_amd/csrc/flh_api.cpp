@@ -153,6 +153,7 @@ struct flh_handle {
     // (mi_cnt: [0] n1, [1] n, [2] survivors), Add_Points is enqueued with launches sized for small_change_max() points; a change
     // that turns out larger is not applied by those launches and replayed by map_settle()
     DevBuf<uint32_t> mi_cnt;
+    DevBuf<uint32_t> mi_tick;          // k_brick_rewrite_heads' tickets (zero between launches)
     DevBuf<uint32_t> mi_far;           // [0] the number of scan points whose nearest map point lies outside the search bound, then the points
     uint32_t mi_pred_n = 0xFFFFFFFFu;  // points of the previous change (the prediction for the next one); unknown at first
     bool mi_deferred = false;          // the pending change was enqueued that way
@@ -489,7 +490,7 @@ void flh_destroy(flh_handle* h) {
     h->ins.release();
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     if (h->h_mi) (void)hipHostFree(h->h_mi);
-    h->map_orig.release(); h->map_next.release(); h->mb_aabb.release(); h->mu_add.release(); h->mi_world.release(); h->mi_cnt.release(); h->mi_far.release();
+    h->map_orig.release(); h->map_next.release(); h->mb_aabb.release(); h->mu_add.release(); h->mi_world.release(); h->mi_cnt.release(); h->mi_far.release(); h->mi_tick.release();
     h->mu_alive.release(); h->mi_cls.release(); h->mu_flags.release(); h->mu_incl.release(); h->mi_blk[0].release(); h->mi_blk[1].release(); h->mu_boxes.release();
     h->map_sorted.release(); h->hash.release(); h->starts.release(); h->slow_list.release(); h->slow_list2.release(); h->slow_ub.release(); h->slow_count.release(); h->tickets.release();
     h->world.release(); h->nn_pts.release(); h->normvec.release(); h->plane.release(); h->nn_idx.release(); h->gsum.release();
@@ -528,7 +529,7 @@ void flh_destroy(flh_handle* h) {
 
 static int map_settle(flh_handle* h);
 static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size_t n2, double ds, const uint32_t* d_cnt = nullptr,
-                             bool table_is_empty = false);
+                             bool inserted = false);
 int flh_map_sync(flh_handle* h) {
     if (!h) return fail("flh_map_sync: null handle");
     return map_settle(h);
@@ -809,7 +810,7 @@ static int map_settle(flh_handle* h) {
 // the handle's stream with launch sizes the host knows (n1, n2; the number of points that survive the down-sampling stays on the
 // device: n bounds it, and entries beyond it carry a sentinel key); the change's counters are collected by map_settle().
 static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size_t n2, double ds, const uint32_t* d_cnt,
-                             bool table_is_empty) {  // table_is_empty: the caller's last kernel has emptied vox_tab for exactly this change
+                             bool inserted) {  // inserted: the caller's kernels have done launch_add_insert's step for exactly this change
     hipStream_t st = h->stream;
     if (map_settle(h) != 0) return -1;
     // d_cnt: the true {n1, n} live on the device (mi_cnt); n1 = n2's sum is then only the bound the launches are sized for
@@ -849,20 +850,29 @@ static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size
     const uint32_t vcap = flh::vox_table_slots((uint32_t)n1);
     if (n1 > 0) {
         HIPC(h->vox_tab.reserve(2 * (size_t)flh::vox_table_slots((uint32_t)std::min<size_t>(nr, 0x7FFFFFFFu))));
-        if (!table_is_empty) HIPC(hipMemsetAsync(h->vox_tab.p, 0xFF, 2 * (size_t)vcap * sizeof(unsigned long long), st));
+        if (!inserted) HIPC(hipMemsetAsync(h->vox_tab.p, 0xFF, 2 * (size_t)vcap * sizeof(unsigned long long), st));
     }
     // where the number of surviving points goes (with device-side lengths the general path's scan runs over the whole bound: the
     // entries behind the change's true end count as "no point", k_add_insert)
     const bool small_path = h->cfg.fused_small_changes != 0 && nu <= flh::small_change_max();
     uint32_t* const d_alive_out = (d_cnt && small_path) ? h->mi_cnt.p + 2 : h->mu_incl.p + (n - 1);
-    HIPC(flh::launch_add_insert(d_add, (uint32_t)n1, nu, ds, h->vox_tab.p, vcap, h->mu_alive.p, h->ctr.p, st, d_cnt));
+    if (!inserted) HIPC(flh::launch_add_insert(d_add, (uint32_t)n1, nu, ds, h->vox_tab.p, vcap, h->mu_alive.p, h->ctr.p, st, d_cnt));
     if (n1 > 0)
         HIPC(flh::launch_add_resolve(h->grid, h->map_sorted.p, d_add, h->vox_tab.p, vcap, (uint32_t)n1, ds, h->dead_id.p, h->live.p,
                                      h->ctr.p, h->mu_alive.p, st, d_cnt));
-    if (h->cfg.fused_small_changes != 0 && nu <= flh::small_change_max()) {
-        // a scan's worth of points: ids, brick keys and their sort in one workgroup (one launch instead of eight)
+    const uint32_t seq = ++h->mi_seq;
+    if (small_path) {
+        // a scan's worth of points: ids, brick keys and their sort in one workgroup (one launch instead of eight), which also lists
+        // the bricks that receive points; the rewrite's last workgroup publishes the change's counters
         HIPC(flh::launch_ins_sort_small(h->grid, d_add, h->mu_alive.p, nu, (uint32_t)h->n_ids, h->map_orig.p, h->dead_id.p, h->ins.p, bk0,
-                                        bk1, h->mb_v1.p, h->ctr.p, d_alive_out, st, d_cnt));
+                                        bk1, h->mb_v1.p, h->ctr.p, d_alive_out, h->mb_v0.p, st, d_cnt));
+        if (h->mi_tick.cap < flh::brick_ticket_words()) {
+            HIPC(h->mi_tick.reserve(flh::brick_ticket_words()));
+            HIPC(hipMemsetAsync(h->mi_tick.p, 0, h->mi_tick.cap * sizeof(uint32_t), st));
+        }
+        HIPC(flh::launch_brick_rewrite_heads(h->grid, h->map_sorted.p, h->starts.p, h->hash.p, h->cap_end.p, h->live.p, h->ctr.p, h->ins.p,
+                                             bk1, h->mb_v1.p, nu, (uint32_t)h->pts_cap, (uint32_t)h->rows_cap, st, d_cnt, h->mb_v0.p,
+                                             h->mi_tick.p, d_alive_out, h->h_mi + 4, seq));
     } else {
         // ids of the survivors, in input order; the brick keys start as sentinels
         HIPC(flh::launch_byte_flags(h->mu_alive.p, nu, 0, h->mu_flags.p, st, bk0));
@@ -876,11 +886,10 @@ static int apply_map_changes(flh_handle* h, const float4* d_add, size_t n1, size
             size_t tb = h->mb_tmp.cap;
             HIPC(flh::sort_brick_pairs(h->mb_tmp.p, tb, bk0, bk1, h->mb_v0.p, h->mb_v1.p, nu, st));
         }
+        HIPC(flh::launch_brick_rewrite(h->grid, h->map_sorted.p, h->starts.p, h->hash.p, h->cap_end.p, h->live.p, h->ctr.p, h->ins.p,
+                                       bk1, h->mb_v1.p, nu, (uint32_t)h->pts_cap, (uint32_t)h->rows_cap, st, d_cnt));
+        HIPC(flh::launch_map_publish(h->ctr.p, d_alive_out, h->h_mi + 4, seq, st, d_cnt, nu));
     }
-    HIPC(flh::launch_brick_rewrite(h->grid, h->map_sorted.p, h->starts.p, h->hash.p, h->cap_end.p, h->live.p, h->ctr.p, h->ins.p,
-                                   bk1, h->mb_v1.p, nu, (uint32_t)h->pts_cap, (uint32_t)h->rows_cap, st, d_cnt));
-    const uint32_t seq = ++h->mi_seq;
-    HIPC(flh::launch_map_publish(h->ctr.p, d_alive_out, h->h_mi + 4, seq, st, d_cnt, nu));
     h->mi_deferred = d_cnt != nullptr;
     h->mi_pending_ds = ds;
     h->map_pending = true;
@@ -2342,10 +2351,31 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
             h->mi_blk_dirty[k] = 0;
         }
     const int par = h->mi_par;  // (flips when the pair classify + compaction has run: N > 0)
+    // A running odometry inserts about as many points with every scan.  When nobody asked for the list lengths, Add_Points is
+    // enqueued right behind the compaction with the lengths read on the device: the host does not stand in the middle of the
+    // call (a wait for the granule, then the launches, while the device idles).  A change that outgrows the launches is
+    // replayed by map_settle().  The launches are sized from the PREVIOUS change (+ 50 %): up to small_change_max() points the
+    // one-workgroup path, above it the general path (scan + device-wide sort over the bound, the entries behind the true end
+    // reading "no point").  The voxel table of that Add_Points is emptied by the classification kernel and filled by the
+    // compaction kernel on their way (no fill launch, no insert launch).
+    const uint32_t cap = flh::small_change_max();
+    const bool no_wait = N > 0 && apply && !n_add && !n_no_downsample && h->mi_pred_n != 0xFFFFFFFFu;
+    size_t bound = 0;
+    unsigned long long* tab_fill = nullptr;
+    uint32_t tab_slots = 0;
+    if (no_wait) {
+        bound = (size_t)h->mi_pred_n + h->mi_pred_n / 2 + 1024;
+        if (h->cfg.fused_small_changes != 0 && bound <= cap) bound = cap;
+        bound = std::min<size_t>(bound, N);
+        tab_slots = flh::vox_table_slots((uint32_t)bound);
+        HIPC(h->vox_tab.reserve(2 * (size_t)tab_slots));
+        HIPC(h->mu_alive.reserve(bound));
+        tab_fill = h->vox_tab.p;
+    }
     HIPC(flh::launch_mi_classify(h->grid, h->grid.hash_mask + 1, (uint32_t)h->M, h->search_state, s_post, h->cur_body,
                                  h->nn_pts.p, nn_idx, h->map_orig.p, (uint32_t)h->n_ids, h->nn_cnt.p, h->cfg.max_sqdist, (int)N,
                                  filter_size_map, flg_EKF_inited, h->live.p, h->mi_world.p, h->mi_cls.p,
-                                 N > 0 ? h->mi_blk[par].p : nullptr, h->mi_far.p, st));
+                                 N > 0 ? h->mi_blk[par].p : nullptr, h->mi_far.p, st, tab_fill, 2u * tab_slots));
     if (h->cur && apply && !n_add && !n_no_downsample) {
         // the last readers of the scan's slot are enqueued; on the no-wait path below nobody waits for them before the ring
         // comes round to this slot again (flh_esekf_run_scans stages two scans ahead): the slot's next staging does
@@ -2361,29 +2391,9 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
         HIPC(h->mu_add.reserve(N + 1));
         HIPC(h->mi_cnt.reserve(4));
         const uint32_t seq = ++h->mi_seq;
-        // A running odometry inserts about as many points with every scan.  When nobody asked for the list lengths, Add_Points is
-        // enqueued right behind the compaction with the lengths read on the device: the host does not stand in the middle of the
-        // call (a wait for the granule, then five launches, while the device idles).  A change that outgrows the launches is
-        // replayed by map_settle().  The launches are sized from the PREVIOUS change (+ 50 %): up to small_change_max() points the
-        // one-workgroup path, above it the general path (scan + device-wide sort over the bound, the entries behind the true end
-        // reading "no point").
-        const uint32_t cap = flh::small_change_max();
-        const bool no_wait = apply && !n_add && !n_no_downsample && h->mi_pred_n != 0xFFFFFFFFu;
-        size_t bound = 0;
-        unsigned long long* tab_fill = nullptr;
-        uint32_t tab_words = 0;
-        if (no_wait) {
-            bound = (size_t)h->mi_pred_n + h->mi_pred_n / 2 + 1024;
-            if (h->cfg.fused_small_changes != 0 && bound <= cap) bound = cap;
-            bound = std::min<size_t>(bound, N);
-            if (bound > 0) {  // the voxel table of that Add_Points is emptied by the compaction kernel on its way (no fill launch)
-                tab_words = 2u * flh::vox_table_slots((uint32_t)bound);
-                HIPC(h->vox_tab.reserve(tab_words));
-                tab_fill = h->vox_tab.p;
-            }
-        }
         HIPC(flh::launch_cls_compact(h->mi_world.p, h->mi_cls.p, h->mi_blk[par].p, h->mi_blk[par ^ 1].p, h->mi_blk_dirty[par ^ 1], (int)N,
-                                     h->mu_add.p, h->h_mi, seq, st, h->mi_cnt.p, tab_fill, tab_words, h->mi_far.p));
+                                     h->mu_add.p, h->h_mi, seq, st, h->mi_cnt.p, h->mi_far.p, tab_fill, tab_slots, filter_size_map,
+                                     h->mu_alive.p, h->ctr.p, (uint32_t)bound));
         h->mi_blk_dirty[par ^ 1] = 0;
         h->mi_blk_dirty[par] = blk_words;
         h->mi_par ^= 1;
@@ -2391,7 +2401,7 @@ int flh_map_incremental(flh_handle* h, const double x[FLH_NSTATE], double filter
             h->mi_valid_N = N;
             h->mi_cls_seq = seq;
             ++h->n_mi_deferred;
-            return apply_map_changes(h, h->mu_add.p, bound, 0, filter_size_map, h->mi_cnt.p, tab_fill != nullptr);
+            return apply_map_changes(h, h->mu_add.p, bound, 0, filter_size_map, h->mi_cnt.p, true);
         }
         if (wait_granule(h, 0, seq, "flh_map_incremental") != 0) return -1;
         c1 = h->h_mi[0];

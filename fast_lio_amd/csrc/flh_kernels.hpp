@@ -87,11 +87,15 @@ hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t 
                               const StateDev& s_post, const float4* body, float4* nn_pts, uint32_t* nn_idx, const float4* map_orig,
                               uint32_t n_ids, const uint8_t* nn_cnt, float max_sqdist, int N, double fsm, int ekf_inited,
                               const uint32_t* live, float4* world_out, uint8_t* cls, uint32_t* blk_cnt /* may be null */,
-                              uint32_t* far /* N + 1 words, far[0] == 0 on entry and on exit */, hipStream_t st);
+                              uint32_t* far /* N + 1 words, far[0] == 0 on entry, re-armed by launch_cls_compact */, hipStream_t st,
+                              unsigned long long* tab_fill = nullptr, uint32_t tab_words = 0);  // tab_fill: a voxel table to empty (0xFF) on the way
 hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* blk_cnt, uint32_t* cnt_next, uint32_t next_words,
                               int N, float4* out, uint32_t* host_counts, uint32_t seq, hipStream_t st, uint32_t* dev_counts = nullptr,
-                              unsigned long long* tab_fill = nullptr, uint32_t tab_words = 0,  // tab_fill: a voxel table to empty (0xFF) on the way
-                              uint32_t* far = nullptr);  // far: launch_mi_classify's list, re-armed (far[0] = 0) for the next call
+                              uint32_t* far = nullptr,  // launch_mi_classify's list, re-armed (far[0] = 0) for the next call
+                              // the Add_Points enqueued behind this kernel (launches sized for ins_bound points; its voxel table of
+                              // ins_cap slots was emptied by launch_mi_classify): the kernel performs launch_add_insert's step itself
+                              unsigned long long* ins_tab = nullptr, uint32_t ins_cap = 0, double ins_ds = 0.0,
+                              uint8_t* ins_alive_new = nullptr, uint32_t* ins_ctr = nullptr, uint32_t ins_bound = 0);
 // dev_counts (the launches of a map change below): {n1, n} in device memory, read by the kernels instead of the host's values, which
 // then only size the launches; a change larger than that does nothing and k_map_publish raises kMapChangeNotApplied
 constexpr uint32_t kMapChangeNotApplied = 0x80000000u;
@@ -105,7 +109,8 @@ hipError_t launch_add_insert(const float4* add, uint32_t n1, uint32_t n, double 
 uint32_t small_change_max();
 hipError_t launch_ins_sort_small(const GridParams& g, const float4* add, const uint8_t* alive_new, uint32_t n, uint32_t n_ids,
                                  float4* map_orig, uint8_t* dead_id, float4* ins, uint32_t* keys_tmp, uint32_t* ks, uint32_t* perm,
-                                 uint32_t* ctr, uint32_t* n_alive_out, hipStream_t st, const uint32_t* dev_counts = nullptr);
+                                 uint32_t* ctr, uint32_t* n_alive_out, uint32_t* heads, hipStream_t st,
+                                 const uint32_t* dev_counts = nullptr);  // heads[0 .. ctr[6]): the sorted positions at which a brick's run starts
 hipError_t sort_brick_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
                             uint32_t n, hipStream_t st);
 hipError_t launch_add_resolve(const GridParams& g, float4* pts_rw, const float4* add, const unsigned long long* tab, uint32_t cap,
@@ -122,6 +127,14 @@ hipError_t launch_ins_prepare(const GridParams& g, const float4* add, const uint
 hipError_t launch_brick_rewrite(const GridParams& g, float4* pts, uint32_t* starts, uint2* hash, uint32_t* cap_end, uint32_t* live,
                                 uint32_t* ctr, const float4* ins, const uint32_t* ks, const uint32_t* perm, uint32_t n,
                                 uint32_t pts_cap, uint32_t rows_cap, hipStream_t st, const uint32_t* dev_counts = nullptr);
+// behind launch_ins_sort_small: the workgroups share out the listed heads, the last one to finish publishes the change's counters
+// (what launch_map_publish does for the general path)
+hipError_t launch_brick_rewrite_heads(const GridParams& g, float4* pts, uint32_t* starts, uint2* hash, uint32_t* cap_end, uint32_t* live,
+                                      uint32_t* ctr, const float4* ins, const uint32_t* ks, const uint32_t* perm, uint32_t n,
+                                      uint32_t pts_cap, uint32_t rows_cap, hipStream_t st, const uint32_t* dev_counts,
+                                      const uint32_t* heads, uint32_t* tick /* brick_ticket_words() words, zero on entry and on exit */,
+                                      const uint32_t* n_alive, uint32_t* host_out, uint32_t seq);
+uint32_t brick_ticket_words();
 hipError_t launch_byte_flags(const uint8_t* in, uint32_t n, int invert, uint32_t* flags, hipStream_t st,
                              uint32_t* keys_sentinel = nullptr);
 hipError_t launch_live_compact(const float4* map_orig, const uint32_t* flags, const uint32_t* incl, uint32_t n_ids, float4* out,

@@ -240,9 +240,12 @@ __global__ void __launch_bounds__(256)
 k_mi_classify(StateDev s, StateDev s_search, const float4* __restrict__ body, NnSrc nn,
               const uint8_t* __restrict__ nn_cnt, float max_sqdist, int N, uint32_t map_points,
               double fsm, int ekf_inited, float4* __restrict__ world_out, uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cnt,
-              uint32_t* __restrict__ far, int defer_far) {
+              uint32_t* __restrict__ far, int defer_far, u64* __restrict__ tab_fill, uint32_t tab_words) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    // the voxel table of the Add_Points that is enqueued behind this call's kernels arrives empty (0xFF: empty keys, maximal
+    // values) without a fill launch of its own; k_cls_compact, two kernels on, starts filling it
+    for (uint32_t j = (uint32_t)i; j < tab_words; j += gridDim.x * 256u) tab_fill[j] = ~0ull;
     bool need = false;
     if (i < N) {
         const float4 b = body[i];
@@ -297,59 +300,6 @@ __device__ __forceinline__ void publish_granule(uint32_t* dst, uint32_t a, uint3
     const u32x4g v = {a, b, c, seq};
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
 }
-// The two lists of map_incremental (src/laserMapping.cpp:463-466: PointToAdd, PointNoNeedDownsample) compacted in ORIGINAL scan
-// order, class 1 first -- ONE kernel (round 5: two library scan kernels over 2 N flags + this one).  k_mi_classify left the
-// lists' members per block of 256 original indices (blk_cnt[0 .. nb): class 1, [nb .. 2 nb): class 2); every workgroup adds up
-// the blocks before its own (and all of them: the class-1 total is where class 2 starts) -- at most a few words per thread -- and
-// places its own 256 entries by ballot.  Also hands the two list lengths on: to the host as a granule {PointToAdd, PointToAdd +
-// PointNoNeedDownsample, 0, seq} (it sizes the launches of Add_Points with them; a copy + stream synchronisation would cost more
-// than this whole kernel), and to dev_counts in device memory, where the kernels of an Add_Points enqueued WITHOUT waiting for the
-// granule read them (MiCounts below).  cnt_next[0 .. next_words): the NEXT call's counters (the other half of a double buffer) as
-// their last use left them, zeroed here.  tab_fill[0 .. tab_words): the voxel table of the Add_Points behind this kernel, emptied here.
-__global__ void __launch_bounds__(256) k_cls_compact(const float4* __restrict__ world, const uint8_t* __restrict__ cls,
-                                                     const uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ cnt_next,
-                                                     uint32_t next_words, int N, float4* __restrict__ out,
-                                                     uint32_t* __restrict__ host_counts, uint32_t seq, uint32_t* __restrict__ dev_counts,
-                                                     u64* __restrict__ tab_fill, uint32_t tab_words, uint32_t* __restrict__ far) {
-    __shared__ uint32_t s_red[4][4], s_wave[4][2];
-    const uint32_t nb = ((uint32_t)N + 255u) >> 8, b = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t v[4] = {0u, 0u, 0u, 0u};  // class 1 before this block, class 1 in all, class 2 before, class 2 in all
-    for (uint32_t j = (uint32_t)tid; j < nb; j += 256u) {
-        const uint32_t c1 = blk_cnt[j], c2 = blk_cnt[nb + j];
-        v[1] += c1; v[3] += c2;
-        if (j < b) { v[0] += c1; v[2] += c2; }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
-        if (lane == 0) s_red[wave][k] = v[k];
-    }
-    const int i = (int)(b * 256u) + tid;
-    const uint8_t c = i < N ? cls[i] : (uint8_t)0;
-    const unsigned long long m1 = __ballot(c == 1), m2 = __ballot(c == 2), lt = (1ull << lane) - 1ull;
-    if (lane == 0) { s_wave[wave][0] = (uint32_t)__popcll(m1); s_wave[wave][1] = (uint32_t)__popcll(m2); }
-    __syncthreads();
-    uint32_t before1 = 0, total1 = 0, before2 = 0, total2 = 0, w1 = 0, w2 = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        before1 += s_red[w][0]; total1 += s_red[w][1]; before2 += s_red[w][2]; total2 += s_red[w][3];
-        if (w < wave) { w1 += s_wave[w][0]; w2 += s_wave[w][1]; }
-    }
-    if (b == 0 && tid == 0) {
-        if (far) far[0] = 0u;  // k_far_search (before this kernel on the stream) has read the list: empty for the next call
-        if (host_counts) publish_granule(host_counts, total1, total1 + total2, 0u, seq);
-        if (dev_counts) { dev_counts[0] = total1; dev_counts[1] = total1 + total2; }
-    }
-    for (uint32_t j = b * 256u + (uint32_t)tid; j < next_words; j += gridDim.x * 256u) cnt_next[j] = 0u;  // (what its last use left)
-    // the voxel table of the Add_Points that is enqueued right behind this kernel arrives empty (0xFF: empty keys, maximal values)
-    // without a fill launch of its own
-    for (uint32_t j = b * 256u + (uint32_t)tid; j < tab_words; j += gridDim.x * 256u) tab_fill[j] = ~0ull;
-    if (c == 1) out[FLH_IDX(207, before1 + w1 + (uint32_t)__popcll(m1 & lt), N)] = world[i];
-    else if (c == 2) out[FLH_IDX(208, total1 + before2 + w2 + (uint32_t)__popcll(m2 & lt), N)] = world[i];
-}
-
 // exact AABB of a point array: ordered-uint encoding of floats + atomics
 __device__ __forceinline__ uint32_t f2ord(float f) {
     const uint32_t u = __float_as_uint(f);
@@ -425,6 +375,19 @@ __device__ __forceinline__ u64 pack_vox(long long kx, long long ky, long long kz
 // alive_new = 0 for these points (k_add_resolve decides), 1 for the n - n1 points inserted as they are; the change's counters
 // (re-index flags, removed points) start at zero.  The table arrives filled with 0xFF (empty keys, maximal values).
 __device__ __forceinline__ uint32_t vox_slot(u64 key, int shift) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> shift); }
+__device__ __forceinline__ void vox_insert(u64* __restrict__ tab, uint32_t mask, int shift, const float4& p, uint32_t i, double ds) {
+    long long kx, ky, kz;
+    vox_of(p.x, p.y, p.z, ds, kx, ky, kz);
+    const u64 key = pack_vox(kx, ky, kz);
+    const u64 val = ((u64)__float_as_uint(dist_to_center(p.x, p.y, p.z, kx, ky, kz, ds)) << 32) | (u64)(~i);
+    uint32_t slot = vox_slot(key, shift);
+    for (;;) {
+        const u64 prev = atomicCAS(tab + 2 * (size_t)FLH_IDX(209, slot, (u64)mask + 1), ~0ull, key);
+        if (prev == ~0ull || prev == key) break;
+        slot = (slot + 1) & mask;
+    }
+    atomicMin(tab + 2 * (size_t)slot + 1, val);
+}
 __global__ void __launch_bounds__(256) k_add_insert(const float4* __restrict__ add, uint32_t n1, uint32_t n, double ds,
                                                     u64* __restrict__ tab, uint32_t mask, int shift, uint8_t* __restrict__ alive_new,
                                                     uint32_t* __restrict__ ctr, MiCounts mc) {
@@ -440,18 +403,86 @@ __global__ void __launch_bounds__(256) k_add_insert(const float4* __restrict__ a
     }
     alive_new[i] = i < n1 ? 0 : 1;
     if (i >= n1) return;
-    const float4 p = add[i];
-    long long kx, ky, kz;
-    vox_of(p.x, p.y, p.z, ds, kx, ky, kz);
-    const u64 key = pack_vox(kx, ky, kz);
-    const u64 val = ((u64)__float_as_uint(dist_to_center(p.x, p.y, p.z, kx, ky, kz, ds)) << 32) | (u64)(~i);
-    uint32_t slot = vox_slot(key, shift);
-    for (;;) {
-        const u64 prev = atomicCAS(tab + 2 * (size_t)FLH_IDX(209, slot, (u64)mask + 1), ~0ull, key);
-        if (prev == ~0ull || prev == key) break;
-        slot = (slot + 1) & mask;
+    vox_insert(tab, mask, shift, add[i], i, ds);
+}
+
+// The two lists of map_incremental (src/laserMapping.cpp:463-466: PointToAdd, PointNoNeedDownsample) compacted in ORIGINAL scan
+// order, class 1 first -- ONE kernel (round 5: two library scan kernels over 2 N flags + this one).  k_mi_classify left the
+// lists' members per block of 256 original indices (blk_cnt[0 .. nb): class 1, [nb .. 2 nb): class 2); every workgroup adds up
+// the blocks before its own (and all of them: the class-1 total is where class 2 starts) -- at most a few words per thread -- and
+// places its own 256 entries by ballot.  Also hands the two list lengths on: to the host as a granule {PointToAdd, PointToAdd +
+// PointNoNeedDownsample, 0, seq} (it sizes the launches of Add_Points with them; a copy + stream synchronisation would cost more
+// than this whole kernel), and to dev_counts in device memory, where the kernels of an Add_Points enqueued WITHOUT waiting for the
+// granule read them (MiCounts).  cnt_next[0 .. next_words): the NEXT call's counters (the other half of a double buffer) as
+// their last use left them, zeroed here.
+// ins.tab != nullptr: that Add_Points is enqueued right behind this kernel with launches sized for ins.bound points, and this
+// kernel does its first step -- what k_add_insert does -- on the way: a point of list 1 enters the voxel table (emptied by
+// k_mi_classify) the moment its place in the list is known.  A change larger than the bound is not applied: no insert, alive_new
+// reads "no point" over the whole bound (k_add_insert's rule).
+struct AddIns {
+    u64* tab;
+    uint32_t mask;
+    int shift;
+    double ds;
+    uint8_t* alive_new;
+    uint32_t* ctr;
+    uint32_t bound;
+};
+__global__ void __launch_bounds__(256) k_cls_compact(const float4* __restrict__ world, const uint8_t* __restrict__ cls,
+                                                     const uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ cnt_next,
+                                                     uint32_t next_words, int N, float4* __restrict__ out,
+                                                     uint32_t* __restrict__ host_counts, uint32_t seq, uint32_t* __restrict__ dev_counts,
+                                                     uint32_t* __restrict__ far, AddIns ins) {
+    __shared__ uint32_t s_red[4][4], s_wave[4][2];
+    const uint32_t nb = ((uint32_t)N + 255u) >> 8, b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t v[4] = {0u, 0u, 0u, 0u};  // class 1 before this block, class 1 in all, class 2 before, class 2 in all
+    for (uint32_t j = (uint32_t)tid; j < nb; j += 256u) {
+        const uint32_t c1 = blk_cnt[j], c2 = blk_cnt[nb + j];
+        v[1] += c1; v[3] += c2;
+        if (j < b) { v[0] += c1; v[2] += c2; }
     }
-    atomicMin(tab + 2 * (size_t)slot + 1, val);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+        if (lane == 0) s_red[wave][k] = v[k];
+    }
+    const int i = (int)(b * 256u) + tid;
+    const uint8_t c = i < N ? cls[i] : (uint8_t)0;
+    const unsigned long long m1 = __ballot(c == 1), m2 = __ballot(c == 2), lt = (1ull << lane) - 1ull;
+    if (lane == 0) { s_wave[wave][0] = (uint32_t)__popcll(m1); s_wave[wave][1] = (uint32_t)__popcll(m2); }
+    __syncthreads();
+    uint32_t before1 = 0, total1 = 0, before2 = 0, total2 = 0, w1 = 0, w2 = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        before1 += s_red[w][0]; total1 += s_red[w][1]; before2 += s_red[w][2]; total2 += s_red[w][3];
+        if (w < wave) { w1 += s_wave[w][0]; w2 += s_wave[w][1]; }
+    }
+    const uint32_t total = total1 + total2;
+    const bool applies = ins.tab != nullptr && total <= ins.bound;
+    if (b == 0 && tid == 0) {
+        if (far) far[0] = 0u;  // k_far_search (before this kernel on the stream) has read the list: empty for the next call
+        if (host_counts) publish_granule(host_counts, total1, total, 0u, seq);
+        if (dev_counts) { dev_counts[0] = total1; dev_counts[1] = total; }
+        if (ins.tab) { ins.ctr[2] = 0u; ins.ctr[3] = 0u; }  // the change's counters (re-index flags, removed points) start at zero
+    }
+    for (uint32_t j = b * 256u + (uint32_t)tid; j < next_words; j += gridDim.x * 256u) cnt_next[j] = 0u;  // (what its last use left)
+    if (ins.tab)  // behind the change's true end (the general path's scan and sort run over the whole bound): "no point"
+        for (uint32_t j = (applies ? total : 0u) + b * 256u + (uint32_t)tid; j < ins.bound; j += gridDim.x * 256u) ins.alive_new[j] = 0;
+    if (c == 1) {
+        const uint32_t at = before1 + w1 + (uint32_t)__popcll(m1 & lt);
+        const float4 p = world[i];
+        out[FLH_IDX(207, at, N)] = p;
+        if (applies) {
+            ins.alive_new[at] = 0;  // (k_add_resolve decides)
+            vox_insert(ins.tab, ins.mask, ins.shift, p, at, ins.ds);
+        }
+    } else if (c == 2) {
+        const uint32_t at = total1 + before2 + w2 + (uint32_t)__popcll(m2 & lt);
+        out[FLH_IDX(208, at, N)] = world[i];
+        if (applies) ins.alive_new[at] = 1;
+    }
 }
 
 // (start, count) of a cell and the rank of its brick
@@ -678,24 +709,21 @@ k_ins_prepare(GridParams g, const float4* __restrict__ add, const uint8_t* __res
     vals[r] = r;
 }
 
-__global__ void __launch_bounds__(128)
-k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g.starts */, uint2* hash /* = g.hash */,
-                uint32_t* __restrict__ cap_end, uint32_t* __restrict__ live, uint32_t* __restrict__ ctr,
-                const float4* __restrict__ ins, const uint32_t* __restrict__ ks, const uint32_t* __restrict__ perm, uint32_t n,
-                uint32_t pts_cap, uint32_t rows_cap, MiCounts mc) {
+// the run of new points that starts at sorted position j enters its brick (HEAD_KNOWN: j is known to be the head of a run)
+template <bool HEAD_KNOWN>
+__device__ __forceinline__ void brick_rewrite_one(const GridParams& g, float4* pts, uint32_t* starts, uint2* hash, uint32_t* __restrict__ cap_end,
+                                                  uint32_t* __restrict__ live, uint32_t* __restrict__ ctr, const float4* __restrict__ ins,
+                                                  const uint32_t* __restrict__ ks, const uint32_t* __restrict__ perm, uint32_t n,
+                                                  uint32_t pts_cap, uint32_t rows_cap, uint32_t j) {
     __shared__ float4 buf[kTile];
     __shared__ uint32_t hist[64], offs[64];
     __shared__ uint32_t s_cnt, s_base, s_rank, s_cap_end, s_ok;
-    const uint32_t j = blockIdx.x;
     const int tid = threadIdx.x;
-    {
-        uint32_t n1_unused = 0;
-        if (!mi_counts(mc, n1_unused, n)) return;
-    }
-    if (j >= n) return;
     const uint32_t key = ks[j];
-    if (key == kEmptyKey) return;           // beyond the surviving points (n is the host's upper bound of their number)
-    if (j > 0 && ks[j - 1] == key) return;  // block-uniform: not the head of its brick's run
+    if (!HEAD_KNOWN) {
+        if (key == kEmptyKey) return;           // beyond the surviving points (n is the host's upper bound of their number)
+        if (j > 0 && ks[j - 1] == key) return;  // block-uniform: not the head of its brick's run
+    }
     uint32_t e = j + 1;
     while (e < n && ks[e] == key) ++e;
     const uint32_t run = e - j;
@@ -799,6 +827,82 @@ k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g
     }
 }
 
+// the counters of a map change and the number of points it inserted, as two granules, each carrying the sequence word (system-scope
+// stores need not reach the host in order): {storage top, bricks, re-index flags, seq} {removed, inserted, points of the change, seq}.
+// A change whose kernels found it larger than their launches (MiCounts) did nothing: flag kMapChangeNotApplied tells the host so.
+struct MapPublish {
+    const uint32_t* n_alive;
+    uint32_t* host_out;
+    uint32_t seq;
+};
+__device__ __forceinline__ void map_publish(const uint32_t* ctr, const MapPublish& pb, const MiCounts& mc) {
+    const uint32_t c0 = __hip_atomic_load(ctr + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                   c1 = __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                   c3 = __hip_atomic_load(ctr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t c2 = __hip_atomic_load(ctr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t na = pb.n_alive ? *pb.n_alive : 0u;
+    uint32_t n1 = 0, n = 0xFFFFFFFFu;  // the size of the change is not this kernel's to know unless the lengths live on the device
+    if (!mi_counts(mc, n1, n)) { c2 |= kMapChangeNotApplied; na = 0u; }
+    publish_granule(pb.host_out, c0, c1, c2, pb.seq);
+    publish_granule(pb.host_out + 4, c3, na, n, pb.seq);
+}
+
+// General path: one workgroup per sorted position, the heads of the runs go on.
+__global__ void __launch_bounds__(128)
+k_brick_rewrite(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g.starts */, uint2* hash /* = g.hash */,
+                uint32_t* __restrict__ cap_end, uint32_t* __restrict__ live, uint32_t* __restrict__ ctr,
+                const float4* __restrict__ ins, const uint32_t* __restrict__ ks, const uint32_t* __restrict__ perm, uint32_t n,
+                uint32_t pts_cap, uint32_t rows_cap, MiCounts mc) {
+    {
+        uint32_t n1_unused = 0;
+        if (!mi_counts(mc, n1_unused, n)) return;
+    }
+    if (blockIdx.x >= n) return;
+    brick_rewrite_one<false>(g, pts, starts, hash, cap_end, live, ctr, ins, ks, perm, n, pts_cap, rows_cap, blockIdx.x);
+}
+// Small changes: k_ins_sort_small has listed the heads of the runs (heads[0 .. ctr[6])), the workgroups share them out -- a scan of
+// a running odometry touches a few hundred bricks, the launch is sized for 8 192 points -- and the LAST workgroup to finish hands
+// the change's counters to the host: the publication needs no launch of its own, and the host, which waits for it before the next
+// scan's first search, sees it a launch earlier.  "Last" by tickets in two levels (tick[32 (1 + g)]: the 32 workgroups of group g,
+// tick[0]: the groups; 128 bytes apart): atomics on ONE address serialise at ~11 ns each -- a thousand workgroups on one ticket
+// were 8 us of this kernel (call 18) -- so only the workgroups that have a brick take one, at most 32 + 32 deep.
+constexpr uint32_t kTickWords = 32u * 33u;
+uint32_t brick_ticket_words() { return kTickWords; }
+__global__ void __launch_bounds__(128)
+k_brick_rewrite_heads(GridParams g, float4* pts /* = g.pts */, uint32_t* starts /* = g.starts */, uint2* hash /* = g.hash */,
+                      uint32_t* __restrict__ cap_end, uint32_t* __restrict__ live, uint32_t* __restrict__ ctr,
+                      const float4* __restrict__ ins, const uint32_t* __restrict__ ks, const uint32_t* __restrict__ perm, uint32_t n,
+                      uint32_t pts_cap, uint32_t rows_cap, MiCounts mc, const uint32_t* __restrict__ heads, uint32_t* __restrict__ tick,
+                      MapPublish pb) {
+    uint32_t n1_unused = 0;
+    const uint32_t nheads = mi_counts(mc, n1_unused, n) ? min(ctr[6], n) : 0u;  // (block-uniform)
+    const uint32_t nw = min(nheads, gridDim.x);                                   // the workgroups that have a brick
+    if (nw == 0u) {  // nothing survived (or the change is larger than its launches): the counters as the earlier kernels left them
+        if (blockIdx.x == 0 && threadIdx.x == 0) map_publish(ctr, pb, mc);
+        return;
+    }
+    if (blockIdx.x >= nw) return;
+    for (uint32_t k = blockIdx.x; k < nheads; k += gridDim.x) {
+        brick_rewrite_one<true>(g, pts, starts, hash, cap_end, live, ctr, ins, ks, perm, n, pts_cap, rows_cap, heads[FLH_IDX(233, k, n)]);
+        __syncthreads();  // the tile and its counters are free for the next brick
+    }
+    if (threadIdx.x == 0) {
+        // The counters the publication reads are thread 0's own device-scope atomics: drained (vmcnt(0)) before the ticket is
+        // taken, read back with agent-scope loads by the last arriver.  No release / acquire fence: at agent scope either one
+        // sweeps the L2 (write-back / invalidate), once per workgroup -- 29 us for this kernel when it was tried (call 17).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t grp = blockIdx.x >> 5, gsize = min(32u, nw - 32u * grp), ngroups = (nw + 31u) >> 5;
+        uint32_t* const tk = tick + 32u * (1u + grp);
+        if (__hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
+            __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the next change's tickets)
+            if (__hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u) {
+                __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                map_publish(ctr, pb, mc);
+            }
+        }
+    }
+}
+
 // Bricks that only LOSE points (Delete_Point_Boxes of lasermap_fov_segment, src/laserMapping.cpp:231-277, for the life of the
 // node): a removal tombstones its slot in place, so the brick's range keeps its length and every later search of its cells still
 // loads and evaluates the tombstones.  After a removal, every brick whose live points have fallen below half of its range is
@@ -892,50 +996,53 @@ __global__ void __launch_bounds__(256) k_live_compact(const float4* __restrict__
 constexpr int kSmallThreads = 1024;
 constexpr int kSmallItems = 8;
 constexpr uint32_t kSmallMax = kSmallThreads * kSmallItems;
-using SmallSort = rocprim::block_radix_sort<uint32_t, kSmallThreads, kSmallItems, uint32_t>;
+template <int ITEMS> using SmallSort = rocprim::block_radix_sort<uint32_t, kSmallThreads, ITEMS, uint32_t>;
 using SmallScan = rocprim::block_scan<uint32_t, kSmallThreads>;
 struct SmallShared {
     union {
-        SmallSort::storage_type sort;
+        SmallSort<8>::storage_type sort8;
+        SmallSort<4>::storage_type sort4;
+        SmallSort<2>::storage_type sort2;
         SmallScan::storage_type scan;
     } st;
     uint32_t red[kSmallThreads / 64][6];
     uint32_t mn[3];
     int bits[3];
+    uint32_t last[kSmallThreads];  // a thread's last sorted key (run heads)
 };
 uint32_t small_change_max() { return kSmallMax; }
+template <int ITEMS> __device__ __forceinline__ typename SmallSort<ITEMS>::storage_type& small_sort_storage(SmallShared& sh);
+template <> __device__ __forceinline__ SmallSort<8>::storage_type& small_sort_storage<8>(SmallShared& sh) { return sh.st.sort8; }
+template <> __device__ __forceinline__ SmallSort<4>::storage_type& small_sort_storage<4>(SmallShared& sh) { return sh.st.sort4; }
+template <> __device__ __forceinline__ SmallSort<2>::storage_type& small_sort_storage<2>(SmallShared& sh) { return sh.st.sort2; }
 
-__global__ void __launch_bounds__(kSmallThreads)
-k_ins_sort_small(GridParams g, const float4* __restrict__ add, const uint8_t* __restrict__ alive_new, uint32_t n, uint32_t n_ids,
-                 float4* __restrict__ map_orig, uint8_t* __restrict__ dead_id, float4* __restrict__ ins, uint32_t* __restrict__ keys_tmp,
-                 uint32_t* __restrict__ ks, uint32_t* __restrict__ perm, uint32_t* __restrict__ ctr, uint32_t* __restrict__ n_alive_out,
-                 MiCounts mc) {
-    __shared__ SmallShared sh;
+// the body for a change of at most ITEMS * 1024 points: the sort's cost goes with the items a thread holds, and the launch is
+// sized for the largest change the path takes -- a scan of a running odometry inserts a fraction of that
+template <int ITEMS>
+__device__ __forceinline__ void ins_sort_small_body(SmallShared& sh, const GridParams& g, const float4* __restrict__ add,
+                                                    const uint8_t* __restrict__ alive_new, uint32_t n, uint32_t n_ids,
+                                                    float4* __restrict__ map_orig, uint8_t* __restrict__ dead_id, float4* __restrict__ ins,
+                                                    uint32_t* __restrict__ keys_tmp, uint32_t* __restrict__ ks, uint32_t* __restrict__ perm,
+                                                    uint32_t* __restrict__ ctr, uint32_t* __restrict__ n_alive_out,
+                                                    uint32_t* __restrict__ heads) {
     const uint32_t tid = threadIdx.x;
-    {
-        uint32_t n1_unused = 0;
-        if (!mi_counts(mc, n1_unused, n)) {  // block-uniform: a change larger than this launch was sized for -- nothing is done
-            if (tid == 0) *n_alive_out = 0u;
-            return;
-        }
-    }
-    // items in blocked arrangement: thread t holds points 8t .. 8t+7, so ranks follow the input order
-    bool valid[kSmallItems];
+    // items in blocked arrangement: thread t holds points ITEMS*t .. ITEMS*t + ITEMS-1, so ranks follow the input order
+    bool valid[ITEMS];
     uint32_t cnt = 0;
 #pragma unroll
-    for (int u = 0; u < kSmallItems; ++u) {
-        const uint32_t i = tid * kSmallItems + u;
+    for (int u = 0; u < ITEMS; ++u) {
+        const uint32_t i = tid * ITEMS + u;
         valid[u] = i < n && alive_new[i] != 0;
         cnt += valid[u] ? 1u : 0u;
     }
     uint32_t base = 0, total = 0;
     SmallScan().exclusive_scan(cnt, base, 0u, total, sh.st.scan);
-    uint32_t key[kSmallItems], val[kSmallItems];
+    uint32_t key[ITEMS], val[ITEMS];
     uint32_t mn[3] = {1023u, 1023u, 1023u}, mx[3] = {0u, 0u, 0u};
     uint32_t r = base;
 #pragma unroll
-    for (int u = 0; u < kSmallItems; ++u) {
-        const uint32_t i = tid * kSmallItems + u;
+    for (int u = 0; u < ITEMS; ++u) {
+        const uint32_t i = tid * ITEMS + u;
         key[u] = 0u;
         val[u] = 0u;
         if (valid[u]) {
@@ -986,17 +1093,37 @@ k_ins_sort_small(GridParams g, const float4* __restrict__ add, const uint8_t* __
     }
     __syncthreads();
     const int b1 = sh.bits[1], b2 = sh.bits[2], nbits = sh.bits[0] + b1 + b2;  // <= 30
-    uint32_t pk[kSmallItems];
+    uint32_t pk[ITEMS];
 #pragma unroll
-    for (int u = 0; u < kSmallItems; ++u) {
+    for (int u = 0; u < ITEMS; ++u) {
         const uint32_t f0 = ((key[u] >> 20) & 1023u) - sh.mn[0], f1 = ((key[u] >> 10) & 1023u) - sh.mn[1], f2 = (key[u] & 1023u) - sh.mn[2];
         pk[u] = valid[u] ? ((f0 << (b1 + b2)) | (f1 << b2) | f2) : (1u << nbits);  // monotone in (z, y, x) brick order; no point: behind all
     }
-    SmallSort().sort(pk, val, sh.st.sort, 0u, (unsigned)nbits + 1u);
-    __syncthreads();  // keys_tmp was written by other threads of this block
+    SmallSort<ITEMS>().sort(pk, val, small_sort_storage<ITEMS>(sh), 0u, (unsigned)nbits + 1u);
+    sh.last[tid] = pk[ITEMS - 1];
+    __syncthreads();  // keys_tmp was written by other threads of this block; the sort's storage is free for the scan
+    // the sorted positions at which a brick's run starts, listed in order for k_brick_rewrite_heads (the packed keys are one to one
+    // with the brick keys)
+    {
+        uint32_t prev = tid ? sh.last[tid - 1] : 0u, hc = 0;
+        bool hd[ITEMS];
 #pragma unroll
-    for (int u = 0; u < kSmallItems; ++u) {
-        const uint32_t j = tid * kSmallItems + u;
+        for (int u = 0; u < ITEMS; ++u) {
+            const uint32_t j = tid * ITEMS + u;
+            hd[u] = j < total && (j == 0u || pk[u] != prev);
+            hc += hd[u] ? 1u : 0u;
+            prev = pk[u];
+        }
+        uint32_t hb = 0, nheads = 0;
+        SmallScan().exclusive_scan(hc, hb, 0u, nheads, sh.st.scan);
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u)
+            if (hd[u]) heads[FLH_IDX(234, hb++, n)] = tid * ITEMS + u;
+        if (tid == 0) ctr[6] = nheads;
+    }
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+        const uint32_t j = tid * ITEMS + u;
         if (j < n) {
             const bool has = j < total;
             perm[j] = has ? val[u] : 0u;
@@ -1005,12 +1132,31 @@ k_ins_sort_small(GridParams g, const float4* __restrict__ add, const uint8_t* __
     }
     if (tid == 0) *n_alive_out = total;
 }
+
+__global__ void __launch_bounds__(kSmallThreads)
+k_ins_sort_small(GridParams g, const float4* __restrict__ add, const uint8_t* __restrict__ alive_new, uint32_t n, uint32_t n_ids,
+                 float4* __restrict__ map_orig, uint8_t* __restrict__ dead_id, float4* __restrict__ ins, uint32_t* __restrict__ keys_tmp,
+                 uint32_t* __restrict__ ks, uint32_t* __restrict__ perm, uint32_t* __restrict__ ctr, uint32_t* __restrict__ n_alive_out,
+                 uint32_t* __restrict__ heads, MiCounts mc) {
+    __shared__ SmallShared sh;
+    {
+        uint32_t n1_unused = 0;
+        if (!mi_counts(mc, n1_unused, n)) {  // block-uniform: a change larger than this launch was sized for -- nothing is done
+            if (threadIdx.x == 0) { *n_alive_out = 0u; ctr[6] = 0u; }
+            return;
+        }
+    }
+    // (block-uniform; the three bodies write the same outputs: a stable sort of the same keys)
+    if (n <= 2u * kSmallThreads) ins_sort_small_body<2>(sh, g, add, alive_new, n, n_ids, map_orig, dead_id, ins, keys_tmp, ks, perm, ctr, n_alive_out, heads);
+    else if (n <= 4u * kSmallThreads) ins_sort_small_body<4>(sh, g, add, alive_new, n, n_ids, map_orig, dead_id, ins, keys_tmp, ks, perm, ctr, n_alive_out, heads);
+    else ins_sort_small_body<8>(sh, g, add, alive_new, n, n_ids, map_orig, dead_id, ins, keys_tmp, ks, perm, ctr, n_alive_out, heads);
+}
 hipError_t launch_ins_sort_small(const GridParams& g, const float4* add, const uint8_t* alive_new, uint32_t n, uint32_t n_ids,
                                  float4* map_orig, uint8_t* dead_id, float4* ins, uint32_t* keys_tmp, uint32_t* ks, uint32_t* perm,
-                                 uint32_t* ctr, uint32_t* n_alive_out, hipStream_t st, const uint32_t* dev_counts) {
+                                 uint32_t* ctr, uint32_t* n_alive_out, uint32_t* heads, hipStream_t st, const uint32_t* dev_counts) {
     if (n == 0 || n > kSmallMax) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_ins_sort_small, dim3(1), dim3(kSmallThreads), 0, st, g, add, alive_new, n, n_ids, map_orig, dead_id, ins, keys_tmp,
-                       ks, perm, ctr, n_alive_out, MiCounts{dev_counts, n});
+                       ks, perm, ctr, n_alive_out, heads, MiCounts{dev_counts, n});
     return hipGetLastError();
 }
 
@@ -1019,38 +1165,33 @@ uint32_t cls_block_words(int N) { return 2u * (((uint32_t)(N > 0 ? N : 1) + 255u
 hipError_t launch_mi_classify(const GridParams& g, uint32_t hash_size, uint32_t map_points, const StateDev& s_search,
                               const StateDev& s_post, const float4* body, float4* nn_pts, uint32_t* nn_idx, const float4* map_orig,
                               uint32_t n_ids, const uint8_t* nn_cnt, float max_sqdist, int N, double fsm, int ekf_inited,
-                              const uint32_t* live, float4* world_out, uint8_t* cls, uint32_t* blk_cnt, uint32_t* far, hipStream_t st) {
-    if (N <= 0) return hipSuccess;
+                              const uint32_t* live, float4* world_out, uint8_t* cls, uint32_t* blk_cnt, uint32_t* far, hipStream_t st,
+                              unsigned long long* tab_fill, uint32_t tab_words) {
+    if (N <= 0) return tab_words ? hipErrorInvalidValue : hipSuccess;
     const NnSrc nn{nn_pts, nn_idx, map_orig, n_ids};
     const int defer_far = (map_points > 0 && ekf_inited) ? 1 : 0;  // else Nearest_Points[i] is empty / nobody looks at it (:463-466)
     hipLaunchKernelGGL(k_mi_classify, dim3(cdiv2(N, 256)), dim3(256), 0, st, s_post, s_search, body, nn, nn_cnt, max_sqdist, N,
-                       map_points, fsm, ekf_inited, world_out, cls, blk_cnt, far, defer_far);
+                       map_points, fsm, ekf_inited, world_out, cls, blk_cnt, far, defer_far, tab_fill, tab_words);
     if (defer_far)
         hipLaunchKernelGGL(k_far_search, dim3(min(cdiv2(N, 4), 512)), dim3(256), 0, st, g, s_post, s_search, body, hash_size, live, nn, nn_cnt,
                            max_sqdist, map_points, fsm, ekf_inited, cls, blk_cnt, far, N);
     return hipGetLastError();
 }
+static int vox_shift(uint32_t cap) { return 64 - (31 - __builtin_clz(cap)); }
 hipError_t launch_cls_compact(const float4* world, const uint8_t* cls, const uint32_t* blk_cnt, uint32_t* cnt_next, uint32_t next_words,
                               int N, float4* out, uint32_t* host_counts, uint32_t seq, hipStream_t st, uint32_t* dev_counts,
-                              unsigned long long* tab_fill, uint32_t tab_words, uint32_t* far) {
+                              uint32_t* far, unsigned long long* ins_tab, uint32_t ins_cap, double ins_ds, uint8_t* ins_alive_new,
+                              uint32_t* ins_ctr, uint32_t ins_bound) {
     if (N <= 0) return hipSuccess;
+    const AddIns ins{ins_tab, ins_tab ? ins_cap - 1u : 0u, ins_tab ? vox_shift(ins_cap) : 0, ins_ds, ins_alive_new, ins_ctr, ins_bound};
     hipLaunchKernelGGL(k_cls_compact, dim3(cdiv2(N, 256)), dim3(256), 0, st, world, cls, blk_cnt, cnt_next, next_words, N, out,
-                       host_counts, seq, dev_counts, tab_fill, tab_words, far);
+                       host_counts, seq, dev_counts, far, ins);
     return hipGetLastError();
 }
-// the counters of a map change and the number of points it inserted, as two granules, each carrying the sequence word (system-scope
-// stores need not reach the host in order): {storage top, bricks, re-index flags, seq} {removed, inserted, points of the change, seq}.
-// A change whose kernels found it larger than their launches (MiCounts) did nothing: flag kMapChangeNotApplied tells the host so.
 __global__ void k_map_publish(const uint32_t* __restrict__ ctr, const uint32_t* __restrict__ n_alive, uint32_t* __restrict__ host_out,
                               uint32_t seq, MiCounts mc) {
     if (threadIdx.x != 0) return;
-    const uint32_t c0 = ctr[0], c1 = ctr[1], c3 = ctr[3];
-    uint32_t c2 = ctr[2];
-    uint32_t na = n_alive ? *n_alive : 0u;
-    uint32_t n1 = 0, n = 0xFFFFFFFFu;  // the size of the change is not this kernel's to know unless the lengths live on the device
-    if (!mi_counts(mc, n1, n)) { c2 |= kMapChangeNotApplied; na = 0u; }
-    publish_granule(host_out, c0, c1, c2, seq);
-    publish_granule(host_out + 4, c3, na, n, seq);
+    map_publish(ctr, MapPublish{n_alive, host_out, seq}, mc);
 }
 hipError_t launch_map_publish(const uint32_t* ctr, const uint32_t* n_alive, uint32_t* host_out, uint32_t seq, hipStream_t st,
                               const uint32_t* dev_counts, uint32_t cap) {
@@ -1070,7 +1211,6 @@ uint32_t vox_table_slots(uint32_t n1) {
     while (cap < 2u * n1 && cap < (1u << 31)) cap <<= 1;
     return cap;
 }
-static int vox_shift(uint32_t cap) { return 64 - (31 - __builtin_clz(cap)); }
 hipError_t launch_add_insert(const float4* add, uint32_t n1, uint32_t n, double ds, u64* tab, uint32_t cap, uint8_t* alive_new,
                              uint32_t* ctr, hipStream_t st, const uint32_t* dev_counts) {
     if (n == 0) return hipSuccess;
@@ -1117,6 +1257,16 @@ hipError_t launch_brick_rewrite(const GridParams& g, float4* pts, uint32_t* star
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_brick_rewrite, dim3(n), dim3(128), 0, st, g, pts, starts, hash, cap_end, live, ctr, ins, ks, perm, n, pts_cap,
                        rows_cap, MiCounts{dev_counts, n});
+    return hipGetLastError();
+}
+hipError_t launch_brick_rewrite_heads(const GridParams& g, float4* pts, uint32_t* starts, uint2* hash, uint32_t* cap_end, uint32_t* live,
+                                      uint32_t* ctr, const float4* ins, const uint32_t* ks, const uint32_t* perm, uint32_t n,
+                                      uint32_t pts_cap, uint32_t rows_cap, hipStream_t st, const uint32_t* dev_counts, const uint32_t* heads,
+                                      uint32_t* tick, const uint32_t* n_alive, uint32_t* host_out, uint32_t seq) {
+    if (n == 0) return hipErrorInvalidValue;
+    static_assert(kTickWords >= 32u * (1u + 1024u / 32u), "a ticket line per 32 workgroups of the launch");
+    hipLaunchKernelGGL(k_brick_rewrite_heads, dim3(std::min(n, 1024u)), dim3(128), 0, st, g, pts, starts, hash, cap_end, live, ctr, ins, ks,
+                       perm, n, pts_cap, rows_cap, MiCounts{dev_counts, n}, heads, tick, MapPublish{n_alive, host_out, seq});
     return hipGetLastError();
 }
 hipError_t launch_byte_flags(const uint8_t* in, uint32_t n, int invert, uint32_t* flags, hipStream_t st, uint32_t* keys_sentinel) {

@@ -132,7 +132,7 @@ def test_map_incremental_matches_oracle(prob, fsm):
     rng = np.random.default_rng(3)
     tail = (pr.body[:400] * 0.0 + rng.uniform(150, 400, (400, 3))).astype(np.float32)
     # ... and of points in the empty space in and around the map, metres to tens of metres from the nearest map point (their
-    # points_near[0] comes from the shell search of k_far_nearest, which must stop at exactly the right shell)
+    # points_near[0] comes from the shell search of k_far_search, which must stop at exactly the right shell)
     lo, hi = pr.map_xyz.min(0) - 30.0, pr.map_xyz.max(0) + 30.0
     Rw, tw = synth.quat_to_R(pr.x_true[3:7]), pr.x_true[0:3]
     gaps_world = rng.uniform(lo, hi, (1500, 3))
@@ -642,14 +642,15 @@ def test_brickwise_updates_and_every_fallback(prob):
 def test_small_changes_in_one_workgroup_equal_the_general_path(prob, downsample):
     """flh_config.fused_small_changes: a change of at most 8192 points gives its surviving points their ids and sorts them by
     brick in one workgroup; larger ones (and every one with the option off) take the scan + device-wide sort.  Same map, same
-    bookkeeping, at the size limit and on both sides of it."""
+    bookkeeping, at the size limit and on both sides of it -- and of the sizes at which the workgroup changes the items a thread
+    sorts (2048, 4096)."""
     pr = prob
     rng = np.random.default_rng(77)
     hs = [capi.Handle(fused_small_changes=f) for f in (1, 0)]
     for h in hs:
         h.map_build(pr.map_xyz)
     cur = pr.map_xyz.astype(np.float32)
-    for n in (1, 2, 63, 1000, 8191, 8192, 8193, 5000):
+    for n in (1, 2, 63, 1000, 2048, 2049, 4096, 4097, 8191, 8192, 8193, 5000):
         add = (cur[rng.integers(0, len(cur), n)] + rng.normal(0, 0.25, (n, 3))).astype(np.float32)
         if n >= 63:  # crowded voxels, exact duplicates, a few new bricks beside the map
             add[: n // 8] = add[n // 8: 2 * (n // 8)]
@@ -662,6 +663,35 @@ def test_small_changes_in_one_workgroup_equal_the_general_path(prob, downsample)
             stats.append(h.map_stats())
         assert stats[0] == stats[1], (n, stats)
     assert search_matches(hs[0], cur, pr.body, pr.x_true) > 1000
+
+
+def test_small_change_in_which_no_point_survives(prob):
+    """Every new point loses its voxel to the point the map already holds there: nothing is inserted, no brick is rewritten --
+    k_brick_rewrite_heads has no workgroup with a brick to take the ticket, its first workgroup publishes the change's counters.
+    Then a change in which exactly one point survives (one workgroup, one ticket per level)."""
+    pr = prob
+    h = capi.Handle()
+    cur = po.map_add(np.zeros((0, 3), np.float32), pr.map_xyz[:20000].astype(np.float32), True, DS)   # one point per voxel
+    h.map_build(cur)
+    centre = (np.floor(cur.astype(np.float64) / DS) * DS + 0.5 * DS).astype(np.float32)
+    lose = cur[:3000] + (cur[:3000] - centre[:3000]) * np.float32(0.05)                                # a little farther from the centre
+    same_voxel = (np.floor(lose.astype(np.float64) / DS) == np.floor(cur[:3000].astype(np.float64) / DS)).all(1)
+    lose = np.ascontiguousarray(lose[same_voxel])
+    assert len(lose) > 2000
+    want = po.map_add(cur, lose, True, DS)
+    same_points(want, cur, "the oracle drops them all")
+    before = h.map_stats()
+    h.map_add(lose, True, DS)
+    same_points(h.map_download(), cur, "nothing survives")
+    after = h.map_stats()
+    assert after["brickwise"] == before["brickwise"] + 1 and after["reindex"] == before["reindex"]
+    assert all(after[k] == before[k] for k in ("slots_used", "ids", "bricks"))
+    one = np.ascontiguousarray(np.vstack([lose[:500], (cur.max(0) + np.float32(3.0))[None, :]]))
+    cur2 = po.map_add(cur, one, True, DS)
+    assert len(cur2) == len(cur) + 1
+    h.map_add(one, True, DS)
+    same_points(h.map_download(), cur2, "one survivor")
+    search_matches(h, cur2, pr.body, pr.x_true)
 
 
 def test_map_add_spanning_kilometres():
