@@ -58,6 +58,28 @@ __device__ __forceinline__ float4 nn_get(const NnSrc& s, size_t at) {
     return v;
 }
 
+// Rows FIRST..4 of query i, all requested before the first is looked at: one round trip for the indices, one for the coordinates
+// (map_incremental's decision used to make them one after the other as it went down the rows -- up to ten dependent trips).  Rows
+// the search did not fill hold whatever the buffer held: the caller looks at rows < nn_cnt only.
+template <int FIRST>
+__device__ __forceinline__ void nn_rows(const NnSrc& s, int i, int N, float4 (&near)[5]) {
+    if (s.idx) {
+        uint32_t id[5];
+#pragma unroll
+        for (int r = FIRST; r < 5; ++r) id[r] = s.idx[(size_t)r * N + i];
+#pragma unroll
+        for (int r = FIRST; r < 5; ++r) {
+            const bool ok = id[r] < s.n_ids;  // else: an empty row (k_nn_gather's rule)
+            float4 v = s.map_orig[FLH_IDX(232, ok ? id[r] : 0u, s.n_ids)];
+            v.w = __uint_as_float(id[r]);
+            near[r] = ok ? v : make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
+        }
+    } else {
+#pragma unroll
+        for (int r = FIRST; r < 5; ++r) near[r] = s.pts[(size_t)r * N + i];
+    }
+}
+
 // the shell search of ONE query by one wave (see above); wx, wy, wz = the world position the last search used
 // Returns the nearest point to every lane (.w = its id; 0xFFFFFFFF: the map holds no live point).
 __device__ __forceinline__ float4 far_search(const GridParams& g, int q, int lane, float wx, float wy, float wz, uint32_t hash_size,
@@ -188,11 +210,11 @@ __device__ __forceinline__ float4 far_search(const GridParams& g, int q, int lan
     return make_float4(__shfl(best_p.x, wl, 64), __shfl(best_p.y, wl, 64), __shfl(best_p.z, wl, 64), __shfl(best_p.w, wl, 64));
 }
 
-// map_incremental's decision for ONE scan point (src/laserMapping.cpp:441-466) given points_near[0] = n0: 0 = skip, 1 = PointToAdd,
-// 2 = PointNoNeedDownsample.  (wx, wy, wz): the point at the POSTERIOR state (:436); (sx, sy, sz): where the last search saw it --
-// pointSearchSqDis is measured from there, with the search's own expression (and bits).
-__device__ __forceinline__ uint8_t mi_decide(const NnSrc& nn, int i, int N, int cnt, int true_cnt, int ekf_inited, double fsm, float max_sqdist,
-                                             float wx, float wy, float wz, float sx, float sy, float sz, const float4& n0) {
+// map_incremental's decision for ONE scan point (src/laserMapping.cpp:441-466) given points_near = near[0 .. cnt): 0 = skip,
+// 1 = PointToAdd, 2 = PointNoNeedDownsample.  (wx, wy, wz): the point at the POSTERIOR state (:436); (sx, sy, sz): where the last
+// search saw it -- pointSearchSqDis is measured from there, with the search's own expression (and bits).
+__device__ __forceinline__ uint8_t mi_decide(int cnt, int true_cnt, int ekf_inited, double fsm, float max_sqdist,
+                                             float wx, float wy, float wz, float sx, float sy, float sz, const float4 (&near)[5]) {
     uint8_t c = 1;  // Nearest_Points[i].empty() || !flg_EKF_inited -> PointToAdd (:463-466)
     if (true_cnt > 0 && ekf_inited) {
         // mid_point members are float: each is a double expression narrowed to float (:443-445)
@@ -200,14 +222,16 @@ __device__ __forceinline__ uint8_t mi_decide(const NnSrc& nn, int i, int N, int 
         const float my = (float)(floor((double)wy / fsm) * fsm + 0.5 * fsm);
         const float mz = (float)(floor((double)wz / fsm) * fsm + 0.5 * fsm);
         const float dist = dist2(wx, wy, wz, mx, my, mz);  // calc_dist (:446)
-        if (fabs((double)(n0.x - mx)) > 0.5 * fsm && fabs((double)(n0.y - my)) > 0.5 * fsm &&
-            fabs((double)(n0.z - mz)) > 0.5 * fsm) {       // :447
+        if (fabs((double)(near[0].x - mx)) > 0.5 * fsm && fabs((double)(near[0].y - my)) > 0.5 * fsm &&
+            fabs((double)(near[0].z - mz)) > 0.5 * fsm) {       // :447
             c = 2;
         } else {
             bool need_add = true;
             if (true_cnt >= 5) {  // points_near.size() < NUM_MATCH_POINTS -> break (:454)
-                for (int r = 0; r < cnt; ++r) {
-                    const float4 pn = r == 0 ? n0 : nn_get(nn, (size_t)r * N + i);
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    if (r >= cnt) break;
+                    const float4 pn = near[r];
                     // pointSearchSqDis[r], the expression (and bits) the search compared (k_fill_d2 writes the same on demand)
                     const float d2r = (__float_as_uint(pn.w) == 0xFFFFFFFFu) ? INFINITY : dist2(sx, sy, sz, pn.x, pn.y, pn.z);
                     if (!(d2r <= max_sqdist)) break;  // beyond the bound: not a vetted neighbour, and too far to veto
@@ -257,12 +281,14 @@ k_mi_classify(StateDev s, StateDev s_search, const float4* __restrict__ body, Nn
         world_out[FLH_IDX(205, o, N)] = make_float4(wx, wy, wz, 0.f);
         const int cnt = nn_cnt[i];                              // found inside the bound, ascending
         const int true_cnt = map_points < 5u ? (int)map_points : 5;  // what the unbounded search returns
-        const float4 n0 = nn_get(nn, (size_t)i);               // points_near[0] as the bounded search left it
+        float4 near[5];                                         // points_near as the bounded search left them
+        nn_rows<0>(nn, i, N, near);
+        const float4 n0 = near[0];
         if (defer_far) {
             need = true;
             if (cnt != 0 && __float_as_uint(n0.w) != 0xFFFFFFFFu && dist2(sx, sy, sz, n0.x, n0.y, n0.z) <= max_sqdist) need = false;
         }
-        if (!need) mi_record(mi_decide(nn, i, N, cnt, true_cnt, ekf_inited, fsm, max_sqdist, wx, wy, wz, sx, sy, sz, n0), o, N, cls, blk_cnt);
+        if (!need) mi_record(mi_decide(cnt, true_cnt, ekf_inited, fsm, max_sqdist, wx, wy, wz, sx, sy, sz, near), o, N, cls, blk_cnt);
     }
     const unsigned long long bal = __ballot(need);
     if (bal == 0ull) return;
@@ -282,12 +308,14 @@ k_far_search(GridParams g, StateDev s, StateDev s_search, const float4* __restri
         const float4 b = body[q];
         float sx, sy, sz;
         body_to_world(s_search, b.x, b.y, b.z, sx, sy, sz);
-        const float4 n0 = far_search(g, q, lane, sx, sy, sz, hash_size, live, nn);  // (also left in row 0 of the neighbour cache)
+        float4 near[5];
+        near[0] = far_search(g, q, lane, sx, sy, sz, hash_size, live, nn);  // (also left in row 0 of the neighbour cache)
         if (lane == 0) {
             float wx, wy, wz;
             body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
             const int true_cnt = map_points < 5u ? (int)map_points : 5;
-            mi_record(mi_decide(nn, q, N, (int)nn_cnt[q], true_cnt, ekf_inited, fsm, max_sqdist, wx, wy, wz, sx, sy, sz, n0),
+            nn_rows<1>(nn, q, N, near);
+            mi_record(mi_decide((int)nn_cnt[q], true_cnt, ekf_inited, fsm, max_sqdist, wx, wy, wz, sx, sy, sz, near),
                       __float_as_uint(b.w), N, cls, blk_cnt);
         }
     }
