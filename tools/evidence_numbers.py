@@ -68,7 +68,7 @@ for cfg in (2, 3, 4, 5):
           f"{b['ms_search_pass'] * 1e3:.1f} / {b['ms_nosearch_pass'] * 1e3:.1f} us  first/later {ro.get('first_search_us')} / {ro.get('later_search_us')}  "
           f"frac {ro.get('frac')}  traffic {ro.get('traffic')}  repeats {(b.get('value_repeats') or {}).get('all')}")
     if cfg == 3:
-        print("   map change kernels:", {k: round(v[1], 2) for k, v in ks.items() if k in ("k_add_resolve", "k_ins_sort_small", "k_brick_rewrite", "k_nn_gather",
+        print("   map change kernels:", {k: round(v[1], 2) for k, v in ks.items() if k in ("k_add_resolve", "k_ins_sort_small", "k_brick_rewrite", "k_brick_rewrite_heads", "k_nn_gather", "k_cls_compact",
                                                                                            "k_far_search", "k_far_nearest", "k_mi_classify", "k_add_insert", "k_map_publish")},
               " mi call ms", b.get("ms_map_incremental_call_per_scan"))
     if cfg == 2:
