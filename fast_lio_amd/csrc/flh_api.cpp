@@ -154,6 +154,7 @@ struct flh_handle {
     // that turns out larger is not applied by those launches and replayed by map_settle()
     DevBuf<uint32_t> mi_cnt;
     DevBuf<uint32_t> mi_tick;          // k_brick_rewrite_heads' tickets (zero between launches)
+    uint64_t n_search_redone = 0;      // searching passes run again because the map change in front of them asked for a re-index / replay
     DevBuf<uint32_t> mi_far;           // [0] the number of scan points whose nearest map point lies outside the search bound, then the points
     uint32_t mi_pred_n = 0xFFFFFFFFu;  // points of the previous change (the prediction for the next one); unknown at first
     bool mi_deferred = false;          // the pending change was enqueued that way
@@ -228,6 +229,8 @@ struct flh_handle {
     uint64_t n_search_pass = 0, n_one_launch = 0, n_nosearch_pass = 0;
     struct PendingEval {           // between flh_eval_begin and flh_eval_end
         bool active = false, do_search = false, granules = false, one_launch = false, timed = false, deferred = false;
+        bool behind_map_change = false;  // enqueued behind a map change whose counters the host has not seen yet (flh_eval_end)
+        uint64_t reindexed = 0, replayed = 0;  // n_reindex / n_mi_replayed at that moment
         int ext = 0;
         double seq = 0;
     } pend;
@@ -733,6 +736,7 @@ int flh_map_build(flh_handle* h, const void* xyz, size_t stride_bytes, size_t M)
 // index is rebuilt from map_orig, which is always complete, and the ids are renumbered 0..M-1.
 static int reindex_from_ids(flh_handle* h) {
     hipStream_t st = h->stream;
+    pre_cancel(h);  // (a pass enqueued ahead of its state would sit in front of the synchronisations below)
     const size_t n_ids = h->n_ids;
     size_t total = 0;
     if (n_ids > 0) {
@@ -790,6 +794,7 @@ static int map_settle(flh_handle* h) {
             if (wait_granule(h, 0, h->mi_cls_seq, "map change (replay)") != 0) return -1;
             const uint32_t c1 = h->h_mi[0], c2 = h->h_mi[1] - h->h_mi[0];
             ++h->n_mi_replayed;
+            pre_cancel(h);  // (a pass enqueued ahead of its state would sit in front of the replayed kernels)
             if (apply_map_changes(h, h->mu_add.p, c1, c2, h->mi_pending_ds) != 0) return -1;
             return map_settle(h);
         }
@@ -1774,10 +1779,12 @@ static int ensure_nn_pts(flh_handle* h) {
 }
 
 static int enqueue_eval(flh_handle* h, const StateDev& s, int do_search, int ext, double* d_out, double seq, hipEvent_t* ev3,
-                        bool host_granules = false, bool rccl = false) {
+                        bool host_granules = false, bool rccl = false, bool behind_map_change = false) {
     const bool timed = ev3 != nullptr;  // four time stamps: first search kernel's start, last one's end, fit kernel's start and end
     hipStream_t st = h->stream;
-    if (h->map_pending && map_settle(h) != 0) return -1;  // a map change under way: its counters (and a re-index it asked for) first
+    // a map change under way: its counters (and a re-index it asked for) first -- unless the caller settles it itself while the pass
+    // waits behind the change on the stream (flh_eval_begin / flh_eval_end)
+    if (h->map_pending && !behind_map_change && map_settle(h) != 0) return -1;
     if (!h->cur_body || !h->selected.p) return fail("flh_eval: no active scan (flh_scan_upload / flh_scan_activate first)");
     if (!h->grid.hash && h->N > 0) return fail("flh_eval: no map (flh_map_build / flh_map_add first)");
     if (!do_search && !h->searched_once && h->N > 0)
@@ -2169,6 +2176,11 @@ int flh_set_prelaunch(flh_handle* h, int on) {
     if (h->pre.off) { pre_cancel(h); h->pre.expect = FLH_NEXT_UNKNOWN; }
     return 0;
 }
+int flh_debug_search_redone(const flh_handle* h, uint64_t* out) {
+    if (!h || !out) return fail("flh_debug_search_redone: null argument");
+    *out = h->n_search_redone;
+    return 0;
+}
 int flh_get_prelaunch_stats(const flh_handle* h, uint64_t out4[4]) {
     if (!h || !out4) return fail("flh_get_prelaunch_stats: null argument");
     out4[0] = h->pre.n_armed; out4[1] = h->pre.n_go; out4[2] = h->pre.n_abort; out4[3] = h->pre.n_gone;
@@ -2209,8 +2221,20 @@ int flh_eval_begin(flh_handle* h, const double rot[4], const double pos[3], cons
         // xGMI bandwidth is irrelevant), then one small kernel publishes the sum + sequence word to pinned host memory
         if (enqueue_eval(h, s, do_search, ext, h->gram.p, 0.0, ev3, false, true) != 0) return -1;
         if (rccl_allreduce_publish(h, pe.seq) != 0) return -1;
-    } else if (enqueue_eval(h, s, do_search, ext, h->h_gram, pe.seq, ev3, pe.granules) != 0) {
-        return -1;
+    } else {
+        // The first search of a scan follows the previous scan's map change (src/laserMapping.cpp:960 after :990 of the scan
+        // before).  A change enqueued without the host's wait publishes its counters when its last kernel ends; waiting for them
+        // HERE would leave the device idle from that moment until this pass's launch has travelled (granule to the host + launch
+        // call + dispatch: ~7 us per scan of the config-3 stream).  The pass kernel needs nothing of those counters -- the index is
+        // updated in place, behind the same pointers -- so it is enqueued behind the change now and the counters are folded in
+        // flh_eval_end; in the rare case that they ask for a re-index or a replay, the pass is run again on the settled map.
+        pe.behind_map_change = h->map_pending && h->mi_deferred && pe.one_launch && pe.granules && h->peer_n <= 1;
+        pe.reindexed = h->n_reindex;
+        pe.replayed = h->n_mi_replayed;
+#ifdef FLH_SETTLE_FIRST  // developer builds (A/B, tools/r06_call24.sh): the change's counters first, as before
+        pe.behind_map_change = false;
+#endif
+        if (enqueue_eval(h, s, do_search, ext, h->h_gram, pe.seq, ev3, pe.granules, false, pe.behind_map_change) != 0) return -1;
     }
     if (h->stats && do_search) HIPC(hipMemcpyAsync(h->h_counter, h->counter.p, sizeof(u64), hipMemcpyDeviceToHost, st));
     if (do_search) { h->n_search_pass++; if (pe.one_launch) h->n_one_launch++; } else h->n_nosearch_pass++;
@@ -2227,8 +2251,21 @@ int flh_eval_end(flh_handle* h, double HTH[144], double HTh[12], int64_t* n_eff,
     h->pend.active = false;
     HIPC(hipSetDevice(h->device));
     hipStream_t st = h->stream;
-    const double seq = pe.seq;
+    double seq = pe.seq;
     const bool do_search = pe.do_search, one_launch = pe.one_launch, timed = pe.timed, deferred = pe.deferred;
+    if (pe.behind_map_change) {
+        // the map change this pass was enqueued behind: its counters now (they were published before the pass started; another
+        // call may have collected them meanwhile)
+        if (map_settle(h) != 0) return -1;
+        if (h->n_reindex != pe.reindexed || h->n_mi_replayed != pe.replayed) {
+            // the pass searched an index that was about to be rebuilt (or a map without the change): once more, on the settled map
+            pre_cancel(h);
+            ++h->n_search_redone;
+            seq = (double)(++h->seq);
+            if (enqueue_eval(h, h->last_state, 1, pe.ext, h->h_gram, seq, nullptr, true) != 0) return -1;
+            if (h->stats) HIPC(hipMemcpyAsync(h->h_counter, h->counter.p, sizeof(u64), hipMemcpyDeviceToHost, st));
+        }
+    }
     if (pe.granules) {
         if (collect_granules(h, seq, do_search, pe.ext) != 0) return -1;
         if (h->stats) HIPC(hipStreamSynchronize(st));  // the candidate counter's copy

@@ -245,7 +245,9 @@ int flh_eval(flh_handle* h, const double rot_xyzw[4], const double pos[3], const
 /* The same evaluation in two halves: flh_eval_begin enqueues the pass and returns, flh_eval_end waits for its normal equations.
  * Between the two the caller's thread may do host work that does not depend on them (the mirror esekf projects the covariance
  * there -- include/fastlio_amd/esekfom.hpp).  One evaluation under way per handle; an error in flh_eval_begin
- * leaves none under way. */
+ * leaves none under way.  A searching evaluation that follows a flh_map_incremental(apply = 1, no counts asked) is enqueued BEHIND
+ * that map change without waiting for its counters; flh_eval_end folds them first and, when they ask for a re-index or a replay of
+ * the change, runs the pass once more on the settled map (the results are those of the settled map either way). */
 int flh_eval_begin(flh_handle* h, const double rot_xyzw[4], const double pos[3], const double offR_xyzw[4], const double offT[3],
                    int do_search, int extrinsic_est_en);
 int flh_eval_end(flh_handle* h, double HTH[144], double HTh[12], int64_t* n_eff, double* total_residual);

@@ -16,6 +16,10 @@ int flh_debug_pass_stamps(flh_handle* h, uint64_t* out, size_t words);
 /* The active scan's device order: order[i] = original index of the point at internal position i (what the staging's sort produced;
  * the tests compare the library's own staging kernels with the vendor sort through it). */
 int flh_debug_scan_order(flh_handle* h, uint32_t* order);
+/* Searching passes that were run a second time: a scan's first search is enqueued behind the previous scan's map change before the
+ * host has seen the change's counters (flh_eval_begin); when they then ask for a re-index or a replay (flh_eval_end), the pass is
+ * repeated on the settled map.  The tests provoke both cases and count them here. */
+int flh_debug_search_redone(const flh_handle* h, uint64_t* out);
 #ifdef __cplusplus
 }
 #endif

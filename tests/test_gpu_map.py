@@ -571,6 +571,47 @@ def test_map_incremental_enqueued_without_the_hosts_wait():
     h.close()
 
 
+def test_first_search_enqueued_behind_the_previous_map_change():
+    """A scan's first searching pass goes onto the stream BEHIND the previous scan's map change, before the host has seen the
+    change's counters (flh_eval_begin; they are folded in flh_eval_end).  Every search must equal the oracle's on the oracle's
+    map after the change -- also when the counters then say "not applied, replay" (a change that outgrew its launches) or "re-index"
+    (points outside the grid): the library repeats the pass on the settled map and counts it."""
+    M, N = 250000, 9000
+    pr0 = synth.make_problem(M, N, "velodyne", cfg=3)
+    scene = pr0.scene
+    h = capi.Handle()
+    h.map_build(pr0.map_xyz)
+    cur = pr0.map_xyz.astype(np.float32)
+    rng = np.random.default_rng(15)
+    grown, outside = (3,), (5,)
+    reindex0 = h.map_stats()["reindex"]
+    for k in range(8):
+        pr = synth.make_problem(M, N, "velodyne", cfg=3, scan_seed=40 + k, scene=scene)
+        body = np.ascontiguousarray(pr.body[:4000])
+        if k in grown:  # new ground: 12 000 points to insert behind a small change (launches for 8 192: replayed)
+            far = rng.uniform(-60, 60, (12000, 3)).astype(np.float32)
+            far[:, 2] = rng.uniform(300, 360, 12000).astype(np.float32)
+            body = np.ascontiguousarray(far)
+        if k in outside:  # a few points beyond the grid's extent: the change flags a re-index
+            out = (cur.max(0) + rng.uniform(200.0, 260.0, (50, 3))).astype(np.float32)
+            body = np.ascontiguousarray(np.vstack([body[:3000], out]))
+        # (from k = 1 on the previous change is still under way here: nothing between it and this search asks for the map)
+        assert search_matches(h, cur, body, pr.x_true) >= 0
+        m = po.Map(cur)
+        sc = po.Scan(body, nthreads=8)
+        sc.h_share_model(m, pr.x_true, True, False)
+        w_ref, c_ref = sc.map_incremental_classify(m, pr.x_true, DS, True)
+        h.map_incremental(pr.x_true, DS, True, apply=True, counts=(k == 0))
+        cur = po.map_add(po.map_add(cur, w_ref[c_ref == 1], True, DS), w_ref[c_ref == 2], False, DS)
+    redone = h.search_redone()
+    same_points(h.map_download(), cur, "map after the stream")
+    st = h.map_change_stats()
+    assert st["enqueued_without_wait"] >= 6 and st["replayed"] >= 1, st
+    assert h.map_stats()["reindex"] > reindex0
+    assert redone >= 2, redone   # the search behind the replayed change and the one behind the re-indexing change
+    h.close()
+
+
 # ---------------------------------------------------------------------------------------------- brick storage paths
 def test_brickwise_updates_and_every_fallback(prob):
     """The map index is changed brick by brick; whatever does not fit falls back to a full re-indexing from the id-ordered
