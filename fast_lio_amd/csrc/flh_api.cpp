@@ -666,7 +666,7 @@ static int rebuild_index_impl(flh_handle* h, DevBuf<float4>& pts, size_t M, bool
     g.starts = h->starts.p;
     g.pts = h->map_sorted.p;
 #ifdef FLH_BOUNDS
-    g.pts_cap = pts_cap; g.rows_cap = rows_cap; g.ids_cap = std::min(h->map_orig.cap, h->dead_id.cap);
+    g.pts_cap = pts_cap; g.rows_cap = rows_cap; g.ids_cap = std::min(pts.cap, h->dead_id.cap);  // (pts becomes map_orig below)
 #endif
     h->grid = g;
     h->nbricks = nbricks;
