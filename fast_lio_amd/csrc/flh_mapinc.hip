@@ -4,15 +4,18 @@
 //                     from the device-resident neighbour cache the last search left behind
 //   k_far_search      points_near[0] of the few scan points with no map point inside the search bound (shell search over bricks),
 //                     and their decision (k_mi_classify lists them)
+//   k_cls_compact     the two lists (PointToAdd, PointNoNeedDownsample) in original scan order, their lengths to host and device;
+//                     on the path without the host's wait also k_add_insert's step
 //   k_add_insert / k_add_resolve   ikdtree.Add_Points(points, downsample) (:470-471): per filter_size_map voxel the point
 //                     nearest to the voxel centre survives [ikd-Tree semantics, recalled-upstream; the oracle
 //                     (oracle_path.c: orc_map_add) states them]; the new points are grouped by voxel in a hash table (no sort)
 //   k_delete_boxes    ikdtree.Delete_Point_Boxes (:275)
 //
-//   k_ins_prepare (k_ins_sort_small for a scan's worth of points) / k_brick_rewrite   the surviving new points enter the brick
-//                     storage: only the bricks that receive points are rewritten (LDS counting sort, in place while they fit
-//                     their slack, else relocated); the whole index is rebuilt only when something no longer fits
-//                     (flh_api.cpp: apply_map_changes)
+//   k_ins_sort_small + k_brick_rewrite_heads (a scan's worth of points) / k_ins_prepare + library sort + k_brick_rewrite +
+//   k_map_publish (larger changes)   the surviving new points enter the brick storage: only the bricks that receive points are
+//                     rewritten (LDS counting sort, in place while they fit their slack, else relocated); the whole index is
+//                     rebuilt only when something no longer fits (flh_api.cpp: apply_map_changes); the change's counters go to
+//                     the host as granules (the last workgroup of k_brick_rewrite_heads, or k_map_publish)
 // Built with -ffp-contract=off like the rest.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
