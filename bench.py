@@ -204,6 +204,12 @@ def main():
     ap.add_argument("--two-streams", action="store_true", help="side legs: also time two scan streams on one GPU")
     ap.add_argument("--cache-dir", default=os.path.join(ROOT, ".bench_cache"),
                     help="where generated scans + priors are kept between runs ('' = do not cache)")
+    ap.add_argument("--diag-fresh-repeats", action="store_true",
+                    help="diagnostic (tools/r06_call28.sh): the repeats of the contract's region run scans nobody has seen yet "
+                         "instead of the region's own (is the region slower because its scans are new, or because it is first?)")
+    ap.add_argument("--diag-pretouch", type=int, default=0,
+                    help="diagnostic: before the warm-up, 1 = every scan's host buffer crosses PCIe once (to a scratch slot), "
+                         "2 = every scan is searched once against the map (resident): which first touch costs the contract's region?")
     ap.add_argument("--fresh-scans", action="store_true",
                     help="generate the scans in this process even when --cache-dir holds them (the condition of the two device faults "
                          "of rounds 2 and 3: 16 host threads allocating right before the GPU work; tools/fault_hunt.sh)")
@@ -336,7 +342,7 @@ def main():
                 self.ms_n, self.n_n = float(rs.ms_nosearch_passes), int(rs.n_nosearch_passes)
                 self.ms_mi = float(rs.ms_map_incremental)
 
-    def run(kfx, hx, jobs, n_warm, n_steps):
+    def run(kfx, hx, jobs, n_warm, n_steps, first=0):
         """W untimed warm-up scans, then EXACTLY n_steps scans inside one native call (flh_esekf_run_scans: the node's main
         loop, scan i+1 staged while scan i updates) bracketed by barrier + device synchronisation; max over ranks."""
         # Everything that costs the HOST time and leaves the device idle -- Python's cyclic GC (kept out of the timed region, as
@@ -355,11 +361,11 @@ def main():
         hx.set_timing_sampling(args.event_stride if args.event_stride > 0 else (0 if PROFILED else stride + 1 - (stride & 1)), True)
         # the stream does not stop at the boundary of the timed region: the first timed scan is staged while the last
         # warm-up scan updates, exactly as every later scan is staged while its predecessor updates
-        kfx.run_scans(jobs, 0, n_warm, ring=args.ring, map_incremental=with_map_inserts, stage_next=True)
+        kfx.run_scans(jobs, first, n_warm, ring=args.ring, map_incremental=with_map_inserts, stage_next=True)
         sync()
         hx.counters(reset=True)  # (the warm-up's samples are dropped)
         t1 = time.perf_counter()
-        rs = kfx.run_scans(jobs, n_warm, n_steps, ring=args.ring, map_incremental=with_map_inserts, first_staged=n_warm > 0)
+        rs = kfx.run_scans(jobs, first + n_warm, n_steps, ring=args.ring, map_incremental=with_map_inserts, first_staged=n_warm > 0)
         sync()
         dt_ = time.perf_counter() - t1
         gc.enable()
@@ -383,6 +389,12 @@ def main():
     replicas_out = None
     repeats = None
     if mode == "streams":
+        if args.diag_pretouch:  # (diagnostic only: never part of a reported line's contract)
+            for i, b in enumerate(bodies):
+                h.scan_upload(b)
+                if args.diag_pretouch >= 2:
+                    h.eval(np.asarray(priors[i][0], np.float64), True, False)
+            sync()
         dt, acc, ctr = run(kf, h, jobs_pipe, args.warmup, args.steps)
         units = args.steps * G
         n_pts = N
@@ -391,8 +403,11 @@ def main():
         # carries a spread beside its one number
         if args.repeats > 0 and not PROFILED:
             vals = [units / dt]
-            for _ in range(args.repeats):
-                dt_r, _a, _c = run(kf, h, jobs_pipe, 2, args.steps)
+            for r_ in range(args.repeats):
+                first_r = (args.warmup + args.steps + r_ * (args.steps + 2)) if args.diag_fresh_repeats else 0
+                if first_r + 2 + args.steps > len(bodies):
+                    first_r = 0
+                dt_r, _a, _c = run(kf, h, jobs_pipe, 2, args.steps, first_r)
                 vals.append(units / dt_r)
             sv = sorted(vals)
             repeats = {"regions": len(vals), "median": round(sv[len(sv) // 2], 3), "min": round(sv[0], 3), "max": round(sv[-1], 3),
