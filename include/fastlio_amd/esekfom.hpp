@@ -269,10 +269,13 @@ class esekf {
                 project_cov(P_, dx_new, dx, x_, x_propagated);  // :1659-1699
             }
 
+            double HTH[144], HTh[12];
+            bool kx_pending = false, six = true;  // (default algebra) K_x not formed yet: only the update's LAST pass reads it
+            Vec<n> dx_;
             if (n > dof_Measurement) {  // :1715-1744 gain form on explicit rows
                 gain_small(dyn_share, dof_Measurement, R, K_h, K_x);
+                dx_ = K_h + (K_x - cov::Identity()) * dx_new;  // :1815
             } else {  // :1782-1809 information form
-                double HTH[144], HTh[12];
                 normal_equations(dyn_share, dof_Measurement, HTH, HTh);
 #ifdef FASTLIO_AMD_REFERENCE_ALGEBRA
                 // the reference's own sequence (:1782,:1802): invert P / R, add HTH, invert again
@@ -281,6 +284,8 @@ class esekf {
                     for (int b = 0; b < 12; ++b) P_temp(a, b) += HTH[a * 12 + b];
                 // only P_inv.block<n,12>(0,0) is read below (:1803-1806): the first 12 columns of the inverse, bit for bit
                 const Mat<n, 12> P_inv = fastlio_amd::inverse_cols<n, 12>(P_temp);
+                gain_from_cols<12>(P_inv, HTH, HTh, K_h, K_x);
+                dx_ = K_h + (K_x - cov::Identity()) * dx_new;  // :1815
 #else
                 // The same 12 columns without either 23x23 inverse.  With A = (P / R)^-1 and U = [I12; 0] the reference forms
                 // (A + U HTH U^T)^-1 and reads its first 12 columns, (A + U HTH U^T)^-1 U.  By the push-through identity that is
@@ -290,27 +295,19 @@ class esekf {
                 // extrinsic estimation rows and columns 6..11 of HTH are zero (laserMapping.cpp:745), the columns 6..11 of
                 // P_inv then only ever multiply zeros, and the first six are B[:, :6] (I + HTH[:6, :6] B[:6, :6])^-1: a 6 x 6
                 // elimination.  The columns that are not computed are left zero.
-                bool six = true;
                 for (int a = 0; a < 12 && six; ++a)
                     for (int b = (a < 6 ? 6 : 0); b < 12; ++b)
                         if (HTH[a * 12 + b] != 0.0) { six = false; break; }
                 for (int a = 6; a < 12; ++a) six = six && HTh[a] == 0.0;
-                const Mat<n, 12> P_inv = six ? info_cols<6>(P_, R, HTH) : info_cols<12>(P_, R, HTH);
+                // The step is on the critical path of the NEXT pass (its state is x_ [+] dx_); K_h and K_x are not: K_x is read
+                // by the final covariance alone (:1836-1924).  With W = P_inv's columns, K_h = W HTh and K_x[:, :12] = W HTH, so
+                //     dx_ = K_h + (K_x - I) dx_new  =  B[:, :NC] S^-1 (HTh + HTH dx_new[:NC]) - dx_new,   S = I + HTH B[:NC, :NC]:
+                // ONE right-hand side instead of 23 and no 23 x NC x NC product per pass; K_x is formed once, for the pass that
+                // ends the update (the reference's sequence: -DFASTLIO_AMD_REFERENCE_ALGEBRA).
+                dx_ = six ? info_step<6>(P_, R, HTH, HTh, dx_new) : info_step<12>(P_, R, HTH, HTh, dx_new);
+                kx_pending = true;
 #endif
-                for (int r = 0; r < n; ++r) {
-                    double s = 0;
-                    for (int c = 0; c < 12; ++c) s += P_inv(r, c) * HTh[c];
-                    K_h[r] = s;
-                }
-                K_x = cov::Zero();
-                for (int r = 0; r < n; ++r)
-                    for (int b = 0; b < 12; ++b) {
-                        double s = 0;
-                        for (int c = 0; c < 12; ++c) s += P_inv(r, c) * HTH[c * 12 + b];
-                        K_x(r, b) = s;
-                    }
             }
-            const Vec<n> dx_ = K_h + (K_x - cov::Identity()) * dx_new;  // :1815
             x_.boxplus(dx_);
             dyn_share.converge = true;
             for (int j = 0; j < n; j++) {
@@ -324,7 +321,13 @@ class esekf {
 
             if (t > 1 || i == maximum_iter - 1) {  // :1834-1928
                 finish_hint(dyn_share);
-                final_cov(P_, K_x, dx_, x_, x_propagated);
+                if (kx_pending) {
+                    const Mat<n, 12> P_inv = six ? info_cols<6>(P_, R, HTH) : info_cols<12>(P_, R, HTH);
+                    if (six) gain_from_cols<6>(P_inv, HTH, HTh, K_h, K_x);
+                    else gain_from_cols<12>(P_inv, HTH, HTh, K_h, K_x);
+                }
+                if (kx_pending && six) final_cov<6>(P_, K_x, dx_, x_, x_propagated);
+                else final_cov<12>(P_, K_x, dx_, x_, x_propagated);
                 stats_.returned_in_loop = 1;
                 const double ms = std::chrono::duration<double, std::milli>(clk::now() - solve_start).count();
                 stats_.solve_ms += ms;
@@ -369,6 +372,49 @@ class esekf {
         x_.build_S2_state();
         x_.build_SO3_state();
         x_.build_vect_state();
+    }
+    // K_h = P_inv HTh, K_x[:, :12] = P_inv HTH (:1803-1806)
+    // (nc = 6: columns 6..11 of P_inv and of HTH are zero -- the terms left out are products with zero)
+    template <int nc>
+    static void gain_from_cols(const Mat<n, 12>& P_inv, const double HTH[144], const double HTh[12], Vec<n>& K_h, cov& K_x) {
+        for (int r = 0; r < n; ++r) {
+            double s = 0;
+            for (int c = 0; c < nc; ++c) s += P_inv(r, c) * HTh[c];
+            K_h[r] = s;
+        }
+        K_x = cov::Zero();
+        for (int r = 0; r < n; ++r)
+            for (int b = 0; b < nc; ++b) {
+                double s = 0;
+                for (int c = 0; c < nc; ++c) s += P_inv(r, c) * HTH[c * 12 + b];
+                K_x(r, b) = s;
+            }
+    }
+    // dx_ of :1815 from one NC x NC elimination with ONE right-hand side (see the call site)
+    template <int NC>
+    static Vec<n> info_step(const cov& P, double R, const double HTH[144], const double HTh[12], const vectorized_state& dx_new) {
+        double S[NC * NC], B11[NC * NC], g[NC], v[NC];
+        const double rinv = 1.0 / R;
+        for (int a = 0; a < NC; ++a)
+            for (int b = 0; b < NC; ++b) B11[a * NC + b] = P(a, b) * rinv;
+        for (int a = 0; a < NC; ++a) {
+            for (int b = 0; b < NC; ++b) {
+                double s = 0;
+                for (int c = 0; c < NC; ++c) s += HTH[a * 12 + c] * B11[c * NC + b];
+                S[a * NC + b] = s + (a == b ? 1.0 : 0.0);
+            }
+            double s = HTh[a];
+            for (int c = 0; c < NC; ++c) s += HTH[a * 12 + c] * dx_new[c];
+            g[a] = s;
+        }
+        fastlio_amd::solve_lu_fixed<NC, 1>(S, g, v);
+        Vec<n> dx;
+        for (int r = 0; r < n; ++r) {
+            double s = 0;
+            for (int c = 0; c < NC; ++c) s += (P(r, c) * rinv) * v[c];
+            dx[r] = s - dx_new[r];
+        }
+        return dx;
     }
     // The first NC columns of P_inv.block<n,12>(0,0) of :1802 as B[:, :NC] (I + HTH[:NC, :NC] B[:NC, :NC])^-1 with B = P / R
     // (see the call site); the other columns are zero
@@ -439,6 +485,9 @@ class esekf {
         }
     }
     // :1836-1924
+    // (nc: the columns of K_x that are not structurally zero -- 6 without extrinsic estimation, else 12: what is left out are
+    // products with zero)
+    template <int nc>
     void final_cov(cov& P, cov& K_x, const Vec<n>& dx_, state& x, state& x_prop) {
         L_ = P;
         for (auto it = x.SO3_state.begin(); it != x.SO3_state.end(); it++) {
@@ -447,7 +496,7 @@ class esekf {
             for (int i = 0; i < 3; i++) seg[i] = dx_[i + idx];
             const fastlio_amd::M3 J = MTK::A_matrix(seg).transpose();
             for (int i = 0; i < n; i++) L_.template set_block<3, 1>(idx, i, J * P.template block<3, 1>(idx, i));
-            for (int i = 0; i < 12; i++) K_x.template set_block<3, 1>(idx, i, J * K_x.template block<3, 1>(idx, i));
+            for (int i = 0; i < nc; i++) K_x.template set_block<3, 1>(idx, i, J * K_x.template block<3, 1>(idx, i));
             for (int i = 0; i < n; i++) {
                 L_.template set_block<1, 3>(i, idx, L_.template block<1, 3>(i, idx) * J.transpose());
                 P.template set_block<1, 3>(i, idx, P.template block<1, 3>(i, idx) * J.transpose());
@@ -463,7 +512,7 @@ class esekf {
             x_prop.S2_Mx(Mx, seg, idx);
             const Mat<2, 2> J = Nx * Mx;
             for (int i = 0; i < n; i++) L_.template set_block<2, 1>(idx, i, J * P.template block<2, 1>(idx, i));
-            for (int i = 0; i < 12; i++) K_x.template set_block<2, 1>(idx, i, J * K_x.template block<2, 1>(idx, i));
+            for (int i = 0; i < nc; i++) K_x.template set_block<2, 1>(idx, i, J * K_x.template block<2, 1>(idx, i));
             for (int i = 0; i < n; i++) {
                 L_.template set_block<1, 2>(i, idx, L_.template block<1, 2>(i, idx) * J.transpose());
                 P.template set_block<1, 2>(i, idx, P.template block<1, 2>(i, idx) * J.transpose());
@@ -473,7 +522,7 @@ class esekf {
         for (int r = 0; r < n; ++r)
             for (int c = 0; c < n; ++c) {
                 double s = 0;
-                for (int k = 0; k < 12; ++k) s += K_x(r, k) * P(k, c);
+                for (int k = 0; k < nc; ++k) s += K_x(r, k) * P(k, c);
                 Pn(r, c) = L_(r, c) - s;
             }
         P = Pn;
