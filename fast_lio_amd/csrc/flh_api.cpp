@@ -1926,6 +1926,16 @@ static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
             }
         }
     };
+    // The granules of a group are nsl x 16 bytes that a DEVICE has just written: the first read of every 64-byte line misses all
+    // the way (~0.1 us), and the pick-up loop -- one load, one compare, one add per granule -- keeps only a handful of those misses
+    // in flight.  The lines of the group that is read NEXT are requested while this one is read: if they have landed they are in
+    // the cache when their turn comes; if not, the request costs nothing that the poll would not have cost.  With the extrinsic
+    // columns a pass publishes 25 x 94 granules = 588 lines (194 without), and a no-search pass's groups land within 3 us of each
+    // other: the host was the last to finish (profiles/r06_call33/: the columns cost k_fit 0.7 us and the pass 3 us).
+    auto prefetch_group = [&](const double* gg) {
+        const char* p = reinterpret_cast<const char*>(gg);
+        for (int b = 0; b < nsl * 16; b += 64) _mm_prefetch(p + b, _MM_HINT_T0);
+    };
     // A one-launch searching pass hands the END of the scan's order to the workgroups dispatched first, and workgroups finish in
     // dispatch order: its groups arrive LAST GROUP FIRST, and a section's header -- group 0's reducer
     // publishes it behind its sums -- is the very last granule of the pass.  Waiting for the header and only then reading 25 x 30
@@ -1980,6 +1990,8 @@ static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
                 if (gi < 0 || !taken[r]) continue;
                 const double* sect = base + (size_t)r * kGranSect * 2;
                 const double* gg = sect + 2 * (1 + (size_t)gi * nsl);
+                if (gi > 0) prefetch_group(gg - 2 * (size_t)nsl);  // (the groups arrive last first)
+                if (gi > 1) prefetch_group(gg - 4 * (size_t)nsl);
                 for (int k = 0; k < nsl; ++k) {
                     const int rc = (r == h->peer_rank) ? wait_for(gg + 2 * k, &val[off[r] + (size_t)gi * nsl + k])
                                                        : wait_hinted(gg + 2 * k, &val[off[r] + (size_t)gi * nsl + k], sect);
@@ -2012,6 +2024,8 @@ static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
         h->sect_ng[r] = cnt / nsl;
         for (int gi = 0; gi < cnt / nsl; ++gi) {
             const double* gg = sect + 2 * (1 + (size_t)gi * nsl);
+            if (gi + 1 < cnt / nsl) prefetch_group(gg + 2 * (size_t)nsl);
+            if (gi + 2 < cnt / nsl) prefetch_group(gg + 4 * (size_t)nsl);
             for (int k = 0; k < nsl; ++k) {
                 double v;
                 if (wait_for(gg + 2 * k, &v) != 0) return -1;
