@@ -130,6 +130,98 @@ def pmc_traffic(args):
             "source": os.path.relpath(path, ROOT) + " (FETCH_SIZE x2 + WRITE_SIZE, KiB)"}
 
 
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            out += list(range(int(a), int(b) + 1))
+        elif part:
+            out.append(int(part))
+    return out
+
+
+def _all_tasks_affinity(cpus):
+    """The affinity of every thread this process has (new threads inherit their creator's)."""
+    for t in os.listdir("/proc/self/task"):
+        try:
+            os.sched_setaffinity(int(t), cpus)
+        except OSError:
+            pass
+
+
+def binding_cpus(mode, bdf, node, local, gpus, sib, l3_of):
+    """Which CPUs `mode` gives the process of GPU `bdf` (pure: tests/test_bench_binding.py).  local: the allowed CPUs of the GPU's
+    NUMA node; gpus: the node's GPUs in PCI order; sib[c]: the hardware threads of c's core; l3_of(c): the CPUs behind c's L3."""
+    cpus, note = sorted(local), f"NUMA node {node} of GPU {bdf}"
+    if mode not in ("share", "l3", "l3smt"):
+        return cpus, note
+    phys = [c for c in sorted(local) if sib[c][0] == c]
+    if bdf not in gpus or len(phys) < 4 * len(gpus):
+        return cpus, note
+    per = len(phys) // len(gpus)
+    i = gpus.index(bdf)
+    share = phys[i * per:(i + 1) * per]
+    note = f"GPU {bdf}: share {i + 1} of {len(gpus)} of NUMA node {node}'s {len(phys)} physical cores"
+    if mode in ("l3", "l3smt"):  # the cores of the share that sit behind ONE L3 (a CCD): the threads' shared lines stay in it
+        l3 = set(l3_of(share[0]))
+        ccd = [c for c in share if c in l3]
+        if len(ccd) >= 4:
+            share = ccd
+            note += f", the {len(ccd)} of them behind one L3"
+    if mode == "l3":  # one hardware thread per core: two of the process's busy threads never share a core
+        return sorted(share), note
+    allowed = set(local)
+    return sorted({t for c in share for t in sib[c] if t in allowed}), note + ", with SMT siblings"
+
+
+def bind_to_gpu(device_index, mode):
+    """One process per GPU, bound to its GPU's share of the host (what `numactl` / the launcher's binding does in a deployment).
+    The update's thread spins on granules the GPU writes over PCIe, the staging thread and the HIP runtime's own threads talk to it
+    through shared cache lines: left to the scheduler on a two-socket host they end up on different sockets, behind different L3s
+    or on the two hardware threads of one core, and the pipelined loop loses 3-9 % (profiles/r06_call36/ ... r06_call38/).
+    The share: the physical cores of the GPU's NUMA node divided among that node's GPUs in PCI order (so eight such processes on
+    an 8-GPU host do not overlap).  Same box, alternating (profiles/r06_call38/): the driver's command 7 649 scans/s unbound,
+    7 893 on the share, 8 042 on the share's cores behind ONE L3 without their SMT siblings; 300 steps 7 858 / 8 435 / 8 592 -- and
+    only the last never fell into the slow mode (whole 37-ms regions 13-17 % low) that the others show now and then.
+    mode: "l3" (default: the cores of the share behind ONE L3, one hardware thread each) | "l3smt" (with the SMT siblings) |
+    "share" (the whole share, with SMT siblings) | "node" | "off".  Returns what was done (for the line's config) or None;
+    never raises."""
+    if mode == "off" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        import glob
+
+        import torch
+
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        dev = f"/sys/bus/pci/devices/{bdf}"
+        node = int(open(dev + "/numa_node").read())
+        allowed = os.sched_getaffinity(0)
+        local = [c for c in _cpulist(open(dev + "/local_cpulist").read()) if c in allowed]
+        if not local:
+            return None
+        gpus, sib, l3_of = [], {}, None
+        if mode in ("share", "l3", "l3smt"):
+            for d in sorted(glob.glob("/sys/bus/pci/devices/*")):
+                try:
+                    if (open(d + "/vendor").read().strip() == "0x1002" and open(d + "/class").read().strip()[:6] in ("0x1200", "0x0302", "0x0380")
+                            and int(open(d + "/numa_node").read()) == node):
+                        gpus.append(os.path.basename(d))
+                except (OSError, ValueError):
+                    pass
+            sib = {c: _cpulist(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read()) for c in local}
+            l3_of = lambda c: _cpulist(open(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list").read())  # noqa: E731
+        cpus, note = binding_cpus(mode, bdf, node, local, gpus, sib, l3_of)
+        before = sorted(allowed)
+        _all_tasks_affinity(cpus)
+        return {"mode": mode, "cpus": len(cpus), "first_cpu": cpus[0], "note": note, "_restore": before}
+    except Exception as e:  # noqa: BLE001 -- no /sys, a container without the files, an old torch: run unbound
+        log(f"[bench] host binding skipped: {e!r}")
+        return None
+
+
 def load_scene(args, M):
     """The seeded scene; the big ones (>= 10M points: tens of seconds of numpy) are kept in --cache-dir between runs."""
     seed = synth.CONFIG_SEED_BASE + args.config
@@ -204,9 +296,15 @@ def main():
     ap.add_argument("--two-streams", action="store_true", help="side legs: also time two scan streams on one GPU")
     ap.add_argument("--cache-dir", default=os.path.join(ROOT, ".bench_cache"),
                     help="where generated scans + priors are kept between runs ('' = do not cache)")
+    ap.add_argument("--bind", default="l3", choices=["l3", "l3smt", "share", "node", "off"],
+                    help="host binding of this process (one process per GPU): l3 = the cores behind one L3 inside the GPU's share of "
+                         "its NUMA node's cores, one hardware thread each (default); l3smt = with their SMT siblings; share = that "
+                         "whole share; node = the whole node; off = leave it to the scheduler")
     ap.add_argument("--diag-fresh-repeats", action="store_true",
                     help="diagnostic (tools/r06_call28.sh): the repeats of the contract's region run scans nobody has seen yet "
                          "instead of the region's own (is the region slower because its scans are new, or because it is first?)")
+    ap.add_argument("--diag-staging", action="store_true",
+                    help="diagnostic: per region, the library's staging / activation counters (flh_debug_stage_stats) -> staging_diag")
     ap.add_argument("--diag-pretouch", type=int, default=0,
                     help="diagnostic: before the warm-up, 1 = every scan's host buffer crosses PCIe once (to a scratch slot), "
                          "2 = every scan is searched once against the map (resident): which first touch costs the contract's region?")
@@ -306,6 +404,8 @@ def main():
     probs, priors = gen(1000 * rank if G > 1 else 0, S)
     S_sh = min(S, 8)
     sh_probs, sh_priors = (gen(0, S_sh) if (rank != 0 and G > 1) else (probs[:S_sh], priors[:S_sh])) if run_shard_leg else (None, None)
+    # (after the scans' generation -- sixteen worker threads -- and before the library's threads and the page-locked buffers exist)
+    binding = bind_to_gpu(local_rank, args.bind)
     # the scans as the node would hold them: host buffers (page-locked so that the DMA engine reads them where they lie)
     bodies = []
     for p in probs:
@@ -342,6 +442,8 @@ def main():
                 self.ms_n, self.n_n = float(rs.ms_nosearch_passes), int(rs.n_nosearch_passes)
                 self.ms_mi = float(rs.ms_map_incremental)
 
+    staging_diag = []  # (--diag-staging)
+
     def run(kfx, hx, jobs, n_warm, n_steps, first=0):
         """W untimed warm-up scans, then EXACTLY n_steps scans inside one native call (flh_esekf_run_scans: the node's main
         loop, scan i+1 staged while scan i updates) bracketed by barrier + device synchronisation; max over ranks."""
@@ -364,10 +466,22 @@ def main():
         kfx.run_scans(jobs, first, n_warm, ring=args.ring, map_incremental=with_map_inserts, stage_next=True)
         sync()
         hx.counters(reset=True)  # (the warm-up's samples are dropped)
+        if args.diag_staging:
+            hx.stage_stats(reset=True)
         t1 = time.perf_counter()
         rs = kfx.run_scans(jobs, first + n_warm, n_steps, ring=args.ring, map_incremental=with_map_inserts, first_staged=n_warm > 0)
         sync()
         dt_ = time.perf_counter() - t1
+        if args.diag_staging:
+            sd = hx.stage_stats()
+            nj, na = max(sd["jobs"], 1.0), max(sd["activations"], 1.0)
+            staging_diag.append({"scans_per_s": round(n_steps / dt_, 1), "ms_search_pass": round(float(rs.ms_search_passes) / max(int(rs.n_search_passes), 1), 4),
+                                 "ms_nosearch_pass": round(float(rs.ms_nosearch_passes) / max(int(rs.n_nosearch_passes), 1), 4),
+                                 "stage_enq_us": round(sd["enq_us"] / nj, 2), "stage_enq_max_us": round(sd["enq_max_us"], 1),
+                                 "h2d_wait_us": round(sd["h2d_wait_us"] / nj, 2), "h2d_wait_max_us": round(sd["h2d_wait_max_us"], 1),
+                                 "act_wait_us": round(sd["act_wait_us"] / na, 2), "act_wait_max_us": round(sd["act_wait_max_us"], 1),
+                                 "act_event_not_ready": int(sd["act_event_not_ready"]), "act_slot_pending": int(sd["act_slot_pending"]),
+                                 "jobs": int(sd["jobs"]), "activations": int(sd["activations"])})
         gc.enable()
         hx.set_timing_stride(0)
         if dist is not None:
@@ -597,6 +711,7 @@ def main():
                                     f", normal equations summed per pass ({used if run_shard_leg else args.exchange})"
                                     if mode in ("shard", "partition") else
                                     f"{G} independent scan streams (one per rank), replicated map, no collective in the data path")),
+                   "host_binding": ({k: v for k, v in binding.items() if not k.startswith("_")} if binding else "none"),
                    "distinct_scans": S, "staging_ring": args.ring, "cell_size_m": args.cell, "lanes_per_query": args.lpq,
                    "searching_pass": "one launch (k_pass)" if one_launch else "three launches (two search stages + fit)",
                    "plane_cache": args.plane_cache, "plane_fit": "fp16 ABLATION (not bit-exact)" if args.plane_fit_dtype else "fp32 (reference-exact)",
@@ -610,6 +725,8 @@ def main():
     }
     if repeats is not None:
         out["value_repeats"] = repeats
+    if staging_diag:
+        out["staging_diag"] = staging_diag  # diagnostic: one entry per region run()
     if with_map_inserts:
         # host time inside flh_map_incremental per scan: enqueueing the classification and the Add_Points work (nobody asks for the
         # two list lengths, so the host does not wait for them when the previous change was of a scan's usual size); the device
@@ -678,6 +795,9 @@ def main():
     # small thread sweep -- the restated k-d tree path stops scaling long before "all cores" on a many-core host
     if rank == 0 and G == 1 and args.cpu_scans > 0:
         from oracle import pyoracle as po
+
+        if binding:  # the CPU baseline gets the whole host, as before: its OpenMP threads are created from here
+            _all_tasks_affinity(binding["_restore"])
 
         m = po.Map(scene.map_xyz)  # k-d tree build is outside the reference's t_update window too
         ncores = os.cpu_count() or 1
@@ -777,7 +897,7 @@ def run_extra_legs_in_child(args):
     cmd = [sys.executable, os.path.abspath(__file__), "--leg", "extras", "--config", str(args.config), "--lpq", str(args.lpq),
            "--cell", str(args.cell), "--pass-kernel", str(args.pass_kernel), "--sort", str(args.sort),
            "--extrinsic-est", str(args.extrinsic_est), "--steps", str(args.steps), "--index-cache", str(args.index_cache), "--stage-sort", str(args.stage_sort),
-           "--prelaunch", str(args.prelaunch)]
+           "--prelaunch", str(args.prelaunch), "--bind", args.bind]
     if args.two_streams:
         cmd.append("--two-streams")
     try:
@@ -796,6 +916,8 @@ def run_extra_legs_in_child(args):
 def extra_legs(args):
     """The child: SURVEY 8(f) timings beside the headline.  Prints one JSON dict."""
     import torch
+
+    bind_to_gpu(0, args.bind)
 
     M, N, sensor = CONFIGS[args.config]
     ext = bool(args.extrinsic_est)

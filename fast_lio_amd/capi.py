@@ -98,7 +98,7 @@ EXPORTS = [
     "flh_scan_stage_async", "flh_scan_wait", "flh_host_alloc", "flh_host_free", "flh_frame_world", "flh_points_body_to_world",
     "flh_esekf_last_error", "flh_rccl_unique_id", "flh_rccl_init_rank", "flh_rccl_init_all", "flh_rccl_destroy", "flh_rccl_size",
     "flh_rccl_rank", "flh_eval_group", "flh_set_owned_interval", "flh_esekf_run_scans", "flh_get_search_counters", "flh_set_timing_sampling",
-    "flh_map_sync", "flh_eval_begin", "flh_eval_end", "flh_debug_bounds", "flh_debug_pass_stamps", "flh_debug_scan_order", "flh_debug_search_redone", "flh_peer_open", "flh_peer_init_all", "flh_peer_close", "flh_peer_size", "flh_peer_rank", "flh_get_pass_stats", "flh_map_change_stats",
+    "flh_map_sync", "flh_eval_begin", "flh_eval_end", "flh_debug_bounds", "flh_debug_pass_stamps", "flh_debug_scan_order", "flh_debug_search_redone", "flh_debug_stage_stats", "flh_peer_open", "flh_peer_init_all", "flh_peer_close", "flh_peer_size", "flh_peer_rank", "flh_get_pass_stats", "flh_map_change_stats",
     "flh_eval_expect_next", "flh_set_prelaunch", "flh_get_prelaunch_stats", "flh_map_storage_stats",
 ]
 
@@ -255,6 +255,7 @@ def _declare(L):
     L.flh_fetch_scan.argtypes = [C.c_void_p, C.c_void_p]
     L.flh_debug_scan_order.argtypes = [C.c_void_p, C.c_void_p]
     L.flh_debug_search_redone.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.flh_debug_stage_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     L.flh_scan_stage_undistorted.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
                                              C.c_int, _f64p, C.c_float, C.c_void_p, C.POINTER(C.c_size_t)]
     L.flh_get_counters.argtypes = [C.c_void_p, _f64p, C.c_int]
@@ -380,6 +381,14 @@ class Handle:
         out = C.c_uint64(0)
         _chk(lib().flh_debug_search_redone(self._h, C.byref(out)), "flh_debug_search_redone")
         return int(out.value)
+
+    def stage_stats(self, reset=False) -> dict:
+        """Developer counters of the staging / activation hand-over -- flh_debug_stage_stats."""
+        out = (C.c_double * 10)()
+        _chk(lib().flh_debug_stage_stats(self._h, out, 1 if reset else 0), "flh_debug_stage_stats")
+        k = ("jobs", "enq_us", "enq_max_us", "h2d_wait_us", "h2d_wait_max_us", "activations", "act_wait_us", "act_wait_max_us",
+             "act_event_not_ready", "act_slot_pending")
+        return {n: float(out[i]) for i, n in enumerate(k)}
 
     def map_download(self) -> np.ndarray:
         out = np.zeros((self.M, 3), np.float32)

@@ -318,6 +318,12 @@ struct flh_handle {
     DevBuf<uint32_t> st_v0, st_v1;
     DevBuf<unsigned char> st_tmp;
     std::atomic<uint64_t> st_posted{0};  // jobs ever handed to the staging thread (what it polls before it sleeps)
+    // developer counters (flh_debug_stage_stats): where a scan's staging and its activation spend their time.  [0..4] are written by
+    // whoever stages (the staging thread in a running stream), [5..9] by the caller's thread; read after the stream has drained
+    struct StageDiag {
+        double n_jobs = 0, enq_us = 0, enq_max_us = 0, h2d_wait_us = 0, h2d_wait_max_us = 0;
+        double n_act = 0, act_wait_us = 0, act_wait_max_us = 0, act_ev_not_ready = 0, act_slept = 0;
+    } sdiag;
     // The pre-launched no-search pass (flh_eval_expect_next; device side: flh_mail_dev.hpp, k_fit_mb in flh_kernels.hip).
     //   expect     what the caller said the evaluation AFTER the next flh_eval_begin will be (consumed by that begin)
     //   armed      a k_fit_mb sits in the stream waiting for mailbox sequence `mseq`; it will publish with granule sequence `eval_seq`
@@ -1198,6 +1204,7 @@ static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size
     if ((stride_bytes < 12 || (stride_bytes & 3)) && N > 0) return fail("scan staging: stride_bytes must be a multiple of 4 and >= 12");
     if (N >= (1ull << 26)) return fail("scan staging: N too large");
     const int lane = (int)((&sl - h->slots) & 1);  // odd slots: the second lane (the ring's scans alternate)
+    const auto t_job = std::chrono::steady_clock::now();
     if (stage_prepare(h, sl, lane) != 0) return -1;
     const StageLane L = stage_lane(h, lane);
     hipStream_t cs = L.cs;
@@ -1232,7 +1239,16 @@ static int stage_into(flh_handle* h, flh_handle::Slot& sl, const void* pts, size
                                        do_sort ? L.m0.p : nullptr, do_sort ? L.v0.p : nullptr, nullptr, cs));
         if (stage_sorted(h, sl, N, do_sort, lane) != 0) return -1;
     }
+    const auto t_enq = std::chrono::steady_clock::now();
     if (direct && wait_reusable && N > 0) HIPC(hipEventSynchronize(sl.h2d_done));
+    {
+        const double e = std::chrono::duration<double, std::micro>(t_enq - t_job).count();
+        const double w = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq).count();
+        flh_handle::StageDiag& d = h->sdiag;
+        d.n_jobs += 1; d.enq_us += e; d.h2d_wait_us += w;
+        if (e > d.enq_max_us) d.enq_max_us = e;
+        if (w > d.h2d_wait_max_us) d.h2d_wait_max_us = w;
+    }
     return 0;
 }
 
@@ -1461,11 +1477,20 @@ static void stop_stager(flh_handle* h) {
 static int activate(flh_handle* h, flh_handle::Slot& sl, bool full_clear) {
     HIPC(hipSetDevice(h->device));
     pre_cancel(h);  // (a pass enqueued ahead for the previous scan that never got its state)
+    const auto t_act = std::chrono::steady_clock::now();
+    if (sl.pending) h->sdiag.act_slept += 1;  // (unguarded look: a counter for developers)
     if (wait_slot(h, sl) != 0) return -1;
+    {
+        const double w = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_act).count();
+        flh_handle::StageDiag& d = h->sdiag;
+        d.n_act += 1; d.act_wait_us += w;
+        if (w > d.act_wait_max_us) d.act_wait_max_us = w;
+    }
     // In a running stream the staging of this scan finished while the previous scan was updated: then no barrier packet goes in
     // front of the scan's first pass, one look at the event instead (same box, two alternating pairs, profiles/r05_call1/:
     // 7 431 / 7 399 -> 7 496 / 7 476 scans/s)
     if (hipEventQuery(sl.ready) != hipSuccess) {
+        h->sdiag.act_ev_not_ready += 1;
         (void)hipGetLastError();  // (not ready is not an error)
         HIPC(hipStreamWaitEvent(h->stream, sl.ready, 0));
     }
@@ -2188,6 +2213,14 @@ int flh_set_prelaunch(flh_handle* h, int on) {
     if (!h) return fail("flh_set_prelaunch: null handle");
     h->pre.off = on == 0;
     if (h->pre.off) { pre_cancel(h); h->pre.expect = FLH_NEXT_UNKNOWN; }
+    return 0;
+}
+int flh_debug_stage_stats(flh_handle* h, double out[10], int reset) {
+    if (!h || !out) return fail("flh_debug_stage_stats: null argument");
+    const flh_handle::StageDiag& d = h->sdiag;
+    const double v[10] = {d.n_jobs, d.enq_us, d.enq_max_us, d.h2d_wait_us, d.h2d_wait_max_us, d.n_act, d.act_wait_us, d.act_wait_max_us, d.act_ev_not_ready, d.act_slept};
+    for (int i = 0; i < 10; ++i) out[i] = v[i];
+    if (reset) h->sdiag = flh_handle::StageDiag();
     return 0;
 }
 int flh_debug_search_redone(const flh_handle* h, uint64_t* out) {

@@ -20,6 +20,11 @@ int flh_debug_scan_order(flh_handle* h, uint32_t* order);
  * host has seen the change's counters (flh_eval_begin); when they then ask for a re-index or a replay (flh_eval_end), the pass is
  * repeated on the settled map.  The tests provoke both cases and count them here. */
 int flh_debug_search_redone(const flh_handle* h, uint64_t* out);
+/* Where a scan's staging and its activation spend their time (counters since the last reset):
+ * out = {stagings, enqueue us (sum), (max), wait for the H2D copy us (sum), (max),
+ *        activations, wait for the slot's staging us (sum), (max), activations whose device-side event was not ready, activations
+ *        that found the slot still with the staging thread}. */
+int flh_debug_stage_stats(flh_handle* h, double out[10], int reset);
 #ifdef __cplusplus
 }
 #endif

@@ -696,9 +696,12 @@ def test_run_scans_native_loop_equals_scan_by_scan_updates(prob):
         kf.update(0.001)
         want.append(kf.get_x())
     jobs = capi.Esekf.make_jobs(bodies, priors)
+    h.stage_stats(reset=True)
     rs = kf.run_scans(jobs, 0, 4, ring=3)
     assert rs.scans == 4 and rs.passes >= 8 and rs.n_search_passes + rs.n_nosearch_passes == rs.passes
     np.testing.assert_array_equal(kf.get_x(), want[3])
+    sd = h.stage_stats()  # the developer counters of the hand-over (flh_debug_stage_stats): every scan staged once, activated once
+    assert sd["jobs"] == 4 and sd["activations"] == 4 and sd["enq_us"] > 0 and sd["act_wait_max_us"] >= 0
     kf.run_scans(jobs, 0, 2, ring=2, stage_next=True)
     np.testing.assert_array_equal(kf.get_x(), want[1])
     kf.run_scans(jobs, 2, 1, ring=2, first_staged=True)
