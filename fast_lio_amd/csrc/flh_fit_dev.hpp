@@ -201,46 +201,7 @@ __device__ __forceinline__ void group_sum_publish(const double* partials, int gr
         if (gout.n_dst > 0 && wl == 0 && group == 0) publish_granule(gout, 0, (double)(ngroups * nsl), seq);  // the section's header
         return;
     }
-    if (!QUADS && nsl > 64 && nsl <= 96) {
-        // k_pass with the extrinsic columns: the three slots of a lane side by side, two quads of units (24 loads) per round --
-        // four round trips where three trips of two made six.  Per slot the same additions in the same order: the same bits.
-        constexpr int NT = 3, Q2 = 2;
-        double s3[NT] = {0.0, 0.0, 0.0};
-        for (int q0 = qlo; q0 < qhi; q0 += Q2) {
-            double pv[NT][4 * Q2];
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) {
-                const int slot = sl + 32 * tt;
-                const int sc = slot < nsl ? slot : nsl - 1;
-#pragma unroll
-                for (int j = 0; j < 4 * Q2; ++j) {
-                    const int u = 4 * q0 + j;  // unit inside the group
-                    pv[tt][j] = (q0 + (j >> 2) < qhi && u < gsize)
-                                    ? __hip_atomic_load(gpart + (size_t)(u0 + u) * nsl + sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                    : 0.0;
-                }
-            }
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                for (int j = 0; j < Q2; ++j) {
-                    const double qv = ((pv[tt][4 * j] + pv[tt][4 * j + 1]) + pv[tt][4 * j + 2]) + pv[tt][4 * j + 3];
-                    if (q0 + j < qhi) s3[tt] += qv;
-                }
-        }
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-            const int slot = sl + 32 * tt;
-            const double other = __shfl_xor(s3[tt], 32, 64);
-            const double total = hi ? other + s3[tt] : s3[tt] + other;  // lower half + upper half on both sides
-            if (hi == 0 && slot < nsl) {
-                if (gout.n_dst > 0) publish_granule(gout, 1 + (size_t)group * nsl + slot, total, seq);
-                else part2[(size_t)group * nsl + slot] = total;
-            }
-        }
-        if (gout.n_dst > 0 && wl == 0 && group == 0) publish_granule(gout, 0, (double)(ngroups * nsl), seq);  // the section's header
-        return;
-    }
+    // (k_pass with the extrinsic columns does not come here: three of its waves take a trip each, group_sum_trip below)
     for (int slot = sl; slot < ((nsl + 31) & ~31); slot += 32) {
         const int sc = slot < nsl ? slot : nsl - 1;
         double s0 = 0.0;
@@ -275,6 +236,45 @@ __device__ __forceinline__ void group_sum_publish(const double* partials, int gr
         }
     }
     if (gout.n_dst > 0 && wl == 0 && group == 0) publish_granule(gout, 0, (double)(ngroups * nsl), seq);  // the section's header
+}
+
+// ONE 32-slot trip of k_pass's group sum (slot = 32 * trip + (lane & 31)) by one wave.  With the extrinsic columns a group's record
+// has 93 slots = three trips; the last arriver's workgroup takes them with three of its waves side by side instead of one wave
+// taking them in turn (extrinsic_est_en = 1 is the reference's default, src/laserMapping.cpp:789; profiles/r06_call33/: the columns
+// cost k_pass 2.5 us, most of it here).  Per slot the additions of group_sum_publish<false> in its order: the same bits.  The
+// section's header stays with the caller.
+__device__ __forceinline__ void group_sum_trip(const double* partials, int group, int gsize, int red, int nsl, const GranOut& gout,
+                                               double seq, int wl, int trip, double* part2) {
+    const gdouble* gpart = (const gdouble*)partials;
+    const int u0 = group * red;
+    const int nq = (gsize + 3) >> 2;
+    const int halfq = (nq + 1) >> 1;
+    const int hi = wl >> 5, sl = wl & 31;
+    const int qlo = hi ? halfq : 0, qhi = hi ? nq : halfq;
+    constexpr int QB = 4;
+    const int slot = sl + 32 * trip;
+    const int sc = slot < nsl ? slot : nsl - 1;
+    double s0 = 0.0;
+    for (int q0 = qlo; q0 < qhi; q0 += QB) {
+        double pv[4 * QB];
+#pragma unroll
+        for (int j = 0; j < 4 * QB; ++j) {
+            const int u = 4 * q0 + j;  // unit inside the group
+            pv[j] = (q0 + (j >> 2) < qhi && u < gsize) ? __hip_atomic_load(gpart + (size_t)(u0 + u) * nsl + sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                       : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            const double qv = ((pv[4 * j] + pv[4 * j + 1]) + pv[4 * j + 2]) + pv[4 * j + 3];
+            if (q0 + j < qhi) s0 += qv;
+        }
+    }
+    const double other = __shfl_xor(s0, 32, 64);
+    const double total = hi ? other + s0 : s0 + other;  // lower half + upper half on both sides
+    if (hi == 0 && slot < nsl) {
+        if (gout.n_dst > 0) publish_granule(gout, 1 + (size_t)group * nsl + slot, total, seq);
+        else part2[(size_t)group * nsl + slot] = total;
+    }
 }
 
 }  // namespace flh

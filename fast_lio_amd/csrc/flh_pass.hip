@@ -98,6 +98,7 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     __shared__ float park[kPassQueries * kParkStride];
     __shared__ uint32_t s_list[64];  // per wave: the slots (0..63) of its queries that go to phase B
     __shared__ uint32_t s_wcnt[NW];
+    __shared__ uint32_t s_last;      // (extrinsic columns) this workgroup is its group's last arriver: three of its waves take the group sum
     const int tid = threadIdx.x;
     // which 64 scan points (a unit of the summation tree) this workgroup takes: the LAST ones first.  Workgroups are dispatched in
     // blockIdx order over ~2 us, and the end of the scan's Morton order is its far field, whose waves are the slowest of the launch
@@ -193,7 +194,26 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     // (lane and wave are derived again rather than kept in registers across phase B)
     int tid_f = threadIdx.x;
     asm volatile("" : "+v"(tid_f));
-    if ((tid_f >> 6) != (int)(((unsigned)unit >> 3) & 3u)) return;
+    const int fitw = (int)(((unsigned)unit >> 3) & 3u);
+    const int myw = __builtin_amdgcn_readfirstlane(tid_f >> 6);
+    // With the extrinsic columns (93 slots = three 32-slot trips of the group sum) the other waves stay: if this workgroup turns out to
+    // be its group's last arriver, two of them take a trip each beside the fit wave's (flh_fit_dev.hpp: group_sum_trip)
+    const bool helpers = ncol == 12;
+    if (myw != fitw) {
+        if (!helpers) return;
+        __syncthreads();  // (1) the fit wave's verdict
+        if (!s_last) return;
+        const int hidx = (myw - fitw - 1) & 3;  // 0, 1, 2
+        if (hidx < 2) {
+            const int nsl_h = gran_section_slots(ncol);
+            const int group_h = unit / red;
+            const int gsize_h = min(red, (int)gridDim.x - group_h * red);
+            group_sum_trip(partials, group_h, gsize_h, red, nsl_h, gout, seq, tid_f & 63, 1 + hidx, group_totals);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();  // (2) the three trips are out: the header may follow
+        return;
+    }
     const int wl = tid_f & 63;
     const int qf = q0 + wl;
     double v[16];
@@ -240,6 +260,20 @@ k_pass(GridParams g, StateDev s, const float4* __restrict__ body, int N, uint32_
     if (wl == 0) tk = __hip_atomic_fetch_add(&tickets[1 + group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
     STAMP(6);  // ticket taken
+    if (helpers) {
+        const bool last = tk == (uint32_t)(gsize - 1);
+        if (wl == 0) s_last = last ? 1u : 0u;
+        __syncthreads();  // (1)
+        if (!last) return;
+        group_sum_trip(partials, group, gsize, red, nsl, gout, seq, wl, 0, group_totals);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // (2)
+        if (gout.n_dst > 0 && wl == 0 && group == 0) publish_granule(gout, 0, (double)(((nblk + red - 1) / red) * nsl), seq);  // the section's header: the pass's last granule
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(7);
+        if (wl == 0) tickets[1 + group] = 0;  // re-arm this group's ticket for the next launch
+        return;
+    }
     if (tk != (uint32_t)(gsize - 1)) return;
     // (gout.n_dst == 0 -- an RCCL communicator is attached -- : the group's totals stay in device memory, group_totals[group][slot];
     // the ranks' totals are all-reduced and the publish kernel adds the groups in the host's order, flh_kernels.hip)
