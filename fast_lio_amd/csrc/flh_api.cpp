@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <emmintrin.h>
+#include <immintrin.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -1917,6 +1918,18 @@ static const GramMap& gram_map(int ncol) {
     static const GramMap m6 = build_gram_map(6), m12 = build_gram_map(12);
     return ncol == 12 ? m12 : m6;
 }
+// Four consecutive granules {value, sequence} (64 bytes) at once: true and their values in out4 when all four carry `seq`.  Two
+// 32-byte loads, one compare: the pick-up of a pass is a loop over 25 x 31 (25 x 93 with the extrinsic columns) granules that all
+// land within a few microseconds of the kernel's end, so what the host spends PER GRANULE is on the critical path of every pass.
+// (Each granule is one 16-byte device store and is read here inside one aligned 16-byte half of a vector load, as before.)
+static inline bool take4(const double* gp, double seq, double* out4) {
+    const __m256d a = _mm256_loadu_pd(gp);       // v0 s0 v1 s1
+    const __m256d b = _mm256_loadu_pd(gp + 4);   // v2 s2 v3 s3
+    const __m256d ss = _mm256_unpackhi_pd(a, b);  // s0 s2 s1 s3
+    if (_mm256_movemask_pd(_mm256_cmp_pd(ss, _mm256_set1_pd(seq), _CMP_EQ_OQ)) != 0xF) return false;
+    _mm256_storeu_pd(out4, _mm256_permute4x64_pd(_mm256_unpacklo_pd(a, b), 0xD8));  // v0 v2 v1 v3 -> v0 v1 v2 v3
+    return true;
+}
 static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
     hipStream_t st = h->stream;
     const int ncol = ext ? 12 : 6;
@@ -2017,9 +2030,10 @@ static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
                 const double* gg = sect + 2 * (1 + (size_t)gi * nsl);
                 if (gi > 0) prefetch_group(gg - 2 * (size_t)nsl);  // (the groups arrive last first)
                 if (gi > 1) prefetch_group(gg - 4 * (size_t)nsl);
+                double* vdst = &val[off[r] + (size_t)gi * nsl];
                 for (int k = 0; k < nsl; ++k) {
-                    const int rc = (r == h->peer_rank) ? wait_for(gg + 2 * k, &val[off[r] + (size_t)gi * nsl + k])
-                                                       : wait_hinted(gg + 2 * k, &val[off[r] + (size_t)gi * nsl + k], sect);
+                    if (k + 4 <= nsl && take4(gg + 2 * k, seq, vdst + k)) { k += 3; continue; }  // four at once when they are there
+                    const int rc = (r == h->peer_rank) ? wait_for(gg + 2 * k, vdst + k) : wait_hinted(gg + 2 * k, vdst + k, sect);
                     if (rc < 0) return -1;
                     if (rc > 0) { taken[r] = false; break; }
                 }
@@ -2037,8 +2051,12 @@ static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
     for (int r = 0; r < h->peer_n; ++r) {  // the sums, in (rank, group) order
         if (taken[r]) {
             const double* val = h->gran_val.data();
-            for (int gi = 0; gi < ng_of[r]; ++gi)
-                for (int k = 0; k < nsl; ++k) sum[k] += val[off[r] + (size_t)gi * nsl + k];
+            for (int gi = 0; gi < ng_of[r]; ++gi) {  // (behind the pass's LAST granule: four slots per step, each slot's additions in group order)
+                const double* vg = val + off[r] + (size_t)gi * nsl;
+                int k = 0;
+                for (; k + 4 <= nsl; k += 4) _mm256_storeu_pd(sum + k, _mm256_add_pd(_mm256_loadu_pd(sum + k), _mm256_loadu_pd(vg + k)));
+                for (; k < nsl; ++k) sum[k] += vg[k];
+            }
             continue;
         }
         const double* sect = base + (size_t)r * kGranSect * 2;
@@ -2052,6 +2070,12 @@ static int collect_granules(flh_handle* h, double seq, int do_search, int ext) {
             if (gi + 1 < cnt / nsl) prefetch_group(gg + 2 * (size_t)nsl);
             if (gi + 2 < cnt / nsl) prefetch_group(gg + 4 * (size_t)nsl);
             for (int k = 0; k < nsl; ++k) {
+                double v4[4];
+                if (k + 4 <= nsl && take4(gg + 2 * k, seq, v4)) {  // four slots at once (each slot's sum keeps its order of additions)
+                    _mm256_storeu_pd(sum + k, _mm256_add_pd(_mm256_loadu_pd(sum + k), _mm256_loadu_pd(v4)));
+                    k += 3;
+                    continue;
+                }
                 double v;
                 if (wait_for(gg + 2 * k, &v) != 0) return -1;
                 sum[k] += v;
