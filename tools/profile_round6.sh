@@ -82,5 +82,7 @@ for rep in 1 2; do
     echo "extrinsic_est=$ext rep $rep: $(python tools/bench_line.py $O/r${RND}_bench_config2_ext${ext}_$rep.json)"
   done
 done
+timeout 600 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -2 | tee $O/r${RND}_smoke.txt
+el "build + smoke"
 el "all done"
 exit 0
