@@ -2241,6 +2241,7 @@ int flh_set_prelaunch(flh_handle* h, int on) {
 }
 int flh_debug_stage_stats(flh_handle* h, double out[10], int reset) {
     if (!h || !out) return fail("flh_debug_stage_stats: null argument");
+    std::lock_guard<std::mutex> sg(h->stage_mu);  // the staging thread writes its counters inside a staging, which holds this lock
     const flh_handle::StageDiag& d = h->sdiag;
     const double v[10] = {d.n_jobs, d.enq_us, d.enq_max_us, d.h2d_wait_us, d.h2d_wait_max_us, d.n_act, d.act_wait_us, d.act_wait_max_us, d.act_ev_not_ready, d.act_slept};
     for (int i = 0; i < 10; ++i) out[i] = v[i];
