@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the tests with timing in them, several times over (a flaky test would stop the driver's -x run).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/r05_flaky; mkdir -p $O
+O=$R/gpurun_out/r06_flaky; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
 for i in $(seq ${TIMING_ROUNDS:-5}); do
