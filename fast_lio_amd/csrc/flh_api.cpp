@@ -1454,9 +1454,11 @@ static void stager_main(flh_handle* h) {
         h->st_done.notify_all();
     }
 }
-static int wait_slot(flh_handle* h, flh_handle::Slot& sl) {
+static int wait_slot(flh_handle* h, flh_handle::Slot& sl, bool* was_pending = nullptr) {
+    if (was_pending) *was_pending = false;
     if (!h->stager.joinable()) return 0;
     std::unique_lock<std::mutex> lk(h->st_mu);
+    if (was_pending) *was_pending = sl.pending;
     h->st_done.wait(lk, [&] { return !sl.pending; });
     if (sl.async_rc != 0) {
         const std::string e = sl.async_err;
@@ -1478,15 +1480,7 @@ static void stop_stager(flh_handle* h) {
 static int activate(flh_handle* h, flh_handle::Slot& sl, bool full_clear) {
     HIPC(hipSetDevice(h->device));
     pre_cancel(h);  // (a pass enqueued ahead for the previous scan that never got its state)
-    const auto t_act = std::chrono::steady_clock::now();
-    if (sl.pending) h->sdiag.act_slept += 1;  // (unguarded look: a counter for developers)
     if (wait_slot(h, sl) != 0) return -1;
-    {
-        const double w = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_act).count();
-        flh_handle::StageDiag& d = h->sdiag;
-        d.n_act += 1; d.act_wait_us += w;
-        if (w > d.act_wait_max_us) d.act_wait_max_us = w;
-    }
     // In a running stream the staging of this scan finished while the previous scan was updated: then no barrier packet goes in
     // front of the scan's first pass, one look at the event instead (same box, two alternating pairs, profiles/r05_call1/:
     // 7 431 / 7 399 -> 7 496 / 7 476 scans/s)
@@ -1707,7 +1701,16 @@ int flh_points_body_to_world(flh_handle* h, const double x[FLH_NSTATE], const vo
 int flh_scan_activate(flh_handle* h, int slot) {
     if (!h) return fail("flh_scan_activate: null handle");
     if (slot < 0 || slot >= FLH_MAX_SLOTS) return fail("flh_scan_activate: bad slot");
-    if (wait_slot(h, h->slots[slot]) != 0) return -1;  // an asynchronous staging of the slot finishes first
+    const auto t_act = std::chrono::steady_clock::now();
+    bool was_pending = false;
+    if (wait_slot(h, h->slots[slot], &was_pending) != 0) return -1;  // an asynchronous staging of the slot finishes first
+    {  // (developer counters: how long the update waited for the staging thread)
+        const double w = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_act).count();
+        flh_handle::StageDiag& d = h->sdiag;
+        d.n_act += 1; d.act_wait_us += w;
+        if (w > d.act_wait_max_us) d.act_wait_max_us = w;
+        if (was_pending) d.act_slept += 1;
+    }
     if (!h->slots[slot].used) return fail("flh_scan_activate: slot not staged");
     return activate(h, h->slots[slot], false);
 }
