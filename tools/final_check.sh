@@ -1,5 +1,5 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r05_final_check; mkdir -p $O; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r06_final_check; mkdir -p $O; export TMPDIR=/tmp
 t0=$(date +%s); el() { echo "[t+$(( $(date +%s) - t0 ))s] $*"; }
 cd $R
 python tools/src_hash.py
